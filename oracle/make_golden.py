@@ -1,0 +1,295 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE'S OWN CLASSES.
+
+Runs only in the build container (needs /root/reference, read-only; nothing is
+copied from it).  The reference's hot-path classes are imported under
+oracle/pyg_shim (see oracle/ref_import.py); every expected output below is
+produced by the reference's `define_G(...)`, `GraphResnetBlock`,
+`FastInstanceNorm`, `SingleBatchGraphNorm`, `HierarchicalData.__inc__`,
+`ImageGraphTextureDataSet`, `Inpainting3DTrainer._graph_forward/compute_loss`
+and `utils.metrics.graph_metrics`.  Fixtures hold DATA only: inputs, seeded
+weights, expected outputs / gradients.
+
+    python oracle/make_golden.py            # rewrites tests/golden/
+"""
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+_REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _REPO)
+warnings.filterwarnings('ignore')
+
+from oracle import ref_import  # noqa: E402
+from surface_texture_inpainting_net_amd.data import HierarchicalBatch  # noqa: E402
+from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh  # noqa: E402
+
+OUT = os.path.join(_REPO, 'tests', 'golden')
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def _randomize_biases(net, gen, scale=0.1):
+    # the reference zero-inits every Linear bias; fixtures use non-zero biases so that
+    # bias handling (incl. the b2 * [indeg > 0] mask) is actually pinned.
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.copy_(torch.randn(p.shape, generator=gen) * scale)
+
+
+def _pack_sample(d, sample):
+    for k in sample.keys():
+        v = sample[k]
+        if torch.is_tensor(v):
+            d['s.' + k] = _np(v)
+
+
+def _model_fixture(name, stin, trainer_mod, cfg, sample, seed, adam_step=False):
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    net = stin.define_G(**cfg)
+    _randomize_biases(net, gen)
+    d = {'cfg': np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)}
+    for k, v in net.state_dict().items():
+        d['sd.' + k] = _np(v)
+    _pack_sample(d, sample)
+    fake = types.SimpleNamespace(models={'graph': net}, criterion=torch.nn.L1Loss(reduction='none'))
+    T = trainer_mod.Inpainting3DTrainer
+    x = sample.x.clone().requires_grad_(True)
+    sample.x = x
+    out = net(sample)
+    pred = T._graph_forward(fake, sample, sample.color)
+    loss = T.compute_loss(fake, pred, sample.color, weights=sample.mask)
+    opt = torch.optim.Adam(net.parameters(), lr=7e-5, weight_decay=0, amsgrad=True) if adam_step else None
+    loss.backward()
+    d['out'] = _np(out)
+    d['pred'] = _np(pred)
+    d['loss'] = _np(loss)
+    d['gx'] = _np(x.grad)
+    for k, p in net.named_parameters():
+        d['g.' + k] = _np(p.grad)
+    if adam_step:
+        opt.step()
+        for k, v in net.state_dict().items():
+            d['sd1.' + k] = _np(v)
+    sample.x = x.detach()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    print(name, 'N0 =', sample.x.shape[0], 'loss =', float(loss), 'params =',
+          sum(p.numel() for p in net.parameters()))
+
+
+def g1_imagegraph(stin, trainer_mod):
+    """Config 1: the reference's own 32x32 grid-graph index maps + small edgeconv net."""
+    ig = ref_import.load_imagegraph_dataset_class()
+    ds = ig.ImageGraphTextureDataSet([], end_level=2, is_train=False, benchmark=False, img_size=32,
+                                     crop_half_width=8, circle_radius=4)
+    gen = torch.Generator().manual_seed(11)
+    img = torch.rand(1024, 3, generator=gen) * 2 - 1
+    mask = (torch.rand(1024, 1, generator=gen) < 0.25)
+    s = HierarchicalBatch()
+    s['x'] = torch.cat([img * ~mask, mask.float()], dim=-1)
+    s['color'] = img
+    s['mask'] = mask.long() * torch.randint(1, 17, (1024, 1), generator=gen)
+    s['edge_index'] = torch.from_numpy(ds.edge_indices_list[0]).t().contiguous()
+    s['hierarchy_edge_index_1'] = torch.from_numpy(ds.edge_indices_list[1]).t().contiguous()
+    s['hierarchy_trace_index_1'] = torch.from_numpy(ds.traces_list[0])
+    s['num_vertices'] = torch.tensor([[1024, 256]], dtype=torch.int32)
+    s['batch'] = torch.zeros(1024, dtype=torch.long)
+    cfg = dict(input_nc=4, output_nc=3, ngf=8, filter_type='edgeconv', norm='instance', n_blocks=2,
+               n_levels=1, pooling_type='max')
+    _model_fixture('g1_imagegraph_edgeconv', stin, trainer_mod, cfg, s, seed=101)
+
+
+def g2_three_level(stin, trainer_mod):
+    for pooling in ('max', 'mean'):
+        s = make_synthetic_mesh(700, 3, seed=2, dilations=(2, 4))
+        cfg = dict(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconvtransinv', norm='instance',
+                   n_blocks=3, n_levels=2, pooling_type=pooling, dilations=[1, 2, 4],
+                   checkpoint_bottleneck=True)
+        _model_fixture('g2_3level_transinv_%s' % pooling, stin, trainer_mod, cfg, s, seed=202)
+
+
+def g3_batch_unequal(stin, trainer_mod):
+    """Two UNEQUAL graphs collated with the reference's HierarchicalData.__inc__ rules."""
+    du = ref_import.load_module('utils.data_utils')
+    from torch_geometric.data import Batch
+    graphs = [make_synthetic_mesh(300, 3, seed=31, dilations=()),
+              make_synthetic_mesh(520, 3, seed=32, dilations=())]
+    items, d_extra = [], {}
+    for gi, g in enumerate(graphs):
+        h = du.HierarchicalData(x=g.x, color=g.color, mask=g.mask, edge_index=g.edge_index)
+        h.num_vertices = g.num_vertices.reshape(-1)
+        for k in g.keys():
+            if k.startswith('hierarchy_'):
+                setattr(h, k, g[k])
+        items.append(h)
+        for k in g.keys():
+            if torch.is_tensor(g[k]):
+                d_extra['g%d.%s' % (gi, k)] = _np(g[k])
+    b = Batch.from_data_list(items)
+    s = HierarchicalBatch()
+    for k in b.keys:
+        s[k] = b[k]
+    s['batch'] = b['batch']
+    assert s.num_vertices.shape == (2, 3)
+    cfg = dict(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconvtransinv', norm='instance',
+               n_blocks=2, n_levels=2, pooling_type='max')
+    _model_fixture('g3_batch2_unequal', stin, trainer_mod, cfg, s, seed=303)
+    np.savez_compressed(os.path.join(OUT, 'g3_graphs.npz'), **d_extra)
+
+
+def g4_per_op(stin):
+    gen = torch.Generator().manual_seed(404)
+    d = {}
+    s = make_synthetic_mesh(200, 2, seed=4, dilations=())
+    ei = s.edge_index
+    n = s.x.shape[0]
+    ecf = ref_import.load_module('models.modules.edge_conv_filter')
+    fin = ref_import.load_module('models.modules.fastinstancenorm')
+    sbg = ref_import.load_module('models.modules.singlebatchgroupnorm')
+    d['ei'] = _np(ei)
+    half = n // 3
+    batch_uneq = torch.cat([torch.zeros(half, dtype=torch.long), torch.ones(n - half, dtype=torch.long)])
+    d['batch_uneq'] = _np(batch_uneq)
+    for tag, cin, cout, batch in (('neq', 6, 8, None), ('eq', 8, 8, None), ('eqb', 8, 8, batch_uneq)):
+        torch.manual_seed(410 + cin + cout)
+        blk = stin.GraphResnetBlock(cin, cout, ecf.get_gcn_filter, fin.FastInstanceNorm, False, True)
+        _randomize_biases(blk, gen)
+        x = torch.randn(n, cin, generator=gen).requires_grad_(True)
+        w = torch.randn(n, cout, generator=gen)
+        y = blk(x, ei, batch)
+        (y * w).sum().backward()
+        d['blk_%s.x' % tag], d['blk_%s.w' % tag], d['blk_%s.y' % tag] = _np(x), _np(w), _np(y)
+        d['blk_%s.gx' % tag] = _np(x.grad)
+        for k, p in blk.named_parameters():
+            d['blk_%s.sd.%s' % (tag, k)] = _np(p)
+            d['blk_%s.g.%s' % (tag, k)] = _np(p.grad)
+    # norms
+    x = torch.randn(60, 5, generator=gen) * 2 + 1
+    d['norm.x'] = _np(x)
+    b_eq = torch.arange(60) // 30
+    b_un = (torch.arange(60) >= 17).long()
+    d['norm.b_eq'], d['norm.b_un'] = _np(b_eq), _np(b_un)
+    fi = fin.FastInstanceNorm(5)
+    for tag, b in (('none', None), ('zeros', torch.zeros(60, dtype=torch.long)), ('eq', b_eq), ('un', b_un)):
+        xx = x.clone().requires_grad_(True)
+        y = fi(xx, b)
+        wv = torch.linspace(-1, 1, y.numel()).view_as(y)
+        (y * wv).sum().backward()
+        d['fin.%s.y' % tag], d['fin.%s.gx' % tag] = _np(y), _np(xx.grad)
+    gn = sbg.SingleBatchGraphNorm(5)
+    with torch.no_grad():
+        gn.weight.copy_(torch.randn(5, generator=gen))
+        gn.bias.copy_(torch.randn(5, generator=gen))
+        gn.mean_scale.copy_(torch.randn(5, generator=gen))
+    d['gn.weight'], d['gn.bias'], d['gn.mean_scale'] = _np(gn.weight), _np(gn.bias), _np(gn.mean_scale)
+    for tag, b in (('none', None), ('un', b_un)):
+        xx = x.clone().requires_grad_(True)
+        y = gn(xx, b)
+        wv = torch.linspace(-1, 1, y.numel()).view_as(y)
+        (y * wv).sum().backward()
+        d['gn.%s.y' % tag], d['gn.%s.gx' % tag] = _np(y), _np(xx.grad)
+        d['gn.%s.gweight' % tag] = _np(gn.weight.grad.clone())
+        d['gn.%s.gmean_scale' % tag] = _np(gn.mean_scale.grad.clone())
+        gn.zero_grad()
+    # pooling through the reference's own _pooling/_unpooling methods (engineered ties, empty cluster)
+    net_max = types.SimpleNamespace(_pooling_type='max')
+    net_mean = types.SimpleNamespace(_pooling_type='mean')
+    P = stin.SurfaceTextureInpaintingNet
+    xv = torch.tensor([[1., 5., 2.], [3., 5., 2.], [3., 1., 2.], [0., 0., 7.], [-1., -2., -3.], [-1., -5., -3.],
+                       [4., 4., 4.]])
+    trace = torch.tensor([0, 0, 0, 2, 4, 4, 2])     # clusters 1 and 3 are empty; ties inside 0 and 4
+    d['pool.x'], d['pool.trace'] = _np(xv), _np(trace)
+    for tag, ns in (('max', net_max), ('mean', net_mean)):
+        xx = xv.clone().requires_grad_(True)
+        y = P._pooling(ns, xx, trace, 5)
+        wv = torch.arange(1., 16.).view(5, 3)
+        (y * wv).sum().backward()
+        d['pool.%s.y' % tag], d['pool.%s.gx' % tag] = _np(y), _np(xx.grad)
+    xx = torch.randn(5, 3, generator=gen).requires_grad_(True)
+    y = P._unpooling(None, xx, trace)
+    wv = torch.arange(1., 22.).view(7, 3)
+    (y * wv).sum().backward()
+    d['unpool.x'], d['unpool.y'], d['unpool.gx'] = _np(xx), _np(y), _np(xx.grad)
+    # batch-vector propagation (models/surfacetextureinpaintingnet.py:421-422, :446-447)
+    from torch_scatter import scatter_max
+    bvec = torch.tensor([0, 0, 0, 1, 1, 1, 1])
+    d['batch.pooled'] = _np(scatter_max(bvec, trace, dim=0, dim_size=5)[0])
+    np.savez_compressed(os.path.join(OUT, 'g4_per_op.npz'), **d)
+    print('g4_per_op', len(d), 'arrays')
+
+
+def g5_sage(stin, trainer_mod):
+    for ft in ('sageconv', 'sageconvtransinv'):
+        s = make_synthetic_mesh(260, 2, seed=5, dilations=())
+        cfg = dict(input_nc=10, output_nc=3, ngf=8, filter_type=ft, norm='instance', n_blocks=2, n_levels=1,
+                   pooling_type='mean')
+        _model_fixture('g5_%s' % ft, stin, trainer_mod, cfg, s, seed=505)
+
+
+def g6_graphnorm(stin, trainer_mod):
+    s = make_synthetic_mesh(260, 2, seed=6, dilations=())
+    cfg = dict(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconv', norm='graph', n_blocks=1, n_levels=1,
+               pooling_type='max')
+    _model_fixture('g6_graphnorm', stin, trainer_mod, cfg, s, seed=606)
+
+
+def g7_train_step(stin, trainer_mod):
+    s = make_synthetic_mesh(500, 3, seed=7, dilations=(2,))
+    cfg = dict(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconvtransinv', norm='instance', n_blocks=2,
+               n_levels=2, pooling_type='max', dilations=[1, 2])
+    _model_fixture('g7_train_step', stin, trainer_mod, cfg, s, seed=707, adam_step=True)
+
+
+def g8_metrics():
+    gm = ref_import.load_module('utils.metrics.graph_metrics')
+    s = make_synthetic_mesh(300, 1, seed=8, dilations=())
+    gen = torch.Generator().manual_seed(808)
+    pred = torch.rand(s.x.shape[0], 3, generator=gen) * 2 - 1
+    d = {'pred': _np(pred), 'ei': _np(s.edge_index),
+         'lap_var': _np(gm.GraphLaplaceVariance()(pred, s.edge_index)),
+         'tv': _np(gm.graph_total_variation(pred, s.edge_index)),
+         'psnr': _np(gm.psnr(pred, s.color, data_range=2.0)), 'color': _np(s.color)}
+    np.savez_compressed(os.path.join(OUT, 'g8_metrics.npz'), **d)
+
+
+def param_counts(stin):
+    """The structural constants SURVEY.md §8(c) records."""
+    out = {}
+    base = dict(output_nc=3, ngf=64, norm='instance', pooling_type='max')
+    out['c1_edgeconv_nl1_nb9'] = sum(p.numel() for p in stin.define_G(
+        input_nc=4, filter_type='edgeconv', n_blocks=9, n_levels=1, **base).parameters())
+    for nl in (2, 3):
+        out['3d_transinv_nl%d_nb9' % nl] = sum(p.numel() for p in stin.define_G(
+            input_nc=10, filter_type='edgeconvtransinv', n_blocks=9, n_levels=nl, **base).parameters())
+    net = stin.define_G(input_nc=10, filter_type='edgeconvtransinv', n_blocks=9, n_levels=2, **base)
+    out['3d_state_dict_keys'] = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with open(os.path.join(OUT, 'param_counts.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print({k: v for k, v in out.items() if not isinstance(v, dict)})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    stin = ref_import.load_model_module()
+    trainer_mod = ref_import.load_trainer3d_module()
+    g1_imagegraph(stin, trainer_mod)
+    g2_three_level(stin, trainer_mod)
+    g3_batch_unequal(stin, trainer_mod)
+    g4_per_op(stin)
+    g5_sage(stin, trainer_mod)
+    g6_graphnorm(stin, trainer_mod)
+    g7_train_step(stin, trainer_mod)
+    g8_metrics()
+    param_counts(stin)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,120 @@
+"""The CPU oracle (oracle/stin_oracle.py) against the golden vectors produced by the
+REFERENCE's own classes (oracle/make_golden.py) - runs on CPU, no GPU needed."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scatter_ops, stin_oracle
+from _golden import MODEL_FIXTURES, ModelFixture, load_npz, rel_err
+
+
+@pytest.mark.parametrize('name', MODEL_FIXTURES)
+def test_oracle_model_matches_reference_fixture(name):
+    fx = ModelFixture(name)
+    net = stin_oracle.define_G(**fx.cfg)
+    assert set(net.state_dict().keys()) == set(fx.state_dict.keys())
+    net.load_state_dict(fx.state_dict)
+    s = fx.sample()
+    s.x = s.x.clone().requires_grad_(True)
+    out = net(s)
+    # same ops in the same order on the same CPU build: forward is expected bit-exact
+    assert torch.equal(out, fx.out), float((out - fx.out).abs().max())
+    pred = stin_oracle.graph_forward(net, s)
+    loss = stin_oracle.compute_loss(pred, s.color, weights=s.mask)
+    assert torch.equal(pred, fx.pred)
+    assert abs(float(loss.detach()) - float(fx.loss)) <= 1e-7
+    loss.backward()
+    assert rel_err(s.x.grad, fx.gx) < 1e-5
+    # some grads are analytically zero (a bias in front of an instance norm): compare against the
+    # fixture-wide gradient scale, not per tensor
+    scale = max(float(g.abs().max()) for g in fx.grads.values())
+    for k, p in net.named_parameters():
+        assert float((p.grad - fx.grads[k]).abs().max()) < 2e-5 * scale, k
+
+
+def test_oracle_train_step_adam_amsgrad():
+    fx = ModelFixture('g7_train_step')
+    net = stin_oracle.define_G(**fx.cfg)
+    net.load_state_dict(fx.state_dict)
+    opt = torch.optim.Adam(net.parameters(), lr=7e-5, weight_decay=0, amsgrad=True)
+    s = fx.sample()
+    loss = stin_oracle.compute_loss(stin_oracle.graph_forward(net, s), s.color, weights=s.mask)
+    loss.backward()
+    opt.step()
+    # first Adam step = lr * g / (|g| + eps): ill-conditioned where g is rounding noise (e.g. the bias in
+    # front of an instance norm has an analytically ZERO gradient), so compare only where |g| is resolved
+    for k, v in net.state_dict().items():
+        ok = fx.grads[k].abs() > 1e-6
+        assert torch.allclose(v[ok], fx.state_dict_after[k][ok], rtol=0, atol=2e-7), k
+        assert float((v - fx.state_dict_after[k]).abs().max()) <= 2 * 7e-5 + 1e-7, k
+
+
+def test_oracle_per_op_fixtures():
+    z = {k: torch.from_numpy(v) for k, v in load_npz('g4_per_op').items()}
+    # norms
+    x = z['norm.x']
+    for tag, b in (('none', None), ('zeros', torch.zeros(60, dtype=torch.long)), ('eq', z['norm.b_eq']),
+                   ('un', z['norm.b_un'])):
+        xx = x.clone().requires_grad_(True)
+        y = stin_oracle.fast_instance_norm(xx, b)
+        assert torch.allclose(y, z['fin.%s.y' % tag], atol=1e-6), tag
+        (y * torch.linspace(-1, 1, y.numel()).view_as(y)).sum().backward()
+        assert torch.allclose(xx.grad, z['fin.%s.gx' % tag], atol=2e-5), tag
+    for tag, b in (('none', None), ('un', z['norm.b_un'])):
+        y = stin_oracle.single_batch_graph_norm(x, z['gn.weight'], z['gn.bias'], z['gn.mean_scale'], b)
+        assert torch.allclose(y, z['gn.%s.y' % tag], atol=1e-6), tag
+    # pooling: engineered ties + empty clusters (arg-first rule, zero fill)
+    xv, trace = z['pool.x'], z['pool.trace']
+    for kind in ('max', 'mean'):
+        xx = xv.clone().requires_grad_(True)
+        y = stin_oracle.pool(xx, trace, 5, kind)
+        assert torch.equal(y, z['pool.%s.y' % kind])
+        (y * torch.arange(1., 16.).view(5, 3)).sum().backward()
+        assert torch.equal(xx.grad, z['pool.%s.gx' % kind])
+    xx = z['unpool.x'].clone().requires_grad_(True)
+    y = stin_oracle.unpool(xx, trace)
+    assert torch.equal(y, z['unpool.y'])
+    (y * torch.arange(1., 22.).view(7, 3)).sum().backward()
+    assert torch.equal(xx.grad, z['unpool.gx'])
+    assert torch.equal(stin_oracle.pool_batch(torch.tensor([0, 0, 0, 1, 1, 1, 1]), trace, 5), z['batch.pooled'])
+
+
+def test_scatter_max_known_answers():
+    """Hand-computed: first occurrence wins ties, empty -> value 0 / arg = len(src)."""
+    src = torch.tensor([[1., 5.], [3., 5.], [3., 1.], [-2., -2.]], requires_grad=True)
+    idx = torch.tensor([0, 0, 0, 2])
+    out, arg = scatter_ops.scatter_max(src, idx, dim=0, dim_size=4)
+    assert out.tolist() == [[3., 5.], [0., 0.], [-2., -2.], [0., 0.]]
+    assert arg.tolist() == [[1, 0], [4, 4], [3, 3], [4, 4]]
+    out.sum().backward()
+    assert src.grad.tolist() == [[0., 1.], [1., 0.], [0., 0.], [1., 1.]]
+    m = scatter_ops.scatter_mean(torch.tensor([[2.], [4.], [9.]]), torch.tensor([1, 1, 3]), dim=0, dim_size=5)
+    assert m.view(-1).tolist() == [0., 3., 0., 9., 0.]
+    mi = scatter_ops.scatter_mean(torch.tensor([3, 4, -7]), torch.tensor([0, 0, 1]), dim=0, dim_size=2)
+    assert mi.tolist() == [3, -7]
+
+
+def test_oracle_metrics_fixture():
+    z = {k: torch.from_numpy(v) for k, v in load_npz('g8_metrics').items()}
+    assert torch.allclose(stin_oracle.graph_laplace_variance(z['pred'], z['ei']), z['lap_var'], rtol=1e-6)
+    assert torch.allclose(stin_oracle.graph_total_variation(z['pred'], z['ei']), z['tv'], rtol=1e-6)
+
+
+@pytest.mark.reference
+def test_oracle_against_live_reference_random_config():
+    """Build-container only: run the reference's own class side by side (fresh seed)."""
+    from oracle import ref_import
+    from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
+    stin = ref_import.load_model_module()
+    cfg = dict(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconvtransinv', norm='instance', n_blocks=3,
+               n_levels=2, pooling_type='max', dilations=[1, 2, 4], checkpoint_bottleneck=True)
+    torch.manual_seed(1234)
+    ref = stin.define_G(**cfg)
+    net = stin_oracle.define_G(**cfg)
+    net.load_state_dict(ref.state_dict())
+    s = make_synthetic_mesh(900, 3, seed=99, dilations=(2, 4))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        a = ref(s)
+    assert torch.equal(a, net(s))
