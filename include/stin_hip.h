@@ -1,0 +1,178 @@
+/*
+ * stin_hip.h - C ABI of libstin_hip.so: the MI355X (gfx950) kernels behind the
+ * STINet graph-convolution hot path.
+ *
+ * The reference (johnpeterflynn/surface-texture-inpainting-net) is 100 % Python and
+ * owns no native ABI: every entry point below replaces a call the reference makes
+ * into the third-party torch_geometric / torch_scatter / ATen kernels.  The cited
+ * file:line is the reference call site whose arithmetic the entry point takes over
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless noted.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Every call
+ *     only ENQUEUES work on that stream: no allocation, no synchronisation, no
+ *     ownership transfer; all buffers (incl. workspaces) are caller-owned and must
+ *     outlive the enqueued work.  Re-entrant per stream, no global mutable state.
+ *   - return value: 0 = ok, < 0 = argument error (STIN_E_*), > 0 = a hipError_t.
+ *   - feature matrices are row-major fp32 with an explicit leading dimension `ld*`
+ *     (in elements) so that column slices of a wider matrix can be passed.
+ *   - graph structure is CSR with int32 `rowptr[N+1]` / `col[E]` (built once per
+ *     sample by stin_csr_from_coo_i64 from the int64 index tensors at the Python
+ *     boundary).  Within a row, entries keep the ORIGINAL edge order (stable),
+ *     so every segmented reduction has a fixed, reproducible summation order -
+ *     no float atomics anywhere.
+ */
+#ifndef STIN_HIP_H
+#define STIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STIN_VERSION 100           /* major*10000 + minor*100 + patch */
+
+#define STIN_OK 0
+#define STIN_E_NULL (-1)           /* required pointer is NULL */
+#define STIN_E_SIZE (-2)           /* negative / inconsistent size or leading dimension */
+#define STIN_E_ALIGN (-3)          /* pointer / ld not aligned as the kernel requires */
+#define STIN_E_WORKSPACE (-4)      /* workspace too small */
+#define STIN_E_UNSUPPORTED (-5)    /* shape outside what this build supports */
+
+typedef void* stin_stream_t;
+
+int stin_version(void);
+/* Static, NUL-terminated description of a return code (host pointer). */
+const char* stin_error_string(int code);
+
+/* ------------------------------------------------------------------ graph plan --
+ * COO -> CSR, grouping `E` (key, val) pairs by key in [0, N).
+ *   rowptr[n] .. rowptr[n+1] delimit the entries of key n, in ORIGINAL pair order;
+ *   col[e]  = val[perm[e]]  (or perm[e] when val == NULL);
+ *   perm[e] = index of the pair now at CSR slot e (may be NULL);
+ *   inv_deg[n] = 1 / max(1, rowptr[n+1]-rowptr[n])       (may be NULL);
+ *   *bad (device int32, may be NULL) is set non-zero when a key is outside [0, N)
+ *   or a val outside [0, val_limit) - the analogue of the IndexError the reference's
+ *   index_select / scatter raise on CPU.
+ * Replaces the implicit indexing of PyG MessagePassing.propagate
+ * (models/modules/edge_conv_filter.py:57 via torch_geometric) and of
+ * torch_scatter (models/surfacetextureinpaintingnet.py:384-386,:422):
+ *   destination CSR: key = edge_index[1], val = edge_index[0]
+ *   source CSR     : key = edge_index[0], val = edge_index[1]
+ *   children CSR   : key = hierarchy_trace_index_l, val = NULL
+ */
+size_t stin_csr_workspace_bytes(int64_t E, int64_t N);
+int stin_csr_from_coo_i64(const int64_t* key, const int64_t* val, int64_t E, int64_t N,
+                          int64_t val_limit, int32_t* rowptr, int32_t* col, int32_t* perm,
+                          float* inv_deg, int32_t* bad, void* workspace, size_t workspace_bytes,
+                          stin_stream_t stream);
+/* dst[i] = (int32) src[i]; *bad set when a value is outside [0, limit). */
+int stin_narrow_i64_to_i32(const int64_t* src, int64_t n, int64_t limit, int32_t* dst, int32_t* bad,
+                           stin_stream_t stream);
+
+/* -------------------------------------------------------- segmented reductions --
+ * out[n, :] = sum_{e in row n} src[col ? col[e] : e, :]        (mean: / max(1, deg))
+ * The standalone scatter-add / scatter-mean (torch_scatter.scatter_{sum,mean},
+ * models/surfacetextureinpaintingnet.py:384; SAGEConv mean aggregation,
+ * models/modules/sage_conv_filter.py:122; backward of `x[traces]`, :391; PyG
+ * aggr='add' in utils/metrics/graph_metrics.py:6-16).
+ */
+int stin_segment_sum_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col,
+                         int64_t N, int C, int mean, float* out, int64_t ld_out, stin_stream_t stream);
+
+/* ------------------------------------------------------------ fused edge stage --
+ * EdgeConv(aggr='mean') after the exact algebraic restructure:
+ *   h[i, :] = (1/max(1,deg i)) * sum_{j in N(i)} ReLU(A[i, :] + B[j, :])
+ * with A = x (Wa-Wb)^T + b1, B = x Wb^T per-VERTEX GEMM outputs.  Takes over the
+ * per-edge gather/cat/Linear/ReLU/scatter chain of PyG EdgeConv
+ * (models/modules/edge_conv_filter.py:46-57,
+ *  models/modules/edge_conv_translation_invariance.py:19-21).
+ *   fwd     : destination CSR.  With indicator != 0 the kernel also writes columns
+ *             H..H+3 of `out` = ([deg i > 0], 0, 0, 0) (needs ldo >= H+4): the following
+ *             per-vertex GEMM against [W2 | b2 | 0 0 0] then yields W2 h + b2 [deg > 0],
+ *             i.e. PyG's "vertices without in-edges aggregate to exactly 0".
+ *   bwd_dst : dA[i,:] = inv_deg[i] * G[i,:] * #{j in N(i) : A[i,:]+B[j,:] > 0}
+ *   bwd_src : dB[j,:] = sum_{i : j in N(i)} inv_deg[i] * G[i,:] * [A[i,:]+B[j,:] > 0]
+ *             (source CSR; the backward scatter-add becomes a gather, no atomics)
+ */
+int stin_edge_relu_mean_fwd_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
+                                const int32_t* rowptr, const int32_t* col, int64_t N, int H,
+                                float* out, int64_t ldo, int indicator, stin_stream_t stream);
+int stin_edge_relu_mean_bwd_dst_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
+                                    const float* G, int64_t ldg, const int32_t* rowptr,
+                                    const int32_t* col, int64_t N, int H, float* dA, int64_t ldda,
+                                    stin_stream_t stream);
+int stin_edge_relu_mean_bwd_src_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
+                                    const float* G, int64_t ldg, const float* inv_deg,
+                                    const int32_t* rowptr_src, const int32_t* col_src, int64_t N, int H,
+                                    float* dB, int64_t lddb, stin_stream_t stream);
+
+/* --------------------------------------------------------------- pool / unpool --
+ * Max pool over the children CSR of each coarse vertex with torch_scatter's CPU
+ * rule: strict '>' walking children in ascending fine-vertex order => the FIRST
+ * maximum wins ties; empty clusters give value 0 and arg = -1
+ * (models/surfacetextureinpaintingnet.py:386).  Backward routes g to arg only.
+ */
+int stin_pool_max_fwd_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                          int64_t n_coarse, int C, float* out, int64_t ldo, int32_t* arg,
+                          stin_stream_t stream);
+int stin_pool_max_bwd_f32(const float* g, int64_t ldg, const int32_t* arg, const int32_t* trace,
+                          int64_t n_fine, int C, float* gx, int64_t ldgx, stin_stream_t stream);
+/* out[v, :] = src[idx[v], :] * (row_scale ? row_scale[idx[v]] : 1): the unpool gather
+ * `x[traces]` (models/surfacetextureinpaintingnet.py:390-391) and the mean-pool backward. */
+int stin_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, const float* row_scale,
+                         int64_t n_out, int C, float* out, int64_t ldo, stin_stream_t stream);
+/* Per-level graph-id vector (int64, bit-exact): scatter_max(batch, trace) and
+ * batch.index_select(0, trace) (models/surfacetextureinpaintingnet.py:421-422,:446-447). */
+int stin_batch_pool_i64(const int64_t* batch, const int32_t* rowptr, const int32_t* col, int64_t n_coarse,
+                        int64_t* out, stin_stream_t stream);
+int stin_gather_i64(const int64_t* src, const int32_t* idx, int64_t n_out, int64_t* out,
+                    stin_stream_t stream);
+
+/* ----------------------------------------------- norm statistics and epilogues --
+ * Column reductions over contiguous row ranges ptr[b]..ptr[b+1] (ptr == NULL: one
+ * range [0, N)), fp64 accumulation in a fixed order, float results out[b, c]:
+ *   STIN_RED_SUM     : sum x
+ *   STIN_RED_CSQ     : sum (x - mean[gid])^2
+ *   STIN_RED_DOT_ELU : out0 = sum dY * xc, out1 = sum dY  with xc = x - mean[gid],
+ *                      dY = gout * ELU'(xc * rstd[gid])
+ *   STIN_RED_COEF_XC : sum coef[sid] * (x - mean[gid])
+ * `gid`/`sid` are per-row int32 group ids (NULL = 0).  They implement
+ * FastInstanceNorm (models/modules/fastinstancenorm.py:42-107) including its
+ * linspace-slice quirk (sums over `ptr` slices, centring through `gid`).
+ * `post` finalises out0 (and out1) from the fp64 sums with the per-range factor
+ * inv_cnt[b] (device float[B]; required unless post == STIN_POST_NONE).
+ * workspace: stin_colreduce_workspace_bytes(C, B) bytes.
+ */
+#define STIN_RED_SUM 0
+#define STIN_RED_CSQ 1
+#define STIN_RED_DOT_ELU 2
+#define STIN_RED_COEF_XC 3
+#define STIN_POST_NONE 0            /* out = s                                  */
+#define STIN_POST_SCALE 1           /* out = s * inv_cnt[b]            (mean)    */
+#define STIN_POST_RSTD 2            /* out = 1/sqrt(s * inv_cnt[b] + eps)        */
+size_t stin_colreduce_workspace_bytes(int C, int B);
+int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const float* gout, int64_t ldg, int64_t N,
+                       int C, const int32_t* ptr, int B, const int32_t* gid, const int32_t* sid,
+                       const float* mean, const float* rstd, const float* coef, int post,
+                       const float* inv_cnt, float eps, float* out0, float* out1,
+                       void* workspace, size_t workspace_bytes, stin_stream_t stream);
+/* y = res + ELU((x - mean[gid]) * rstd[gid])    (res may be NULL; act: 1 = ELU, 0 = none)
+ * GraphResnetBlock epilogue (models/surfacetextureinpaintingnet.py:510-521) and the
+ * tail norm+ELU (:465-466). */
+int stin_norm_act_res_fwd_f32(const float* x, int64_t ldx, const float* mean, const float* rstd,
+                              const int32_t* gid, const float* res, int64_t ldres, int64_t N, int C, int act,
+                              float* y, int64_t ldy, stin_stream_t stream);
+/* dx = a[gid] * dY + k[sid] * (x - mean[gid]) + m[sid],  dY = gout * act'((x-mean[gid])*rstd[gid]) */
+int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_t ldg, const float* mean,
+                          const float* rstd, const float* a, const float* k, const float* m,
+                          const int32_t* gid, const int32_t* sid, int64_t N, int C, int act, float* dx,
+                          int64_t lddx, stin_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STIN_HIP_H */

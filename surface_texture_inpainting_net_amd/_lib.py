@@ -1,0 +1,91 @@
+"""ctypes binding of libstin_hip.so (the C ABI declared in include/stin_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the
+import of the HIP path fails loudly (``StinLibraryError``).  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C surface_texture_inpainting_net_amd/csrc``.
+"""
+import ctypes
+import os
+
+# PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It MUST
+# be in the process before libstin_hip.so is dlopen'ed so that the library's NEEDED libamdhip64.so.7
+# resolves to that same runtime instance; loading /opt/rocm's copy next to torch's gives a second runtime
+# that sees no device (hipErrorNoDevice on the first launch).
+import torch  # noqa: F401  (side effect: loads the HIP runtime torch uses)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libstin_hip.so')
+
+c_i64, c_i32, c_int, c_f32 = ctypes.c_int64, ctypes.c_int32, ctypes.c_int, ctypes.c_float
+c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
+
+
+class StinLibraryError(RuntimeError):
+    pass
+
+
+class StinError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); mirrors include/stin_hip.h one to one
+SIGNATURES = {
+    'stin_version': (c_int, []),
+    'stin_error_string': (ctypes.c_char_p, [c_int]),
+    'stin_csr_workspace_bytes': (c_size, [c_i64, c_i64]),
+    'stin_csr_from_coo_i64': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                      c_size, c_ptr]),
+    'stin_narrow_i64_to_i32': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    'stin_segment_sum_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
+    'stin_edge_relu_mean_fwd_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64,
+                                            c_int, c_ptr]),
+    'stin_edge_relu_mean_bwd_dst_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int,
+                                                c_ptr, c_i64, c_ptr]),
+    'stin_edge_relu_mean_bwd_src_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64,
+                                                c_int, c_ptr, c_i64, c_ptr]),
+    'stin_pool_max_fwd_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_ptr]),
+    'stin_pool_max_bwd_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    'stin_gather_rows_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    'stin_batch_pool_i64': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'stin_gather_i64': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'stin_colreduce_workspace_bytes': (c_size, [c_int, c_int]),
+    'stin_colreduce_f32': (c_int, [c_int, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr,
+                                   c_ptr, c_ptr, c_int, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    'stin_norm_act_res_fwd_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,
+                                          c_i64, c_ptr]),
+    'stin_norm_act_bwd_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                      c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
+}
+
+_lib = None
+
+
+def load():
+    """-> the ctypes CDLL with argtypes/restype set for every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StinLibraryError(
+            'libstin_hip.so not found at %s - the HIP extension must be built (no CPU/eager fallback exists): '
+            'run `make -C %s`' % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise StinLibraryError('cannot load %s: %s' % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise StinLibraryError('libstin_hip.so lacks symbol %s (stale build?)' % name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what=''):
+    if code != 0:
+        msg = load().stin_error_string(int(code)).decode()
+        raise StinError('%s failed: %s (code %d)' % (what or 'stin call', msg, code))

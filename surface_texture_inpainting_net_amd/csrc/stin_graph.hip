@@ -1,0 +1,576 @@
+// Graph kernels of the STINet hot path for gfx950: CSR gather + segmented reduction with a
+// fixed summation order (no float atomics).  One GROUP of G lanes (G = 1..64, a power of two)
+// owns one destination row; each lane holds VPL float4 channel chunks, so a wave64 covers
+// 64/G rows and every neighbour-row gather is a run of coalesced 16-byte loads.  U neighbour
+// rows are requested before the first is consumed (memory-level parallelism; mean mesh
+// degree is ~6).  Contract: include/stin_hip.h.
+#include "stin_common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int G, int VPL>
+struct Lane {
+    int lg;        // lane within the group
+    int64_t row;   // row owned by the group
+    __device__ __forceinline__ Lane() {
+        lg = threadIdx.x % G;
+        row = (int64_t)blockIdx.x * (BLOCK / G) + threadIdx.x / G;
+    }
+    __device__ __forceinline__ int chan(int k) const { return (k * G + lg) * 4; }
+};
+
+// ------------------------------------------------------------------ edge stage, forward
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_fwd(const float* __restrict__ A, int64_t lda,
+                                                    const float* __restrict__ B, int64_t ldb,
+                                                    const int32_t* __restrict__ rowptr,
+                                                    const int32_t* __restrict__ col, int64_t N, int H,
+                                                    float* __restrict__ out, int64_t ldo, int indicator) {
+    Lane<G, VPL> L;
+    if (L.row >= N) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    float4 a[VPL], acc[VPL];
+    bool on[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        on[k] = L.chan(k) < H;
+        a[k] = on[k] ? ld4(A + L.row * lda + L.chan(k)) : f4zero();
+        acc[k] = f4zero();
+    }
+    for (int e = beg; e < end; e += U) {
+        float4 b[U][VPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = min(e + u, end - 1);          // clamped: branch-free, always a valid row
+            const int64_t j = col[ee];
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) b[u][k] = on[k] ? ld4(B + j * ldb + L.chan(k)) : f4zero();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float w = (e + u < end) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                acc[k].x += w * fmaxf(a[k].x + b[u][k].x, 0.f);
+                acc[k].y += w * fmaxf(a[k].y + b[u][k].y, 0.f);
+                acc[k].z += w * fmaxf(a[k].z + b[u][k].z, 0.f);
+                acc[k].w += w * fmaxf(a[k].w + b[u][k].w, 0.f);
+            }
+        }
+    }
+    const int deg = end - beg;
+    const float s = 1.0f / (float)(deg > 0 ? deg : 1);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (on[k]) st4(out + L.row * ldo + L.chan(k), make_float4(acc[k].x * s, acc[k].y * s, acc[k].z * s, acc[k].w * s));
+    if (indicator && L.lg == 0) st4(out + L.row * ldo + H, make_float4(deg > 0 ? 1.f : 0.f, 0.f, 0.f, 0.f));
+}
+
+// ------------------------------------------ edge stage, backward w.r.t. A (destination CSR)
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst(const float* __restrict__ A, int64_t lda,
+                                                        const float* __restrict__ B, int64_t ldb,
+                                                        const float* __restrict__ Gr, int64_t ldg,
+                                                        const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, int64_t N, int H,
+                                                        float* __restrict__ dA, int64_t ldda) {
+    Lane<G, VPL> L;
+    if (L.row >= N) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    float4 a[VPL], cnt[VPL];
+    bool on[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        on[k] = L.chan(k) < H;
+        a[k] = on[k] ? ld4(A + L.row * lda + L.chan(k)) : f4zero();
+        cnt[k] = f4zero();
+    }
+    for (int e = beg; e < end; e += U) {
+        float4 b[U][VPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = min(e + u, end - 1);
+            const int64_t j = col[ee];
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) b[u][k] = on[k] ? ld4(B + j * ldb + L.chan(k)) : f4zero();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float w = (e + u < end) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                cnt[k].x += (a[k].x + b[u][k].x > 0.f) ? w : 0.f;
+                cnt[k].y += (a[k].y + b[u][k].y > 0.f) ? w : 0.f;
+                cnt[k].z += (a[k].z + b[u][k].z > 0.f) ? w : 0.f;
+                cnt[k].w += (a[k].w + b[u][k].w > 0.f) ? w : 0.f;
+            }
+        }
+    }
+    const int deg = end - beg;
+    const float s = 1.0f / (float)(deg > 0 ? deg : 1);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (on[k]) {
+            const float4 g = ld4(Gr + L.row * ldg + L.chan(k));
+            st4(dA + L.row * ldda + L.chan(k),
+                make_float4(g.x * s * cnt[k].x, g.y * s * cnt[k].y, g.z * s * cnt[k].z, g.w * s * cnt[k].w));
+        }
+}
+
+// ----------------------------------------------- edge stage, backward w.r.t. B (source CSR)
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_src(const float* __restrict__ A, int64_t lda,
+                                                        const float* __restrict__ B, int64_t ldb,
+                                                        const float* __restrict__ Gr, int64_t ldg,
+                                                        const float* __restrict__ inv_deg,
+                                                        const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, int64_t N, int H,
+                                                        float* __restrict__ dB, int64_t lddb) {
+    Lane<G, VPL> L;
+    if (L.row >= N) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    float4 b[VPL], acc[VPL];
+    bool on[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        on[k] = L.chan(k) < H;
+        b[k] = on[k] ? ld4(B + L.row * ldb + L.chan(k)) : f4zero();
+        acc[k] = f4zero();
+    }
+    for (int e = beg; e < end; e += U) {
+        float4 a[U][VPL], g[U][VPL];
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = min(e + u, end - 1);
+            const int64_t i = col[ee];
+            w[u] = (e + u < end) ? inv_deg[i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                a[u][k] = on[k] ? ld4(A + i * lda + L.chan(k)) : f4zero();
+                g[u][k] = on[k] ? ld4(Gr + i * ldg + L.chan(k)) : f4zero();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                acc[k].x += (a[u][k].x + b[k].x > 0.f) ? w[u] * g[u][k].x : 0.f;
+                acc[k].y += (a[u][k].y + b[k].y > 0.f) ? w[u] * g[u][k].y : 0.f;
+                acc[k].z += (a[u][k].z + b[k].z > 0.f) ? w[u] * g[u][k].z : 0.f;
+                acc[k].w += (a[u][k].w + b[k].w > 0.f) ? w[u] * g[u][k].w : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (on[k]) st4(dB + L.row * lddb + L.chan(k), acc[k]);
+}
+
+// --------------------------------------------------------------- segment sum / mean
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_segment_sum(const float* __restrict__ src, int64_t lds_,
+                                                       const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, int64_t N, int C,
+                                                       int mean, float* __restrict__ out, int64_t ldo) {
+    Lane<G, VPL> L;
+    if (L.row >= N) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    float4 acc[VPL];
+    bool on[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        on[k] = L.chan(k) < C;
+        acc[k] = f4zero();
+    }
+    for (int e = beg; e < end; e += U) {
+        float4 v[U][VPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = min(e + u, end - 1);
+            const int64_t j = col != nullptr ? (int64_t)col[ee] : (int64_t)ee;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) v[u][k] = on[k] ? ld4(src + j * lds_ + L.chan(k)) : f4zero();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float w = (e + u < end) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                acc[k].x += w * v[u][k].x;
+                acc[k].y += w * v[u][k].y;
+                acc[k].z += w * v[u][k].z;
+                acc[k].w += w * v[u][k].w;
+            }
+        }
+    }
+    float s = 1.f;
+    if (mean) {
+        const int deg = end - beg;
+        s = 1.0f / (float)(deg > 0 ? deg : 1);
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (on[k]) st4(out + L.row * ldo + L.chan(k), make_float4(acc[k].x * s, acc[k].y * s, acc[k].z * s, acc[k].w * s));
+}
+
+// ------------------------------------------------------------------------- max pool
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_pool_max_fwd(const float* __restrict__ x, int64_t ldx,
+                                                        const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, int64_t N, int C,
+                                                        float* __restrict__ out, int64_t ldo,
+                                                        int32_t* __restrict__ arg) {
+    Lane<G, VPL> L;
+    if (L.row >= N) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    float4 best[VPL];
+    int4 who[VPL];
+    bool on[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        on[k] = L.chan(k) < C;
+        best[k] = f4zero();
+        who[k] = make_int4(-1, -1, -1, -1);
+    }
+    for (int e = beg; e < end; e += U) {
+        float4 v[U][VPL];
+        int id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = min(e + u, end - 1);
+            id[u] = col[ee];
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) v[u][k] = on[k] ? ld4(x + (int64_t)id[u] * ldx + L.chan(k)) : f4zero();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e + u < end) {
+#pragma unroll
+                for (int k = 0; k < VPL; ++k) {
+                    // first element initialises; afterwards strict '>' => first maximum wins ties
+                    if (who[k].x < 0 || v[u][k].x > best[k].x) { best[k].x = v[u][k].x; who[k].x = id[u]; }
+                    if (who[k].y < 0 || v[u][k].y > best[k].y) { best[k].y = v[u][k].y; who[k].y = id[u]; }
+                    if (who[k].z < 0 || v[u][k].z > best[k].z) { best[k].z = v[u][k].z; who[k].z = id[u]; }
+                    if (who[k].w < 0 || v[u][k].w > best[k].w) { best[k].w = v[u][k].w; who[k].w = id[u]; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (on[k]) {
+            st4(out + L.row * ldo + L.chan(k), best[k]);
+            *reinterpret_cast<int4*>(arg + L.row * (int64_t)C + L.chan(k)) = who[k];
+        }
+}
+
+template <int G, int VPL>
+__global__ __launch_bounds__(BLOCK) void k_pool_max_bwd(const float* __restrict__ g, int64_t ldg,
+                                                        const int32_t* __restrict__ arg,
+                                                        const int32_t* __restrict__ trace, int64_t N, int C,
+                                                        float* __restrict__ gx, int64_t ldgx) {
+    Lane<G, VPL> L;
+    if (L.row >= N) return;
+    const int64_t t = trace[L.row];
+    const int v = (int)L.row;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (L.chan(k) < C) {
+            const float4 gg = ld4(g + t * ldg + L.chan(k));
+            const int4 w = *reinterpret_cast<const int4*>(arg + t * (int64_t)C + L.chan(k));
+            st4(gx + L.row * ldgx + L.chan(k),
+                make_float4(w.x == v ? gg.x : 0.f, w.y == v ? gg.y : 0.f, w.z == v ? gg.z : 0.f, w.w == v ? gg.w : 0.f));
+        }
+}
+
+template <int G, int VPL>
+__global__ __launch_bounds__(BLOCK) void k_gather_rows(const float* __restrict__ src, int64_t lds_,
+                                                       const int32_t* __restrict__ idx,
+                                                       const float* __restrict__ row_scale, int64_t N, int C,
+                                                       float* __restrict__ out, int64_t ldo) {
+    Lane<G, VPL> L;
+    if (L.row >= N) return;
+    const int64_t t = idx[L.row];
+    const float s = row_scale != nullptr ? row_scale[t] : 1.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (L.chan(k) < C) {
+            const float4 v = ld4(src + t * lds_ + L.chan(k));
+            st4(out + L.row * ldo + L.chan(k), make_float4(v.x * s, v.y * s, v.z * s, v.w * s));
+        }
+}
+
+// ------------------------------------------------- scalar fallbacks (C % 4 != 0 / unaligned)
+enum ScalarOp { OP_EDGE_FWD, OP_EDGE_BWD_DST, OP_EDGE_BWD_SRC, OP_SEG_SUM, OP_POOL_MAX, OP_POOL_MAX_BWD, OP_GATHER };
+
+template <int OP>
+__global__ void k_scalar(const float* __restrict__ p0, int64_t ld0, const float* __restrict__ p1, int64_t ld1,
+                         const float* __restrict__ p2, int64_t ld2, const float* __restrict__ vec,
+                         const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N, int C,
+                         int flag, float* __restrict__ out, int64_t ldo, int32_t* __restrict__ iout) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * C) return;
+    const int64_t r = t / C;
+    const int c = (int)(t % C);
+    if (OP == OP_POOL_MAX_BWD) {  // p0 = g, col = trace, iout = arg
+        const int64_t k = col[r];
+        out[r * ldo + c] = (iout[k * C + c] == (int)r) ? p0[k * ld0 + c] : 0.f;
+        return;
+    }
+    if (OP == OP_GATHER) {  // p0 = src, col = idx, vec = row_scale
+        const int64_t k = col[r];
+        out[r * ldo + c] = p0[k * ld0 + c] * (vec != nullptr ? vec[k] : 1.f);
+        return;
+    }
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    const int deg = end - beg;
+    const float s = 1.0f / (float)(deg > 0 ? deg : 1);
+    float acc = 0.f;
+    if (OP == OP_EDGE_FWD) {  // p0 = A, p1 = B
+        const float a = p0[r * ld0 + c];
+        for (int e = beg; e < end; ++e) acc += fmaxf(a + p1[(int64_t)col[e] * ld1 + c], 0.f);
+        out[r * ldo + c] = acc * s;
+        if (flag && c < 4) out[r * ldo + C + c] = (c == 0 && deg > 0) ? 1.f : 0.f;
+    } else if (OP == OP_EDGE_BWD_DST) {  // p0 = A, p1 = B, p2 = G
+        const float a = p0[r * ld0 + c];
+        for (int e = beg; e < end; ++e) acc += (a + p1[(int64_t)col[e] * ld1 + c] > 0.f) ? 1.f : 0.f;
+        out[r * ldo + c] = p2[r * ld2 + c] * s * acc;
+    } else if (OP == OP_EDGE_BWD_SRC) {  // p0 = A, p1 = B, p2 = G, vec = inv_deg
+        const float b = p1[r * ld1 + c];
+        for (int e = beg; e < end; ++e) {
+            const int64_t i = col[e];
+            acc += (p0[i * ld0 + c] + b > 0.f) ? vec[i] * p2[i * ld2 + c] : 0.f;
+        }
+        out[r * ldo + c] = acc;
+    } else if (OP == OP_SEG_SUM) {  // p0 = src, flag = mean
+        for (int e = beg; e < end; ++e) acc += p0[(col != nullptr ? (int64_t)col[e] : (int64_t)e) * ld0 + c];
+        out[r * ldo + c] = flag ? acc * s : acc;
+    } else if (OP == OP_POOL_MAX) {  // p0 = x
+        float best = 0.f;
+        int who = -1;
+        for (int e = beg; e < end; ++e) {
+            const int id = col[e];
+            const float v = p0[(int64_t)id * ld0 + c];
+            if (who < 0 || v > best) { best = v; who = id; }
+        }
+        out[r * ldo + c] = best;
+        iout[r * C + c] = who;
+    }
+}
+
+__global__ void k_batch_pool(const int64_t* __restrict__ batch, const int32_t* __restrict__ rowptr,
+                             const int32_t* __restrict__ col, int64_t N, int64_t* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    int64_t best = 0;  // torch_scatter: empty segment -> 0
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    for (int e = beg; e < end; ++e) {
+        const int64_t v = batch[col[e]];
+        if (e == beg || v > best) best = v;
+    }
+    out[r] = best;
+}
+
+__global__ void k_gather_i64(const int64_t* __restrict__ src, const int32_t* __restrict__ idx, int64_t N,
+                             int64_t* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < N) out[r] = src[idx[r]];
+}
+
+inline bool vec_ok(int C, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+    if (C % 4 != 0 || C > 64 * 8 * 4) return false;
+    for (const void* p : ptrs)
+        if (p != nullptr && !stin_aligned16(p)) return false;
+    for (int64_t ld : lds)
+        if (ld % 4 != 0) return false;
+    return true;
+}
+
+inline unsigned grid_rows(int64_t N, int G) { return (unsigned)((N + (BLOCK / G) - 1) / (BLOCK / G)); }
+inline unsigned grid_elems(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+// Dispatch on (G, VPL) for a channel count C (C % 4 == 0, C <= 2048).  U_ is chosen per VPL so that
+// roughly 8 float4 gathers per lane are in flight.
+#define STIN_DISPATCH(C_, KERNEL, UBASE, ...)                                                                \
+    do {                                                                                                     \
+        const int c4_ = (C_) / 4;                                                                            \
+        const int g_ = stin_group_lanes(c4_);                                                                \
+        const int vpl_ = (c4_ + g_ - 1) / g_;                                                                \
+        const unsigned grid_ = grid_rows(N, g_);                                                             \
+        if (g_ == 1) hipLaunchKernelGGL((KERNEL<1, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);        \
+        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<2, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<4, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<8, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<16, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<32, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<64, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<64, 2, (UBASE + 1) / 2>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<64, 4, (UBASE + 3) / 4>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<64, 8, (UBASE + 7) / 8>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);     \
+    } while (0)
+
+#define STIN_DISPATCH_NOU(C_, KERNEL, ...)                                                                   \
+    do {                                                                                                     \
+        const int c4_ = (C_) / 4;                                                                            \
+        const int g_ = stin_group_lanes(c4_);                                                                \
+        const int vpl_ = (c4_ + g_ - 1) / g_;                                                                \
+        const unsigned grid_ = grid_rows(N, g_);                                                             \
+        if (g_ == 1) hipLaunchKernelGGL((KERNEL<1, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<2, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<4, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<8, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<16, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<32, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<64, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<64, 2>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<64, 4>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<64, 8>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);          \
+    } while (0)
+
+}  // namespace
+
+extern "C" int stin_edge_relu_mean_fwd_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
+                                           const int32_t* rowptr, const int32_t* col, int64_t N, int H, float* out,
+                                           int64_t ldo, int indicator, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && H > 0 && lda >= H && ldb >= H && ldo >= H + (indicator ? 4 : 0), STIN_E_SIZE);
+    STIN_REQUIRE(!indicator || H >= 4, STIN_E_UNSUPPORTED);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(A && B && rowptr && out, STIN_E_NULL);
+    if (vec_ok(H, {A, B, out}, {lda, ldb, ldo})) {
+        STIN_DISPATCH(H, k_edge_fwd, 8, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator);
+    } else {
+        hipLaunchKernelGGL((k_scalar<OP_EDGE_FWD>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
+                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, rowptr, col, N, H, indicator, out, ldo,
+                           (int32_t*)nullptr);
+    }
+    return stin_launch_status();
+}
+
+extern "C" int stin_edge_relu_mean_bwd_dst_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* G,
+                                               int64_t ldg, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
+                                               float* dA, int64_t ldda, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && H > 0 && lda >= H && ldb >= H && ldg >= H && ldda >= H, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(A && B && G && rowptr && dA, STIN_E_NULL);
+    if (vec_ok(H, {A, B, G, dA}, {lda, ldb, ldg, ldda})) {
+        STIN_DISPATCH(H, k_edge_bwd_dst, 8, A, lda, B, ldb, G, ldg, rowptr, col, N, H, dA, ldda);
+    } else {
+        hipLaunchKernelGGL((k_scalar<OP_EDGE_BWD_DST>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
+                           G, ldg, (const float*)nullptr, rowptr, col, N, H, 0, dA, ldda, (int32_t*)nullptr);
+    }
+    return stin_launch_status();
+}
+
+extern "C" int stin_edge_relu_mean_bwd_src_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* G,
+                                               int64_t ldg, const float* inv_deg, const int32_t* rowptr_src,
+                                               const int32_t* col_src, int64_t N, int H, float* dB, int64_t lddb,
+                                               stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && H > 0 && lda >= H && ldb >= H && ldg >= H && lddb >= H, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(A && B && G && inv_deg && rowptr_src && dB, STIN_E_NULL);
+    if (vec_ok(H, {A, B, G, dB}, {lda, ldb, ldg, lddb})) {
+        STIN_DISPATCH(H, k_edge_bwd_src, 4, A, lda, B, ldb, G, ldg, inv_deg, rowptr_src, col_src, N, H, dB, lddb);
+    } else {
+        hipLaunchKernelGGL((k_scalar<OP_EDGE_BWD_SRC>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
+                           G, ldg, inv_deg, rowptr_src, col_src, N, H, 0, dB, lddb, (int32_t*)nullptr);
+    }
+    return stin_launch_status();
+}
+
+extern "C" int stin_segment_sum_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col,
+                                    int64_t N, int C, int mean, float* out, int64_t ld_out, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && C > 0 && ld_src >= C && ld_out >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(src && rowptr && out, STIN_E_NULL);
+    if (vec_ok(C, {src, out}, {ld_src, ld_out})) {
+        STIN_DISPATCH(C, k_segment_sum, 8, src, ld_src, rowptr, col, N, C, mean, out, ld_out);
+    } else {
+        hipLaunchKernelGGL((k_scalar<OP_SEG_SUM>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, src, ld_src,
+                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
+                           rowptr, col, N, C, mean, out, ld_out, (int32_t*)nullptr);
+    }
+    return stin_launch_status();
+}
+
+extern "C" int stin_pool_max_fwd_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                                     int64_t N, int C, float* out, int64_t ldo, int32_t* arg, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldo >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(x && rowptr && col && out && arg, STIN_E_NULL);
+    if (vec_ok(C, {x, out, arg}, {ldx, ldo})) {
+        STIN_DISPATCH(C, k_pool_max_fwd, 4, x, ldx, rowptr, col, N, C, out, ldo, arg);
+    } else {
+        hipLaunchKernelGGL((k_scalar<OP_POOL_MAX>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, x, ldx,
+                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
+                           rowptr, col, N, C, 0, out, ldo, arg);
+    }
+    return stin_launch_status();
+}
+
+extern "C" int stin_pool_max_bwd_f32(const float* g, int64_t ldg, const int32_t* arg, const int32_t* trace,
+                                     int64_t N, int C, float* gx, int64_t ldgx, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && C > 0 && ldg >= C && ldgx >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(g && arg && trace && gx, STIN_E_NULL);
+    if (vec_ok(C, {g, gx, arg}, {ldg, ldgx})) {
+        STIN_DISPATCH_NOU(C, k_pool_max_bwd, g, ldg, arg, trace, N, C, gx, ldgx);
+    } else {
+        hipLaunchKernelGGL((k_scalar<OP_POOL_MAX_BWD>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, g, ldg,
+                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
+                           (const int32_t*)nullptr, trace, N, C, 0, gx, ldgx, const_cast<int32_t*>(arg));
+    }
+    return stin_launch_status();
+}
+
+extern "C" int stin_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, const float* row_scale,
+                                    int64_t N, int C, float* out, int64_t ldo, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && C > 0 && ld_src >= C && ldo >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(src && idx && out, STIN_E_NULL);
+    if (vec_ok(C, {src, out}, {ld_src, ldo})) {
+        STIN_DISPATCH_NOU(C, k_gather_rows, src, ld_src, idx, row_scale, N, C, out, ldo);
+    } else {
+        hipLaunchKernelGGL((k_scalar<OP_GATHER>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, src, ld_src,
+                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, row_scale,
+                           (const int32_t*)nullptr, idx, N, C, 0, out, ldo, (int32_t*)nullptr);
+    }
+    return stin_launch_status();
+}
+
+extern "C" int stin_batch_pool_i64(const int64_t* batch, const int32_t* rowptr, const int32_t* col, int64_t N,
+                                   int64_t* out, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N >= 0, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(batch && rowptr && col && out, STIN_E_NULL);
+    hipLaunchKernelGGL(k_batch_pool, dim3(grid_elems(N)), dim3(BLOCK), 0, (hipStream_t)stream_, batch, rowptr, col, N, out);
+    return stin_launch_status();
+}
+
+extern "C" int stin_gather_i64(const int64_t* src, const int32_t* idx, int64_t N, int64_t* out, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N >= 0, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(src && idx && out, STIN_E_NULL);
+    hipLaunchKernelGGL(k_gather_i64, dim3(grid_elems(N)), dim3(BLOCK), 0, (hipStream_t)stream_, src, idx, N, out);
+    return stin_launch_status();
+}

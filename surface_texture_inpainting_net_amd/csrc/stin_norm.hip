@@ -1,0 +1,284 @@
+// Column statistics (fixed-order fp64 accumulation, two-stage, no atomics) and the fused
+// normalise / ELU / residual epilogues of GraphResnetBlock for gfx950.
+// Contract: include/stin_hip.h.  All of these are HBM-streaming kernels: 16-byte loads,
+// one pass over [N, C] per call.
+#include "stin_common.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int MAX_SLABS = 2048;  // B * chunks-per-segment upper bound (workspace sizing)
+
+template <int VW> struct V;
+template <> struct V<4> {
+    float v[4];
+    __device__ __forceinline__ static V load(const float* p) { V r; float4 t = ld4(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r; }
+    __device__ __forceinline__ void store(float* p) const { st4(p, make_float4(v[0], v[1], v[2], v[3])); }
+};
+template <> struct V<1> {
+    float v[1];
+    __device__ __forceinline__ static V load(const float* p) { V r; r.v[0] = *p; return r; }
+    __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
+};
+
+__device__ __forceinline__ float elu_grad_from_pre(float n) { return n > 0.f ? 1.f : __expf(n); }
+
+// grid = (chunks, B). partial layout: [b][chunk][o][C] doubles, o in {0,1}.
+template <int MODE, int VW>
+__global__ __launch_bounds__(BLOCK) void k_colreduce(const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ gout, int64_t ldg, int64_t N, int C,
+                                                     const int32_t* __restrict__ ptr, const int32_t* __restrict__ gid,
+                                                     const int32_t* __restrict__ sid, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ coef,
+                                                     double* __restrict__ partial) {
+    constexpr int NOUT = (MODE == STIN_RED_DOT_ELU) ? 2 : 1;
+    __shared__ double sm[NOUT][BLOCK][VW];
+    const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
+    const int64_t r0 = ptr != nullptr ? ptr[b] : 0;
+    const int64_t r1 = ptr != nullptr ? ptr[b + 1] : N;
+    const int CV = C / VW;
+    const int CG = CV < BLOCK ? CV : BLOCK;
+    const int RL = BLOCK / CG;
+    const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+    const bool live = rl < RL;
+    for (int cv = cg; cv < CV; cv += CG) {   // uniform trip count across the block (cg < CG <= CV)
+        const int c = cv * VW;
+        double acc0[VW], acc1[VW];
+#pragma unroll
+        for (int i = 0; i < VW; ++i) { acc0[i] = 0.0; acc1[i] = 0.0; }
+        if (live) {
+            for (int64_t r = r0 + (int64_t)chunk * RL + rl; r < r1; r += (int64_t)nch * RL) {
+                const V<VW> xv = V<VW>::load(x + r * ldx + c);
+                if (MODE == STIN_RED_SUM) {
+#pragma unroll
+                    for (int i = 0; i < VW; ++i) acc0[i] += (double)xv.v[i];
+                } else {
+                    const int g = gid != nullptr ? gid[r] : 0;
+                    const V<VW> mu = V<VW>::load(mean + (int64_t)g * C + c);
+                    if (MODE == STIN_RED_CSQ) {
+#pragma unroll
+                        for (int i = 0; i < VW; ++i) { const float d = xv.v[i] - mu.v[i]; acc0[i] += (double)(d * d); }
+                    } else if (MODE == STIN_RED_DOT_ELU) {
+                        const V<VW> rs = V<VW>::load(rstd + (int64_t)g * C + c);
+                        const V<VW> go = V<VW>::load(gout + r * ldg + c);
+#pragma unroll
+                        for (int i = 0; i < VW; ++i) {
+                            const float xc = xv.v[i] - mu.v[i];
+                            const float dy = go.v[i] * elu_grad_from_pre(xc * rs.v[i]);
+                            acc0[i] += (double)(dy * xc);
+                            acc1[i] += (double)dy;
+                        }
+                    } else {  // STIN_RED_COEF_XC
+                        const int s = sid != nullptr ? sid[r] : 0;
+                        const V<VW> cf = V<VW>::load(coef + (int64_t)s * C + c);
+#pragma unroll
+                        for (int i = 0; i < VW; ++i) acc0[i] += (double)(cf.v[i] * (xv.v[i] - mu.v[i]));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+            sm[0][threadIdx.x][i] = acc0[i];
+            if (NOUT == 2) sm[NOUT - 1][threadIdx.x][i] = acc1[i];
+        }
+        __syncthreads();
+        if (rl == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                double t[VW];
+#pragma unroll
+                for (int i = 0; i < VW; ++i) t[i] = 0.0;
+                for (int k = 0; k < RL; ++k)
+#pragma unroll
+                    for (int i = 0; i < VW; ++i) t[i] += sm[o][k * CG + cg][i];
+                double* dst = partial + (((int64_t)b * nch + chunk) * NOUT + o) * C + c;
+#pragma unroll
+                for (int i = 0; i < VW; ++i) dst[i] = t[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_colreduce_final(const double* __restrict__ partial, int nch, int nout, int C, int B, int post,
+                                  const float* __restrict__ inv_cnt, float eps, float* __restrict__ out0,
+                                  float* __restrict__ out1) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C * nout) return;
+    const int c = t % C, o = (t / C) % nout, b = t / (C * nout);
+    double s = 0.0;
+    for (int k = 0; k < nch; ++k) s += partial[(((int64_t)b * nch + k) * nout + o) * C + c];
+    float r = (float)s;
+    if (post == STIN_POST_SCALE) r = r * inv_cnt[b];
+    else if (post == STIN_POST_RSTD) r = 1.0f / sqrtf(r * inv_cnt[b] + eps);
+    (o == 0 ? out0 : out1)[(int64_t)b * C + c] = r;
+}
+
+template <int VW>
+__global__ __launch_bounds__(BLOCK) void k_norm_fwd(const float* __restrict__ x, int64_t ldx,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const int32_t* __restrict__ gid, const float* __restrict__ res,
+                                                    int64_t ldres, int64_t N, int C, int act, float* __restrict__ y,
+                                                    int64_t ldy) {
+    const int CV = C / VW;
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N * CV) return;
+    const int64_t r = t / CV;
+    const int c = (int)(t % CV) * VW;
+    const int g = gid != nullptr ? gid[r] : 0;
+    const V<VW> xv = V<VW>::load(x + r * ldx + c);
+    const V<VW> mu = V<VW>::load(mean + (int64_t)g * C + c);
+    const V<VW> rs = V<VW>::load(rstd + (int64_t)g * C + c);
+    V<VW> o;
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+        float n = (xv.v[i] - mu.v[i]) * rs.v[i];
+        if (act) n = n > 0.f ? n : expm1f(n);
+        o.v[i] = n;
+    }
+    if (res != nullptr) {
+        const V<VW> rv = V<VW>::load(res + r * ldres + c);
+#pragma unroll
+        for (int i = 0; i < VW; ++i) o.v[i] += rv.v[i];
+    }
+    o.store(y + r * ldy + c);
+}
+
+template <int VW>
+__global__ __launch_bounds__(BLOCK) void k_norm_bwd(const float* __restrict__ x, int64_t ldx,
+                                                    const float* __restrict__ gout, int64_t ldg,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const float* __restrict__ a, const float* __restrict__ kk,
+                                                    const float* __restrict__ m, const int32_t* __restrict__ gid,
+                                                    const int32_t* __restrict__ sid, int64_t N, int C, int act,
+                                                    float* __restrict__ dx, int64_t lddx) {
+    const int CV = C / VW;
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N * CV) return;
+    const int64_t r = t / CV;
+    const int c = (int)(t % CV) * VW;
+    const int g = gid != nullptr ? gid[r] : 0;
+    const int s = sid != nullptr ? sid[r] : 0;
+    const V<VW> xv = V<VW>::load(x + r * ldx + c);
+    const V<VW> go = V<VW>::load(gout + r * ldg + c);
+    const V<VW> mu = V<VW>::load(mean + (int64_t)g * C + c);
+    const V<VW> rs = V<VW>::load(rstd + (int64_t)g * C + c);
+    const V<VW> av = V<VW>::load(a + (int64_t)g * C + c);
+    const V<VW> kv = V<VW>::load(kk + (int64_t)s * C + c);
+    const V<VW> mv = V<VW>::load(m + (int64_t)s * C + c);
+    V<VW> o;
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+        const float xc = xv.v[i] - mu.v[i];
+        const float dy = act ? go.v[i] * elu_grad_from_pre(xc * rs.v[i]) : go.v[i];
+        o.v[i] = av.v[i] * dy + kv.v[i] * xc + mv.v[i];
+    }
+    o.store(dx + r * lddx + c);
+}
+
+inline bool vec4_ok(int C, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+    if (C % 4 != 0) return false;
+    for (const void* p : ptrs)
+        if (p != nullptr && !stin_aligned16(p)) return false;
+    for (int64_t ld : lds)
+        if (ld % 4 != 0) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" size_t stin_colreduce_workspace_bytes(int C, int B) {
+    if (C <= 0 || B <= 0) return 0;
+    const size_t slabs = (size_t)(B > MAX_SLABS ? B : MAX_SLABS);
+    return slabs * 2 * (size_t)C * sizeof(double) + 256;
+}
+
+extern "C" int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const float* gout, int64_t ldg, int64_t N, int C,
+                                  const int32_t* ptr, int B, const int32_t* gid, const int32_t* sid, const float* mean,
+                                  const float* rstd, const float* coef, int post, const float* inv_cnt, float eps,
+                                  float* out0, float* out1, void* workspace, size_t workspace_bytes,
+                                  stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(mode >= STIN_RED_SUM && mode <= STIN_RED_COEF_XC, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(N >= 0 && C > 0 && B > 0 && ldx >= C, STIN_E_SIZE);
+    STIN_REQUIRE((ptr != nullptr) || B == 1, STIN_E_SIZE);
+    STIN_REQUIRE(x && out0 && workspace, STIN_E_NULL);
+    STIN_REQUIRE(post >= STIN_POST_NONE && post <= STIN_POST_RSTD, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(post == STIN_POST_NONE || inv_cnt != nullptr, STIN_E_NULL);
+    if (mode != STIN_RED_SUM) STIN_REQUIRE(mean != nullptr, STIN_E_NULL);
+    if (mode == STIN_RED_DOT_ELU) STIN_REQUIRE(gout && rstd && out1 && ldg >= C, STIN_E_NULL);
+    if (mode == STIN_RED_COEF_XC) STIN_REQUIRE(coef != nullptr, STIN_E_NULL);
+    STIN_REQUIRE(workspace_bytes >= stin_colreduce_workspace_bytes(C, B), STIN_E_WORKSPACE);
+    double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+
+    const bool vec = vec4_ok(C, {x, gout, mean, rstd, coef}, {ldx, gout ? ldg : 0});
+    const int VW = vec ? 4 : 1;
+    const int CV = C / VW;
+    const int CG = CV < BLOCK ? CV : BLOCK;
+    const int RL = BLOCK / CG;
+    int64_t want = (N / B + (int64_t)RL * 16 - 1) / ((int64_t)RL * 16);
+    int cap = MAX_SLABS / B;
+    if (cap < 1) cap = 1;
+    int nch = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+    const int nout = mode == STIN_RED_DOT_ELU ? 2 : 1;
+    dim3 grid((unsigned)nch, (unsigned)B);
+#define STIN_RED_LAUNCH(M)                                                                                          \
+    do {                                                                                                            \
+        if (vec) hipLaunchKernelGGL((k_colreduce<M, 4>), grid, dim3(BLOCK), 0, stream, x, ldx, gout, ldg, N, C, ptr, gid, sid, mean, rstd, coef, partial); \
+        else hipLaunchKernelGGL((k_colreduce<M, 1>), grid, dim3(BLOCK), 0, stream, x, ldx, gout, ldg, N, C, ptr, gid, sid, mean, rstd, coef, partial);     \
+    } while (0)
+    switch (mode) {
+        case STIN_RED_SUM: STIN_RED_LAUNCH(STIN_RED_SUM); break;
+        case STIN_RED_CSQ: STIN_RED_LAUNCH(STIN_RED_CSQ); break;
+        case STIN_RED_DOT_ELU: STIN_RED_LAUNCH(STIN_RED_DOT_ELU); break;
+        default: STIN_RED_LAUNCH(STIN_RED_COEF_XC); break;
+    }
+#undef STIN_RED_LAUNCH
+    const int total = B * C * nout;
+    hipLaunchKernelGGL(k_colreduce_final, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, partial,
+                       nch, nout, C, B, post, inv_cnt, eps, out0, out1);
+    return stin_launch_status();
+}
+
+extern "C" int stin_norm_act_res_fwd_f32(const float* x, int64_t ldx, const float* mean, const float* rstd,
+                                         const int32_t* gid, const float* res, int64_t ldres, int64_t N, int C, int act,
+                                         float* y, int64_t ldy, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldy >= C && (res == nullptr || ldres >= C), STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(x && mean && rstd && y, STIN_E_NULL);
+    if (vec4_ok(C, {x, mean, rstd, res, y}, {ldx, ldy, res ? ldres : 0})) {
+        const int64_t n = N * (C / 4);
+        hipLaunchKernelGGL((k_norm_fwd<4>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, mean,
+                           rstd, gid, res, ldres, N, C, act, y, ldy);
+    } else {
+        const int64_t n = N * C;
+        hipLaunchKernelGGL((k_norm_fwd<1>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, mean,
+                           rstd, gid, res, ldres, N, C, act, y, ldy);
+    }
+    return stin_launch_status();
+}
+
+extern "C" int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_t ldg, const float* mean,
+                                     const float* rstd, const float* a, const float* k, const float* m,
+                                     const int32_t* gid, const int32_t* sid, int64_t N, int C, int act, float* dx,
+                                     int64_t lddx, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldg >= C && lddx >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(x && gout && mean && rstd && a && k && m && dx, STIN_E_NULL);
+    if (vec4_ok(C, {x, gout, mean, rstd, a, k, m, dx}, {ldx, ldg, lddx})) {
+        const int64_t n = N * (C / 4);
+        hipLaunchKernelGGL((k_norm_bwd<4>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, gout,
+                           ldg, mean, rstd, a, k, m, gid, sid, N, C, act, dx, lddx);
+    } else {
+        const int64_t n = N * C;
+        hipLaunchKernelGGL((k_norm_bwd<1>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, gout,
+                           ldg, mean, rstd, a, k, m, gid, sid, N, C, act, dx, lddx);
+    }
+    return stin_launch_status();
+}

@@ -1,0 +1,340 @@
+"""torch.autograd bindings of the HIP kernels (libstin_hip.so) - the operator layer
+the nn.Modules in surfacetextureinpaintingnet.py are written on.
+
+Every function here runs on GPU tensors only and calls through the C ABI
+(include/stin_hip.h); there is no eager/CPU fallback.  Dense per-vertex GEMMs use
+torch.mm / addmm (rocBLAS / hipBLASLt) - plain library GEMMs.
+"""
+import torch
+
+from . import _lib
+from .plan import _ptr, _stream
+
+EPS = 1e-5
+RED_SUM, RED_CSQ, RED_DOT_ELU, RED_COEF_XC = 0, 1, 2, 3
+POST_NONE, POST_SCALE, POST_RSTD = 0, 1, 2
+
+
+def _mat(t):
+    """2-D fp32 GPU tensor with unit inner stride -> (tensor, ld)."""
+    assert t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda, (t.shape, t.dtype, t.device)
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+def _call(name, *args):
+    _lib.check(getattr(_lib.load(), name)(*args), name)
+
+
+# ------------------------------------------------------------------ raw kernel wrappers
+def edge_relu_mean_fwd(A, B, csr, out, indicator=False):
+    A, lda = _mat(A)
+    B, ldb = _mat(B)
+    H = A.shape[1]
+    _call('stin_edge_relu_mean_fwd_f32', _ptr(A), lda, _ptr(B), ldb, _ptr(csr.rowptr), _ptr(csr.col), A.shape[0], H,
+          _ptr(out), out.stride(0), int(indicator), _stream(A))
+    return out
+
+
+def edge_relu_mean_bwd_dst(A, B, G, csr, dA):
+    A, lda = _mat(A)
+    B, ldb = _mat(B)
+    G, ldg = _mat(G)
+    _call('stin_edge_relu_mean_bwd_dst_f32', _ptr(A), lda, _ptr(B), ldb, _ptr(G), ldg, _ptr(csr.rowptr), _ptr(csr.col),
+          A.shape[0], A.shape[1], _ptr(dA), dA.stride(0), _stream(A))
+    return dA
+
+
+def edge_relu_mean_bwd_src(A, B, G, inv_deg, csr_src, dB):
+    A, lda = _mat(A)
+    B, ldb = _mat(B)
+    G, ldg = _mat(G)
+    _call('stin_edge_relu_mean_bwd_src_f32', _ptr(A), lda, _ptr(B), ldb, _ptr(G), ldg, _ptr(inv_deg),
+          _ptr(csr_src.rowptr), _ptr(csr_src.col), A.shape[0], A.shape[1], _ptr(dB), dB.stride(0), _stream(A))
+    return dB
+
+
+def segment_sum(src, rowptr, col, n_rows, mean=False):
+    src, ld = _mat(src)
+    out = torch.empty(n_rows, src.shape[1], dtype=torch.float32, device=src.device)
+    _call('stin_segment_sum_f32', _ptr(src), ld, _ptr(rowptr), _ptr(col), n_rows, src.shape[1], int(mean), _ptr(out),
+          out.stride(0) if n_rows > 1 else src.shape[1], _stream(src))
+    return out
+
+
+def gather_rows(src, idx, row_scale=None):
+    src, ld = _mat(src)
+    n = idx.numel()
+    out = torch.empty(n, src.shape[1], dtype=torch.float32, device=src.device)
+    _call('stin_gather_rows_f32', _ptr(src), ld, _ptr(idx), _ptr(row_scale), n, src.shape[1], _ptr(out), src.shape[1],
+          _stream(src))
+    return out
+
+
+def batch_pool(batch, pool):
+    out = torch.empty(pool.n_coarse, dtype=torch.int64, device=batch.device)
+    _call('stin_batch_pool_i64', _ptr(batch), _ptr(pool.children.rowptr), _ptr(pool.children.col), pool.n_coarse, _ptr(out),
+          _stream(batch))
+    return out
+
+
+def batch_unpool(batch, pool):
+    out = torch.empty(pool.n_fine, dtype=torch.int64, device=batch.device)
+    _call('stin_gather_i64', _ptr(batch), _ptr(pool.trace), pool.n_fine, _ptr(out), _stream(batch))
+    return out
+
+
+def colreduce(mode, x, groups, ptr, *, gout=None, mean=None, rstd=None, coef=None, post=POST_NONE, eps=EPS,
+              use_sid=False):
+    """Column sums of `x` rows over the ranges `ptr` (None: all rows) -> [B, C] (two for DOT_ELU)."""
+    lib = _lib.load()
+    x, ldx = _mat(x)
+    N, C = x.shape
+    B = groups.B
+    out0 = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    out1 = torch.empty(B, C, dtype=torch.float32, device=x.device) if mode == RED_DOT_ELU else None
+    ldg = 0
+    if gout is not None:
+        gout, ldg = _mat(gout)
+    ws_bytes = lib.stin_colreduce_workspace_bytes(C, B)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    _call('stin_colreduce_f32', mode, _ptr(x), ldx, _ptr(gout), ldg, N, C, _ptr(ptr), B, _ptr(groups.gid),
+          _ptr(groups.sid if use_sid else None), _ptr(mean), _ptr(rstd), _ptr(coef), post, _ptr(groups.inv_cnt),
+          float(eps), _ptr(out0), _ptr(out1), _ptr(ws), ws_bytes, _stream(x))
+    return (out0, out1) if out1 is not None else out0
+
+
+def colsum(x):
+    """[N, C] -> [C] column sums (bias gradients), fixed summation order."""
+    class _One:
+        B, gid, sid, inv_cnt = 1, None, None, None
+    return colreduce(RED_SUM, x, _One, None).view(-1)
+
+
+def instance_stats(x, groups):
+    """-> (mean, rstd) [B, C]: biased variance, eps inside the sqrt (F.instance_norm /
+    FastInstanceNorm semantics, reference models/modules/fastinstancenorm.py:44-98)."""
+    mean = colreduce(RED_SUM, x, groups, groups.ptr_sum, post=POST_SCALE)
+    rstd = colreduce(RED_CSQ, x, groups, groups.ptr_sum, mean=mean, post=POST_RSTD)
+    return mean, rstd
+
+
+def norm_act_res_fwd(x, mean, rstd, groups, res=None, act=True):
+    x, ldx = _mat(x)
+    N, C = x.shape
+    ldres = 0
+    if res is not None:
+        res, ldres = _mat(res)
+    y = torch.empty(N, C, dtype=torch.float32, device=x.device)
+    _call('stin_norm_act_res_fwd_f32', _ptr(x), ldx, _ptr(mean), _ptr(rstd), _ptr(groups.gid), _ptr(res), ldres, N, C,
+          int(act), _ptr(y), C, _stream(x))
+    return y
+
+
+def instance_norm_act_bwd(x, gout, mean, rstd, groups, act=True, out=None):
+    """d/dx of y = act((x - mean[g]) * rstd[g]) with the statistics taken over `groups`
+    (incl. the linspace-slice quirk: sums over slices sigma, centring through g)."""
+    x, ldx = _mat(x)
+    gout, ldg = _mat(gout)
+    N, C = x.shape
+    if act:
+        T1, S0 = colreduce(RED_DOT_ELU, x, groups, groups.ptr_true, gout=gout, mean=mean, rstd=rstd)
+    else:
+        # without activation dY = gout: sum dY*xc and sum dY via the same kernel with rstd = 0 -> ELU'(0)=1
+        T1, S0 = colreduce(RED_DOT_ELU, x, groups, groups.ptr_true, gout=gout, mean=mean, rstd=torch.zeros_like(rstd))
+    inv_cnt = groups.inv_cnt.view(-1, 1)
+    k = -(rstd * rstd * rstd) * T1 * inv_cnt                       # indexed by the SUM slice (sid)
+    if not groups.quirk:
+        m = -(rstd * S0) * inv_cnt                                  # sum_g xc = 0 when slices == graphs
+    else:
+        U = colreduce(RED_COEF_XC, x, groups, groups.ptr_true, mean=mean, coef=k, use_sid=True)
+        m = -(rstd * S0 + U) * inv_cnt
+    dx = out if out is not None else torch.empty(N, C, dtype=torch.float32, device=x.device)
+    _call('stin_norm_act_bwd_f32', _ptr(x), ldx, _ptr(gout), ldg, _ptr(mean), _ptr(rstd), _ptr(rstd), _ptr(k.contiguous()),
+          _ptr(m.contiguous()), _ptr(groups.gid), _ptr(groups.sid), N, C, int(act), _ptr(dx), dx.stride(0), _stream(x))
+    return dx
+
+
+# ----------------------------------------------------------------------- autograd ops
+class EdgeConvBlockFn(torch.autograd.Function):
+    """One GraphResnetBlock with an EdgeConv(mean) filter and instance norm, fused at the
+    autograd level (reference models/surfacetextureinpaintingnet.py:507-521):
+
+        Y   = x Wcat^T + bcat          Wcat = [Wa-Wb ; Wb ; Ws]   (per-VERTEX GEMM)
+        h   = mean_j ReLU(A_i + B_j)   A = Y[:, :H], B = Y[:, H:2H]   (HIP edge stage)
+        agg = [h | deg>0] [W2 | b2]^T                              (per-VERTEX GEMM)
+        out = (Y[:, 2H:] or x) + ELU(InstanceNorm(agg))            (HIP epilogue)
+
+    Only per-vertex tensors are saved; ReLU masks are recomputed in backward."""
+
+    @staticmethod
+    def forward(ctx, x, wcat, bcat, w2e, edges, groups, H, has_shortcut):
+        x, _ = _mat(x)
+        N = x.shape[0]
+        Y = torch.addmm(bcat, x, wcat.t())
+        hE = torch.empty(N, H + 4, dtype=torch.float32, device=x.device)
+        edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True)
+        agg = torch.mm(hE, w2e.t())
+        mean, rstd = instance_stats(agg, groups)
+        res = Y[:, 2 * H:] if has_shortcut else x
+        out = norm_act_res_fwd(agg, mean, rstd, groups, res=res, act=True)
+        ctx.save_for_backward(x, wcat, w2e, Y, hE, agg, mean, rstd)
+        ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut = edges, groups, H, has_shortcut
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wcat, w2e, Y, hE, agg, mean, rstd = ctx.saved_tensors
+        edges, groups, H = ctx.edges, ctx.groups, ctx.H
+        g, _ = _mat(g)
+        dagg = instance_norm_act_bwd(agg, g, mean, rstd, groups, act=True)
+        dw2e = torch.mm(dagg.t(), hE)
+        dhE = torch.mm(dagg, w2e)
+        dY = torch.empty_like(Y)
+        A, B = Y[:, :H], Y[:, H:2 * H]
+        edge_relu_mean_bwd_dst(A, B, dhE[:, :H], edges.by_dst, dY[:, :H])
+        edge_relu_mean_bwd_src(A, B, dhE[:, :H], edges.inv_deg, edges.by_src, dY[:, H:2 * H])
+        if ctx.has_shortcut:
+            dY[:, 2 * H:].copy_(g)
+        dwcat = torch.mm(dY.t(), x)
+        dbcat = colsum(dY)
+        dx = torch.mm(dY, wcat)
+        if not ctx.has_shortcut:
+            dx.add_(g)
+        return dx, dwcat, dbcat, dw2e, None, None, None, None
+
+
+class EdgeReluMeanFn(torch.autograd.Function):
+    """h = mean_j ReLU(A_i + B_j) as a standalone differentiable op."""
+
+    @staticmethod
+    def forward(ctx, A, B, edges):
+        A, _ = _mat(A)
+        B, _ = _mat(B)
+        out = torch.empty(A.shape[0], A.shape[1], dtype=torch.float32, device=A.device)
+        edge_relu_mean_fwd(A, B, edges.by_dst, out)
+        ctx.save_for_backward(A, B)
+        ctx.edges = edges
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        g, _ = _mat(g)
+        dA = torch.empty_like(A)
+        dB = torch.empty_like(B)
+        edge_relu_mean_bwd_dst(A, B, g, ctx.edges.by_dst, dA)
+        edge_relu_mean_bwd_src(A, B, g, ctx.edges.inv_deg, ctx.edges.by_src, dB)
+        return dA, dB, None
+
+
+class NeighborMeanFn(torch.autograd.Function):
+    """agg_i = mean_{j in N(i)} x_j (SAGEConv aggregation; sum for mean=False)."""
+
+    @staticmethod
+    def forward(ctx, x, edges, mean):
+        ctx.edges, ctx.mean = edges, mean
+        return segment_sum(x, edges.by_dst.rowptr, edges.by_dst.col, edges.n, mean=mean)
+
+    @staticmethod
+    def backward(ctx, g):
+        e = ctx.edges
+        if ctx.mean:
+            g = g * e.inv_deg.view(-1, 1)
+        return segment_sum(g, e.by_src.rowptr, e.by_src.col, e.n, mean=False), None, None
+
+
+class ScatterAddFn(torch.autograd.Function):
+    """out[n] = sum_{e: index[e]=n} src[e]  (torch_scatter.scatter_sum with a prebuilt CSR)."""
+
+    @staticmethod
+    def forward(ctx, src, csr):
+        ctx.csr = csr
+        return segment_sum(src, csr.rowptr, csr.perm, csr.n_rows, mean=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError('ScatterAddFn is forward-only (benchmark / metrics op)')
+
+
+class PoolMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pool):
+        x, ldx = _mat(x)
+        C = x.shape[1]
+        out = torch.empty(pool.n_coarse, C, dtype=torch.float32, device=x.device)
+        arg = torch.empty(pool.n_coarse, C, dtype=torch.int32, device=x.device)
+        _call('stin_pool_max_fwd_f32', _ptr(x), ldx, _ptr(pool.children.rowptr), _ptr(pool.children.col), pool.n_coarse, C,
+              _ptr(out), C, _ptr(arg), _stream(x))
+        ctx.save_for_backward(arg)
+        ctx.pool = pool
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        pool = ctx.pool
+        g, ldg = _mat(g)
+        C = g.shape[1]
+        gx = torch.empty(pool.n_fine, C, dtype=torch.float32, device=g.device)
+        _call('stin_pool_max_bwd_f32', _ptr(g), ldg, _ptr(arg), _ptr(pool.trace), pool.n_fine, C, _ptr(gx), C, _stream(g))
+        return gx, None
+
+
+class PoolMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pool):
+        ctx.pool = pool
+        return segment_sum(x, pool.children.rowptr, pool.children.col, pool.n_coarse, mean=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        return gather_rows(g, ctx.pool.trace, ctx.pool.inv_count), None
+
+
+class UnpoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pool):
+        ctx.pool = pool
+        return gather_rows(x, pool.trace)
+
+    @staticmethod
+    def backward(ctx, g):
+        p = ctx.pool
+        return segment_sum(g, p.children.rowptr, p.children.col, p.n_coarse, mean=False), None
+
+
+class InstanceNormActResFn(torch.autograd.Function):
+    """y = res + act(InstanceNorm(x)) (res optional, act = ELU or identity)."""
+
+    @staticmethod
+    def forward(ctx, x, res, groups, act):
+        x, _ = _mat(x)
+        mean, rstd = instance_stats(x, groups)
+        y = norm_act_res_fwd(x, mean, rstd, groups, res=res, act=act)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.groups, ctx.act, ctx.has_res = groups, act, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, rstd = ctx.saved_tensors
+        dx = instance_norm_act_bwd(x, g, mean, rstd, ctx.groups, act=ctx.act)
+        return dx, (g if ctx.has_res else None), None, None
+
+
+class SliceSumFn(torch.autograd.Function):
+    """[N, C] -> [B, C] sums over contiguous row ranges (SingleBatchGraphNorm statistics)."""
+
+    @staticmethod
+    def forward(ctx, x, groups):
+        ctx.groups = groups
+        return colreduce(RED_SUM, x, groups, groups.ptr_sum)
+
+    @staticmethod
+    def backward(ctx, g):
+        gr = ctx.groups
+        if gr.sid is None:
+            return g.expand(gr.n_rows, -1).contiguous(), None
+        return g.index_select(0, gr.sid.long()), None

@@ -1,0 +1,220 @@
+"""Graph-conv filters and norms of the hot path, on the HIP operator layer.
+
+Host-side mirror of the reference's models/modules/*: same factory names, argument
+meaning, parameter names (``nn.0``/``nn.2``, ``sage1.lin_l``/``sage1.lin_r``,
+``weight``/``bias``/``mean_scale``, ``module.*``) and error behaviour, so that
+reference checkpoints load unchanged.  The arithmetic runs in libstin_hip.so.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as SF
+from .plan import EdgeSet, NormGroups
+
+
+def _as_edges(edges, n):
+    """EdgeSet, or a raw int64 [2, E] edge_index (external callers) -> EdgeSet."""
+    if isinstance(edges, EdgeSet):
+        return edges
+    bad = torch.zeros(1, dtype=torch.int32, device=edges.device)
+    es = EdgeSet(edges, n, bad)
+    if int(bad.item()) != 0:
+        raise IndexError('edge_index out of range for %d vertices' % n)
+    return es
+
+
+def _as_groups(batch, n, device, linspace_quirk=True):
+    """NormGroups, None (single instance), or a raw int64 batch vector -> NormGroups."""
+    if isinstance(batch, NormGroups):
+        return batch
+    if batch is None:
+        return NormGroups(n, device)
+    nb = int(batch.max()) + 1                      # same host sync the reference does (fastinstancenorm.py:51)
+    counts = torch.bincount(batch, minlength=nb).cpu()
+    return NormGroups(n, device, batch, counts, linspace_quirk)
+
+
+class EdgeConv(nn.Module):
+    """EdgeConv(nn=Seq(Lin, ReLU, Lin), aggr='mean') - PyG's EdgeConv as the reference
+    configures it (models/modules/edge_conv_filter.py:46-57), evaluated in the exact
+    per-vertex form  W2 mean_j ReLU(A_i + B_j) + b2 [deg_i > 0]  (DESIGN.md §2)."""
+    trans_inv = False
+
+    def __init__(self, nn_seq, aggr='mean'):
+        super().__init__()
+        if aggr != 'mean':
+            raise NotImplementedError("only aggr='mean' is on the STINet path (the linear restructure needs it)")
+        self.nn = nn_seq
+        self.aggr = aggr
+
+    def hidden(self):
+        return self.nn[0].out_features
+
+    def fused_weights(self, shortcut=None):
+        """-> (Wcat [2H(+Cout), Cin], bcat, W2e [Cout, H+4]) from the reference-layout parameters."""
+        lin1, lin2 = self.nn[0], self.nn[2]
+        W1, H = lin1.weight, lin1.out_features
+        b1 = lin1.bias if lin1.bias is not None else W1.new_zeros(H)
+        if self.trans_inv:                      # nn(x_j - x_i): A = -x W1^T + b1, B = x W1^T
+            rows = [-W1, W1]
+        else:                                   # nn([x_i, x_j - x_i]): A = x (Wa - Wb)^T + b1, B = x Wb^T
+            cin = W1.shape[1] // 2
+            rows = [W1[:, :cin] - W1[:, cin:], W1[:, cin:]]
+        biases = [b1, b1.new_zeros(H)]
+        if shortcut is not None:
+            rows.append(shortcut.weight)
+            biases.append(shortcut.bias if shortcut.bias is not None else b1.new_zeros(shortcut.out_features))
+        b2 = lin2.bias if lin2.bias is not None else W1.new_zeros(lin2.out_features)
+        w2e = torch.cat([lin2.weight, b2[:, None], b2.new_zeros(b2.shape[0], 3)], dim=1)
+        return torch.cat(rows, 0), torch.cat(biases, 0), w2e
+
+    def forward(self, x, edge_index):
+        edges = _as_edges(edge_index, x.shape[0])
+        wcat, bcat, w2e = self.fused_weights()
+        H = self.hidden()
+        Y = torch.addmm(bcat, x, wcat.t())
+        h = SF.EdgeReluMeanFn.apply(Y[:, :H], Y[:, H:], edges)
+        has_in = (edges.by_dst.rowptr[1:] > edges.by_dst.rowptr[:-1]).to(h.dtype).unsqueeze(1)
+        return F.linear(h, self.nn[2].weight) + has_in * w2e[:, H]
+
+    def __repr__(self):
+        return '{}(nn={}, aggr={})'.format(self.__class__.__name__, self.nn, self.aggr)
+
+
+class EdgeConvTransInv(EdgeConv):
+    """First-layer EdgeConv whose message is nn(x_j - x_i)
+    (models/modules/edge_conv_translation_invariance.py:9-24)."""
+    trans_inv = True
+
+
+def get_gcn_filter(input_size, output_size, activation=nn.ReLU, inplace=False, aggregation='mean', bias=True,
+                   module=None, double_input=True, with_norm=False):
+    """Same arguments as the reference's edge_conv_filter.get_gcn_filter (:10-57)."""
+    assert input_size >= 0
+    assert output_size >= 0
+    if with_norm:
+        raise NotImplementedError('with_norm=True (BatchNorm inside the edge MLP) is only used by SingleConvMeshNet, '
+                                  'which is outside the STINet hot path')
+    if activation is not nn.ReLU:
+        raise NotImplementedError('the fused edge stage implements ReLU only')
+    cin = 2 * input_size if double_input else input_size
+    if module is None:
+        module = EdgeConv
+    inner = nn.Sequential(nn.Linear(cin, 2 * output_size, bias=bias), nn.ReLU(inplace=inplace),
+                          nn.Linear(2 * output_size, output_size, bias=bias))
+    return module(inner, aggr=aggregation)
+
+
+class SAGEConv(nn.Module):
+    """lin_l(mean_j x_j) + lin_r(x_i) (PyG SAGEConv, root_weight=True, normalize=False)."""
+    trans_inv = False
+
+    def __init__(self, in_channels, out_channels, normalize=False, root_weight=True, bias=True):
+        super().__init__()
+        assert not normalize and root_weight
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=bias)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x, edge_index, size=None):
+        edges = _as_edges(edge_index, x.shape[0])
+        agg = SF.NeighborMeanFn.apply(x, edges, True)
+        if self.trans_inv:
+            # message: x_j[:, 3:9] -= x_i[:, 3:9] (models/modules/sage_conv_filter.py:87-90); under the mean this is
+            # agg[:, 3:9] - x_i[:, 3:9] * [deg_i > 0]
+            has_in = (edges.by_dst.rowptr[1:] > edges.by_dst.rowptr[:-1]).to(x.dtype).unsqueeze(1)
+            agg = torch.cat([agg[:, :3], agg[:, 3:9] - x[:, 3:9] * has_in, agg[:, 9:]], dim=1)
+        return self.lin_l(agg) + self.lin_r(x)
+
+
+class SAGEConvTransInv(SAGEConv):
+    trans_inv = True
+
+
+class SumSAGEConv(nn.Module):
+    def __init__(self, module, *args, **kwargs):
+        super().__init__()
+        self.sage1 = module(*args, **kwargs)
+
+    def forward(self, x, edge_index, size=None):
+        return self.sage1(x, edge_index, size)
+
+
+def get_sage_filter(input_size, output_size, activation=None, inplace=False, aggregation='mean', bias=True,
+                    module=None, double_input=False):
+    """Same arguments as the reference's sage_conv_filter.get_gcn_filter (:102-138)."""
+    assert input_size >= 0
+    assert output_size >= 0
+    if module is None:
+        module = SAGEConv
+    return SumSAGEConv(module, input_size, output_size, normalize=False, root_weight=True, bias=bias)
+
+
+class FastInstanceNorm(nn.Module):
+    """Per-graph instance norm on [N, C] node features, no affine, no running stats
+    (models/modules/fastinstancenorm.py:42-107; the shipped default `norm: instance`)."""
+
+    def __init__(self, in_channels, eps=1e-5, momentum=0.1, affine=False, track_running_stats=False):
+        super().__init__()
+        if affine or track_running_stats:
+            raise NotImplementedError('FastInstanceNorm is used with affine=False, track_running_stats=False')
+        self.num_features, self.eps = in_channels, eps
+        self.linspace_quirk = True
+
+    def forward(self, x, batch=None):
+        groups = _as_groups(batch, x.shape[0], x.device, self.linspace_quirk)
+        return SF.InstanceNormActResFn.apply(x, None, groups, False)
+
+    def __repr__(self):
+        return '{}({})'.format(self.__class__.__name__, self.num_features)
+
+
+class SingleBatchGraphNorm(nn.Module):
+    """weight * (x - mean_scale * mean) / sqrt(mean(x^2) + eps) + bias over linspace row
+    slices - the reference's GraphNorm variant incl. its raw-x^2 variance
+    (models/modules/singlebatchgroupnorm.py:46-71)."""
+
+    def __init__(self, in_channels, eps=1e-5):
+        super().__init__()
+        self.in_channels, self.eps = in_channels, eps
+        self.weight = nn.Parameter(torch.ones(in_channels))
+        self.bias = nn.Parameter(torch.zeros(in_channels))
+        self.mean_scale = nn.Parameter(torch.ones(in_channels))
+
+    def forward(self, x, batch=None):
+        groups = _as_groups(batch, x.shape[0], x.device, True)
+        if groups.B == 1:
+            n = torch.full((1, 1), float(x.shape[0]), device=x.device)
+        else:
+            n = (groups.ptr_sum[1:] - groups.ptr_sum[:-1]).to(x.dtype).unsqueeze(1)
+        mean = SF.SliceSumFn.apply(x, groups) / n
+        ex2 = SF.SliceSumFn.apply(x * x, groups) / n
+        if groups.gid is not None:
+            mean = mean.index_select(0, groups.gid.long())
+            ex2 = ex2.index_select(0, groups.gid.long())
+        out = x - mean * self.mean_scale
+        return self.weight * out / (ex2 + self.eps).sqrt() + self.bias
+
+    def __repr__(self):
+        return '{}({})'.format(self.__class__.__name__, self.in_channels)
+
+
+class BatchNorm2Param(nn.Module):
+    """PyG BatchNorm (BatchNorm1d held as ``.module``) that ignores ``batch``
+    (models/surfacetextureinpaintingnet.py:236-241)."""
+
+    def __init__(self, in_channels, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.module = nn.BatchNorm1d(in_channels, eps, momentum, affine, track_running_stats)
+
+    def forward(self, x, batch=None):
+        return self.module(x)
+
+
+class Identity(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+    def forward(self, x, batch=None):
+        return x

@@ -1,0 +1,208 @@
+"""Graph plan: the per-sample CSR structures every kernel of the hot path runs on.
+
+Built ONCE per sample on the GPU (stin_csr_from_coo_i64) and cached on the sample
+object, shared by all blocks of a level:
+  * per edge set: destination CSR (row i -> sources j, original edge order) for the
+    forward gather / dA pass, source CSR (row j -> targets i) for the dB pass, and
+    inv_deg = 1 / max(1, in-degree);
+  * per pooling level: int32 trace, children CSR (fine vertices of each coarse
+    vertex, ascending), inv_count;
+  * per level: instance-norm row groups (gid / slice ids) for batched samples.
+Indices are int64 at the Python boundary (as in the reference) and int32 inside.
+"""
+import torch
+
+from . import _lib
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class CSR:
+    __slots__ = ('rowptr', 'col', 'perm', 'inv_deg', 'n_rows', 'n_entries')
+
+    def __init__(self, rowptr, col, perm, inv_deg, n_rows, n_entries):
+        self.rowptr, self.col, self.perm, self.inv_deg = rowptr, col, perm, inv_deg
+        self.n_rows, self.n_entries = n_rows, n_entries
+
+
+def build_csr(key, val, n_rows, val_limit, bad, want_perm=False):
+    """key/val: int64 device tensors [E] (val may be None) -> CSR grouped by key."""
+    lib = _lib.load()
+    assert key.dtype == torch.int64 and key.is_cuda and key.is_contiguous()
+    E = key.numel()
+    dev = key.device
+    rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if want_perm else None
+    inv_deg = torch.empty(max(n_rows, 1), dtype=torch.float32, device=dev)
+    ws_bytes = lib.stin_csr_workspace_bytes(E, n_rows)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    if val is not None:
+        assert val.dtype == torch.int64 and val.is_contiguous() and val.numel() == E
+    _lib.check(lib.stin_csr_from_coo_i64(_ptr(key), _ptr(val), E, n_rows, val_limit, _ptr(rowptr), _ptr(col),
+                                         _ptr(perm), _ptr(inv_deg), _ptr(bad), _ptr(ws), ws_bytes, _stream(key)),
+               'stin_csr_from_coo_i64')
+    return CSR(rowptr, col[:E], None if perm is None else perm[:E], inv_deg[:n_rows], n_rows, E)
+
+
+class EdgeSet:
+    """One directed edge set of one level (edge_index[0] = source j, [1] = target i)."""
+
+    def __init__(self, edge_index, n, bad):
+        assert edge_index.dim() == 2 and edge_index.shape[0] == 2, 'edge_index must be [2, E]'
+        self.n = n
+        src = edge_index[0].contiguous()
+        dst = edge_index[1].contiguous()
+        self.by_dst = build_csr(dst, src, n, n, bad)      # rows = targets, col = sources
+        self.by_src = build_csr(src, dst, n, n, bad)      # rows = sources, col = targets
+        self.inv_deg = self.by_dst.inv_deg                # 1 / max(1, in-degree)
+        self.n_edges = dst.numel()
+
+
+class PoolMap:
+    """trace: fine vertex -> coarse vertex (hierarchy_trace_index_l)."""
+
+    def __init__(self, trace, n_fine, n_coarse, bad):
+        lib = _lib.load()
+        assert trace.numel() == n_fine
+        trace = trace.contiguous()
+        self.n_fine, self.n_coarse = n_fine, n_coarse
+        self.children = build_csr(trace, None, n_coarse, n_fine, bad)   # col = fine ids, ascending
+        self.inv_count = self.children.inv_deg
+        self.trace = torch.empty(max(n_fine, 1), dtype=torch.int32, device=trace.device)[:n_fine]
+        _lib.check(lib.stin_narrow_i64_to_i32(_ptr(trace), n_fine, n_coarse, _ptr(self.trace), _ptr(bad),
+                                              _stream(trace)), 'stin_narrow_i64_to_i32')
+
+
+class NormGroups:
+    """Row groups for the per-graph instance norm at one level.
+
+    Single graph (or the whole-batch norm of the io blocks): one range,
+    ids None.  Batched: ``gid`` = graph id per row (centring/scaling, true counts),
+    ``ptr``/``sid`` = the row ranges the SUMS run over - the reference's
+    ``linspace(0, N, B+1)`` slices when ``linspace_quirk`` (fastinstancenorm.py:53-82,
+    SURVEY Q2) else the true per-graph ranges."""
+
+    def __init__(self, n_rows, device, batch=None, counts=None, linspace_quirk=True):
+        self.n_rows = n_rows
+        self.device = device
+        if batch is None:
+            self.B = 1
+            self.gid = self.sid = self.ptr_sum = self.ptr_true = None
+            self.inv_cnt = torch.full((1,), 1.0 / max(n_rows, 1), dtype=torch.float32, device=device)
+            self.quirk = False
+            return
+        B = int(counts.numel())
+        self.B = B
+        self.gid = batch.to(torch.int32).contiguous()
+        true_ptr = torch.zeros(B + 1, dtype=torch.int64)
+        true_ptr[1:] = torch.cumsum(counts.to(torch.int64), 0)
+        if linspace_quirk:
+            sum_ptr = torch.linspace(0, n_rows, B + 1, dtype=torch.int).to(torch.int64)
+        else:
+            sum_ptr = true_ptr
+        self.quirk = bool((sum_ptr != true_ptr).any())
+        self.ptr_true = true_ptr.to(torch.int32).to(device)
+        self.ptr_sum = sum_ptr.to(torch.int32).to(device)
+        sid = torch.repeat_interleave(torch.arange(B, dtype=torch.int32), (sum_ptr[1:] - sum_ptr[:-1]))
+        self.sid = sid.to(device) if self.quirk else self.gid
+        self.inv_cnt = (1.0 / counts.to(torch.float32).clamp(min=1)).to(device)
+
+
+class GraphPlan:
+    """All CSR structures of one (possibly batched) hierarchical sample."""
+
+    def __init__(self, sample, linspace_quirk=True, validate=True):
+        x = sample.x
+        assert x.is_cuda, 'the HIP path needs the sample on the GPU (sample.to("cuda"))'
+        self.device = x.device
+        self.linspace_quirk = linspace_quirk
+        nv = sample.num_vertices
+        nv = nv.detach().to('cpu', torch.int64)          # [B, L]; one tiny D2H copy per sample
+        if nv.dim() == 1:
+            nv = nv.view(1, -1)
+        self.num_vertices = nv
+        self.level_sizes = [int(v) for v in nv.sum(dim=0)]
+        self.num_graphs = int(nv.shape[0])
+        self._sample = sample
+        self._bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._edges = {}
+        self._pools = {}
+        self._norms = {}
+        self._batch = {}
+        self._validate = validate
+        self._validated = False
+
+    # ---- lazily built pieces ------------------------------------------------------
+    def edges(self, key, level):
+        if key not in self._edges:
+            ei = self._sample.edge_index if key == 'edge_index' else self._sample[key]
+            self._edges[key] = EdgeSet(ei, self.level_sizes[level], self._bad)
+            self._validated = False
+        return self._edges[key]
+
+    def edges_from_tensor(self, edge_index, n):
+        key = ('tensor', edge_index.data_ptr(), tuple(edge_index.shape), n)
+        if key not in self._edges:
+            self._edges[key] = EdgeSet(edge_index, n, self._bad)
+            self._validated = False
+        return self._edges[key]
+
+    def pool(self, level):
+        """level >= 1: map from level-1 (fine) to level (coarse)."""
+        if level not in self._pools:
+            trace = self._sample['hierarchy_trace_index_%d' % level]
+            self._pools[level] = PoolMap(trace, self.level_sizes[level - 1], self.level_sizes[level], self._bad)
+            self._validated = False
+        return self._pools[level]
+
+    def batch_vector(self, level):
+        """int64 graph id per vertex of `level` (None for a single graph), propagated exactly
+        like the reference: scatter_max(batch, trace) going down
+        (models/surfacetextureinpaintingnet.py:421-422)."""
+        if self.num_graphs == 1:
+            return None
+        if level not in self._batch:
+            if level == 0:
+                self._batch[0] = self._sample.batch.contiguous()
+            else:
+                from . import functional as F_
+                self._batch[level] = F_.batch_pool(self.batch_vector(level - 1), self.pool(level))
+        return self._batch[level]
+
+    def norm_groups(self, level, whole_batch=False):
+        key = (level, whole_batch)
+        if key not in self._norms:
+            n = self.level_sizes[level]
+            if self.num_graphs == 1 or whole_batch:
+                self._norms[key] = NormGroups(n, self.device)
+            else:
+                self._norms[key] = NormGroups(n, self.device, self.batch_vector(level), self.num_vertices[:, level],
+                                              self.linspace_quirk)
+        return self._norms[key]
+
+    def validate(self):
+        """One host sync per sample: raise like the reference's CPU IndexError when any
+        index was out of range (kernels clamp such indices, so nothing faulted)."""
+        if self._validate and not self._validated:
+            if int(self._bad.item()) != 0:
+                raise IndexError('edge / trace index out of range for the level sizes in sample.num_vertices')
+            self._validated = True
+
+
+def plan_for(sample, **kw):
+    """The cached GraphPlan of `sample` (built on first use)."""
+    plan = getattr(sample, '_plan_cache', None)
+    if plan is None or plan.device != sample.x.device:
+        plan = GraphPlan(sample, **kw)
+        try:
+            sample._plan_cache = plan
+        except Exception:  # foreign sample types without attribute assignment
+            pass
+    return plan

@@ -1,0 +1,209 @@
+"""SurfaceTextureInpaintingNet on MI355X: the reference's nn.Module surface
+(models/surfacetextureinpaintingnet.py: define_G :157-199, SurfaceTextureInpaintingNet
+:202-471, GraphResnetBlock :474-521) - same constructor arguments, ``forward(sample)``
+contract and state_dict keys - with every graph operation executed by the hand-written
+HIP kernels of libstin_hip.so through functional.py.  Drop-in for the graph branch of
+``define_G``; the 2-D Conv2d baselines (filter_type conv2d / cfconv2d) are out of scope.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as SF
+from . import modules as M
+from .plan import EdgeSet, NormGroups, plan_for
+
+
+class GraphResnetBlock(nn.Module):
+    """conv -> norm -> ELU, plus residual (Linear shortcut when Cin != Cout)."""
+
+    def __init__(self, dim_in, dim_out, get_gcn_filter, norm_layer, inplace, use_bias, is_checkpointed=False,
+                 module=None, double_input=None):
+        super().__init__()
+        self.dim_in, self.dim_out = dim_in, dim_out
+        self.act = nn.ELU()
+        if module is not None:
+            self.first_filter = get_gcn_filter(dim_in, dim_out, inplace=inplace, bias=use_bias, module=module,
+                                               double_input=double_input)
+        else:
+            self.first_filter = get_gcn_filter(dim_in, dim_out, inplace=inplace, bias=use_bias)
+        if is_checkpointed and issubclass(norm_layer, M.BatchNorm2Param):
+            self.first_norm = norm_layer(dim_out, momentum=math.sqrt(0.1))
+        else:
+            self.first_norm = norm_layer(dim_out)
+        if dim_in != dim_out:
+            self.shortcut = nn.Linear(dim_in, dim_out)
+
+    def forward(self, x, edges, batch=None):
+        n = x.shape[0]
+        edges = M._as_edges(edges, n)
+        fused = isinstance(self.first_filter, M.EdgeConv) and isinstance(self.first_norm, M.FastInstanceNorm)
+        if fused:
+            groups = M._as_groups(batch, n, x.device, self.first_norm.linspace_quirk)
+            shortcut = self.shortcut if self.dim_in != self.dim_out else None
+            wcat, bcat, w2e = self.first_filter.fused_weights(shortcut)
+            return SF.EdgeConvBlockFn.apply(x, wcat, bcat, w2e, edges, groups, self.first_filter.hidden(),
+                                            shortcut is not None)
+        out = self.first_filter(x, edges)
+        res = self.shortcut(x) if self.dim_in != self.dim_out else x
+        if isinstance(self.first_norm, M.FastInstanceNorm):
+            groups = M._as_groups(batch, n, x.device, self.first_norm.linspace_quirk)
+            return SF.InstanceNormActResFn.apply(out, res, groups, True)
+        return res + self.act(self.first_norm(out, batch))
+
+
+class SurfaceTextureInpaintingNet(nn.Module):
+    """ResNet-style U-shaped GNN over a mesh hierarchy (see the module docstring)."""
+
+    def __init__(self, input_nc, output_nc, filter_type, ngf=64, norm_type='instance', n_blocks=6, n_levels=2,
+                 n_repeated_io_convs=1, pooling_type='mean', checkpoint_bottleneck=False,
+                 num_blocks_per_uncheckpointed_block=1, use_label_embedding=False, num_classes=None,
+                 num_embedding=None, dilations=None):
+        assert (n_blocks >= 0)
+        super().__init__()
+        if filter_type in ('edgeconv', 'edgeconvtransinv'):
+            get_gcn_filter = M.get_gcn_filter
+        elif filter_type in ('sageconv', 'sageconvtransinv'):
+            get_gcn_filter = M.get_sage_filter
+        else:
+            raise NotImplementedError('No filter implemented for gcn filter type {}'.format(filter_type))
+        if norm_type == 'batch':
+            self.norm, self.using_norm = M.BatchNorm2Param, True
+        elif norm_type == 'instance':
+            self.norm, self.using_norm = M.FastInstanceNorm, True
+        elif norm_type == 'graph':
+            self.norm, self.using_norm = M.SingleBatchGraphNorm, True
+        else:
+            self.norm, self.using_norm = M.Identity, False
+        self._pooling_type = pooling_type
+        self.checkpoint_bottleneck = checkpoint_bottleneck          # accepted for config compatibility: the HIP
+        self.num_blocks_per_uncheckpointed_block = num_blocks_per_uncheckpointed_block  # blocks save only per-vertex
+        self._use_embedding = use_label_embedding                   # tensors, so no recompute is needed
+        self.dilations = list(dilations) if dilations is not None else [1] * n_blocks
+        # batched-norm compatibility switch: True reproduces the reference's linspace slices
+        self.compat_linspace_norm = True
+        inplace, use_bias = False, True
+        if self._use_embedding:  # created but never used by forward, as in the reference (:277-278, :409-410)
+            self.label_embedding = nn.Embedding(num_classes, num_embedding, padding_idx=0)
+
+        blocks = []
+        for i in range(n_repeated_io_convs):
+            cout = ngf if i == n_repeated_io_convs - 1 else input_nc
+            if i == 0:
+                first, double_input = {
+                    'edgeconvtransinv': (M.EdgeConvTransInv, False), 'edgeconv': (None, True),
+                    'sageconvtransinv': (M.SAGEConvTransInv, False), 'sageconv': (None, False)}[filter_type]
+                blocks.append(GraphResnetBlock(input_nc, cout, get_gcn_filter, self.norm, inplace, use_bias,
+                                               module=first, double_input=double_input))
+            else:
+                blocks.append(GraphResnetBlock(input_nc, cout, get_gcn_filter, self.norm, inplace, use_bias))
+        self.input_blocks = nn.ModuleList(blocks)
+
+        blocks = []
+        for i in range(n_levels):
+            cin = ngf * 2 ** i
+            if i == 0 and self._use_embedding:
+                cin += num_embedding
+            blocks.append(GraphResnetBlock(cin, ngf * 2 ** (i + 1), get_gcn_filter, self.norm, inplace, use_bias))
+        self.encoder_blocks = nn.ModuleList(blocks)
+
+        width = ngf * 2 ** n_levels
+        self.bottleneck_blocks = nn.ModuleList(
+            [GraphResnetBlock(width, width, get_gcn_filter, self.norm, inplace, use_bias,
+                              is_checkpointed=self.checkpoint_bottleneck) for _ in range(n_blocks)])
+        self.decoder_blocks = nn.ModuleList(
+            [GraphResnetBlock(ngf * 2 ** (n_levels - i), int(ngf * 2 ** (n_levels - i) / 2), get_gcn_filter, self.norm,
+                              inplace, use_bias) for i in range(n_levels)])
+        self.output_blocks = nn.ModuleList(
+            [GraphResnetBlock(ngf, ngf, get_gcn_filter, self.norm, inplace, use_bias) for _ in range(n_repeated_io_convs)])
+        self.final_linear1 = nn.Linear(ngf, ngf, bias=use_bias)
+        self.final_norm1 = self.norm(ngf)
+        self.final_linear2 = nn.Linear(ngf, output_nc)
+        for m in self.modules():                                    # reference zeroes every Linear bias (:360-374)
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+    # -- pooling ------------------------------------------------------------------------
+    def _pooling(self, vertex_features, pool_map):
+        if self._pooling_type == 'mean':
+            return SF.PoolMeanFn.apply(vertex_features, pool_map)
+        if self._pooling_type == 'max':
+            return SF.PoolMaxFn.apply(vertex_features, pool_map)
+        raise ValueError('Unknown pooling type {}'.format(self._pooling_type))
+
+    def _unpooling(self, vertex_features, pool_map):
+        return SF.UnpoolFn.apply(vertex_features, pool_map)
+
+    def _norm_arg(self, plan, level, whole_batch=False):
+        """What a block's norm receives: NormGroups for the instance norm; for the other norms the
+        reference's `batch` tensor / None."""
+        if self.norm is M.FastInstanceNorm:
+            g = plan.norm_groups(level, whole_batch)
+            return g
+        return None if whole_batch else plan.batch_vector(level)
+
+    def forward(self, sample):
+        plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm)
+        for m in self.modules():
+            if isinstance(m, M.FastInstanceNorm):
+                m.linspace_quirk = self.compat_linspace_norm
+        num_levels = len(self.decoder_blocks) + 1
+        out = sample.x
+        e0 = plan.edges('edge_index', 0)
+        for blk in self.input_blocks:                               # norm over the WHOLE batch (reference :406-407)
+            out = blk(out, e0, self._norm_arg(plan, 0, whole_batch=True))
+        for i, blk in enumerate(self.encoder_blocks):
+            level = i + 1
+            out = self._pooling(out, plan.pool(level))
+            out = blk(out, plan.edges('hierarchy_edge_index_%d' % level, level), self._norm_arg(plan, level))
+        last = num_levels - 1
+        for i, blk in enumerate(self.bottleneck_blocks):
+            if self.dilations[i] > 1:
+                key = 'hierarchy_dil_{}_edge_index_{}'.format(self.dilations[i], last)
+            else:
+                key = 'hierarchy_edge_index_{}'.format(last)
+            edges = e0 if last == 0 and self.dilations[i] <= 1 else plan.edges(key, last)
+            out = blk(out, edges, self._norm_arg(plan, last))
+        for i, blk in enumerate(self.decoder_blocks):
+            level = i + 1
+            out = self._unpooling(out, plan.pool(num_levels - level))
+            tgt = num_levels - level - 1
+            edges = e0 if tgt == 0 else plan.edges('hierarchy_edge_index_%d' % tgt, tgt)
+            out = blk(out, edges, self._norm_arg(plan, tgt))
+        for blk in self.output_blocks:
+            out = blk(out, e0, self._norm_arg(plan, 0, whole_batch=True))
+        out = self.final_linear1(out)
+        if self.norm is M.FastInstanceNorm:                         # per-graph branch even for B = 1 (:465, Q3)
+            out = SF.InstanceNormActResFn.apply(out, None, plan.norm_groups(0), True)
+        else:
+            out = F.elu(self.final_norm1(out, batch=sample.batch))
+        out = torch.tanh(self.final_linear2(out))
+        plan.validate()
+        return out
+
+
+def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[]):
+    """Reference :138-154: only moves the net to gpu_ids[0]; weights keep torch's default init."""
+    if len(gpu_ids) > 0:
+        net.to(gpu_ids[0])
+    return net
+
+
+def define_G(input_nc, output_nc, ngf, filter_type, norm='batch', dilation_order=0, use_dropout=False, n_blocks=6,
+             n_levels=2, n_repeated_io_convs=1, init_type='normal', pooling_type='stride',
+             io_receptive_field_type='large', checkpoint_bottleneck=False, num_blocks_per_uncheckpointed_block=1,
+             use_label_embedding=False, num_classes=None, num_embedding=None, dilations=None, init_gain=0.02,
+             gpu_ids=[]):
+    """Create the generator - same signature as the reference's define_G (:157-161)."""
+    if filter_type in ('conv2d', 'cfconv2d'):
+        raise NotImplementedError('the dense Conv2d baselines (Resnet2D) are outside the STINet graph hot path')
+    net = SurfaceTextureInpaintingNet(
+        input_nc, output_nc, filter_type, ngf, norm_type=norm, n_blocks=n_blocks, n_levels=n_levels,
+        n_repeated_io_convs=n_repeated_io_convs, pooling_type=pooling_type,
+        checkpoint_bottleneck=checkpoint_bottleneck,
+        num_blocks_per_uncheckpointed_block=num_blocks_per_uncheckpointed_block,
+        use_label_embedding=use_label_embedding, num_classes=num_classes, num_embedding=num_embedding,
+        dilations=dilations)
+    return init_net(net, init_type, init_gain, gpu_ids)
