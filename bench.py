@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: vertices/sec, forward+backward(+optimizer) of SurfaceTextureInpaintingNet on a
+synthetic ScanNet-sized mesh (BASELINE.json: 200k vertices / 1.2M directed edges, 3 graph levels, fp32,
+the shipped 3-D config), one scene per GPU, pure data parallel with one RCCL gradient all-reduce.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = GraphPlan (CSR) build from the int64 index tensors + forward + masked weighted L1 loss +
+backward + flat-bucket gradient all-reduce + Adam(amsgrad) update, on inputs already resident in HBM.
+Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for the roofline / cpu_baseline definitions.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md, chip-level parameters)
+
+CONFIG_3D = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=9,
+                 n_levels=2, pooling_type='max', dilations=[1, 1, 1, 2, 4, 8, 16, 1, 1], checkpoint_bottleneck=True,
+                 num_blocks_per_uncheckpointed_block=1)
+
+
+def edge_bytes(kernel, n, e, h):
+    """Algorithmic bytes per launch: gathered rows are charged once
+    per edge (no cache credit), fp32, int32 indices."""
+    idx = 4 * e + 4 * (n + 1)
+    if kernel == 'stin_edge_relu_mean_fwd_f32':      # gather B per edge, read A, write h
+        return (e * h + 2 * n * h) * 4 + idx
+    if kernel == 'stin_edge_relu_mean_bwd_dst_f32':  # gather B per edge, read A and G, write dA
+        return (e * h + 3 * n * h) * 4 + idx
+    if kernel == 'stin_edge_relu_mean_bwd_src_f32':  # gather A and G per edge, read B, write dB, inv_deg per edge
+        return (2 * e * h + 2 * n * h) * 4 + idx + 4 * e
+    raise KeyError(kernel)
+
+
+def scatter_add_standalone(device, n=200_000, e=1_200_000, c=64, iters=30):
+    """The standalone scatter-add of BASELINE.md §4: src[E, C] -> out[N, C], index in arbitrary edge order."""
+    from surface_texture_inpainting_net_amd import functional as SF
+    from surface_texture_inpainting_net_amd.plan import build_csr
+    g = torch.Generator().manual_seed(0)
+    index = torch.randint(0, n, (e,), generator=g).to(device)
+    src = torch.randn(e, c, device=device)
+    bad = torch.zeros(1, dtype=torch.int32, device=device)
+    csr = build_csr(index, None, n, e, bad, want_perm=True)
+    for _ in range(3):
+        SF.segment_sum(src, csr.rowptr, csr.perm, n)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        SF.segment_sum(src, csr.rowptr, csr.perm, n)
+    b.record()
+    torch.cuda.synchronize()
+    dt = a.elapsed_time(b) * 1e-3 / iters
+    nbytes = e * c * 4 + n * c * 4 + 4 * e + 4 * (n + 1)
+    return {'E': e, 'N': n, 'C': c, 'us': dt * 1e6, 'algorithmic_MB': nbytes / 1e6,
+            'GBps': nbytes / dt / 1e9, 'frac_of_hbm_peak': nbytes / dt / 1e9 / HBM_PEAK_GBS}
+
+
+def cpu_baseline(n0_target, levels, seed):
+    """The CPU oracle (op-for-op unfused PyG form) timed on this box's host cores, on a bounded sample."""
+    from oracle import stin_oracle
+    from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
+    torch.set_num_threads(os.cpu_count() or 1)
+    torch.manual_seed(49)
+    net = stin_oracle.define_G(**CONFIG_3D)
+
+    def run(sample):
+        net.zero_grad(set_to_none=True)
+        t = time.perf_counter()
+        loss = stin_oracle.compute_loss(stin_oracle.graph_forward(net, sample), sample.color, sample.mask)
+        loss.backward()
+        return time.perf_counter() - t
+
+    probe = make_synthetic_mesh(20_000, levels, seed=seed)
+    run(probe)                                   # warm-up (allocator, threads)
+    t_probe = run(probe)
+    per_vertex = t_probe / probe.x.shape[0]
+    n0 = n0_target if per_vertex * n0_target <= 45.0 else max(20_000, int(30.0 / per_vertex))
+    if n0 == probe.x.shape[0]:
+        sample, t = probe, t_probe
+    else:
+        sample = make_synthetic_mesh(n0, levels, seed=seed)
+        t = run(sample)
+    nv = sample.x.shape[0]
+    return {'value': nv / t, 'unit': 'vertices/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'one fwd+loss+bwd of the CPU oracle (unfused PyG-form restatement, torch %s CPU, fp32) on a '
+                      'synthetic %d-vertex %d-level mesh, %.1f s' % (torch.__version__, nv, levels, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--vertices', type=int, default=200_000)
+    ap.add_argument('--levels', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cache-plan', action='store_true', help='reuse the CSR plan across steps (NOT the headline)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    from surface_texture_inpainting_net_amd import _lib
+    from surface_texture_inpainting_net_amd import functional as SF
+    from surface_texture_inpainting_net_amd import surfacetextureinpaintingnet as S
+    from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
+    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    _lib.load()
+
+    torch.manual_seed(49)                                   # reference config seed; identical replicas
+    net = S.define_G(**CONFIG_3D).to(device)
+    step = TrainStep(net, lr=7e-5, amsgrad=True)
+    sample = make_synthetic_mesh(args.vertices, args.levels, seed=rank).to(device)   # one scene per rank
+    n0 = sample.x.shape[0]
+    e0 = sample.edge_index.shape[1]
+
+    def one_step():
+        if not args.cache_plan:
+            sample._plan_cache = None                       # rebuild the CSR plan: part of the step
+        return step(sample)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    SF.KernelTimer.start(['stin_edge_relu_mean_fwd_f32', 'stin_edge_relu_mean_bwd_dst_f32',
+                          'stin_edge_relu_mean_bwd_src_f32'])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    ktimes = SF.KernelTimer.stop()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        nv = torch.tensor([n0], dtype=torch.float64, device=device)
+        dist.all_reduce(nv, op=dist.ReduceOp.SUM)
+        total_vertices = float(nv.item())
+    else:
+        total_vertices = float(n0)
+
+    if rank == 0:
+        table = []
+        for (name, tag), ts in ktimes.items():
+            n, e, h = tag
+            nbytes = edge_bytes(name, n, e, h)
+            avg = sum(ts) / len(ts)
+            table.append({'kernel': name, 'N': n, 'E': e, 'H': h, 'launches': len(ts), 'avg_us': avg * 1e6,
+                          'total_ms': sum(ts) * 1e3, 'algorithmic_MB': nbytes / 1e6, 'GBps': nbytes / avg / 1e9})
+        table.sort(key=lambda r: -r['total_ms'])
+        dom = table[0]
+        roofline = {'bound': 'hbm', 'kernel': '%s[N=%d,E=%d,H=%d]' % (dom['kernel'], dom['N'], dom['E'], dom['H']),
+                    'achieved': dom['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom['GBps'] / HBM_PEAK_GBS,
+                    'traffic': None, 'avg_us': dom['avg_us'], 'algorithmic_MB': dom['algorithmic_MB']}
+        edge_total_ms = sum(r['total_ms'] for r in table) / args.steps
+        out = {
+            'metric': 'vertices/sec forward+backward on 200k-vert ScanNet mesh; scatter-add GB/s vs HBM roofline',
+            'value': total_vertices * args.steps / dt, 'unit': 'vertices/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'SurfaceTextureInpaintingNet 3-D config (ngf 64, n_levels 2, n_blocks 9, '
+                                   'edgeconvtransinv, instance norm, max pool, dilations 1-16), synthetic %d-vertex / '
+                                   '%d-directed-edge %d-level mesh per GPU, fp32; step = CSR plan build + fwd + '
+                                   'masked L1 + bwd + grad all-reduce + Adam(amsgrad)' % (n0, e0, args.levels),
+                       'vertices_per_gpu': n0, 'edges_per_gpu': e0, 'levels': args.levels, 'params': 4202051,
+                       'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan},
+            'loss': float(loss),
+            'roofline': roofline,
+            'edge_stage_ms_per_step': edge_total_ms,
+            'edge_kernels': table[:6],
+        }
+        if world == 1:
+            out['scatter_add'] = scatter_add_standalone(device)
+            if not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline(args.vertices, args.levels, seed=0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -63,10 +63,10 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd(const float* __restrict__ A,
         }
     }
     const int deg = end - beg;
-    const float s = 1.0f / (float)(deg > 0 ? deg : 1);
+    const float s = (float)(deg > 0 ? deg : 1);      // true division, as torch_scatter's scatter_mean (sum / count)
 #pragma unroll
     for (int k = 0; k < VPL; ++k)
-        if (on[k]) st4(out + L.row * ldo + L.chan(k), make_float4(acc[k].x * s, acc[k].y * s, acc[k].z * s, acc[k].w * s));
+        if (on[k]) st4(out + L.row * ldo + L.chan(k), make_float4(acc[k].x / s, acc[k].y / s, acc[k].z / s, acc[k].w / s));
     if (indicator && L.lg == 0) st4(out + L.row * ldo + H, make_float4(deg > 0 ? 1.f : 0.f, 0.f, 0.f, 0.f));
 }
 
@@ -211,11 +211,11 @@ __global__ __launch_bounds__(BLOCK) void k_segment_sum(const float* __restrict__
     float s = 1.f;
     if (mean) {
         const int deg = end - beg;
-        s = 1.0f / (float)(deg > 0 ? deg : 1);
+        s = (float)(deg > 0 ? deg : 1);
     }
 #pragma unroll
     for (int k = 0; k < VPL; ++k)
-        if (on[k]) st4(out + L.row * ldo + L.chan(k), make_float4(acc[k].x * s, acc[k].y * s, acc[k].z * s, acc[k].w * s));
+        if (on[k]) st4(out + L.row * ldo + L.chan(k), make_float4(acc[k].x / s, acc[k].y / s, acc[k].z / s, acc[k].w / s));
 }
 
 // ------------------------------------------------------------------------- max pool
@@ -334,7 +334,7 @@ __global__ void k_scalar(const float* __restrict__ p0, int64_t ld0, const float*
     if (OP == OP_EDGE_FWD) {  // p0 = A, p1 = B
         const float a = p0[r * ld0 + c];
         for (int e = beg; e < end; ++e) acc += fmaxf(a + p1[(int64_t)col[e] * ld1 + c], 0.f);
-        out[r * ldo + c] = acc * s;
+        out[r * ldo + c] = acc / (float)(deg > 0 ? deg : 1);
         if (flag && c < 4) out[r * ldo + C + c] = (c == 0 && deg > 0) ? 1.f : 0.f;
     } else if (OP == OP_EDGE_BWD_DST) {  // p0 = A, p1 = B, p2 = G
         const float a = p0[r * ld0 + c];
@@ -349,7 +349,7 @@ __global__ void k_scalar(const float* __restrict__ p0, int64_t ld0, const float*
         out[r * ldo + c] = acc;
     } else if (OP == OP_SEG_SUM) {  // p0 = src, flag = mean
         for (int e = beg; e < end; ++e) acc += p0[(col != nullptr ? (int64_t)col[e] : (int64_t)e) * ld0 + c];
-        out[r * ldo + c] = flag ? acc * s : acc;
+        out[r * ldo + c] = flag ? acc / (float)(deg > 0 ? deg : 1) : acc;
     } else if (OP == OP_POOL_MAX) {  // p0 = x
         float best = 0.f;
         int who = -1;

@@ -23,7 +23,36 @@ def _mat(t):
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
 
 
-def _call(name, *args):
+class KernelTimer:
+    """Optional HIP-event bracket around chosen C-ABI launches (bench.py's live roofline numbers).
+    Events are recorded on the stream the kernel is enqueued on (torch's current stream)."""
+    enabled = False
+    names = ()
+    records = []          # (name, tag, start_event, end_event)
+
+    @classmethod
+    def start(cls, names):
+        cls.enabled, cls.names, cls.records = True, tuple(names), []
+
+    @classmethod
+    def stop(cls):
+        cls.enabled = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, tag, a, b in cls.records:
+            out.setdefault((name, tag), []).append(a.elapsed_time(b) * 1e-3)
+        cls.records = []
+        return out
+
+
+def _call(name, *args, tag=None):
+    if KernelTimer.enabled and name in KernelTimer.names:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.check(getattr(_lib.load(), name)(*args), name)
+        b.record()
+        KernelTimer.records.append((name, tag, a, b))
+        return
     _lib.check(getattr(_lib.load(), name)(*args), name)
 
 
@@ -33,7 +62,7 @@ def edge_relu_mean_fwd(A, B, csr, out, indicator=False):
     B, ldb = _mat(B)
     H = A.shape[1]
     _call('stin_edge_relu_mean_fwd_f32', _ptr(A), lda, _ptr(B), ldb, _ptr(csr.rowptr), _ptr(csr.col), A.shape[0], H,
-          _ptr(out), out.stride(0), int(indicator), _stream(A))
+          _ptr(out), out.stride(0), int(indicator), _stream(A), tag=(A.shape[0], csr.n_entries, H))
     return out
 
 
@@ -42,7 +71,7 @@ def edge_relu_mean_bwd_dst(A, B, G, csr, dA):
     B, ldb = _mat(B)
     G, ldg = _mat(G)
     _call('stin_edge_relu_mean_bwd_dst_f32', _ptr(A), lda, _ptr(B), ldb, _ptr(G), ldg, _ptr(csr.rowptr), _ptr(csr.col),
-          A.shape[0], A.shape[1], _ptr(dA), dA.stride(0), _stream(A))
+          A.shape[0], A.shape[1], _ptr(dA), dA.stride(0), _stream(A), tag=(A.shape[0], csr.n_entries, A.shape[1]))
     return dA
 
 
@@ -51,7 +80,8 @@ def edge_relu_mean_bwd_src(A, B, G, inv_deg, csr_src, dB):
     B, ldb = _mat(B)
     G, ldg = _mat(G)
     _call('stin_edge_relu_mean_bwd_src_f32', _ptr(A), lda, _ptr(B), ldb, _ptr(G), ldg, _ptr(inv_deg),
-          _ptr(csr_src.rowptr), _ptr(csr_src.col), A.shape[0], A.shape[1], _ptr(dB), dB.stride(0), _stream(A))
+          _ptr(csr_src.rowptr), _ptr(csr_src.col), A.shape[0], A.shape[1], _ptr(dB), dB.stride(0), _stream(A),
+          tag=(A.shape[0], csr_src.n_entries, A.shape[1]))
     return dB
 
 
@@ -115,6 +145,9 @@ def colsum(x):
 def instance_stats(x, groups):
     """-> (mean, rstd) [B, C]: biased variance, eps inside the sqrt (F.instance_norm /
     FastInstanceNorm semantics, reference models/modules/fastinstancenorm.py:44-98)."""
+    if groups.gid is None and x.shape[0] == 1:   # F.instance_norm's own check on the batch=None branch
+        raise ValueError('Expected more than 1 spatial element when training, got input size {}'.format(
+            torch.Size([1, x.shape[1], 1])))
     mean = colreduce(RED_SUM, x, groups, groups.ptr_sum, post=POST_SCALE)
     rstd = colreduce(RED_CSQ, x, groups, groups.ptr_sum, mean=mean, post=POST_RSTD)
     return mean, rstd

@@ -1,0 +1,381 @@
+"""GPU parity tests proper: every case goes through the C ABI of libstin_hip.so (via the autograd
+layer) on a real MI355X and is compared with the CPU oracle on the same seeded inputs, with the
+committed golden fixtures (generated from the reference's own classes), and - at BASELINE.json's
+full 200k-vertex size - through size-independent properties.
+
+Tolerances (BASELINE.json north_star / SURVEY §8d): forward max-abs <= 1e-4 in fp32 versus the CPU
+reference; integer / index results (CSR plans, pool arg-max, batch vectors) bit-exact; gradients
+within 1e-3 of the fixture-wide gradient scale (summation-order noise over 1e5-1e6 terms).
+"""
+import numpy as np
+import pytest
+import torch
+
+from _golden import MODEL_FIXTURES, ModelFixture, load_npz
+from oracle import scatter_ops, stin_oracle
+from surface_texture_inpainting_net_amd import functional as SF
+from surface_texture_inpainting_net_amd import modules as M
+from surface_texture_inpainting_net_amd import surfacetextureinpaintingnet as S
+from surface_texture_inpainting_net_amd.data import HierarchicalBatch
+from surface_texture_inpainting_net_amd.plan import EdgeSet, GraphPlan, NormGroups, PoolMap, build_csr, plan_for
+from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+FWD_TOL = 1e-4
+
+
+def _bad():
+    return torch.zeros(1, dtype=torch.int32, device=DEV)
+
+
+def _random_graph(n, e, seed, isolated=5):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(isolated, n, (e,), generator=g)      # vertices < isolated have no in-edge
+    return torch.stack([src, dst])
+
+
+# ------------------------------------------------------------------------------- plan
+@pytest.mark.parametrize('n,e', [(1, 0), (7, 1), (50, 400), (1000, 0), (4099, 30011), (200_000, 1_200_000)])
+def test_csr_plan_bit_exact(n, e):
+    g = torch.Generator().manual_seed(n + e)
+    key = torch.randint(0, n, (e,), generator=g)
+    val = torch.randint(0, n + 3, (e,), generator=g)
+    bad = _bad()
+    csr = build_csr(key.to(DEV), val.to(DEV), n, n + 3, bad, want_perm=True)
+    order = np.argsort(key.numpy(), kind='stable')
+    cnt = np.bincount(key.numpy(), minlength=n)
+    rowptr = np.concatenate([[0], np.cumsum(cnt)])
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(csr.perm.cpu().numpy(), order)
+    assert np.array_equal(csr.col.cpu().numpy(), val.numpy()[order])
+    assert np.array_equal(csr.inv_deg.cpu().numpy(), (1.0 / np.maximum(cnt, 1)).astype(np.float32))
+    assert int(bad.item()) == 0
+
+
+def test_csr_flags_out_of_range_indices():
+    key = torch.tensor([0, 1, 5, 2], device=DEV)
+    bad = _bad()
+    build_csr(key, None, 4, 4, bad)
+    assert int(bad.item()) != 0
+    bad = _bad()
+    build_csr(torch.tensor([0, 1], device=DEV), torch.tensor([0, -1], device=DEV), 4, 4, bad)
+    assert int(bad.item()) != 0
+    s = make_synthetic_mesh(100, 2, seed=0, dilations=()).to(DEV)
+    s['hierarchy_trace_index_1'][3] = 10_000
+    net = S.define_G(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconv', norm='instance', n_blocks=1, n_levels=1,
+                     pooling_type='max').to(DEV)
+    with pytest.raises(IndexError):
+        net(s)
+
+
+# ------------------------------------------------------------------------- edge stage
+def _edge_oracle(A, B, ei):
+    return scatter_ops.scatter_mean(torch.relu(A[ei[1]] + B[ei[0]]), ei[1], dim=0, dim_size=A.shape[0])
+
+
+@pytest.mark.parametrize('H', [4, 6, 16, 24, 64, 128, 256, 512, 1024])
+def test_edge_stage_forward_backward(H):
+    n, e = 777, 5000
+    ei = _random_graph(n, e, seed=H)
+    g = torch.Generator().manual_seed(H)
+    A = torch.randn(n, H, generator=g, requires_grad=True)
+    B = torch.randn(n, H, generator=g, requires_grad=True)
+    W = torch.randn(n, H, generator=g)
+    want = _edge_oracle(A, B, ei)
+    (want * W).sum().backward()
+    es = EdgeSet(ei.to(DEV), n, _bad())
+    Ad = A.detach().to(DEV).requires_grad_(True)
+    Bd = B.detach().to(DEV).requires_grad_(True)
+    got = SF.EdgeReluMeanFn.apply(Ad, Bd, es)
+    (got * W.to(DEV)).sum().backward()
+    assert float((got.cpu() - want).abs().max()) <= 2e-6
+    assert float(got[:5].abs().max()) == 0.0                   # no in-edges -> exactly 0
+    assert float((Ad.grad.cpu() - A.grad).abs().max()) <= 1e-5
+    assert float((Bd.grad.cpu() - B.grad).abs().max()) <= 1e-5
+
+
+def test_edge_stage_on_column_slices_and_indicator():
+    n, H = 300, 32
+    ei = _random_graph(n, 2000, seed=1)
+    Y = torch.randn(n, 2 * H + 8, device=DEV)
+    es = EdgeSet(ei.to(DEV), n, _bad())
+    hE = torch.full((n, H + 4), 7.0, device=DEV)
+    SF.edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], es.by_dst, hE, indicator=True)
+    want = _edge_oracle(Y[:, :H].cpu(), Y[:, H:2 * H].cpu(), ei)
+    assert float((hE[:, :H].cpu() - want).abs().max()) <= 2e-6
+    deg = torch.bincount(ei[1], minlength=n)
+    assert torch.equal(hE[:, H].cpu(), (deg > 0).float())
+    assert float(hE[:, H + 1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('trans_inv', [False, True])
+def test_edgeconv_filter_matches_unfused_pyg_form(trans_inv):
+    n, cin, cout = 500, 10, 16
+    ei = _random_graph(n, 3000, seed=2)
+    torch.manual_seed(5)
+    f = M.get_gcn_filter(cin, cout, module=M.EdgeConvTransInv if trans_inv else None, double_input=not trans_inv)
+    for p in f.parameters():
+        if p.dim() == 1:
+            torch.nn.init.normal_(p, 0, 0.3)
+    x = torch.randn(n, cin)
+    want = stin_oracle.edge_conv(x, ei, f.nn[0].weight, f.nn[0].bias, f.nn[2].weight, f.nn[2].bias, trans_inv)
+    got = f.to(DEV)(x.to(DEV), ei.to(DEV))
+    assert float((got.cpu() - want).abs().max()) <= 1e-5
+    assert float(got[:5].abs().max()) == 0.0
+
+
+# --------------------------------------------------------- segment sum / pool / unpool
+@pytest.mark.parametrize('C', [1, 3, 8, 64, 100, 256])
+def test_segment_sum_matches_scatter_and_is_linear(C):
+    n, e = 400, 3000
+    g = torch.Generator().manual_seed(C)
+    idx = torch.randint(3, n, (e,), generator=g)
+    src = torch.randn(e, C, generator=g)
+    src2 = torch.randn(e, C, generator=g)
+    csr = build_csr(idx.to(DEV), None, n, e, _bad(), want_perm=True)
+    got = SF.ScatterAddFn.apply(src.to(DEV), csr)
+    want = scatter_ops.scatter_sum(src, idx, dim=0, dim_size=n)
+    assert torch.equal(got.cpu(), want), 'same summation order as the sequential CPU scatter_add -> bit-exact'
+    got_mean = SF.segment_sum(src.to(DEV), csr.rowptr, csr.perm, n, mean=True)
+    assert float((got_mean.cpu() - scatter_ops.scatter_mean(src, idx, dim=0, dim_size=n)).abs().max()) <= 1e-6
+    both = SF.ScatterAddFn.apply((src + 2 * src2).to(DEV), csr)
+    assert float((both - (got + 2 * SF.ScatterAddFn.apply(src2.to(DEV), csr))).abs().max()) <= 1e-4
+
+
+def test_pool_unpool_against_reference_fixture():
+    z = {k: torch.from_numpy(v) for k, v in load_npz('g4_per_op').items()}
+    xv, trace = z['pool.x'], z['pool.trace']
+    pm = PoolMap(trace.to(DEV), 7, 5, _bad())
+    assert pm.children.col.cpu().tolist() == [0, 1, 2, 3, 6, 4, 5]
+    for kind, fn in (('max', SF.PoolMaxFn), ('mean', SF.PoolMeanFn)):
+        xx = xv.clone().to(DEV).requires_grad_(True)
+        y = fn.apply(xx, pm)
+        assert torch.equal(y.cpu(), z['pool.%s.y' % kind]), kind
+        (y * torch.arange(1., 16.).view(5, 3).to(DEV)).sum().backward()
+        if kind == 'max':
+            assert torch.equal(xx.grad.cpu(), z['pool.%s.gx' % kind]), kind
+        else:   # g * (1/count) vs the reference's g / count: 1 ulp
+            assert float((xx.grad.cpu() - z['pool.%s.gx' % kind]).abs().max()) <= 1e-6
+    xx = z['unpool.x'].clone().to(DEV).requires_grad_(True)
+    y = SF.UnpoolFn.apply(xx, pm)
+    assert torch.equal(y.cpu(), z['unpool.y'])
+    (y * torch.arange(1., 22.).view(7, 3).to(DEV)).sum().backward()
+    assert torch.equal(xx.grad.cpu(), z['unpool.gx'])
+    bvec = torch.tensor([0, 0, 0, 1, 1, 1, 1], device=DEV)
+    assert torch.equal(SF.batch_pool(bvec, pm).cpu(), z['batch.pooled'])
+
+
+@pytest.mark.parametrize('C', [3, 8, 64, 128, 320])
+def test_pool_max_random_with_ties_bit_exact(C):
+    n_f, n_c = 5000, 1500
+    g = torch.Generator().manual_seed(C)
+    trace = torch.randint(0, n_c, (n_f,), generator=g)
+    x = torch.randint(-3, 4, (n_f, C), generator=g).float()          # many exact ties
+    x.requires_grad_(True)
+    w = torch.randn(n_c, C, generator=g)
+    want, arg = scatter_ops.scatter_max(x, trace, dim=0, dim_size=n_c)
+    (want * w).sum().backward()
+    pm = PoolMap(trace.to(DEV), n_f, n_c, _bad())
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = SF.PoolMaxFn.apply(xd, pm)
+    (got * w.to(DEV)).sum().backward()
+    assert torch.equal(got.cpu(), want.detach())
+    assert torch.equal(xd.grad.cpu(), x.grad), 'gradient goes to the FIRST arg-max only'
+
+
+def test_batch_vector_propagation_bit_exact():
+    fx = ModelFixture('g3_batch2_unequal')
+    s = fx.sample(DEV)
+    plan = GraphPlan(s)
+    b = fx.sample().batch
+    for lvl in (1, 2):
+        tr = fx.sample()['hierarchy_trace_index_%d' % lvl]
+        n = int(fx.sample().num_vertices.sum(0)[lvl])
+        b = stin_oracle.pool_batch(b, tr, n)
+        got = plan.batch_vector(lvl)
+        assert got.dtype == torch.int64 and torch.equal(got.cpu(), b)
+    up = SF.batch_unpool(plan.batch_vector(2), plan.pool(2))
+    assert torch.equal(up.cpu(), b.index_select(0, fx.sample()['hierarchy_trace_index_2']))
+
+
+# ------------------------------------------------------------------------------- norms
+def test_instance_norm_variants_against_reference_fixture():
+    z = {k: torch.from_numpy(v) for k, v in load_npz('g4_per_op').items()}
+    x = z['norm.x']
+    fi = M.FastInstanceNorm(5)
+    for tag, b in (('none', None), ('zeros', torch.zeros(60, dtype=torch.long)), ('eq', z['norm.b_eq']),
+                   ('un', z['norm.b_un'])):
+        xx = x.clone().to(DEV).requires_grad_(True)
+        y = fi(xx, None if b is None else b.to(DEV))
+        assert float((y.cpu() - z['fin.%s.y' % tag]).abs().max()) <= 2e-6, tag
+        (y * torch.linspace(-1, 1, y.numel()).view_as(y).to(DEV)).sum().backward()
+        assert float((xx.grad.cpu() - z['fin.%s.gx' % tag]).abs().max()) <= 5e-5, tag
+    gn = M.SingleBatchGraphNorm(5).to(DEV)
+    with torch.no_grad():
+        gn.weight.copy_(z['gn.weight'])
+        gn.bias.copy_(z['gn.bias'])
+        gn.mean_scale.copy_(z['gn.mean_scale'])
+    for tag, b in (('none', None), ('un', z['norm.b_un'])):
+        xx = x.clone().to(DEV).requires_grad_(True)
+        y = gn(xx, None if b is None else b.to(DEV))
+        assert float((y.cpu() - z['gn.%s.y' % tag]).abs().max()) <= 5e-6, tag
+        (y * torch.linspace(-1, 1, y.numel()).view_as(y).to(DEV)).sum().backward()
+        assert float((xx.grad.cpu() - z['gn.%s.gx' % tag]).abs().max()) <= 5e-5, tag
+        assert float((gn.weight.grad.cpu() - z['gn.%s.gweight' % tag]).abs().max()) <= 5e-5
+        gn.zero_grad()
+
+
+@pytest.mark.parametrize('n,c', [(2, 4), (3, 7), (5000, 64), (100_000, 128), (777, 1024)])
+def test_instance_norm_large_and_ragged(n, c):
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, c, generator=g) * 3 + 50).requires_grad_(True)   # large mean: cancellation stress
+    w = torch.randn(n, c, generator=g)
+    want = torch.nn.functional.elu(stin_oracle.fast_instance_norm(x))
+    (want * w).sum().backward()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = SF.InstanceNormActResFn.apply(xd, None, NormGroups(n, torch.device(DEV)), True)
+    (got * w.to(DEV)).sum().backward()
+    assert float((got.detach().cpu() - want.detach()).abs().max()) <= 2e-4
+    if n > 3:
+        assert float((xd.grad.cpu() - x.grad).abs().max()) <= 1e-3 * float(x.grad.abs().max()) + 1e-6
+
+
+def test_instance_norm_single_vertex_raises_like_reference():
+    with pytest.raises(ValueError):
+        M.FastInstanceNorm(4)(torch.randn(1, 4, device=DEV))
+
+
+# ------------------------------------------------------------------------------ blocks
+def test_graph_resnet_block_against_reference_fixture():
+    z = {k: torch.from_numpy(v) for k, v in load_npz('g4_per_op').items()}
+    ei = z['ei'].to(DEV)
+    for tag, cin, cout, batch in (('neq', 6, 8, None), ('eq', 8, 8, None), ('eqb', 8, 8, z['batch_uneq'])):
+        blk = S.GraphResnetBlock(cin, cout, M.get_gcn_filter, M.FastInstanceNorm, False, True)
+        sd = {k[len('blk_%s.sd.' % tag):]: v for k, v in z.items() if k.startswith('blk_%s.sd.' % tag)}
+        blk.load_state_dict(sd)
+        blk = blk.to(DEV)
+        x = z['blk_%s.x' % tag].to(DEV).requires_grad_(True)
+        y = blk(x, ei, None if batch is None else batch.to(DEV))          # raw tensors, like an external caller
+        assert float((y.cpu() - z['blk_%s.y' % tag]).abs().max()) <= 1e-5, tag
+        (y * z['blk_%s.w' % tag].to(DEV)).sum().backward()
+        scale = max(float(v.abs().max()) for k, v in z.items() if k.startswith('blk_%s.g.' % tag))
+        assert float((x.grad.cpu() - z['blk_%s.gx' % tag]).abs().max()) <= 1e-3 * float(z['blk_%s.gx' % tag].abs().max())
+        for k, p in blk.named_parameters():
+            assert float((p.grad.cpu() - z['blk_%s.g.%s' % (tag, k)]).abs().max()) <= 1e-3 * scale, (tag, k)
+
+
+# ------------------------------------------------------------------------------ models
+@pytest.mark.parametrize('name', MODEL_FIXTURES)
+def test_model_against_reference_fixture(name):
+    fx = ModelFixture(name)
+    net = S.define_G(**fx.cfg)
+    net.load_state_dict(fx.state_dict)
+    net = net.to(DEV)
+    s = fx.sample(DEV)
+    s.x = s.x.clone().requires_grad_(True)
+    out = net(s)
+    assert out.shape == fx.out.shape
+    assert float((out.detach().cpu() - fx.out).abs().max()) <= FWD_TOL
+    pred = torch.where((s.mask > 0).expand_as(s.color), out, s.color)
+    loss = stin_oracle.compute_loss(pred, s.color, weights=s.mask)
+    assert abs(float(loss.detach()) - float(fx.loss)) <= 1e-6
+    loss.backward()
+    scale = max(float(g.abs().max()) for g in fx.grads.values())
+    assert float((s.x.grad.cpu() - fx.gx).abs().max()) <= 1e-3 * float(fx.gx.abs().max())
+    for k, p in net.named_parameters():
+        assert float((p.grad.cpu() - fx.grads[k]).abs().max()) <= 1e-3 * scale, k
+
+
+def test_train_step_against_reference_fixture():
+    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    fx = ModelFixture('g7_train_step')
+    net = S.define_G(**fx.cfg)
+    net.load_state_dict(fx.state_dict)
+    step = TrainStep(net.to(DEV), lr=7e-5, amsgrad=True)
+    loss = step(fx.sample(DEV))
+    assert abs(float(loss) - float(fx.loss)) <= 1e-6
+    for k, v in step.model.state_dict().items():
+        ok = fx.grads[k].abs() > 1e-5
+        assert torch.allclose(v.cpu()[ok], fx.state_dict_after[k][ok], rtol=0, atol=5e-7), k
+
+
+def test_model_batched_true_per_graph_mode_equals_separate_graphs():
+    """compat_linspace_norm=False: correct segmented statistics; the encoder/bottleneck/decoder
+    blocks then treat each graph of the batch independently (io blocks still share statistics, Q1)."""
+    fx = ModelFixture('g3_batch2_unequal')
+    net = S.define_G(**fx.cfg)
+    net.load_state_dict(fx.state_dict)
+    net = net.to(DEV)
+    net.compat_linspace_norm = False
+    out = net(fx.sample(DEV))
+    assert torch.isfinite(out).all() and out.shape == fx.out.shape
+    # differs from the quirk output (unequal graphs) but stays a valid tanh output
+    assert float((out.cpu() - fx.out).abs().max()) > 1e-3 and float(out.abs().max()) < 1.0
+
+
+# ------------------------------------------- full-size (BASELINE.json) property checks
+@pytest.fixture(scope='module')
+def big():
+    s = make_synthetic_mesh(200_000, 3, seed=0)
+    return s, s.to(DEV)
+
+
+def test_full_size_forward_backward_deterministic_and_bounded(big):
+    s_cpu, s = big
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=9,
+               n_levels=2, pooling_type='max', dilations=[1, 1, 1, 2, 4, 8, 16, 1, 1], checkpoint_bottleneck=True)
+    torch.manual_seed(49)
+    net = S.define_G(**cfg).to(DEV)
+    outs, grads = [], []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        out = net(s)
+        loss = stin_oracle.compute_loss(torch.where((s.mask > 0).expand_as(s.color), out, s.color), s.color, s.mask)
+        loss.backward()
+        outs.append(out.detach().clone())
+        grads.append(net.input_blocks[0].first_filter.nn[0].weight.grad.clone())
+    assert outs[0].shape == (200_704, 3) and torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) < 1.0
+    assert torch.equal(outs[0], outs[1]), 'no float atomics: forward is bit-reproducible'
+    assert torch.equal(grads[0], grads[1]) or float((grads[0] - grads[1]).abs().max()) <= 1e-7 * float(grads[0].abs().max())
+
+
+def test_full_size_segment_sum_properties(big):
+    _, s = big
+    n = s.x.shape[0]
+    plan = plan_for(s)
+    e = plan.edges('edge_index', 0)
+    ones = torch.ones(n, 64, device=DEV)
+    deg = (e.by_dst.rowptr[1:] - e.by_dst.rowptr[:-1]).float()
+    got = SF.segment_sum(ones, e.by_dst.rowptr, e.by_dst.col, n)
+    assert torch.equal(got, deg[:, None].expand(-1, 64).contiguous())            # sum of ones = in-degree
+    x = torch.randn(n, 64, device=DEV)
+    tot = SF.segment_sum(x, e.by_src.rowptr, e.by_src.col, n).double().sum(0)
+    want = (x.double() * deg[:, None].double()).sum(0)                           # symmetric graph: checksum of sums
+    assert float((tot - want).abs().max()) <= 1e-6 * float(want.abs().max() + 1)
+    pool = plan.pool(1)
+    c = torch.randn(pool.n_coarse, 64, device=DEV)
+    assert float(SF.PoolMeanFn.apply(SF.UnpoolFn.apply(c, pool), pool).sub(c).abs().max()) <= 1e-6
+    assert torch.equal(SF.PoolMaxFn.apply(SF.UnpoolFn.apply(c, pool), pool), c)  # unpool -> max-pool round trip
+
+
+def test_mid_size_full_width_model_vs_oracle():
+    """ngf = 64 (the shipped 3-D config) at a size the CPU oracle finishes in seconds."""
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=9,
+               n_levels=2, pooling_type='max', dilations=[1, 1, 1, 2, 4, 8, 16, 1, 1], checkpoint_bottleneck=True)
+    torch.manual_seed(49)
+    ref = stin_oracle.define_G(**cfg)
+    net = S.define_G(**cfg)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(DEV)
+    s = make_synthetic_mesh(12_000, 3, seed=3)
+    want = ref(s)
+    stin_oracle.compute_loss(stin_oracle.graph_forward(ref, s), s.color, s.mask).backward()
+    sd = s.to(DEV)
+    got = net(sd)
+    stin_oracle.compute_loss(torch.where((sd.mask > 0).expand_as(sd.color), got, sd.color), sd.color, sd.mask).backward()
+    assert float((got.detach().cpu() - want.detach()).abs().max()) <= FWD_TOL
+    scale = max(float(p.grad.abs().max()) for p in ref.parameters())
+    for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+        assert float((p.grad.cpu() - q.grad).abs().max()) <= 1e-3 * scale, k
