@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int MAX_SLABS = 2048;  // B * chunks-per-segment upper bound (workspace sizing)
+constexpr int MAX_SLABS = 1024;  // B * chunks-per-segment upper bound (workspace sizing)
 
 template <int VW> struct V;
 template <> struct V<4> {
@@ -101,18 +101,40 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce(const float* __restrict__ x
     }
 }
 
-__global__ void k_colreduce_final(const double* __restrict__ partial, int nch, int nout, int C, int B, int post,
-                                  const float* __restrict__ inv_cnt, float eps, float* __restrict__ out0,
-                                  float* __restrict__ out1) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * C * nout) return;
-    const int c = t % C, o = (t / C) % nout, b = t / (C * nout);
-    double s = 0.0;
-    for (int k = 0; k < nch; ++k) s += partial[(((int64_t)b * nch + k) * nout + o) * C + c];
-    float r = (float)s;
-    if (post == STIN_POST_SCALE) r = r * inv_cnt[b];
-    else if (post == STIN_POST_RSTD) r = 1.0f / sqrtf(r * inv_cnt[b] + eps);
-    (o == 0 ? out0 : out1)[(int64_t)b * C + c] = r;
+// Second stage: out[b, o, c] = post(sum_k partial[b, k, o, c]).  One 256-thread block per 16 columns:
+// 16 k-lanes x 16 columns, each k-lane walks the chunk list with stride 16 (coalesced 128-byte reads),
+// then a fixed-order LDS reduction across the k-lanes -> deterministic.
+constexpr int FIN_COLS = 16, FIN_KL = 16;
+__global__ __launch_bounds__(BLOCK) void k_colreduce_final(const double* __restrict__ partial, int nch, int nout, int C,
+                                                           int B, int post, const float* __restrict__ inv_cnt, float eps,
+                                                           float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ double sm[FIN_KL][FIN_COLS + 1];
+    const int tx = threadIdx.x % FIN_COLS, ty = threadIdx.x / FIN_COLS;
+    const int c = blockIdx.x * FIN_COLS + tx, o = blockIdx.y, b = blockIdx.z;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < C) {
+        const double* p = partial + ((int64_t)b * nch * nout + o) * C + c;
+        const int64_t stride = (int64_t)nout * C;
+        int k = ty;
+        for (; k + 3 * FIN_KL < nch; k += 4 * FIN_KL) {
+            s0 += p[(int64_t)k * stride];
+            s1 += p[(int64_t)(k + FIN_KL) * stride];
+            s2 += p[(int64_t)(k + 2 * FIN_KL) * stride];
+            s3 += p[(int64_t)(k + 3 * FIN_KL) * stride];
+        }
+        for (; k < nch; k += FIN_KL) s0 += p[(int64_t)k * stride];
+    }
+    sm[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < FIN_KL; ++k) s += sm[k][tx];
+        float r = (float)s;
+        if (post == STIN_POST_SCALE) r = r * inv_cnt[b];
+        else if (post == STIN_POST_RSTD) r = 1.0f / sqrtf(r * inv_cnt[b] + eps);
+        (o == 0 ? out0 : out1)[(int64_t)b * C + c] = r;
+    }
 }
 
 template <int VW>
@@ -236,9 +258,8 @@ extern "C" int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const f
         default: STIN_RED_LAUNCH(STIN_RED_COEF_XC); break;
     }
 #undef STIN_RED_LAUNCH
-    const int total = B * C * nout;
-    hipLaunchKernelGGL(k_colreduce_final, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, partial,
-                       nch, nout, C, B, post, inv_cnt, eps, out0, out1);
+    hipLaunchKernelGGL(k_colreduce_final, dim3((unsigned)((C + FIN_COLS - 1) / FIN_COLS), (unsigned)nout, (unsigned)B),
+                       dim3(BLOCK), 0, stream, partial, nch, nout, C, B, post, inv_cnt, eps, out0, out1);
     return stin_launch_status();
 }
 

@@ -41,7 +41,7 @@ def test_library_host_only_entry_points():
     assert lib.stin_version() == 100
     assert lib.stin_error_string(0) == b'ok'
     assert b'workspace' in lib.stin_error_string(-4)
-    assert lib.stin_colreduce_workspace_bytes(64, 1) >= 2048 * 2 * 64 * 8
+    assert lib.stin_colreduce_workspace_bytes(64, 1) >= 1024 * 2 * 64 * 8
     assert lib.stin_colreduce_workspace_bytes(0, 1) == 0
 
 
