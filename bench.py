@@ -68,10 +68,11 @@ def scatter_add_standalone(device, n=200_000, e=1_200_000, c=64, iters=30):
 
 
 def cpu_baseline(n0_target, levels, seed):
-    """The CPU oracle (op-for-op unfused PyG form) timed on this box's host cores, on a bounded sample."""
+    """The CPU oracle (op-for-op unfused PyG form) timed on this box's host cores, on a bounded sample
+    (~10-30 s of CPU work).  Thread count: the fastest of a short probe over {8, 16, 32, 64} (torch's CPU
+    index/scatter ops slow down badly when oversubscribed across a 256-thread host); reported as `cores`."""
     from oracle import stin_oracle
     from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
-    torch.set_num_threads(os.cpu_count() or 1)
     torch.manual_seed(49)
     net = stin_oracle.define_G(**CONFIG_3D)
 
@@ -82,20 +83,30 @@ def cpu_baseline(n0_target, levels, seed):
         loss.backward()
         return time.perf_counter() - t
 
-    probe = make_synthetic_mesh(20_000, levels, seed=seed)
-    run(probe)                                   # warm-up (allocator, threads)
-    t_probe = run(probe)
-    per_vertex = t_probe / probe.x.shape[0]
-    n0 = n0_target if per_vertex * n0_target <= 45.0 else max(20_000, int(30.0 / per_vertex))
-    if n0 == probe.x.shape[0]:
-        sample, t = probe, t_probe
+    probe = make_synthetic_mesh(10_000, levels, seed=seed)
+    ncpu = os.cpu_count() or 1
+    best_t, best_threads = None, None
+    for th in [t for t in (8, 16, 32, 64) if t <= ncpu] or [ncpu]:
+        torch.set_num_threads(th)
+        run(probe)                               # warm-up (allocator, thread pool)
+        t = run(probe)
+        if best_t is None or t < best_t:
+            best_t, best_threads = t, th
+        if t > 8.0:                              # keep the probe itself bounded
+            break
+    torch.set_num_threads(best_threads)
+    per_vertex = best_t / probe.x.shape[0]
+    n0 = n0_target if per_vertex * n0_target <= 30.0 else max(10_000, int(20.0 / per_vertex))
+    if n0 <= probe.x.shape[0]:
+        sample, t = probe, run(probe)
     else:
         sample = make_synthetic_mesh(n0, levels, seed=seed)
         t = run(sample)
     nv = sample.x.shape[0]
-    return {'value': nv / t, 'unit': 'vertices/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': 'one fwd+loss+bwd of the CPU oracle (unfused PyG-form restatement, torch %s CPU, fp32) on a '
-                      'synthetic %d-vertex %d-level mesh, %.1f s' % (torch.__version__, nv, levels, t)}
+    return {'value': nv / t, 'unit': 'vertices/s', 'cores': best_threads, 'kind': 'port',
+            'sample': 'one fwd+loss+bwd of the CPU oracle (unfused PyG-form restatement, torch %s CPU, fp32, %d of %d '
+                      'host threads) on a synthetic %d-vertex %d-level mesh, %.1f s'
+                      % (torch.__version__, best_threads, ncpu, nv, levels, t)}
 
 
 def main():
