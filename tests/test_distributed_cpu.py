@@ -1,0 +1,79 @@
+"""World-size-2 gloo tests (CPU) of the data-parallel step harness: flat-bucket gradient all-reduce,
+replica broadcast, identical Adam updates.  The model here is the CPU oracle (tests may use it); the
+harness code under test (train_step.TrainStep / FlatGradBucket) is the one bench.py runs over RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+CFG = dict(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconvtransinv', norm='instance', n_blocks=2, n_levels=1,
+           pooling_type='max')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import stin_oracle
+    from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
+    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    torch.manual_seed(100 + rank)                       # DIFFERENT init per rank: broadcast must fix it
+    net = stin_oracle.define_G(**CFG)
+    step = TrainStep(net, lr=1e-3, amsgrad=True)
+    p0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    sample = make_synthetic_mesh(300 + 100 * rank, 2, seed=rank, dilations=())     # unequal scenes
+    loss = step(sample)
+    flat_grad = step.bucket.flat.clone()
+    p1 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    torch.save({'p0': p0, 'p1': p1, 'grad': flat_grad, 'loss': loss}, os.path.join(out_dir, 'r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_manual_average(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / 'r0.pt')
+    r1 = torch.load(tmp_path / 'r1.pt')
+    assert torch.equal(r0['p0'], r1['p0']), 'replicas identical after the flat broadcast'
+    assert torch.equal(r0['grad'], r1['grad']), 'all-reduced gradients identical on both ranks'
+    assert torch.equal(r0['p1'], r1['p1']), 'identical Adam update on both ranks'
+    assert not torch.equal(r0['p0'], r0['p1'])
+    # single-process reference: mean of the two per-scene gradients at the broadcast weights
+    from oracle import stin_oracle
+    from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
+    from surface_texture_inpainting_net_amd.train_step import compute_loss, graph_forward
+    torch.manual_seed(100)
+    net = stin_oracle.define_G(**CFG)
+    torch.nn.utils.vector_to_parameters(r0['p0'], net.parameters())
+    grads = []
+    for rank in range(2):
+        net.zero_grad(set_to_none=True)
+        s = make_synthetic_mesh(300 + 100 * rank, 2, seed=rank, dilations=())
+        compute_loss(graph_forward(net, s), s.color, s.mask).backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]))
+    want = (grads[0] + grads[1]) / 2
+    assert float((r0['grad'] - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
+
+
+def test_flat_bucket_views_survive_zero_grad():
+    from surface_texture_inpainting_net_amd.train_step import FlatGradBucket
+    lin = torch.nn.Linear(4, 3)
+    b = FlatGradBucket(lin.parameters())
+    assert b.flat.numel() == 15
+    lin(torch.ones(2, 4)).sum().backward()
+    assert float(b.flat.abs().sum()) > 0 and lin.weight.grad.data_ptr() == b.flat.data_ptr()
+    lin.zero_grad(set_to_none=True)
+    b.zero()
+    assert lin.weight.grad is not None and float(b.flat.abs().sum()) == 0.0
