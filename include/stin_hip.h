@@ -172,6 +172,23 @@ int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_
                           const int32_t* gid, const int32_t* sid, int64_t N, int C, int act, float* dx,
                           int64_t lddx, stin_stream_t stream);
 
+/* ------------------------------------------------------------ per-vertex GEMMs --
+ * Exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) GEMMs for the tall-skinny per-VERTEX products the
+ * restructure leaves (reference: the per-EDGE aten::addmm of Lin1/Lin2 in
+ * models/modules/edge_conv_filter.py:47-52, the shortcut Linear at
+ * models/surfacetextureinpaintingnet.py:515-516 and the tail Linears :464,:467).
+ *   nt: C[M, Nc] = A[M, K] . W[Nc, K]^T (+ bias[Nc])      forward, and dgrad with W := W^T
+ *   tn: dW[Nc, K (+1)] = G[M, Nc]^T . [X[M, K] | 1]       weight gradient; with ones_column the
+ *       extra last column is the bias gradient (column sums of G).  Split over M into slabs that
+ *       are summed in a fixed order (deterministic, no atomics).
+ */
+int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, int64_t M,
+                     int Nc, int K, float* C, int64_t ldc, stin_stream_t stream);
+size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int ones_column);
+int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
+                     int ones_column, float* dW, int64_t lddw, void* workspace, size_t workspace_bytes,
+                     stin_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,8 @@ Every function here runs on GPU tensors only and calls through the C ABI
 (include/stin_hip.h); there is no eager/CPU fallback.  Dense per-vertex GEMMs use
 torch.mm / addmm (rocBLAS / hipBLASLt) - plain library GEMMs.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -189,6 +191,76 @@ def instance_norm_act_bwd(x, gout, mean, rstd, groups, act=True, out=None):
     return dx
 
 
+# debugging aid for A/B numerics checks only: STIN_GEMM_BACKEND=blas routes the dense GEMMs to torch.mm
+_GEMM_BLAS_NT = os.environ.get('STIN_GEMM_BACKEND', 'mfma') in ('blas', 'blas_nt')
+_GEMM_BLAS_TN = os.environ.get('STIN_GEMM_BACKEND', 'mfma') in ('blas', 'blas_tn')
+
+
+def gemm_nt(A, W, bias=None, out=None):
+    """A[M, K] . W[Nc, K]^T (+ bias) -> [M, Nc]  (hand-written fp32 MFMA kernel)."""
+    if _GEMM_BLAS_NT:
+        r = torch.mm(A, W.t()) if bias is None else torch.addmm(bias, A, W.t())
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+    A, lda = _mat(A)
+    W, ldw = _mat(W)
+    M, K = A.shape
+    Nc = W.shape[0]
+    assert W.shape[1] == K
+    if out is None:
+        out = torch.empty(M, Nc, dtype=torch.float32, device=A.device)
+    _call('stin_gemm_nt_f32', _ptr(A), lda, _ptr(W), ldw, _ptr(bias), M, Nc, K, _ptr(out),
+          out.stride(0) if M > 1 else max(Nc, out.stride(0)), _stream(A), tag=(M, Nc, K))
+    return out
+
+
+def gemm_tn(G, X, ones_column=False):
+    """G[M, Nc]^T . [X[M, K] | 1] -> [Nc, K (+1)]  (weight gradient; last column = bias gradient)."""
+    if _GEMM_BLAS_TN:
+        r = torch.mm(G.t(), X)
+        return torch.cat([r, G.sum(0)[:, None]], 1) if ones_column else r
+    lib = _lib.load()
+    G, ldg = _mat(G)
+    X, ldx = _mat(X)
+    M, Nc = G.shape
+    K = X.shape[1]
+    assert X.shape[0] == M
+    Kp = K + int(ones_column)
+    out = torch.empty(Nc, Kp, dtype=torch.float32, device=G.device)
+    ws_bytes = lib.stin_gemm_tn_workspace_bytes(M, Nc, K, int(ones_column))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)
+    _call('stin_gemm_tn_f32', _ptr(G), ldg, _ptr(X), ldx, M, Nc, K, int(ones_column), _ptr(out), Kp, _ptr(ws), ws_bytes,
+          _stream(G), tag=(M, Nc, K))
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the MFMA kernels (the tail Linears and the generic filter paths)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, _ = _mat(x)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return gemm_nt(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g, _ = _mat(g)
+        dwb = gemm_tn(g, x, ones_column=ctx.has_bias)
+        dx = gemm_nt(g, weight.t().contiguous())
+        if ctx.has_bias:
+            return dx, dwb[:, :-1], dwb[:, -1]
+        return dx, dwb, None
+
+
+def linear(x, weight, bias=None):
+    return LinearFn.apply(x, weight, bias)
+
+
 # ----------------------------------------------------------------------- autograd ops
 class EdgeConvBlockFn(torch.autograd.Function):
     """One GraphResnetBlock with an EdgeConv(mean) filter and instance norm, fused at the
@@ -205,10 +277,10 @@ class EdgeConvBlockFn(torch.autograd.Function):
     def forward(ctx, x, wcat, bcat, w2e, edges, groups, H, has_shortcut):
         x, _ = _mat(x)
         N = x.shape[0]
-        Y = torch.addmm(bcat, x, wcat.t())
+        Y = gemm_nt(x, wcat, bcat)
         hE = torch.empty(N, H + 4, dtype=torch.float32, device=x.device)
         edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True)
-        agg = torch.mm(hE, w2e.t())
+        agg = gemm_nt(hE, w2e)
         mean, rstd = instance_stats(agg, groups)
         res = Y[:, 2 * H:] if has_shortcut else x
         out = norm_act_res_fwd(agg, mean, rstd, groups, res=res, act=True)
@@ -222,20 +294,19 @@ class EdgeConvBlockFn(torch.autograd.Function):
         edges, groups, H = ctx.edges, ctx.groups, ctx.H
         g, _ = _mat(g)
         dagg = instance_norm_act_bwd(agg, g, mean, rstd, groups, act=True)
-        dw2e = torch.mm(dagg.t(), hE)
-        dhE = torch.mm(dagg, w2e)
+        dw2e = gemm_tn(dagg, hE)
+        dhE = gemm_nt(dagg, w2e.t().contiguous())
         dY = torch.empty_like(Y)
         A, B = Y[:, :H], Y[:, H:2 * H]
         edge_relu_mean_bwd_dst(A, B, dhE[:, :H], edges.by_dst, dY[:, :H])
         edge_relu_mean_bwd_src(A, B, dhE[:, :H], edges.inv_deg, edges.by_src, dY[:, H:2 * H])
         if ctx.has_shortcut:
             dY[:, 2 * H:].copy_(g)
-        dwcat = torch.mm(dY.t(), x)
-        dbcat = colsum(dY)
-        dx = torch.mm(dY, wcat)
+        dwb = gemm_tn(dY, x, ones_column=True)                   # [Yw, Cin + 1]: weight grad | bias grad
+        dx = gemm_nt(dY, wcat.t().contiguous())
         if not ctx.has_shortcut:
             dx.add_(g)
-        return dx, dwcat, dbcat, dw2e, None, None, None, None
+        return dx, dwb[:, :-1], dwb[:, -1], dw2e, None, None, None, None
 
 
 class EdgeReluMeanFn(torch.autograd.Function):

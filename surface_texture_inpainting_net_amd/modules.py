@@ -73,10 +73,10 @@ class EdgeConv(nn.Module):
         edges = _as_edges(edge_index, x.shape[0])
         wcat, bcat, w2e = self.fused_weights()
         H = self.hidden()
-        Y = torch.addmm(bcat, x, wcat.t())
+        Y = SF.linear(x, wcat, bcat)
         h = SF.EdgeReluMeanFn.apply(Y[:, :H], Y[:, H:], edges)
         has_in = (edges.by_dst.rowptr[1:] > edges.by_dst.rowptr[:-1]).to(h.dtype).unsqueeze(1)
-        return F.linear(h, self.nn[2].weight) + has_in * w2e[:, H]
+        return SF.linear(h, self.nn[2].weight) + has_in * w2e[:, H]
 
     def __repr__(self):
         return '{}(nn={}, aggr={})'.format(self.__class__.__name__, self.nn, self.aggr)
@@ -125,7 +125,7 @@ class SAGEConv(nn.Module):
             # agg[:, 3:9] - x_i[:, 3:9] * [deg_i > 0]
             has_in = (edges.by_dst.rowptr[1:] > edges.by_dst.rowptr[:-1]).to(x.dtype).unsqueeze(1)
             agg = torch.cat([agg[:, :3], agg[:, 3:9] - x[:, 3:9] * has_in, agg[:, 9:]], dim=1)
-        return self.lin_l(agg) + self.lin_r(x)
+        return SF.linear(agg, self.lin_l.weight, self.lin_l.bias) + SF.linear(x, self.lin_r.weight)
 
 
 class SAGEConvTransInv(SAGEConv):

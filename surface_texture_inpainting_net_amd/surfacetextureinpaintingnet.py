@@ -47,7 +47,7 @@ class GraphResnetBlock(nn.Module):
             return SF.EdgeConvBlockFn.apply(x, wcat, bcat, w2e, edges, groups, self.first_filter.hidden(),
                                             shortcut is not None)
         out = self.first_filter(x, edges)
-        res = self.shortcut(x) if self.dim_in != self.dim_out else x
+        res = SF.linear(x, self.shortcut.weight, self.shortcut.bias) if self.dim_in != self.dim_out else x
         if isinstance(self.first_norm, M.FastInstanceNorm):
             groups = M._as_groups(batch, n, x.device, self.first_norm.linspace_quirk)
             return SF.InstanceNormActResFn.apply(out, res, groups, True)
@@ -174,12 +174,12 @@ class SurfaceTextureInpaintingNet(nn.Module):
             out = blk(out, edges, self._norm_arg(plan, tgt))
         for blk in self.output_blocks:
             out = blk(out, e0, self._norm_arg(plan, 0, whole_batch=True))
-        out = self.final_linear1(out)
+        out = SF.linear(out, self.final_linear1.weight, self.final_linear1.bias)
         if self.norm is M.FastInstanceNorm:                         # per-graph branch even for B = 1 (:465, Q3)
             out = SF.InstanceNormActResFn.apply(out, None, plan.norm_groups(0), True)
         else:
             out = F.elu(self.final_norm1(out, batch=sample.batch))
-        out = torch.tanh(self.final_linear2(out))
+        out = torch.tanh(SF.linear(out, self.final_linear2.weight, self.final_linear2.bias))
         plan.validate()
         return out
 
