@@ -117,6 +117,7 @@ def main():
     ap.add_argument('--vertices', type=int, default=200_000)
     ap.add_argument('--levels', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--time-gemms', action='store_true', help='also bracket every MFMA GEMM launch with HIP events')
     ap.add_argument('--cache-plan', action='store_true', help='reuse the CSR plan across steps (NOT the headline)')
     args = ap.parse_args()
 
@@ -159,7 +160,7 @@ def main():
         one_step()
     fence()
     SF.KernelTimer.start(['stin_edge_relu_mean_fwd_f32', 'stin_edge_relu_mean_bwd_dst_f32',
-                          'stin_edge_relu_mean_bwd_src_f32'])
+                          'stin_edge_relu_mean_bwd_src_f32'] + (['stin_gemm_nt_f32', 'stin_gemm_tn_f32'] if args.time_gemms else []))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
@@ -177,8 +178,15 @@ def main():
         total_vertices = float(n0)
 
     if rank == 0:
-        table = []
+        table, gemms = [], []
         for (name, tag), ts in ktimes.items():
+            if 'gemm' in name:
+                m, nc, k = tag
+                avg = sum(ts) / len(ts)
+                gemms.append({'kernel': name, 'M': m, 'Nc': nc, 'K': k, 'launches': len(ts), 'avg_us': avg * 1e6,
+                              'total_ms': sum(ts) * 1e3, 'TFLOPs': 2.0 * m * nc * k / avg / 1e12,
+                              'GBps_min_traffic': 4.0 * (m * nc + m * k + nc * k) / avg / 1e9})
+                continue
             n, e, h = tag
             nbytes = edge_bytes(name, n, e, h)
             avg = sum(ts) / len(ts)
@@ -206,6 +214,13 @@ def main():
             'edge_stage_ms_per_step': edge_total_ms,
             'edge_kernels': table[:6],
         }
+        if gemms:
+            gemms.sort(key=lambda r: -r['total_ms'])
+            flops = sum(2.0 * r['M'] * r['Nc'] * r['K'] * r['launches'] for r in gemms)
+            tsum = sum(r['total_ms'] for r in gemms) * 1e-3
+            out['gemm'] = {'ms_per_step': tsum / args.steps * 1e3, 'GFLOP_per_step': flops / args.steps / 1e9,
+                           'TFLOPs': flops / tsum / 1e12, 'mfma_f32_peak_TFLOPs': 157.3,
+                           'mfma_utilisation': flops / tsum / 1e12 / 157.3, 'kernels': gemms[:24]}
         if world == 1:
             out['scatter_add'] = scatter_add_standalone(device)
             if not args.no_cpu_baseline:

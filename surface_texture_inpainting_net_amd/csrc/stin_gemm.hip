@@ -144,95 +144,92 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt(const float* __restrict__ A, 
 }
 
 // ----------------------------------------------------------------------------- TN
-// One WAVE per (64-row i-tile of Nc, 64-col j-tile of K+ones, row chunk): fragments come straight from
+// One WAVE per (64-row i-tile of Nc, 64-col j-tile of K, row chunk): fragments come straight from
 // global memory (for the reduction over rows m both operands are lane-contiguous: lane l reads
 // G[m + (l>>5)][i0 + (l&31)] and X[m + (l>>5)][j0 + (l&31)], 2 x 128-byte segments per instruction).
-// Partial tiles go to a slab [chunk][Nc][Kp]; k_reduce_slabs sums them in chunk order (deterministic).
-constexpr int TN_UNROLL = 4;   // m-pairs in flight per wave
-constexpr int TN_FLUSH = 64;   // rows per MFMA accumulation chain (multiple of 2 * TN_UNROLL)
+// The bias gradient (column sums of G) rides along on the VALU in the j-tile-0 waves and lands in
+// slab column K.  Partial tiles go to a slab [chunk][Nc][Kp]; k_reduce_slabs sums them in chunk order
+// (deterministic).  Work items are numbered so that the waves of one row chunk share an XCD
+// (blockIdx % 8 is the observed XCD round-robin): the chunk's G / X rows are then served by that L2.
+constexpr int TN_UNROLL = 8;   // m-pairs in flight per wave (32 dword loads)
 
 __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, int64_t ldg,
                                                    const float* __restrict__ X, int64_t ldx, int64_t M, int Nc,
                                                    int K, int Kp, int rows_per_chunk, int tiles_i, int tiles_j,
-                                                   int64_t n_items, float* __restrict__ slab) {
+                                                   int64_t chunks, float* __restrict__ slab) {
     const int lane = threadIdx.x & 63;
-    const int64_t item = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);   // wave-uniform
-    if (item >= n_items) return;
-    const int tj = (int)(item % tiles_j);
-    const int ti = (int)((item / tiles_j) % tiles_i);
-    const int64_t chunk = item / ((int64_t)tiles_j * tiles_i);
+    const int wave = threadIdx.x >> 6;
+    // block b -> (xcd-affine chunk, tile group); 4 waves = 4 consecutive tiles of the same chunk
+    const int tiles = tiles_i * tiles_j;
+    const int groups = (tiles + 3) / 4;                        // blocks per chunk
+    const int64_t b = blockIdx.x;
+    const int64_t xcd = b % 8, q = b / 8;
+    const int64_t chunk = (q / groups) * 8 + xcd;
+    const int tile = (int)(q % groups) * 4 + wave;             // wave-uniform
+    if (chunk >= chunks || tile >= tiles) return;
+    const int tj = tile % tiles_j, ti = tile / tiles_j;
     const int kh = lane >> 5, li = lane & 31;
     const int i0 = ti * 64, j0 = tj * 64;
     const int64_t mb = chunk * rows_per_chunk;
     const int64_t me = (mb + rows_per_chunk < M) ? mb + rows_per_chunk : M;
 
-    // Two-level accumulation: the MFMA chain is restarted every TN_FLUSH rows and folded into `tot`
-    // with plain adds, so no fp32 running sum is longer than TN_FLUSH (resp. rows/TN_FLUSH) terms.
-    // Weight gradients after an instance norm cancel heavily (sum |terms| >> |result|); one long
-    // sequential chain loses ~10x more accuracy there than the blocked sums BLAS libraries use.
-    f32x16 tot[2][2];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tot[a][b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    float gsum[2] = {0.f, 0.f};
 
     const int ci[2] = {i0 + li, i0 + 32 + li};
     const int cj[2] = {j0 + li, j0 + 32 + li};
     const bool gi[2] = {ci[0] < Nc, ci[1] < Nc};
     const bool xj[2] = {cj[0] < K, cj[1] < K};
-    const float one[2] = {cj[0] == K && Kp > K ? 1.f : 0.f, cj[1] == K && Kp > K ? 1.f : 0.f};   // virtual ones column
 
-    for (int64_t mf = mb; mf < me; mf += TN_FLUSH) {
-        const int64_t mfe = (mf + TN_FLUSH < me) ? mf + TN_FLUSH : me;
-        f32x16 acc[2][2];
+    for (int64_t m = mb; m < me; m += 2 * TN_UNROLL) {
+        float g[TN_UNROLL][2], x[TN_UNROLL][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int u = 0; u < TN_UNROLL; ++u) {
+            const int64_t row = m + 2 * u + kh;
+            const bool ok = row < me;
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-        for (int64_t m = mf; m < mfe; m += 2 * TN_UNROLL) {
-            float g[TN_UNROLL][2], x[TN_UNROLL][2];
-#pragma unroll
-            for (int u = 0; u < TN_UNROLL; ++u) {
-                const int64_t row = m + 2 * u + kh;
-                const bool ok = row < mfe;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    g[u][t] = (ok && gi[t]) ? G[row * ldg + ci[t]] : 0.f;
-                    x[u][t] = ok ? (xj[t] ? X[row * ldx + cj[t]] : one[t]) : 0.f;
-                }
+            for (int t = 0; t < 2; ++t) {
+                g[u][t] = (ok && gi[t]) ? G[row * ldg + ci[t]] : 0.f;
+                x[u][t] = (ok && xj[t]) ? X[row * ldx + cj[t]] : 0.f;
             }
-#pragma unroll
-            for (int u = 0; u < TN_UNROLL; ++u)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[u][a], x[u][b], acc[a][b], 0, 0, 0);
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int u = 0; u < TN_UNROLL; ++u) {
+            gsum[0] += g[u][0];
+            gsum[1] += g[u][1];
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tot[a][b][r] += acc[a][b][r];
+                for (int c = 0; c < 2; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[u][a], x[u][c], acc[a][c], 0, 0, 0);
+        }
     }
 
     float* out = slab + chunk * (int64_t)Nc * Kp;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int col = j0 + b * 32 + li;
-        if (col >= Kp) continue;
+    for (int c = 0; c < 2; ++c) {
+        const int col = j0 + c * 32 + li;
+        if (col >= K) continue;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < Nc) out[(int64_t)row * Kp + col] = tot[a][b][r];
+                if (row < Nc) out[(int64_t)row * Kp + col] = acc[a][c][r];
             }
+    }
+    if (Kp > K && tj == 0) {   // bias-gradient column: even rows (lanes 0-31) + odd rows (lanes 32-63)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float other = __shfl_xor(gsum[t], 32);
+            if (kh == 0 && gi[t]) out[(int64_t)ci[t] * Kp + K] = gsum[t] + other;
+        }
     }
 }
 
@@ -254,10 +251,10 @@ __global__ void k_reduce_slabs(const float* __restrict__ slab, int64_t chunks, i
 
 inline int tn_rows_per_chunk(int64_t M, int tiles) {
     // aim for >= ~2048 waves in flight, at least 256 and at most 2048 rows per wave, even row counts
-    int64_t chunks = (2048 + tiles - 1) / tiles;
+    int64_t chunks = (4096 + tiles - 1) / tiles;
     int64_t rows = (M + chunks - 1) / chunks;
     if (rows < 256) rows = 256;
-    if (rows > 1024) rows = 1024;
+    if (rows > 2048) rows = 2048;
     rows = (rows + 2 * TN_UNROLL - 1) / (2 * TN_UNROLL) * (2 * TN_UNROLL);
     return (int)rows;
 }
@@ -278,9 +275,13 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
         if (vec) hipLaunchKernelGGL((k_gemm_nt<BM_, BN_, WM_, WN_, true>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, M, Nc, K, C, ldc); \
         else hipLaunchKernelGGL((k_gemm_nt<BM_, BN_, WM_, WN_, false>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, M, Nc, K, C, ldc);    \
     } while (0)
-    if (Nc > 64 && Nc % 128 == 0) STIN_NT(128, 128, 2, 2);
-    else if (Nc > 32) STIN_NT(128, 64, 2, 2);
-    else STIN_NT(128, 32, 4, 1);
+    // Tile choice: the largest tile that still leaves >= ~6 blocks per CU (256 CUs), so that the tail
+    // wave of blocks does not idle half the chip on the M ~ 2e4 levels.
+    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Nc + bn - 1) / bn); };
+    if (Nc <= 32) STIN_NT(128, 32, 4, 1);
+    else if (Nc % 128 == 0 && blocks(128, 128) >= 1536) STIN_NT(128, 128, 2, 2);
+    else if (blocks(128, 64) >= 1536) STIN_NT(128, 64, 2, 2);
+    else STIN_NT(64, 64, 2, 2);
 #undef STIN_NT
     return stin_launch_status();
 }
@@ -288,7 +289,7 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
 extern "C" size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int ones_column) {
     if (M < 0 || Nc <= 0 || K <= 0) return 0;
     const int Kp = K + (ones_column ? 1 : 0);
-    const int tiles = ((Nc + 63) / 64) * ((Kp + 63) / 64);
+    const int tiles = ((Nc + 63) / 64) * ((K + 63) / 64);
     const int rows = tn_rows_per_chunk(M, tiles);
     const int64_t chunks = (M + rows - 1) / rows;
     return (size_t)(chunks > 0 ? chunks : 1) * Nc * Kp * sizeof(float) + 256;
@@ -304,14 +305,15 @@ extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int
     STIN_REQUIRE(dW && workspace && (M == 0 || (G && X)), STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_gemm_tn_workspace_bytes(M, Nc, K, ones_column), STIN_E_WORKSPACE);
     float* slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    const int tiles_i = (Nc + 63) / 64, tiles_j = (Kp + 63) / 64;
+    const int tiles_i = (Nc + 63) / 64, tiles_j = (K + 63) / 64;
     const int rows = tn_rows_per_chunk(M, tiles_i * tiles_j);
     const int64_t chunks = M > 0 ? (M + rows - 1) / rows : 0;
     const int64_t n = (int64_t)Nc * Kp;
     if (chunks > 0) {
-        const int64_t items = chunks * tiles_i * tiles_j;
-        hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)((items + 3) / 4)), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K,
-                           Kp, rows, tiles_i, tiles_j, items, slab);
+        const int64_t groups = (tiles_i * tiles_j + 3) / 4;
+        const int64_t blocks = ((chunks + 7) / 8) * 8 * groups;      // 8 chunks (one per XCD) x groups per round
+        hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, rows,
+                           tiles_i, tiles_j, chunks, slab);
     }
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, slab, chunks, n,
                        Kp, dW, lddw);
