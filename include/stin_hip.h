@@ -177,17 +177,20 @@ int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_
  * restructure leaves (reference: the per-EDGE aten::addmm of Lin1/Lin2 in
  * models/modules/edge_conv_filter.py:47-52, the shortcut Linear at
  * models/surfacetextureinpaintingnet.py:515-516 and the tail Linears :464,:467).
- *   nt: C[M, Nc] = A[M, K] . W[Nc, K]^T (+ bias[Nc])      forward, and dgrad with W := W^T
- *   tn: dW[Nc, K (+1)] = G[M, Nc]^T . [X[M, K] | 1]       weight gradient; with ones_column the
- *       extra last column is the bias gradient (column sums of G).  Split over M into slabs that
- *       are summed in a fixed order (deterministic, no atomics).
+ *   nt: C[M, Nc] = A[M, K] . W[Nc, K]^T + bias[Nc] * (row_mask ? row_mask[m * ld_mask] : 1)
+ *       forward, and dgrad with W := W^T.  row_mask = the [deg > 0] indicator gives PyG's
+ *       "no in-edges -> exactly 0" (bias only where a vertex aggregated something).
+ *   tn: dW[Nc, K (+1)] = G[M, Nc]^T . [X[M, K] | w]       weight gradient; with ones_column the
+ *       extra last column is the bias gradient sum_m w[m] G[m, :] (w = row_weight or 1).
+ *       Split over M into slabs that are summed in a fixed order (deterministic, no atomics).
  */
-int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, int64_t M,
-                     int Nc, int K, float* C, int64_t ldc, stin_stream_t stream);
+int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                     const float* row_mask, int64_t ld_mask, int64_t M, int Nc, int K, float* C, int64_t ldc,
+                     stin_stream_t stream);
 size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int ones_column);
 int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
-                     int ones_column, float* dW, int64_t lddw, void* workspace, size_t workspace_bytes,
-                     stin_stream_t stream);
+                     int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
+                     void* workspace, size_t workspace_bytes, stin_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -24,8 +24,9 @@ constexpr int BK = 32;
 template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_gemm_nt(const float* __restrict__ A, int64_t lda,
                                                    const float* __restrict__ W, int64_t ldw,
-                                                   const float* __restrict__ bias, int64_t M, int Nc, int K,
-                                                   float* __restrict__ C, int64_t ldc) {
+                                                   const float* __restrict__ bias,
+                                                   const float* __restrict__ row_mask, int64_t ld_mask, int64_t M,
+                                                   int Nc, int K, float* __restrict__ C, int64_t ldc) {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
     constexpr int A_F4 = BM * BK / 4 / BLOCK, W_F4 = BN * BK / 4 / BLOCK;   // float4 per thread per tile
     static_assert(A_F4 >= 1 && W_F4 >= 1, "tile too small for 256 threads");
@@ -137,132 +138,216 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt(const float* __restrict__ A, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < M) C[row * ldc + col] = acc[i][j][r] + bv;
+                if (row < M) C[row * ldc + col] = acc[i][j][r] + (row_mask != nullptr ? bv * row_mask[row * ld_mask] : bv);
             }
         }
     }
 }
 
 // ----------------------------------------------------------------------------- TN
-// One WAVE per (64-row i-tile of Nc, 64-col j-tile of K, row chunk): fragments come straight from
-// global memory (for the reduction over rows m both operands are lane-contiguous: lane l reads
-// G[m + (l>>5)][i0 + (l&31)] and X[m + (l>>5)][j0 + (l&31)], 2 x 128-byte segments per instruction).
-// The bias gradient (column sums of G) rides along on the VALU in the j-tile-0 waves and lands in
-// slab column K.  Partial tiles go to a slab [chunk][Nc][Kp]; k_reduce_slabs sums them in chunk order
-// (deterministic).  Work items are numbered so that the waves of one row chunk share an XCD
-// (blockIdx % 8 is the observed XCD round-robin): the chunk's G / X rows are then served by that L2.
-constexpr int TN_UNROLL = 8;   // m-pairs in flight per wave (32 dword loads)
+// dW tile TI x TJ per 256-thread block, reduction over a chunk of rows m.  Both operands are
+// row-major with m as the slow index, so a 32-row slab of G (TI columns) and X (TJ columns) is staged
+// in LDS exactly as it lies in memory (16-byte global loads, ds_write_b128, double buffered, the next
+// slab's loads in flight during the MFMAs) and the MFMA fragments are stride-1 ds_read_b32:
+// A[i][k] = Gs[k][i], B[k][j] = Xs[k][j] with k = the row inside the slab.  4 waves as 2 x 2, each
+// (TI/2) x (TJ/2).  The bias gradient sum_m w[m] G[m, :] is accumulated on the VALU by the staging
+// threads of the j-tile-0 blocks.  Partial tiles go to slab[chunk][Nc][Kp]; k_reduce_slabs adds them
+// in a fixed order.  Blocks are numbered so that all tiles of one row chunk share an XCD
+// (blockIdx % 8 is the observed XCD round-robin): the chunk's rows are re-read from that L2.
+constexpr int TN_R = 32;   // rows per LDS slab
 
+template <int TI, int TJ, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, int64_t ldg,
                                                    const float* __restrict__ X, int64_t ldx, int64_t M, int Nc,
-                                                   int K, int Kp, int rows_per_chunk, int tiles_i, int tiles_j,
-                                                   int64_t chunks, float* __restrict__ slab) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    // block b -> (xcd-affine chunk, tile group); 4 waves = 4 consecutive tiles of the same chunk
+                                                   int K, int Kp, const float* __restrict__ row_w, int64_t ld_w,
+                                                   int rows_per_chunk, int tiles_i, int tiles_j, int64_t chunks,
+                                                   float* __restrict__ slab) {
+    constexpr int MT = TI / 64, NT = TJ / 64;                    // 32x32 MFMA tiles per wave
+    constexpr int GF4 = TN_R * TI / 4 / BLOCK, XF4 = TN_R * TJ / 4 / BLOCK;   // float4 per thread per slab
+    constexpr int GC4 = TI / 4, XC4 = TJ / 4;                    // float4 columns
+    __shared__ float Gs[2][TN_R][TI];
+    __shared__ float Xs[2][TN_R][TJ];
+    __shared__ float bsum[BLOCK / GC4][TI + 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
     const int tiles = tiles_i * tiles_j;
-    const int groups = (tiles + 3) / 4;                        // blocks per chunk
     const int64_t b = blockIdx.x;
     const int64_t xcd = b % 8, q = b / 8;
-    const int64_t chunk = (q / groups) * 8 + xcd;
-    const int tile = (int)(q % groups) * 4 + wave;             // wave-uniform
-    if (chunk >= chunks || tile >= tiles) return;
+    const int64_t chunk = (q / tiles) * 8 + xcd;
+    const int tile = (int)(q % tiles);
+    if (chunk >= chunks) return;                                  // block-uniform
     const int tj = tile % tiles_j, ti = tile / tiles_j;
-    const int kh = lane >> 5, li = lane & 31;
-    const int i0 = ti * 64, j0 = tj * 64;
+    const int i0 = ti * TI, j0 = tj * TJ;
     const int64_t mb = chunk * rows_per_chunk;
     const int64_t me = (mb + rows_per_chunk < M) ? mb + rows_per_chunk : M;
+    const bool want_bias = (Kp > K) && (tj == 0);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < NT; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-    float gsum[2] = {0.f, 0.f};
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    const int ci[2] = {i0 + li, i0 + 32 + li};
-    const int cj[2] = {j0 + li, j0 + 32 + li};
-    const bool gi[2] = {ci[0] < Nc, ci[1] < Nc};
-    const bool xj[2] = {cj[0] < K, cj[1] < K};
+    const int gc = tid % GC4, gr = tid / GC4;    // staging coordinates in the G slab (rows gr + s * BLOCK/GC4)
+    const int xc = tid % XC4, xr = tid / XC4;
+    float4 rg[GF4], rx[XF4];
+    float rwt[GF4];
 
-    for (int64_t m = mb; m < me; m += 2 * TN_UNROLL) {
-        float g[TN_UNROLL][2], x[TN_UNROLL][2];
+    auto load_slab = [&](int64_t m0) {
 #pragma unroll
-        for (int u = 0; u < TN_UNROLL; ++u) {
-            const int64_t row = m + 2 * u + kh;
-            const bool ok = row < me;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                g[u][t] = (ok && gi[t]) ? G[row * ldg + ci[t]] : 0.f;
-                x[u][t] = (ok && xj[t]) ? X[row * ldx + cj[t]] : 0.f;
+        for (int s = 0; s < GF4; ++s) {
+            const int64_t row = m0 + gr + s * (BLOCK / GC4);
+            const int col = i0 + gc * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float w = 0.f;
+            if (row < me) {
+                const float* p = G + row * ldg + col;
+                if (VEC) {
+                    if (col < Nc) v = ld4(p);
+                } else {
+                    if (col + 0 < Nc) v.x = p[0];
+                    if (col + 1 < Nc) v.y = p[1];
+                    if (col + 2 < Nc) v.z = p[2];
+                    if (col + 3 < Nc) v.w = p[3];
+                }
+                if (want_bias) w = row_w != nullptr ? row_w[row * ld_w] : 1.f;
             }
+            rg[s] = v;
+            rwt[s] = w;
         }
 #pragma unroll
-        for (int u = 0; u < TN_UNROLL; ++u) {
-            gsum[0] += g[u][0];
-            gsum[1] += g[u][1];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[u][a], x[u][c], acc[a][c], 0, 0, 0);
+        for (int s = 0; s < XF4; ++s) {
+            const int64_t row = m0 + xr + s * (BLOCK / XC4);
+            const int col = j0 + xc * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < me) {
+                const float* p = X + row * ldx + col;
+                if (VEC) {
+                    if (col < K) v = ld4(p);
+                } else {
+                    if (col + 0 < K) v.x = p[0];
+                    if (col + 1 < K) v.y = p[1];
+                    if (col + 2 < K) v.z = p[2];
+                    if (col + 3 < K) v.w = p[3];
+                }
+            }
+            rx[s] = v;
         }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < GF4; ++s) {
+            st4(&Gs[buf][gr + s * (BLOCK / GC4)][gc * 4], rg[s]);
+            bs.x += rwt[s] * rg[s].x;
+            bs.y += rwt[s] * rg[s].y;
+            bs.z += rwt[s] * rg[s].z;
+            bs.w += rwt[s] * rg[s].w;
+        }
+#pragma unroll
+        for (int s = 0; s < XF4; ++s) st4(&Xs[buf][xr + s * (BLOCK / XC4)][xc * 4], rx[s]);
+    };
+
+    const int kh = lane >> 5, li = lane & 31;
+    load_slab(mb);
+    store_slab(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t m0 = mb; m0 < me; m0 += TN_R) {
+        const bool more = m0 + TN_R < me;
+        if (more) load_slab(m0 + TN_R);                           // in flight during the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < TN_R; kk += 2) {
+            float a[MT], c[NT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[t] = Gs[buf][kk + kh][wi * (TI / 2) + t * 32 + li];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) c[t] = Xs[buf][kk + kh][wj * (TJ / 2) + t * 32 + li];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], c[u], acc[t][u], 0, 0, 0);
+        }
+        if (more) store_slab(buf ^ 1);                            // the other buffer: last read one iteration ago
+        __syncthreads();
+        buf ^= 1;
     }
 
     float* out = slab + chunk * (int64_t)Nc * Kp;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int col = j0 + c * 32 + li;
+    for (int u = 0; u < NT; ++u) {
+        const int col = j0 + wj * (TJ / 2) + u * 32 + li;
         if (col >= K) continue;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = i0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < Nc) out[(int64_t)row * Kp + col] = acc[a][c][r];
+                const int row = i0 + wi * (TI / 2) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < Nc) out[(int64_t)row * Kp + col] = acc[t][u][r];
             }
     }
-    if (Kp > K && tj == 0) {   // bias-gradient column: even rows (lanes 0-31) + odd rows (lanes 32-63)
+    if (want_bias) {                                              // block-uniform branch
+        st4(&bsum[gr][gc * 4], bs);
+        __syncthreads();
+        if (tid < TI) {
+            float t = 0.f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float other = __shfl_xor(gsum[t], 32);
-            if (kh == 0 && gi[t]) out[(int64_t)ci[t] * Kp + K] = gsum[t] + other;
+            for (int r = 0; r < BLOCK / GC4; ++r) t += bsum[r][tid];
+            if (i0 + tid < Nc) out[(int64_t)(i0 + tid) * Kp + K] = t;
         }
     }
 }
 
-__global__ void k_reduce_slabs(const float* __restrict__ slab, int64_t chunks, int64_t n, int Kp,
-                               float* __restrict__ out, int64_t ldo) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+// out[t] = sum_c slab[c][t]: 16 chunk-lanes x 16 consecutive elements per block, each chunk-lane walks
+// the chunk list with stride 16 (4 loads in flight), then a fixed-order LDS reduction -> deterministic.
+constexpr int RS_COLS = 16, RS_KL = 16;
+__global__ __launch_bounds__(BLOCK) void k_reduce_slabs(const float* __restrict__ slab, int64_t chunks, int64_t n,
+                                                        int Kp, float* __restrict__ out, int64_t ldo) {
+    __shared__ float sm[RS_KL][RS_COLS + 1];
+    const int tx = threadIdx.x % RS_COLS, ty = threadIdx.x / RS_COLS;
+    const int64_t t = (int64_t)blockIdx.x * RS_COLS + tx;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int64_t c = 0;
-    for (; c + 3 < chunks; c += 4) {
-        s0 += slab[c * n + t];
-        s1 += slab[(c + 1) * n + t];
-        s2 += slab[(c + 2) * n + t];
-        s3 += slab[(c + 3) * n + t];
+    if (t < n) {
+        int64_t c = ty;
+        for (; c + 3 * RS_KL < chunks; c += 4 * RS_KL) {
+            s0 += slab[c * n + t];
+            s1 += slab[(c + RS_KL) * n + t];
+            s2 += slab[(c + 2 * RS_KL) * n + t];
+            s3 += slab[(c + 3 * RS_KL) * n + t];
+        }
+        for (; c < chunks; c += RS_KL) s0 += slab[c * n + t];
     }
-    for (; c < chunks; ++c) s0 += slab[c * n + t];
-    out[(t / Kp) * ldo + (t % Kp)] = (s0 + s1) + (s2 + s3);
+    sm[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0 && t < n) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < RS_KL; ++k) s += sm[k][tx];
+        out[(t / Kp) * ldo + (t % Kp)] = s;
+    }
 }
 
+inline int tn_tile(int n) { return n > 64 ? 128 : 64; }
+
 inline int tn_rows_per_chunk(int64_t M, int tiles) {
-    // aim for >= ~2048 waves in flight, at least 256 and at most 2048 rows per wave, even row counts
-    int64_t chunks = (4096 + tiles - 1) / tiles;
+    // ~768 blocks in flight (2 per CU resident, 3 rounds), chunks a multiple of the LDS slab
+    int64_t chunks = (768 + tiles - 1) / tiles;
     int64_t rows = (M + chunks - 1) / chunks;
-    if (rows < 256) rows = 256;
-    if (rows > 2048) rows = 2048;
-    rows = (rows + 2 * TN_UNROLL - 1) / (2 * TN_UNROLL) * (2 * TN_UNROLL);
+    if (rows < 4 * TN_R) rows = 4 * TN_R;
+    if (rows > 128 * TN_R) rows = 128 * TN_R;
+    rows = (rows + TN_R - 1) / TN_R * TN_R;
     return (int)rows;
 }
 
 }  // namespace
 
-extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, int64_t M,
-                                int Nc, int K, float* C, int64_t ldc, stin_stream_t stream_) {
+extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                                const float* row_mask, int64_t ld_mask, int64_t M, int Nc, int K, float* C, int64_t ldc,
+                                stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
@@ -272,8 +357,8 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
 #define STIN_NT(BM_, BN_, WM_, WN_)                                                                              \
     do {                                                                                                         \
         dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((Nc + BN_ - 1) / BN_));                            \
-        if (vec) hipLaunchKernelGGL((k_gemm_nt<BM_, BN_, WM_, WN_, true>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, M, Nc, K, C, ldc); \
-        else hipLaunchKernelGGL((k_gemm_nt<BM_, BN_, WM_, WN_, false>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, M, Nc, K, C, ldc);    \
+        if (vec) hipLaunchKernelGGL((k_gemm_nt<BM_, BN_, WM_, WN_, true>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, M, Nc, K, C, ldc); \
+        else hipLaunchKernelGGL((k_gemm_nt<BM_, BN_, WM_, WN_, false>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, M, Nc, K, C, ldc);    \
     } while (0)
     // Tile choice: the largest tile that still leaves >= ~6 blocks per CU (256 CUs), so that the tail
     // wave of blocks does not idle half the chip on the M ~ 2e4 levels.
@@ -289,15 +374,16 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
 extern "C" size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int ones_column) {
     if (M < 0 || Nc <= 0 || K <= 0) return 0;
     const int Kp = K + (ones_column ? 1 : 0);
-    const int tiles = ((Nc + 63) / 64) * ((K + 63) / 64);
+    const int TI = tn_tile(Nc), TJ = tn_tile(K);
+    const int tiles = ((Nc + TI - 1) / TI) * ((K + TJ - 1) / TJ);
     const int rows = tn_rows_per_chunk(M, tiles);
     const int64_t chunks = (M + rows - 1) / rows;
     return (size_t)(chunks > 0 ? chunks : 1) * Nc * Kp * sizeof(float) + 256;
 }
 
 extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
-                                int ones_column, float* dW, int64_t lddw, void* workspace, size_t workspace_bytes,
-                                stin_stream_t stream_) {
+                                int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
+                                void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     const int Kp = K + (ones_column ? 1 : 0);
@@ -305,17 +391,27 @@ extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int
     STIN_REQUIRE(dW && workspace && (M == 0 || (G && X)), STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_gemm_tn_workspace_bytes(M, Nc, K, ones_column), STIN_E_WORKSPACE);
     float* slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    const int tiles_i = (Nc + 63) / 64, tiles_j = (K + 63) / 64;
+    const int TI = tn_tile(Nc), TJ = tn_tile(K);
+    const int tiles_i = (Nc + TI - 1) / TI, tiles_j = (K + TJ - 1) / TJ;
     const int rows = tn_rows_per_chunk(M, tiles_i * tiles_j);
     const int64_t chunks = M > 0 ? (M + rows - 1) / rows : 0;
     const int64_t n = (int64_t)Nc * Kp;
     if (chunks > 0) {
-        const int64_t groups = (tiles_i * tiles_j + 3) / 4;
-        const int64_t blocks = ((chunks + 7) / 8) * 8 * groups;      // 8 chunks (one per XCD) x groups per round
-        hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, rows,
-                           tiles_i, tiles_j, chunks, slab);
+        const bool vec = (Nc % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldx % 4 == 0) && stin_aligned16(G) &&
+                         stin_aligned16(X);
+        const int64_t blocks = ((chunks + 7) / 8) * 8 * (int64_t)tiles_i * tiles_j;   // 8 chunks (one per XCD) per round
+#define STIN_TN(TI_, TJ_)                                                                                            \
+    do {                                                                                                             \
+        if (vec) hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
+        else hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
+    } while (0)
+        if (TI == 128 && TJ == 128) STIN_TN(128, 128);
+        else if (TI == 128) STIN_TN(128, 64);
+        else if (TJ == 128) STIN_TN(64, 128);
+        else STIN_TN(64, 64);
+#undef STIN_TN
     }
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, slab, chunks, n,
-                       Kp, dW, lddw);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, chunks,
+                       n, Kp, dW, lddw);
     return stin_launch_status();
 }

@@ -196,10 +196,16 @@ _GEMM_BLAS_NT = os.environ.get('STIN_GEMM_BACKEND', 'mfma') in ('blas', 'blas_nt
 _GEMM_BLAS_TN = os.environ.get('STIN_GEMM_BACKEND', 'mfma') in ('blas', 'blas_tn')
 
 
-def gemm_nt(A, W, bias=None, out=None):
-    """A[M, K] . W[Nc, K]^T (+ bias) -> [M, Nc]  (hand-written fp32 MFMA kernel)."""
+def gemm_nt(A, W, bias=None, out=None, row_mask=None):
+    """A[M, K] . W[Nc, K]^T + bias * row_mask -> [M, Nc]  (hand-written fp32 MFMA kernel).
+    row_mask: optional [M] column view (stride = its row pitch) multiplying the bias per row."""
     if _GEMM_BLAS_NT:
-        r = torch.mm(A, W.t()) if bias is None else torch.addmm(bias, A, W.t())
+        if bias is None:
+            r = torch.mm(A, W.t())
+        elif row_mask is None:
+            r = torch.addmm(bias, A, W.t())
+        else:
+            r = torch.mm(A, W.t()) + row_mask.reshape(-1, 1) * bias
         if out is not None:
             out.copy_(r)
             return out
@@ -211,16 +217,21 @@ def gemm_nt(A, W, bias=None, out=None):
     assert W.shape[1] == K
     if out is None:
         out = torch.empty(M, Nc, dtype=torch.float32, device=A.device)
-    _call('stin_gemm_nt_f32', _ptr(A), lda, _ptr(W), ldw, _ptr(bias), M, Nc, K, _ptr(out),
+    _call('stin_gemm_nt_f32', _ptr(A), lda, _ptr(W), ldw, _ptr(bias), _ptr(row_mask),
+          row_mask.stride(0) if row_mask is not None else 0, M, Nc, K, _ptr(out),
           out.stride(0) if M > 1 else max(Nc, out.stride(0)), _stream(A), tag=(M, Nc, K))
     return out
 
 
-def gemm_tn(G, X, ones_column=False):
-    """G[M, Nc]^T . [X[M, K] | 1] -> [Nc, K (+1)]  (weight gradient; last column = bias gradient)."""
+def gemm_tn(G, X, ones_column=False, row_weight=None):
+    """G[M, Nc]^T . [X[M, K] | w] -> [Nc, K (+1)]  (weight gradient; last column = bias gradient
+    sum_m w[m] G[m, :], w = row_weight (an [M] column view) or 1)."""
     if _GEMM_BLAS_TN:
         r = torch.mm(G.t(), X)
-        return torch.cat([r, G.sum(0)[:, None]], 1) if ones_column else r
+        if not ones_column:
+            return r
+        gs = G.sum(0) if row_weight is None else (G * row_weight.reshape(-1, 1)).sum(0)
+        return torch.cat([r, gs[:, None]], 1)
     lib = _lib.load()
     G, ldg = _mat(G)
     X, ldx = _mat(X)
@@ -231,8 +242,9 @@ def gemm_tn(G, X, ones_column=False):
     out = torch.empty(Nc, Kp, dtype=torch.float32, device=G.device)
     ws_bytes = lib.stin_gemm_tn_workspace_bytes(M, Nc, K, int(ones_column))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)
-    _call('stin_gemm_tn_f32', _ptr(G), ldg, _ptr(X), ldx, M, Nc, K, int(ones_column), _ptr(out), Kp, _ptr(ws), ws_bytes,
-          _stream(G), tag=(M, Nc, K))
+    _call('stin_gemm_tn_f32', _ptr(G), ldg, _ptr(X), ldx, M, Nc, K, int(ones_column), _ptr(row_weight),
+          row_weight.stride(0) if row_weight is not None else 0, _ptr(out), Kp, _ptr(ws), ws_bytes, _stream(G),
+          tag=(M, Nc, K))
     return out
 
 
@@ -280,7 +292,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         Y = gemm_nt(x, wcat, bcat)
         hE = torch.empty(N, H + 4, dtype=torch.float32, device=x.device)
         edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True)
-        agg = gemm_nt(hE, w2e)
+        agg = gemm_nt(hE[:, :H], w2e[:, :H], w2e[:, H].contiguous(), row_mask=hE[:, H])
         mean, rstd = instance_stats(agg, groups)
         res = Y[:, 2 * H:] if has_shortcut else x
         out = norm_act_res_fwd(agg, mean, rstd, groups, res=res, act=True)
@@ -294,12 +306,13 @@ class EdgeConvBlockFn(torch.autograd.Function):
         edges, groups, H = ctx.edges, ctx.groups, ctx.H
         g, _ = _mat(g)
         dagg = instance_norm_act_bwd(agg, g, mean, rstd, groups, act=True)
-        dw2e = gemm_tn(dagg, hE)
-        dhE = gemm_nt(dagg, w2e.t().contiguous())
+        dw2 = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H])     # [Cout, H + 1] = dW2 | db2
+        dw2e = torch.cat([dw2, dw2.new_zeros(dw2.shape[0], 3)], dim=1)
+        dhE = gemm_nt(dagg, w2e[:, :H].t().contiguous())                           # [N, H]
         dY = torch.empty_like(Y)
         A, B = Y[:, :H], Y[:, H:2 * H]
-        edge_relu_mean_bwd_dst(A, B, dhE[:, :H], edges.by_dst, dY[:, :H])
-        edge_relu_mean_bwd_src(A, B, dhE[:, :H], edges.inv_deg, edges.by_src, dY[:, H:2 * H])
+        edge_relu_mean_bwd_dst(A, B, dhE, edges.by_dst, dY[:, :H])
+        edge_relu_mean_bwd_src(A, B, dhE, edges.inv_deg, edges.by_src, dY[:, H:2 * H])
         if ctx.has_shortcut:
             dY[:, 2 * H:].copy_(g)
         dwb = gemm_tn(dY, x, ones_column=True)                   # [Yw, Cin + 1]: weight grad | bias grad
