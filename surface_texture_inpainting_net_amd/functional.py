@@ -179,10 +179,13 @@ def instance_norm_act_bwd(x, gout, mean, rstd, groups, act=True, out=None):
         # without activation dY = gout: sum dY*xc and sum dY via the same kernel with rstd = 0 -> ELU'(0)=1
         T1, S0 = colreduce(RED_DOT_ELU, x, groups, groups.ptr_true, gout=gout, mean=mean, rstd=torch.zeros_like(rstd))
     inv_cnt = groups.inv_cnt.view(-1, 1)
-    k = -(rstd * rstd * rstd) * T1 * inv_cnt                       # indexed by the SUM slice (sid)
-    if not groups.quirk:
-        m = -(rstd * S0) * inv_cnt                                  # sum_g xc = 0 when slices == graphs
+    if not groups.quirk:                                            # sum_g xc = 0 when slices == graphs
+        k = torch.empty_like(rstd)
+        m = torch.empty_like(rstd)
+        _call('stin_norm_bwd_coef_f32', _ptr(T1), _ptr(S0), _ptr(rstd), _ptr(groups.inv_cnt), rstd.shape[0], C, _ptr(k),
+              _ptr(m), _stream(x))
     else:
+        k = -(rstd * rstd * rstd) * T1 * inv_cnt                   # indexed by the SUM slice (sid)
         U = colreduce(RED_COEF_XC, x, groups, groups.ptr_true, mean=mean, coef=k, use_sid=True)
         m = -(rstd * S0 + U) * inv_cnt
     dx = out if out is not None else torch.empty(N, C, dtype=torch.float32, device=x.device)
@@ -276,50 +279,73 @@ def linear(x, weight, bias=None):
 # ----------------------------------------------------------------------- autograd ops
 class EdgeConvBlockFn(torch.autograd.Function):
     """One GraphResnetBlock with an EdgeConv(mean) filter and instance norm, fused at the
-    autograd level (reference models/surfacetextureinpaintingnet.py:507-521):
+    autograd level (reference models/surfacetextureinpaintingnet.py:507-521), taking the
+    reference-layout parameters directly:
 
-        Y   = x Wcat^T + bcat          Wcat = [Wa-Wb ; Wb ; Ws]   (per-VERTEX GEMM)
+        Y   = x Wcat^T + bcat          Wcat = [Wa-Wb ; Wb ; Ws]   (per-VERTEX MFMA GEMM)
         h   = mean_j ReLU(A_i + B_j)   A = Y[:, :H], B = Y[:, H:2H]   (HIP edge stage)
-        agg = [h | deg>0] [W2 | b2]^T                              (per-VERTEX GEMM)
+        agg = h W2^T + b2 [deg > 0]                                (per-VERTEX MFMA GEMM, masked bias)
         out = (Y[:, 2H:] or x) + ELU(InstanceNorm(agg))            (HIP epilogue)
 
     Only per-vertex tensors are saved; ReLU masks are recomputed in backward."""
 
     @staticmethod
-    def forward(ctx, x, wcat, bcat, w2e, edges, groups, H, has_shortcut):
+    def forward(ctx, x, W1, b1, W2, b2, Ws, bs, edges, groups, trans_inv):
         x, _ = _mat(x)
-        N = x.shape[0]
+        N, Cin = x.shape
+        H, Cout = W1.shape[0], W2.shape[0]
+        has_shortcut = Ws is not None
+        Yw = 2 * H + (Cout if has_shortcut else 0)
+        dev = x.device
+        pack = torch.empty(Yw * Cin * 2 + Yw + H * Cout, dtype=torch.float32, device=dev)
+        wcat = pack[:Yw * Cin].view(Yw, Cin)
+        wcatT = pack[Yw * Cin:2 * Yw * Cin].view(Cin, Yw)
+        w2T = pack[2 * Yw * Cin:2 * Yw * Cin + H * Cout].view(H, Cout)
+        bcat = pack[2 * Yw * Cin + H * Cout:]
+        W1c, W2c = W1.contiguous(), W2.contiguous()
+        _call('stin_edgeconv_pack_f32', _ptr(W1c), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2c), Cin, H, Cout,
+              int(has_shortcut), int(trans_inv), _ptr(wcat), _ptr(bcat), _ptr(wcatT), _ptr(w2T), _stream(x))
         Y = gemm_nt(x, wcat, bcat)
-        hE = torch.empty(N, H + 4, dtype=torch.float32, device=x.device)
+        hE = torch.empty(N, H + 4, dtype=torch.float32, device=dev)
         edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True)
-        agg = gemm_nt(hE[:, :H], w2e[:, :H], w2e[:, H].contiguous(), row_mask=hE[:, H])
+        agg = gemm_nt(hE[:, :H], W2c, b2, row_mask=hE[:, H])
         mean, rstd = instance_stats(agg, groups)
         res = Y[:, 2 * H:] if has_shortcut else x
         out = norm_act_res_fwd(agg, mean, rstd, groups, res=res, act=True)
-        ctx.save_for_backward(x, wcat, w2e, Y, hE, agg, mean, rstd)
-        ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut = edges, groups, H, has_shortcut
+        ctx.save_for_backward(x, Y, hE, agg, mean, rstd, wcatT, w2T)
+        ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut, ctx.trans_inv = edges, groups, H, has_shortcut, trans_inv
+        ctx.has_b1, ctx.has_b2, ctx.has_bs = b1 is not None, b2 is not None, bs is not None
+        ctx.w1_shape = tuple(W1.shape)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, wcat, w2e, Y, hE, agg, mean, rstd = ctx.saved_tensors
+        x, Y, hE, agg, mean, rstd, wcatT, w2T = ctx.saved_tensors
         edges, groups, H = ctx.edges, ctx.groups, ctx.H
+        Cin, Cout = x.shape[1], agg.shape[1]
         g, _ = _mat(g)
         dagg = instance_norm_act_bwd(agg, g, mean, rstd, groups, act=True)
-        dw2 = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H])     # [Cout, H + 1] = dW2 | db2
-        dw2e = torch.cat([dw2, dw2.new_zeros(dw2.shape[0], 3)], dim=1)
-        dhE = gemm_nt(dagg, w2e[:, :H].t().contiguous())                           # [N, H]
+        dw2b = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H])     # [Cout, H + 1] = dW2 | db2
+        dhE = gemm_nt(dagg, w2T)                                                   # [N, H] = dagg W2
         dY = torch.empty_like(Y)
         A, B = Y[:, :H], Y[:, H:2 * H]
         edge_relu_mean_bwd_dst(A, B, dhE, edges.by_dst, dY[:, :H])
         edge_relu_mean_bwd_src(A, B, dhE, edges.inv_deg, edges.by_src, dY[:, H:2 * H])
         if ctx.has_shortcut:
             dY[:, 2 * H:].copy_(g)
-        dwb = gemm_tn(dY, x, ones_column=True)                   # [Yw, Cin + 1]: weight grad | bias grad
-        dx = gemm_nt(dY, wcat.t().contiguous())
+        dwb = gemm_tn(dY, x, ones_column=True)                   # [Yw, Cin + 1]: packed weight grad | bias grad
+        dx = gemm_nt(dY, wcatT)                                  # dY Wcat
         if not ctx.has_shortcut:
             dx.add_(g)
-        return dx, dwb[:, :-1], dwb[:, -1], dw2e, None, None, None, None
+        dW1 = torch.empty(ctx.w1_shape, dtype=torch.float32, device=x.device)
+        db1 = torch.empty(H, dtype=torch.float32, device=x.device) if ctx.has_b1 else None
+        dWs = torch.empty(Cout, Cin, dtype=torch.float32, device=x.device) if ctx.has_shortcut else None
+        dbs = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bs else None
+        _call('stin_edgeconv_unpack_grads_f32', _ptr(dwb), Cin, H, Cout, int(ctx.has_shortcut), int(ctx.trans_inv),
+              _ptr(dW1), _ptr(db1), _ptr(dWs), _ptr(dbs), _stream(x))
+        dW2 = dw2b[:, :H]
+        db2 = dw2b[:, H] if ctx.has_b2 else None
+        return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None
 
 
 class EdgeReluMeanFn(torch.autograd.Function):

@@ -43,9 +43,11 @@ class GraphResnetBlock(nn.Module):
         if fused:
             groups = M._as_groups(batch, n, x.device, self.first_norm.linspace_quirk)
             shortcut = self.shortcut if self.dim_in != self.dim_out else None
-            wcat, bcat, w2e = self.first_filter.fused_weights(shortcut)
-            return SF.EdgeConvBlockFn.apply(x, wcat, bcat, w2e, edges, groups, self.first_filter.hidden(),
-                                            shortcut is not None)
+            lin1, lin2 = self.first_filter.nn[0], self.first_filter.nn[2]
+            return SF.EdgeConvBlockFn.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias,
+                                            None if shortcut is None else shortcut.weight,
+                                            None if shortcut is None else shortcut.bias, edges, groups,
+                                            self.first_filter.trans_inv)
         out = self.first_filter(x, edges)
         res = SF.linear(x, self.shortcut.weight, self.shortcut.bias) if self.dim_in != self.dim_out else x
         if isinstance(self.first_norm, M.FastInstanceNorm):
