@@ -44,6 +44,28 @@ def edge_bytes(kernel, n, e, h):
     raise KeyError(kernel)
 
 
+def pmc_traffic_bytes(kernel, n, e, h):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json, collected at
+    the headline level-0 shape with profiles/pmc_kernels.py; FETCH_SIZE doubled per the gfx950 correction)."""
+    import glob
+    if (n, e) != (200704, 1200642):
+        return None
+    c4 = h // 4
+    g = 1
+    while g < c4 and g < 64:
+        g *= 2
+    vpl = (c4 + g - 1) // g
+    base = 4 if kernel.endswith('bwd_src_f32') else 8
+    short = {'stin_edge_relu_mean_fwd_f32': 'k_edge_fwd', 'stin_edge_relu_mean_bwd_dst_f32': 'k_edge_bwd_dst',
+             'stin_edge_relu_mean_bwd_src_f32': 'k_edge_bwd_src'}[kernel]
+    key = '%s<%d, %d, %d>' % (short, g, vpl, max(1, (base + vpl - 1) // vpl))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files:
+        return None
+    rec = json.load(open(files[-1])).get(key)
+    return None if rec is None else rec['hbm_MB_per_launch'] * 1e6
+
+
 def scatter_add_standalone(device, n=200_000, e=1_200_000, c=64, iters=30):
     """The standalone scatter-add of BASELINE.md §4: src[E, C] -> out[N, C], index in arbitrary edge order."""
     from surface_texture_inpainting_net_amd import functional as SF
@@ -196,7 +218,9 @@ def main():
         dom = table[0]
         roofline = {'bound': 'hbm', 'kernel': '%s[N=%d,E=%d,H=%d]' % (dom['kernel'], dom['N'], dom['E'], dom['H']),
                     'achieved': dom['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom['GBps'] / HBM_PEAK_GBS,
-                    'traffic': None, 'avg_us': dom['avg_us'], 'algorithmic_MB': dom['algorithmic_MB']}
+                    'traffic': pmc_traffic_bytes(dom['kernel'], dom['N'], dom['E'], dom['H']),
+                    'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC: (2*FETCH_SIZE + WRITE_SIZE) KiB, profiles/)',
+                    'avg_us': dom['avg_us'], 'algorithmic_bytes': dom['algorithmic_MB'] * 1e6}
         edge_total_ms = sum(r['total_ms'] for r in table) / args.steps
         out = {
             'metric': 'vertices/sec forward+backward on 200k-vert ScanNet mesh; scatter-add GB/s vs HBM roofline',

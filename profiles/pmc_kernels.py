@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Launch the roofline kernels a few times each at the headline shapes, for rocprofv3 PMC passes:
+
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 profiles/pmc_kernels.py
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 profiles/pmc_kernels.py
+
+(separate passes: FETCH_SIZE and WRITE_SIZE do not fit one TCC pass - MI355X_MICROARCH.md "rocprofv3 PMC slots").
+profiles/pmc_summarize.py turns the two counter CSVs into profiles/rNN_pmc_traffic.json."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from surface_texture_inpainting_net_amd import functional as SF  # noqa: E402
+from surface_texture_inpainting_net_amd.plan import build_csr, plan_for  # noqa: E402
+from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh  # noqa: E402
+
+dev = torch.device('cuda:0')
+s = make_synthetic_mesh(200_000, 1, seed=0, dilations=()).to(dev)
+plan = plan_for(s)
+e = plan.edges('edge_index', 0)
+n, H = s.x.shape[0], 128
+A, B, G = (torch.randn(n, H, device=dev) for _ in range(3))
+out = torch.empty(n, H, device=dev)
+for _ in range(5):
+    SF.edge_relu_mean_fwd(A, B, e.by_dst, out)
+    SF.edge_relu_mean_bwd_dst(A, B, G, e.by_dst, out)
+    SF.edge_relu_mean_bwd_src(A, B, G, e.inv_deg, e.by_src, out)
+# standalone scatter-add: src[E, 64] -> out[N, 64], index in arbitrary edge order
+g = torch.Generator().manual_seed(0)
+idx = torch.randint(0, 200_000, (1_200_000,), generator=g).to(dev)
+src = torch.randn(1_200_000, 64, device=dev)
+bad = torch.zeros(1, dtype=torch.int32, device=dev)
+csr = build_csr(idx, None, 200_000, 1_200_000, bad, want_perm=True)
+for _ in range(5):
+    SF.segment_sum(src, csr.rowptr, csr.perm, 200_000)
+torch.cuda.synchronize()

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""usage: pmc_summarize.py <fetch counter_collection.csv> <write counter_collection.csv> > profiles/rNN_pmc_traffic.json
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB, and on gfx950
+FETCH_SIZE reports exactly half of a wide (16 B/lane) coalesced read stream (MI355X_MICROARCH.md §HBM)."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r.get('Counter_Name') != counter:
+            continue
+        name = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
+        name = re.sub(r'^void ', '', name)
+        name = re.sub(r'\(.*', '', name)
+        acc[name].append(float(r['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    f = per_kernel(sys.argv[1], 'FETCH_SIZE')
+    w = per_kernel(sys.argv[2], 'WRITE_SIZE')
+    out = {}
+    for k in sorted(set(f) & set(w)):
+        if not k.startswith('k_'):
+            continue
+        out[k] = {'FETCH_SIZE_KiB': f[k], 'WRITE_SIZE_KiB': w[k],
+                  'hbm_read_MB_corrected': 2 * f[k] * 1024 / 1e6, 'hbm_write_MB': w[k] * 1024 / 1e6,
+                  'hbm_MB_per_launch': (2 * f[k] + w[k]) * 1024 / 1e6}
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == '__main__':
+    main()
