@@ -180,13 +180,18 @@ int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_
  *   nt: C[M, Nc] = A[M, K] . W[Nc, K]^T + bias[Nc] * (row_mask ? row_mask[m * ld_mask] : 1)
  *       forward, and dgrad with W := W^T.  row_mask = the [deg > 0] indicator gives PyG's
  *       "no in-edges -> exactly 0" (bias only where a vertex aggregated something).
+ *       `precision` picks the matrix-core path: exact fp32 MFMA, or the bf16 cores (16x the fp32
+ *       MFMA rate) on operands split on the fly into 2 or 3 bf16 pieces with fp32 accumulation.
  *   tn: dW[Nc, K (+1)] = G[M, Nc]^T . [X[M, K] | w]       weight gradient; with ones_column the
  *       extra last column is the bias gradient sum_m w[m] G[m, :] (w = row_weight or 1).
  *       Split over M into slabs that are summed in a fixed order (deterministic, no atomics).
  */
+#define STIN_GEMM_F32 0      /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain                          */
+#define STIN_GEMM_BF16X3 2   /* fp32 operands split into 2 bf16 pieces, 3 bf16 MFMAs, ~2^-17 / product */
+#define STIN_GEMM_BF16X6 3   /* 3 pieces (exact split), 6 bf16 MFMAs, ~2^-22 / product                 */
 int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                      const float* row_mask, int64_t ld_mask, int64_t M, int Nc, int K, float* C, int64_t ldc,
-                     stin_stream_t stream);
+                     int precision, stin_stream_t stream);
 size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int ones_column);
 int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
                      int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,

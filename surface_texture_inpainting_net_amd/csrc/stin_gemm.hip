@@ -144,6 +144,159 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt(const float* __restrict__ A, 
     }
 }
 
+// ------------------------------------------------------------------- NT, split-bf16
+// The same product on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate) with each
+// fp32 operand split on the fly into NS bf16 pieces (x = x0 + x1 (+ x2), piece p = bf16(residual)):
+//   NS = 2: A0 B0 + A0 B1 + A1 B0                     (3 MFMAs, ~2^-17 per-product error: backward GEMMs)
+//   NS = 3: + A0 B2 + A2 B0 + A1 B1                   (6 MFMAs, x0+x1+x2 is exact, dropped terms 2^-24)
+// fp32 accumulation inside the MFMA.  LDS tiles are [rows][BK] bf16 with K contiguous (as in global
+// memory, no transpose), row pitch 80 B = conflict-free ds_read_b128 fragments
+// (lane l: row l&31, k = 8*(l>>5) .. +7 of a 16-wide k-step).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BKH = 32;          // k per LDS tile (two MFMA k-steps of 16)
+constexpr int PITCH = BKH + 8;   // bf16 elements per LDS row (80 bytes)
+
+template <int NS>
+__device__ __forceinline__ void split_store(float4 v, __bf16* dst, int plane_stride) {
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+        bf16x4 h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h[i] = (__bf16)r[i];
+            r[i] -= (float)h[i];
+        }
+        *reinterpret_cast<bf16x4*>(dst + p * plane_stride) = h;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool VEC>
+__global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict__ A, int64_t lda,
+                                                         const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ row_mask, int64_t ld_mask,
+                                                         int64_t M, int Nc, int K, float* __restrict__ C,
+                                                         int64_t ldc) {
+    constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
+    constexpr int A_F4 = BM * BKH / 4 / BLOCK, W_F4 = BN * BKH / 4 / BLOCK;
+    static_assert(A_F4 >= 1 && W_F4 >= 1, "tile too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) __bf16 As[NS][BM][PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[NS][BN][PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int kq = tid % (BKH / 4), r0 = tid / (BKH / 4);
+    constexpr int RSTEP = BLOCK / (BKH / 4);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[A_F4], rw[W_F4];
+    auto load_tiles = [&](int k0) {
+        const int k = k0 + kq * 4;
+#pragma unroll
+        for (int s = 0; s < A_F4; ++s) {
+            const int64_t row = m0 + r0 + s * RSTEP;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < M) {
+                const float* p = A + row * lda + k;
+                if (VEC) {
+                    if (k < K) v = ld4(p);
+                } else {
+                    if (k + 0 < K) v.x = p[0];
+                    if (k + 1 < K) v.y = p[1];
+                    if (k + 2 < K) v.z = p[2];
+                    if (k + 3 < K) v.w = p[3];
+                }
+            }
+            ra[s] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < W_F4; ++s) {
+            const int row = n0 + r0 + s * RSTEP;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < Nc) {
+                const float* p = W + (int64_t)row * ldw + k;
+                if (VEC) {
+                    if (k < K) v = ld4(p);
+                } else {
+                    if (k + 0 < K) v.x = p[0];
+                    if (k + 1 < K) v.y = p[1];
+                    if (k + 2 < K) v.z = p[2];
+                    if (k + 3 < K) v.w = p[3];
+                }
+            }
+            rw[s] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int s = 0; s < A_F4; ++s) split_store<NS>(ra[s], &As[0][r0 + s * RSTEP][kq * 4], BM * PITCH);
+#pragma unroll
+        for (int s = 0; s < W_F4; ++s) split_store<NS>(rw[s], &Ws[0][r0 + s * RSTEP][kq * 4], BN * PITCH);
+    };
+
+    const int kh = lane >> 5, li = lane & 31;
+    load_tiles(0);
+    for (int k0 = 0; k0 < K; k0 += BKH) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (k0 + BKH < K) load_tiles(k0 + BKH);
+#pragma unroll
+        for (int ks = 0; ks < BKH; ks += 16) {
+            bf16x8 a[NS][MT], b[NS][NT];
+#pragma unroll
+            for (int p = 0; p < NS; ++p) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    a[p][i] = *reinterpret_cast<const bf16x8*>(&As[p][wm * TM + i * 32 + li][ks + 8 * kh]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    b[p][j] = *reinterpret_cast<const bf16x8*>(&Ws[p][wn * TN + j * 32 + li][ks + 8 * kh]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    // smallest terms first
+                    if (NS == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * TN + j * 32 + li;
+        if (col >= Nc) continue;
+        const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < M) C[row * ldc + col] = acc[i][j][r] + (row_mask != nullptr ? bv * row_mask[row * ld_mask] : bv);
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- TN
 // dW tile TI x TJ per 256-thread block, reduction over a chunk of rows m.  Both operands are
 // row-major with m as the slow index, so a 32-row slab of G (TI columns) and X (TJ columns) is staged
@@ -347,27 +500,38 @@ inline int tn_rows_per_chunk(int64_t M, int tiles) {
 
 extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                                 const float* row_mask, int64_t ld_mask, int64_t M, int Nc, int K, float* C, int64_t ldc,
-                                stin_stream_t stream_) {
+                                int precision, stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
+    STIN_REQUIRE(precision == STIN_GEMM_F32 || precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6,
+                 STIN_E_UNSUPPORTED);
     if (M == 0) return STIN_OK;
     STIN_REQUIRE(A && W && C, STIN_E_NULL);
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldw % 4 == 0) && stin_aligned16(A) && stin_aligned16(W);
-#define STIN_NT(BM_, BN_, WM_, WN_)                                                                              \
-    do {                                                                                                         \
-        dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((Nc + BN_ - 1) / BN_));                            \
-        if (vec) hipLaunchKernelGGL((k_gemm_nt<BM_, BN_, WM_, WN_, true>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, M, Nc, K, C, ldc); \
-        else hipLaunchKernelGGL((k_gemm_nt<BM_, BN_, WM_, WN_, false>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, M, Nc, K, C, ldc);    \
-    } while (0)
     // Tile choice: the largest tile that still leaves >= ~6 blocks per CU (256 CUs), so that the tail
     // wave of blocks does not idle half the chip on the M ~ 2e4 levels.
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Nc + bn - 1) / bn); };
-    if (Nc <= 32) STIN_NT(128, 32, 4, 1);
-    else if (Nc % 128 == 0 && blocks(128, 128) >= 1536) STIN_NT(128, 128, 2, 2);
-    else if (blocks(128, 64) >= 1536) STIN_NT(128, 64, 2, 2);
-    else STIN_NT(64, 64, 2, 2);
+#define STIN_NT_ARGS A, lda, W, ldw, bias, row_mask, ld_mask, M, Nc, K, C, ldc
+#define STIN_NT(KERNEL, BM_, BN_, WM_, WN_, ...)                                                                  \
+    do {                                                                                                          \
+        dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((Nc + BN_ - 1) / BN_));                             \
+        if (vec) hipLaunchKernelGGL((KERNEL<BM_, BN_, WM_, WN_, ##__VA_ARGS__, true>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS); \
+        else hipLaunchKernelGGL((KERNEL<BM_, BN_, WM_, WN_, ##__VA_ARGS__, false>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS);    \
+    } while (0)
+#define STIN_NT_PICK(KERNEL, ...)                                                              \
+    do {                                                                                       \
+        if (Nc <= 32) STIN_NT(KERNEL, 128, 32, 4, 1, ##__VA_ARGS__);                           \
+        else if (Nc % 128 == 0 && blocks(128, 128) >= 1536) STIN_NT(KERNEL, 128, 128, 2, 2, ##__VA_ARGS__); \
+        else if (blocks(128, 64) >= 1536) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);       \
+        else STIN_NT(KERNEL, 64, 64, 2, 2, ##__VA_ARGS__);                                     \
+    } while (0)
+    if (precision == STIN_GEMM_BF16X3) STIN_NT_PICK(k_gemm_nt_bf16s, 2);
+    else if (precision == STIN_GEMM_BF16X6) STIN_NT_PICK(k_gemm_nt_bf16s, 3);
+    else STIN_NT_PICK(k_gemm_nt);
+#undef STIN_NT_PICK
 #undef STIN_NT
+#undef STIN_NT_ARGS
     return stin_launch_status();
 }
 

@@ -146,6 +146,27 @@ def test_gemm_nt_and_tn_against_fp64(M, Nc, K):
     assert torch.equal(got_tn2, got_tn[:, :-1]), 'deterministic slab order'
 
 
+@pytest.mark.parametrize('M,Nc,K', [(4097, 320, 64), (2500, 256, 260), (513, 256, 1280), (1000, 128, 10)])
+def test_gemm_nt_precision_modes(M, Nc, K):
+    """fp32 MFMA chain vs the split-bf16 paths (fp32 accumulate): error against fp64, relative to the
+    result scale.  x6 (exact 3-piece split) must be at least as good as fp32; x3 within 2e-5."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(Nc, K, generator=g) * 0.1).to(DEV)
+    b = torch.randn(Nc, generator=g).to(DEV)
+    want = A.double() @ W.double().t() + b.double()
+    scale = float(want.abs().max())
+    err = {p: float((SF.gemm_nt(A, W, b, precision=p).double() - want).abs().max()) / scale
+           for p in (SF.GEMM_F32, SF.GEMM_BF16X3, SF.GEMM_BF16X6)}
+    assert err[SF.GEMM_F32] <= 3e-6
+    assert err[SF.GEMM_BF16X6] <= 3e-6
+    assert err[SF.GEMM_BF16X3] <= 2e-5
+    small = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)          # exactly representable: all paths exact
+    wi = torch.randint(-3, 4, (Nc, K), generator=g).float().to(DEV)
+    for p in (SF.GEMM_F32, SF.GEMM_BF16X3, SF.GEMM_BF16X6):
+        assert torch.equal(SF.gemm_nt(small, wi, precision=p).double(), small.double() @ wi.double().t())
+
+
 def test_gemm_nt_on_strided_views_and_linear_autograd():
     g = torch.Generator().manual_seed(3)
     big = torch.randn(500, 200, generator=g).to(DEV)
@@ -355,6 +376,15 @@ def test_model_batched_true_per_graph_mode_equals_separate_graphs():
     assert torch.isfinite(out).all() and out.shape == fx.out.shape
     # differs from the quirk output (unequal graphs) but stays a valid tanh output
     assert float((out.cpu() - fx.out).abs().max()) > 1e-3 and float(out.abs().max()) < 1.0
+
+
+def test_graph_metrics_against_reference_fixture():
+    from surface_texture_inpainting_net_amd import metrics
+    z = {k: torch.from_numpy(v) for k, v in load_npz('g8_metrics').items()}
+    pred, ei = z['pred'].to(DEV), z['ei'].to(DEV)
+    assert torch.allclose(metrics.graph_laplace_variance(pred, ei).cpu(), z['lap_var'], rtol=1e-5)
+    assert torch.allclose(metrics.graph_total_variation(pred, ei).cpu(), z['tv'], rtol=1e-5)
+    assert torch.allclose(metrics.psnr(pred, z['color'].to(DEV), data_range=2.0).cpu(), z['psnr'], rtol=1e-5)
 
 
 # ------------------------------------------- full-size (BASELINE.json) property checks
