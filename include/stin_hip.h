@@ -195,7 +195,7 @@ int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, c
 size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int ones_column);
 int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
                      int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
-                     void* workspace, size_t workspace_bytes, stin_stream_t stream);
+                     int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream);
 
 /* ------------------------------------------------------- parameter-side helpers --
  * pack: the reference-layout EdgeConv parameters (first_filter.nn.0.{weight,bias} = W1 [H, 2Cin]

@@ -455,6 +455,187 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, 
     }
 }
 
+// ------------------------------------------------------------------- TN, split-bf16
+// Same contract as k_gemm_tn on the bf16 matrix cores.  The reduction index is the ROW m, so the MFMA
+// fragments need 8 consecutive m for one column: each staging thread loads a 4(rows) x 4(cols) fp32 patch
+// (4 x 16-byte loads), splits it into NS bf16 pieces, transposes it in registers and writes one 8-byte
+// (4 consecutive m) run per column into Gt[piece][col][m] / Xt[piece][col][m] (row pitch 80 B; lanes of a
+// 16-lane group differ in the row group first => conflict-free ds_write_b64 and ds_read_b128).
+constexpr int TNB_R = 32;                  // rows (m) per LDS slab = two MFMA k-steps of 16
+constexpr int TNB_PITCH = TNB_R + 8;       // bf16 per LDS row (80 bytes)
+
+template <int TI, int TJ, int NS, bool VEC>
+__global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict__ G, int64_t ldg,
+                                                         const float* __restrict__ X, int64_t ldx, int64_t M,
+                                                         int Nc, int K, int Kp, const float* __restrict__ row_w,
+                                                         int64_t ld_w, int rows_per_chunk, int tiles_i, int tiles_j,
+                                                         int64_t chunks, float* __restrict__ slab) {
+    constexpr int MT = TI / 64, NT = TJ / 64;
+    constexpr int ITEMS = 2 * (TI + TJ);                          // 4x4 patches per slab (G then X)
+    constexpr int PASSES = ITEMS / BLOCK;                          // 1, 1.5 -> handled as 2 with a guard, or 2
+    constexpr int NPASS = (ITEMS + BLOCK - 1) / BLOCK;
+    __shared__ __attribute__((aligned(16))) __bf16 Gt[NS][TI][TNB_PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Xt[NS][TJ][TNB_PITCH];
+    __shared__ float bsum[8][TI + 4];
+    (void)PASSES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int tiles = tiles_i * tiles_j;
+    const int64_t b = blockIdx.x;
+    const int64_t xcd = b % 8, q = b / 8;
+    const int64_t chunk = (q / tiles) * 8 + xcd;
+    const int tile = (int)(q % tiles);
+    if (chunk >= chunks) return;
+    const int tj = tile % tiles_j, ti = tile / tiles_j;
+    const int i0 = ti * TI, j0 = tj * TJ;
+    const int64_t mb = chunk * rows_per_chunk;
+    const int64_t me = (mb + rows_per_chunk < M) ? mb + rows_per_chunk : M;
+    const bool want_bias = (Kp > K) && (tj == 0);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);                  // bias-gradient partial (columns of this thread's G patch)
+
+    float4 patch[NPASS][4];
+    float pw[4];
+    auto load_slab = [&](int64_t m0) {
+#pragma unroll
+        for (int s = 0; s < NPASS; ++s) {
+            const int item = tid + s * BLOCK;
+            const bool isG = item < 2 * TI;
+            const int it = isG ? item : item - 2 * TI;
+            const int rg = it % 8, c4 = it / 8;
+            const bool live = item < ITEMS;
+            const float* base = isG ? G : X;
+            const int64_t ld = isG ? ldg : ldx;
+            const int col = (isG ? i0 : j0) + c4 * 4;
+            const int lim = isG ? Nc : K;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = m0 + rg * 4 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live && row < me) {
+                    const float* p = base + row * ld + col;
+                    if (VEC) {
+                        if (col < lim) v = ld4(p);
+                    } else {
+                        if (col + 0 < lim) v.x = p[0];
+                        if (col + 1 < lim) v.y = p[1];
+                        if (col + 2 < lim) v.z = p[2];
+                        if (col + 3 < lim) v.w = p[3];
+                    }
+                }
+                patch[s][r] = v;
+                if (s == 0) pw[r] = (want_bias && row < me) ? (row_w != nullptr ? row_w[row * ld_w] : 1.f) : 0.f;
+            }
+        }
+    };
+    auto store_slab = [&](int buf) {
+        (void)buf;
+#pragma unroll
+        for (int s = 0; s < NPASS; ++s) {
+            const int item = tid + s * BLOCK;
+            if (item >= ITEMS) continue;
+            const bool isG = item < 2 * TI;
+            const int it = isG ? item : item - 2 * TI;
+            const int rg = it % 8, c4 = it / 8;
+            if (s == 0 && isG) {                                   // 2*TI >= 128: pass 0 holds every G patch of TI=128; see below for TI=64
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bs.x += pw[r] * patch[s][r].x;
+                    bs.y += pw[r] * patch[s][r].y;
+                    bs.z += pw[r] * patch[s][r].z;
+                    bs.w += pw[r] * patch[s][r].w;
+                }
+            }
+            __bf16* dst = isG ? &Gt[0][c4 * 4][rg * 4] : &Xt[0][c4 * 4][rg * 4];
+            const int plane = (isG ? TI : TJ) * TNB_PITCH;
+            float col[4][4] = {{patch[s][0].x, patch[s][1].x, patch[s][2].x, patch[s][3].x},
+                               {patch[s][0].y, patch[s][1].y, patch[s][2].y, patch[s][3].y},
+                               {patch[s][0].z, patch[s][1].z, patch[s][2].z, patch[s][3].z},
+                               {patch[s][0].w, patch[s][1].w, patch[s][2].w, patch[s][3].w}};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int p = 0; p < NS; ++p) {
+                    bf16x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        h[r] = (__bf16)col[c][r];
+                        col[c][r] -= (float)h[r];
+                    }
+                    *reinterpret_cast<bf16x4*>(dst + p * plane + c * TNB_PITCH) = h;
+                }
+            }
+        }
+    };
+
+    const int kh = lane >> 5, li = lane & 31;
+    for (int64_t m0 = mb; m0 < me; m0 += TNB_R) {
+        load_slab(m0);
+        __syncthreads();                                           // previous slab's fragment reads are done
+        store_slab(0);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < TNB_R; ks += 16) {
+            bf16x8 a[NS][MT], c[NS][NT];
+#pragma unroll
+            for (int p = 0; p < NS; ++p) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    a[p][t] = *reinterpret_cast<const bf16x8*>(&Gt[p][wi * (TI / 2) + t * 32 + li][ks + 8 * kh]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    c[p][t] = *reinterpret_cast<const bf16x8*>(&Xt[p][wj * (TJ / 2) + t * 32 + li][ks + 8 * kh]);
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    if (NS == 3) {
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][t], c[1][u], acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][t], c[2][u], acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][t], c[0][u], acc[t][u], 0, 0, 0);
+                    }
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][t], c[1][u], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][t], c[0][u], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][t], c[0][u], acc[t][u], 0, 0, 0);
+                }
+        }
+    }
+
+    float* out = slab + chunk * (int64_t)Nc * Kp;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int col = j0 + wj * (TJ / 2) + u * 32 + li;
+        if (col >= K) continue;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wi * (TI / 2) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < Nc) out[(int64_t)row * Kp + col] = acc[t][u][r];
+            }
+    }
+    if (want_bias) {                                              // block-uniform
+        // pass-0 G patches: item = tid < 2*TI, row group tid % 8, column group tid / 8
+        if (tid < 2 * TI) st4(&bsum[tid % 8][(tid / 8) * 4], bs);
+        __syncthreads();
+        if (tid < TI) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += bsum[r][tid];
+            if (i0 + tid < Nc) out[(int64_t)(i0 + tid) * Kp + K] = t;
+        }
+    }
+}
+
 // out[t] = sum_c slab[c][t]: 16 chunk-lanes x 16 consecutive elements per block, each chunk-lane walks
 // the chunk list with stride 16 (4 loads in flight), then a fixed-order LDS reduction -> deterministic.
 constexpr int RS_COLS = 16, RS_KL = 16;
@@ -547,13 +728,15 @@ extern "C" size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int one
 
 extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
                                 int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
-                                void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+                                int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     const int Kp = K + (ones_column ? 1 : 0);
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && ldg >= Nc && ldx >= K && lddw >= Kp, STIN_E_SIZE);
     STIN_REQUIRE(dW && workspace && (M == 0 || (G && X)), STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_gemm_tn_workspace_bytes(M, Nc, K, ones_column), STIN_E_WORKSPACE);
+    STIN_REQUIRE(precision == STIN_GEMM_F32 || precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6,
+                 STIN_E_UNSUPPORTED);
     float* slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     const int TI = tn_tile(Nc), TJ = tn_tile(K);
     const int tiles_i = (Nc + TI - 1) / TI, tiles_j = (K + TJ - 1) / TJ;
@@ -569,10 +752,23 @@ extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int
         if (vec) hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
         else hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
     } while (0)
-        if (TI == 128 && TJ == 128) STIN_TN(128, 128);
-        else if (TI == 128) STIN_TN(128, 64);
-        else if (TJ == 128) STIN_TN(64, 128);
-        else STIN_TN(64, 64);
+#define STIN_TNB(TI_, TJ_, NS_)                                                                                      \
+    do {                                                                                                             \
+        if (vec) hipLaunchKernelGGL((k_gemm_tn_bf16s<TI_, TJ_, NS_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
+        else hipLaunchKernelGGL((k_gemm_tn_bf16s<TI_, TJ_, NS_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
+    } while (0)
+#define STIN_TN_PICK(LAUNCH, ...)                                   \
+    do {                                                            \
+        if (TI == 128 && TJ == 128) LAUNCH(128, 128, ##__VA_ARGS__); \
+        else if (TI == 128) LAUNCH(128, 64, ##__VA_ARGS__);          \
+        else if (TJ == 128) LAUNCH(64, 128, ##__VA_ARGS__);          \
+        else LAUNCH(64, 64, ##__VA_ARGS__);                          \
+    } while (0)
+        if (precision == STIN_GEMM_BF16X3) STIN_TN_PICK(STIN_TNB, 2);
+        else if (precision == STIN_GEMM_BF16X6) STIN_TN_PICK(STIN_TNB, 3);
+        else STIN_TN_PICK(STIN_TN);
+#undef STIN_TN_PICK
+#undef STIN_TNB
 #undef STIN_TN
     }
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, chunks,

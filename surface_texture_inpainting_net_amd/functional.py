@@ -235,7 +235,7 @@ def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32):
     return out
 
 
-def gemm_tn(G, X, ones_column=False, row_weight=None):
+def gemm_tn(G, X, ones_column=False, row_weight=None, precision=GEMM_F32):
     """G[M, Nc]^T . [X[M, K] | w] -> [Nc, K (+1)]  (weight gradient; last column = bias gradient
     sum_m w[m] G[m, :], w = row_weight (an [M] column view) or 1)."""
     if _GEMM_BLAS_TN:
@@ -255,7 +255,8 @@ def gemm_tn(G, X, ones_column=False, row_weight=None):
     ws_bytes = lib.stin_gemm_tn_workspace_bytes(M, Nc, K, int(ones_column))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)
     _call('stin_gemm_tn_f32', _ptr(G), ldg, _ptr(X), ldx, M, Nc, K, int(ones_column), _ptr(row_weight),
-          row_weight.stride(0) if row_weight is not None else 0, _ptr(out), Kp, _ptr(ws), ws_bytes, _stream(G),
+          row_weight.stride(0) if row_weight is not None else 0, _ptr(out), Kp, int(precision), _ptr(ws), ws_bytes,
+          _stream(G),
           tag=(M, Nc, K))
     return out
 
@@ -274,7 +275,7 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g, _ = _mat(g)
-        dwb = gemm_tn(g, x, ones_column=ctx.has_bias)
+        dwb = gemm_tn(g, x, ones_column=ctx.has_bias, precision=PREC_BWD)
         dx = gemm_nt(g, weight.t().contiguous(), precision=PREC_BWD)
         if ctx.has_bias:
             return dx, dwb[:, :-1], dwb[:, -1]
@@ -334,7 +335,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         Cin, Cout = x.shape[1], agg.shape[1]
         g, _ = _mat(g)
         dagg = instance_norm_act_bwd(agg, g, mean, rstd, groups, act=True)
-        dw2b = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H])     # [Cout, H + 1] = dW2 | db2
+        dw2b = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H], precision=PREC_BWD)   # [Cout, H + 1] = dW2 | db2
         dhE = gemm_nt(dagg, w2T, precision=PREC_BWD)                                             # [N, H] = dagg W2
         dY = torch.empty_like(Y)
         A, B = Y[:, :H], Y[:, H:2 * H]
@@ -342,7 +343,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         edge_relu_mean_bwd_src(A, B, dhE, edges.inv_deg, edges.by_src, dY[:, H:2 * H])
         if ctx.has_shortcut:
             dY[:, 2 * H:].copy_(g)
-        dwb = gemm_tn(dY, x, ones_column=True)                   # [Yw, Cin + 1]: packed weight grad | bias grad
+        dwb = gemm_tn(dY, x, ones_column=True, precision=PREC_BWD)           # [Yw, Cin + 1]: packed weight grad | bias grad
         dx = gemm_nt(dY, wcatT, precision=PREC_BWD)                            # dY Wcat
         if not ctx.has_shortcut:
             dx.add_(g)
