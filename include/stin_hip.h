@@ -56,7 +56,9 @@ const char* stin_error_string(int code);
  *   inv_deg[n] = 1 / max(1, rowptr[n+1]-rowptr[n])       (may be NULL);
  *   *bad (device int32, may be NULL) is set non-zero when a key is outside [0, N)
  *   or a val outside [0, val_limit) - the analogue of the IndexError the reference's
- *   index_select / scatter raise on CPU.
+ *   index_select / scatter raise on CPU; such pairs are left out of the CSR.
+ * Implementation: counting sort (integer-atomic histogram, one scan, atomic fill, rank within
+ * row) - the result is the stable order above regardless of atomic arrival order.
  * Replaces the implicit indexing of PyG MessagePassing.propagate
  * (models/modules/edge_conv_filter.py:57 via torch_geometric) and of
  * torch_scatter (models/surfacetextureinpaintingnet.py:384-386,:422):
@@ -69,6 +71,12 @@ int stin_csr_from_coo_i64(const int64_t* key, const int64_t* val, int64_t E, int
                           int64_t val_limit, int32_t* rowptr, int32_t* col, int32_t* perm,
                           float* inv_deg, int32_t* bad, void* workspace, size_t workspace_bytes,
                           stin_stream_t stream);
+/* Both CSRs of one directed edge set in the same launches: by destination (col = sources, inv_deg =
+ * 1/max(1, in-degree)) for the forward gather and dA, by source (col = targets) for dB. */
+int stin_csr_pair_from_edges_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N,
+                                 int32_t* rowptr_dst, int32_t* col_dst, float* inv_deg_dst,
+                                 int32_t* rowptr_src, int32_t* col_src, int32_t* bad, void* workspace,
+                                 size_t workspace_bytes, stin_stream_t stream);
 /* dst[i] = (int32) src[i]; *bad set when a value is outside [0, limit). */
 int stin_narrow_i64_to_i32(const int64_t* src, int64_t n, int64_t limit, int32_t* dst, int32_t* bad,
                            stin_stream_t stream);

@@ -1,6 +1,12 @@
-// COO -> CSR graph-plan construction on the GPU (one-off per sample, not a hot op):
-// stable LSD radix sort of (key, pair-id) with rocPRIM, binary-searched row pointers,
-// gathered column ids.  See include/stin_hip.h for the contract.
+// COO -> CSR graph-plan construction on the GPU (once per sample): a counting sort.
+//   1. count    : integer atomicAdd histogram of the keys (result independent of arrival order)
+//   2. scan     : one rocPRIM inclusive scan -> row pointers
+//   3. fill     : atomic cursor per row drops each pair id into its row (arrival order arbitrary)
+//   4. rank     : every slot finds its rank among the pair ids of its row and moves there
+//                 => within a row entries are in ORIGINAL pair order, exactly a stable sort,
+//                 deterministic although steps 1 and 3 use atomics.
+// Both CSRs of an edge set (by destination and by source) are built by the same launches.
+// Contract: include/stin_hip.h.
 #include <cstring>
 #include <cstdlib>
 #include <rocprim/rocprim.hpp>
@@ -8,58 +14,105 @@
 
 namespace {
 
-__global__ void k_prepare(const int64_t* __restrict__ key, const int64_t* __restrict__ val, int64_t E, int64_t N,
-                          int64_t val_limit, int32_t* __restrict__ key32, int32_t* __restrict__ iota,
-                          int32_t* __restrict__ bad) {
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int T = 256;
+
+// sides: 0 = group by a[e] with value b[e]; 1 (pair mode only) = group by b[e] with value a[e].
+__global__ void k_count(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t E, int64_t N,
+                        int64_t b_limit, int pair, int32_t* __restrict__ cnt, int32_t* __restrict__ bad) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
-    int64_t k = key[e];
-    bool oob = (k < 0) | (k >= N);
-    if (val != nullptr) {
-        int64_t v = val[e];
-        oob |= (v < 0) | (v >= val_limit);
+    int64_t ka = a[e];
+    bool oob = (ka < 0) | (ka >= N);
+    int64_t kb = 0;
+    if (b != nullptr) {
+        kb = b[e];
+        oob |= (kb < 0) | (kb >= b_limit);
     }
     if (oob) {
         if (bad != nullptr) atomicOr(bad, 1);
-        k = 0;  // keep every later kernel in bounds; the host raises before using the plan
+        return;                      // dropped from the plan; the host raises IndexError before using it
     }
-    key32[e] = (int32_t)k;
-    iota[e] = (int32_t)e;
+    atomicAdd(&cnt[1 + ka], 1);
+    if (pair) atomicAdd(&cnt[1 + N + kb], 1);
 }
 
-__global__ void k_rowptr(const int32_t* __restrict__ sorted_key, int64_t E, int64_t N, int32_t* __restrict__ rowptr,
-                         float* __restrict__ inv_deg) {
-    int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// cnt (inclusive-scanned, cnt[0] = 0) -> rowptr(s), cursors, inv_deg
+__global__ void k_rows(const int32_t* __restrict__ scanned, int64_t N, int pair, int32_t* __restrict__ rowptr0,
+                       int32_t* __restrict__ rowptr1, int32_t* __restrict__ cursor, float* __restrict__ inv_deg0,
+                       float* __restrict__ inv_deg1) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n > N) return;
-    // lower_bound(sorted_key, n)
-    int64_t lo = 0, hi = E;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (sorted_key[mid] < (int32_t)n) lo = mid + 1; else hi = mid;
-    }
-    rowptr[n] = (int32_t)lo;
-    if (inv_deg != nullptr && n < N) {
-        int64_t lo2 = lo, hi2 = E;
-        while (lo2 < hi2) {
-            int64_t mid = (lo2 + hi2) >> 1;
-            if (sorted_key[mid] < (int32_t)(n + 1)) lo2 = mid + 1; else hi2 = mid;
+    const int32_t p0 = scanned[n];
+    rowptr0[n] = p0;
+    if (n < N) {
+        cursor[n] = p0;
+        if (inv_deg0 != nullptr) {
+            const int32_t d = scanned[n + 1] - p0;
+            inv_deg0[n] = 1.0f / (float)(d > 0 ? d : 1);
         }
-        int64_t deg = lo2 - lo;
-        inv_deg[n] = 1.0f / (float)(deg > 0 ? deg : 1);
+    }
+    if (pair) {
+        const int32_t total0 = scanned[N];
+        const int32_t p1 = scanned[N + n] - total0;
+        rowptr1[n] = p1;
+        if (n < N) {
+            cursor[N + n] = p1;
+            if (inv_deg1 != nullptr) {
+                const int32_t d = scanned[N + n + 1] - total0 - p1;
+                inv_deg1[n] = 1.0f / (float)(d > 0 ? d : 1);
+            }
+        }
     }
 }
 
-__global__ void k_col(const int64_t* __restrict__ val, const int32_t* __restrict__ perm, int64_t E, int64_t val_limit,
-                      int32_t* __restrict__ col) {
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_fill(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t E, int64_t N,
+                       int64_t b_limit, int pair, int32_t* __restrict__ cursor, int32_t* __restrict__ tmp_id0,
+                       int32_t* __restrict__ tmp_key0, int32_t* __restrict__ tmp_id1, int32_t* __restrict__ tmp_key1) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
-    int32_t p = perm[e];
-    if (val == nullptr) {
-        col[e] = p;
-    } else {
-        int64_t v = val[p];
-        col[e] = (v < 0 || v >= val_limit) ? 0 : (int32_t)v;
+    const int64_t ka = a[e];
+    const int64_t kb = b != nullptr ? b[e] : 0;
+    if (ka < 0 || ka >= N || (b != nullptr && (kb < 0 || kb >= b_limit))) return;
+    const int32_t s0 = atomicAdd(&cursor[ka], 1);
+    tmp_id0[s0] = (int32_t)e;
+    tmp_key0[s0] = (int32_t)ka;
+    if (pair) {
+        const int32_t s1 = atomicAdd(&cursor[N + kb], 1);
+        tmp_id1[s1] = (int32_t)e;
+        tmp_key1[s1] = (int32_t)kb;
     }
+}
+
+// slot t of side `side`: rank of its pair id within its row -> final position
+__global__ void k_rank(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t N, int64_t n_slots0,
+                       int64_t n_slots1, const int32_t* __restrict__ rowptr0, const int32_t* __restrict__ rowptr1,
+                       const int32_t* __restrict__ tmp_id0, const int32_t* __restrict__ tmp_key0,
+                       const int32_t* __restrict__ tmp_id1, const int32_t* __restrict__ tmp_key1,
+                       int32_t* __restrict__ col0, int32_t* __restrict__ perm0, int32_t* __restrict__ col1,
+                       int32_t* __restrict__ perm1) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int side = 0;
+    if (t >= n_slots0) {
+        t -= n_slots0;
+        side = 1;
+        if (t >= n_slots1) return;
+    }
+    const int32_t* ids = side ? tmp_id1 : tmp_id0;
+    const int32_t* keys = side ? tmp_key1 : tmp_key0;
+    const int32_t* rowptr = side ? rowptr1 : rowptr0;
+    if (t >= rowptr[N]) return;      // fewer slots than pairs when out-of-range pairs were dropped
+    const int32_t row = keys[t];
+    const int32_t beg = rowptr[row], end = rowptr[row + 1];
+    const int32_t mine = ids[t];
+    int32_t rank = 0;
+    for (int32_t u = beg; u < end; ++u) rank += (ids[u] < mine) ? 1 : 0;
+    const int32_t pos = beg + rank;
+    int32_t* col = side ? col1 : col0;
+    int32_t* perm = side ? perm1 : perm0;
+    // value stored with the entry: the OTHER endpoint (or the pair id itself when there is no value array)
+    const int64_t* other = side ? a : b;
+    col[pos] = other != nullptr ? (int32_t)other[mine] : mine;
+    if (perm != nullptr) perm[pos] = mine;
 }
 
 __global__ void k_narrow(const int64_t* __restrict__ src, int64_t n, int64_t limit, int32_t* __restrict__ dst,
@@ -75,63 +128,98 @@ __global__ void k_narrow(const int64_t* __restrict__ src, int64_t n, int64_t lim
 }
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+inline unsigned grid_for(int64_t n) { return (unsigned)((n + T - 1) / T); }
 
-inline int key_bits(int64_t N) {
-    int b = 1;
-    while (((int64_t)1 << b) < N && b < 31) ++b;
-    return b;
+size_t scan_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, bytes, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)(n > 0 ? n : 1),
+                                  rocprim::plus<int32_t>(), (hipStream_t)0);
+    return bytes;
 }
 
-size_t sort_temp_bytes(int64_t E, int64_t N) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr,
-                                    (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)(E > 0 ? E : 1), 0,
-                                    key_bits(N), (hipStream_t)0);
-    return bytes;
+struct Layout {
+    size_t cnt, cursor, id0, key0, id1, key1, scan, total;
+};
+
+Layout layout(int64_t E, int64_t N, int pair) {
+    Layout L;
+    const size_t sides = pair ? 2 : 1;
+    const size_t e = (size_t)(E > 0 ? E : 1);
+    size_t off = 0;
+    L.cnt = off;    off += align_up((sides * N + 2) * sizeof(int32_t));
+    L.cursor = off; off += align_up((sides * N + 2) * sizeof(int32_t));
+    L.id0 = off;    off += align_up(e * sizeof(int32_t));
+    L.key0 = off;   off += align_up(e * sizeof(int32_t));
+    L.id1 = off;    off += pair ? align_up(e * sizeof(int32_t)) : 0;
+    L.key1 = off;   off += pair ? align_up(e * sizeof(int32_t)) : 0;
+    L.scan = off;   off += align_up(scan_temp_bytes((int64_t)(sides * N + 1)));
+    L.total = off + 256;
+    return L;
+}
+
+int build(const int64_t* a, const int64_t* b, int64_t E, int64_t N, int64_t b_limit, int pair, int32_t* rowptr0,
+          int32_t* col0, int32_t* perm0, float* inv_deg0, int32_t* rowptr1, int32_t* col1, int32_t* perm1,
+          float* inv_deg1, int32_t* bad, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const Layout L = layout(E, N, pair);
+    STIN_REQUIRE(workspace_bytes >= L.total, STIN_E_WORKSPACE);
+    char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    int32_t* cnt = reinterpret_cast<int32_t*>(ws + L.cnt);
+    int32_t* cursor = reinterpret_cast<int32_t*>(ws + L.cursor);
+    int32_t* id0 = reinterpret_cast<int32_t*>(ws + L.id0);
+    int32_t* key0 = reinterpret_cast<int32_t*>(ws + L.key0);
+    int32_t* id1 = reinterpret_cast<int32_t*>(ws + L.id1);
+    int32_t* key1 = reinterpret_cast<int32_t*>(ws + L.key1);
+    const int64_t sides = pair ? 2 : 1;
+    const int64_t n_cnt = sides * N + 1;
+
+    hipError_t err = hipMemsetAsync(cnt, 0, (size_t)n_cnt * sizeof(int32_t), stream);
+    if (err != hipSuccess) return (int)err;
+    if (E > 0) hipLaunchKernelGGL(k_count, dim3(grid_for(E)), dim3(T), 0, stream, a, b, E, N, b_limit, pair, cnt, bad);
+    size_t scan_bytes = scan_temp_bytes(n_cnt);
+    err = rocprim::inclusive_scan(ws + L.scan, scan_bytes, cnt, cnt, (size_t)n_cnt, rocprim::plus<int32_t>(), stream);
+    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(k_rows, dim3(grid_for(N + 1)), dim3(T), 0, stream, cnt, N, pair, rowptr0, rowptr1, cursor,
+                       inv_deg0, inv_deg1);
+    if (E > 0) {
+        hipLaunchKernelGGL(k_fill, dim3(grid_for(E)), dim3(T), 0, stream, a, b, E, N, b_limit, pair, cursor, id0, key0, id1,
+                           key1);
+        // out-of-range pairs were dropped, so the slot counts are the scanned totals; over-launch with E per side and
+        // let the kernel stop at the true totals (read from rowptr[N] would need a sync): slots beyond the total
+        // hold stale ids, so bound the grid by E and guard by row ranges instead.
+        hipLaunchKernelGGL(k_rank, dim3(grid_for(sides * E)), dim3(T), 0, stream, a, b, N, E, pair ? E : 0, rowptr0, rowptr1,
+                           id0, key0, id1, key1, col0, perm0, col1, perm1);
+    }
+    return stin_launch_status();
 }
 
 }  // namespace
 
 extern "C" size_t stin_csr_workspace_bytes(int64_t E, int64_t N) {
     if (E < 0 || N < 0) return 0;
-    size_t e = (size_t)(E > 0 ? E : 1);
-    return 4 * align_up(e * sizeof(int32_t)) + align_up(sort_temp_bytes(E, N)) + 256;
+    return layout(E, N, 1).total;   // sized for the pair build (covers the single build)
 }
 
 extern "C" int stin_csr_from_coo_i64(const int64_t* key, const int64_t* val, int64_t E, int64_t N, int64_t val_limit,
                                      int32_t* rowptr, int32_t* col, int32_t* perm, float* inv_deg, int32_t* bad,
                                      void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
     stin_clear_stale_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    STIN_REQUIRE(E >= 0 && N >= 0 && N < ((int64_t)1 << 31) && E < ((int64_t)1 << 31), STIN_E_SIZE);
-    STIN_REQUIRE(rowptr != nullptr && (E == 0 || (key != nullptr && col != nullptr)), STIN_E_NULL);
-    STIN_REQUIRE(workspace != nullptr, STIN_E_NULL);
-    STIN_REQUIRE(workspace_bytes >= stin_csr_workspace_bytes(E, N), STIN_E_WORKSPACE);
+    STIN_REQUIRE(E >= 0 && N >= 0 && N < ((int64_t)1 << 30) && E < ((int64_t)1 << 30), STIN_E_SIZE);
+    STIN_REQUIRE(rowptr != nullptr && workspace != nullptr && (E == 0 || (key != nullptr && col != nullptr)), STIN_E_NULL);
     if (val != nullptr) STIN_REQUIRE(val_limit >= 0 && val_limit < ((int64_t)1 << 31), STIN_E_SIZE);
+    return build(key, val, E, N, val_limit, 0, rowptr, col, perm, inv_deg, nullptr, nullptr, nullptr, nullptr, bad,
+                 workspace, workspace_bytes, (hipStream_t)stream_);
+}
 
-    char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    size_t e = (size_t)(E > 0 ? E : 1);
-    size_t slab = align_up(e * sizeof(int32_t));
-    int32_t* key_in = reinterpret_cast<int32_t*>(ws);
-    int32_t* key_out = reinterpret_cast<int32_t*>(ws + slab);
-    int32_t* iota = reinterpret_cast<int32_t*>(ws + 2 * slab);
-    int32_t* perm_ws = reinterpret_cast<int32_t*>(ws + 3 * slab);
-    void* sort_tmp = ws + 4 * slab;
-    size_t sort_bytes = sort_temp_bytes(E, N);
-    int32_t* perm_out = perm != nullptr ? perm : perm_ws;
-
-    const int T = 256;
-    if (E > 0) {
-        hipLaunchKernelGGL(k_prepare, dim3((unsigned)((E + T - 1) / T)), dim3(T), 0, stream, key, val, E, N, val_limit,
-                           key_in, iota, bad);
-        hipError_t err = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, (const int32_t*)key_in, key_out,
-                                                   (const int32_t*)iota, perm_out, (size_t)E, 0, key_bits(N), stream);
-        if (err != hipSuccess) return (int)err;
-        hipLaunchKernelGGL(k_col, dim3((unsigned)((E + T - 1) / T)), dim3(T), 0, stream, val, perm_out, E, val_limit, col);
-    }
-    hipLaunchKernelGGL(k_rowptr, dim3((unsigned)((N + 1 + T - 1) / T)), dim3(T), 0, stream, key_out, E, N, rowptr,
-                       inv_deg);
-    return stin_launch_status();
+extern "C" int stin_csr_pair_from_edges_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N,
+                                            int32_t* rowptr_dst, int32_t* col_dst, float* inv_deg_dst,
+                                            int32_t* rowptr_src, int32_t* col_src, int32_t* bad, void* workspace,
+                                            size_t workspace_bytes, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(E >= 0 && N >= 0 && N < ((int64_t)1 << 30) && E < ((int64_t)1 << 30), STIN_E_SIZE);
+    STIN_REQUIRE(rowptr_dst && rowptr_src && workspace && (E == 0 || (src && dst && col_dst && col_src)), STIN_E_NULL);
+    // side 0 groups by dst (value = src), side 1 groups by src (value = dst)
+    return build(dst, src, E, N, N, 1, rowptr_dst, col_dst, nullptr, inv_deg_dst, rowptr_src, col_src, nullptr, nullptr,
+                 bad, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 extern "C" int stin_narrow_i64_to_i32(const int64_t* src, int64_t n, int64_t limit, int32_t* dst, int32_t* bad,
@@ -140,8 +228,6 @@ extern "C" int stin_narrow_i64_to_i32(const int64_t* src, int64_t n, int64_t lim
     STIN_REQUIRE(n >= 0, STIN_E_SIZE);
     if (n == 0) return STIN_OK;
     STIN_REQUIRE(src != nullptr && dst != nullptr, STIN_E_NULL);
-    const int T = 256;
-    hipLaunchKernelGGL(k_narrow, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, (hipStream_t)stream_, src, n, limit, dst,
-                       bad);
+    hipLaunchKernelGGL(k_narrow, dim3(grid_for(n)), dim3(T), 0, (hipStream_t)stream_, src, n, limit, dst, bad);
     return stin_launch_status();
 }

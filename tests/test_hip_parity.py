@@ -54,6 +54,22 @@ def test_csr_plan_bit_exact(n, e):
     assert int(bad.item()) == 0
 
 
+@pytest.mark.parametrize('n,e', [(5, 0), (64, 500), (4099, 30011), (200_000, 1_200_000)])
+def test_edge_csr_pair_bit_exact(n, e):
+    g = torch.Generator().manual_seed(7 * n + e)
+    ei = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g)])
+    bad = _bad()
+    es = EdgeSet(ei.to(DEV), n, bad)
+    src, dst = ei[0].numpy(), ei[1].numpy()
+    for csr, key, val in ((es.by_dst, dst, src), (es.by_src, src, dst)):
+        order = np.argsort(key, kind='stable')
+        cnt = np.bincount(key, minlength=n)
+        assert np.array_equal(csr.rowptr.cpu().numpy(), np.concatenate([[0], np.cumsum(cnt)]))
+        assert np.array_equal(csr.col.cpu().numpy(), val[order])
+    assert np.array_equal(es.inv_deg.cpu().numpy(), (1.0 / np.maximum(np.bincount(dst, minlength=n), 1)).astype(np.float32))
+    assert int(bad.item()) == 0
+
+
 def test_csr_flags_out_of_range_indices():
     key = torch.tensor([0, 1, 5, 2], device=DEV)
     bad = _bad()
