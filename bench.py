@@ -41,6 +41,10 @@ def edge_bytes(kernel, n, e, h):
         return (e * h + 3 * n * h) * 4 + idx
     if kernel == 'stin_edge_relu_mean_bwd_src_f32':  # gather A and G per edge, read B, write dB, inv_deg per edge
         return (2 * e * h + 2 * n * h) * 4 + idx + 4 * e
+    if kernel == 'stin_edge_relu_mean_bwd_dst_mask_f32':  # stream the H-bit masks of the in-edges, read G, write dA
+        return e * h // 8 + 2 * n * h * 4 + 4 * (n + 1)
+    if kernel == 'stin_edge_relu_mean_bwd_src_mask_f32':  # gather G per edge + its mask words, col/xslot/inv_deg, write dB
+        return e * h * 4 + e * h // 8 + 12 * e + n * h * 4 + 4 * (n + 1)
     raise KeyError(kernel)
 
 
@@ -57,7 +61,9 @@ def pmc_traffic_bytes(kernel, n, e, h):
     vpl = (c4 + g - 1) // g
     base = 4 if kernel.endswith('bwd_src_f32') else 8
     short = {'stin_edge_relu_mean_fwd_f32': 'k_edge_fwd', 'stin_edge_relu_mean_bwd_dst_f32': 'k_edge_bwd_dst',
-             'stin_edge_relu_mean_bwd_src_f32': 'k_edge_bwd_src'}[kernel]
+             'stin_edge_relu_mean_bwd_src_f32': 'k_edge_bwd_src',
+             'stin_edge_relu_mean_bwd_dst_mask_f32': 'k_edge_bwd_dst_mask',
+             'stin_edge_relu_mean_bwd_src_mask_f32': 'k_edge_bwd_src_mask'}[kernel]
     key = '%s<%d, %d, %d>' % (short, g, vpl, max(1, (base + vpl - 1) // vpl))
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
     if not files:
@@ -182,7 +188,8 @@ def main():
         one_step()
     fence()
     SF.KernelTimer.start(['stin_edge_relu_mean_fwd_f32', 'stin_edge_relu_mean_bwd_dst_f32',
-                          'stin_edge_relu_mean_bwd_src_f32'] + (['stin_gemm_nt_f32', 'stin_gemm_tn_f32'] if args.time_gemms else []))
+                          'stin_edge_relu_mean_bwd_src_f32', 'stin_edge_relu_mean_bwd_dst_mask_f32',
+                          'stin_edge_relu_mean_bwd_src_mask_f32'] + (['stin_gemm_nt_f32', 'stin_gemm_tn_f32'] if args.time_gemms else []))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()

@@ -29,18 +29,23 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd(const float* __restrict__ A,
                                                     const float* __restrict__ B, int64_t ldb,
                                                     const int32_t* __restrict__ rowptr,
                                                     const int32_t* __restrict__ col, int64_t N, int H,
-                                                    float* __restrict__ out, int64_t ldo, int indicator) {
+                                                    float* __restrict__ out, int64_t ldo, int indicator,
+                                                    uint32_t* __restrict__ mask) {
     Lane<G, VPL> L;
-    if (L.row >= N) return;
-    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    // With a mask output the 8-lane nibble gather below needs every lane of the wave alive: rows past N
+    // run on an empty segment instead of returning (G >= 8 on that path, so whole 8-lane sets share a row).
+    const bool row_ok = L.row < N;
+    if (!row_ok && mask == nullptr) return;
+    const int beg = row_ok ? rowptr[L.row] : 0, end = row_ok ? rowptr[L.row + 1] : 0;
     float4 a[VPL], acc[VPL];
     bool on[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
-        on[k] = L.chan(k) < H;
+        on[k] = row_ok && L.chan(k) < H;
         a[k] = on[k] ? ld4(A + L.row * lda + L.chan(k)) : f4zero();
         acc[k] = f4zero();
     }
+    const int mwords = H >> 5;                            // mask words per edge slot (natural channel order)
     for (int e = beg; e < end; e += U) {
         float4 b[U][VPL];
 #pragma unroll
@@ -55,13 +60,27 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd(const float* __restrict__ A,
             const float w = (e + u < end) ? 1.f : 0.f;
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {
-                acc[k].x += w * fmaxf(a[k].x + b[u][k].x, 0.f);
-                acc[k].y += w * fmaxf(a[k].y + b[u][k].y, 0.f);
-                acc[k].z += w * fmaxf(a[k].z + b[u][k].z, 0.f);
-                acc[k].w += w * fmaxf(a[k].w + b[u][k].w, 0.f);
+                const float tx = a[k].x + b[u][k].x, ty = a[k].y + b[u][k].y;
+                const float tz = a[k].z + b[u][k].z, tw = a[k].w + b[u][k].w;
+                acc[k].x += w * fmaxf(tx, 0.f);
+                acc[k].y += w * fmaxf(ty, 0.f);
+                acc[k].z += w * fmaxf(tz, 0.f);
+                acc[k].w += w * fmaxf(tw, 0.f);
+                if (G >= 8 && mask != nullptr) {
+                    // bit c of the slot's mask = [A_i[c] + B_j[c] > 0]; this lane owns channels chan(k)..+3 = one
+                    // nibble; 8 neighbouring lanes assemble one 32-bit word (3 xor-shuffles), lane%8 == 0 stores
+                    uint32_t nib = (tx > 0.f ? 1u : 0u) | (ty > 0.f ? 2u : 0u) | (tz > 0.f ? 4u : 0u) | (tw > 0.f ? 8u : 0u);
+                    uint32_t v = nib << (4 * (L.lg & 7));
+                    v |= __shfl_xor(v, 1);
+                    v |= __shfl_xor(v, 2);
+                    v |= __shfl_xor(v, 4);
+                    if ((L.lg & 7) == 0 && on[k] && e + u < end)
+                        mask[(int64_t)(e + u) * mwords + (L.chan(k) >> 5)] = v;
+                }
             }
         }
     }
+    if (!row_ok) return;
     const int deg = end - beg;
     const float s = (float)(deg > 0 ? deg : 1);      // true division, as torch_scatter's scatter_mean (sum / count)
 #pragma unroll
@@ -163,6 +182,112 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_src(const float* __restrict_
                 acc[k].y += (a[u][k].y + b[k].y > 0.f) ? w[u] * g[u][k].y : 0.f;
                 acc[k].z += (a[u][k].z + b[k].z > 0.f) ? w[u] * g[u][k].z : 0.f;
                 acc[k].w += (a[u][k].w + b[k].w > 0.f) ? w[u] * g[u][k].w : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (on[k]) st4(dB + L.row * lddb + L.chan(k), acc[k]);
+}
+
+// ----------------------------- edge stage backward from the saved ReLU bit-mask (no recompute)
+// dA[i,c] = G[i,c]/deg_i * popcount_e mask[e][c] over the in-edge slots e of i: a pure streaming kernel
+// (reads H/8 bytes per edge instead of gathering a B row).
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask(const float* __restrict__ Gr, int64_t ldg,
+                                                             const uint32_t* __restrict__ mask,
+                                                             const int32_t* __restrict__ rowptr, int64_t N, int H,
+                                                             float* __restrict__ dA, int64_t ldda) {
+    Lane<G, VPL> L;
+    if (L.row >= N) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    const int mwords = H >> 5;
+    int cnt[VPL][4];
+    bool on[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        on[k] = L.chan(k) < H;
+        cnt[k][0] = cnt[k][1] = cnt[k][2] = cnt[k][3] = 0;
+    }
+    for (int e = beg; e < end; e += U) {
+        uint32_t wv[U][VPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = min(e + u, end - 1);
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) wv[u][k] = on[k] ? mask[(int64_t)ee * mwords + (L.chan(k) >> 5)] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e + u < end) {
+#pragma unroll
+                for (int k = 0; k < VPL; ++k) {
+                    const uint32_t nib = wv[u][k] >> (4 * (L.lg & 7));
+                    cnt[k][0] += nib & 1u;
+                    cnt[k][1] += (nib >> 1) & 1u;
+                    cnt[k][2] += (nib >> 2) & 1u;
+                    cnt[k][3] += (nib >> 3) & 1u;
+                }
+            }
+        }
+    }
+    const int deg = end - beg;
+    const float s = 1.0f / (float)(deg > 0 ? deg : 1);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (on[k]) {
+            const float4 g = ld4(Gr + L.row * ldg + L.chan(k));
+            st4(dA + L.row * ldda + L.chan(k), make_float4(g.x * s * (float)cnt[k][0], g.y * s * (float)cnt[k][1],
+                                                           g.z * s * (float)cnt[k][2], g.w * s * (float)cnt[k][3]));
+        }
+}
+
+// dB[j,c] = sum over out-edges (j -> i) of inv_deg[i] * G[i,c] * mask[xslot][c]: gathers G rows and 32-bit mask
+// words (xslot = destination-CSR slot of the same edge), half the bytes of the recompute form.
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask(const float* __restrict__ Gr, int64_t ldg,
+                                                             const float* __restrict__ inv_deg,
+                                                             const uint32_t* __restrict__ mask,
+                                                             const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col,
+                                                             const int32_t* __restrict__ xslot, int64_t N, int H,
+                                                             float* __restrict__ dB, int64_t lddb) {
+    Lane<G, VPL> L;
+    if (L.row >= N) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    const int mwords = H >> 5;
+    float4 acc[VPL];
+    bool on[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        on[k] = L.chan(k) < H;
+        acc[k] = f4zero();
+    }
+    for (int e = beg; e < end; e += U) {
+        float4 g[U][VPL];
+        uint32_t wv[U][VPL];
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = min(e + u, end - 1);
+            const int64_t i = col[ee];
+            const int64_t xs = xslot[ee];
+            w[u] = (e + u < end) ? inv_deg[i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                g[u][k] = on[k] ? ld4(Gr + i * ldg + L.chan(k)) : f4zero();
+                wv[u][k] = on[k] ? mask[xs * mwords + (L.chan(k) >> 5)] : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                const uint32_t nib = wv[u][k] >> (4 * (L.lg & 7));
+                acc[k].x += (nib & 1u) ? w[u] * g[u][k].x : 0.f;
+                acc[k].y += (nib & 2u) ? w[u] * g[u][k].y : 0.f;
+                acc[k].z += (nib & 4u) ? w[u] * g[u][k].z : 0.f;
+                acc[k].w += (nib & 8u) ? w[u] * g[u][k].w : 0.f;
             }
         }
     }
@@ -436,15 +561,16 @@ inline unsigned grid_elems(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOC
 
 extern "C" int stin_edge_relu_mean_fwd_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
                                            const int32_t* rowptr, const int32_t* col, int64_t N, int H, float* out,
-                                           int64_t ldo, int indicator, stin_stream_t stream_) {
+                                           int64_t ldo, int indicator, uint32_t* mask, stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(N >= 0 && H > 0 && lda >= H && ldb >= H && ldo >= H + (indicator ? 4 : 0), STIN_E_SIZE);
     STIN_REQUIRE(!indicator || H >= 4, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(mask == nullptr || (H % 32 == 0 && vec_ok(H, {A, B, out}, {lda, ldb, ldo})), STIN_E_UNSUPPORTED);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(A && B && rowptr && out, STIN_E_NULL);
     if (vec_ok(H, {A, B, out}, {lda, ldb, ldo})) {
-        STIN_DISPATCH(H, k_edge_fwd, 8, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator);
+        STIN_DISPATCH(H, k_edge_fwd, 8, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
     } else {
         hipLaunchKernelGGL((k_scalar<OP_EDGE_FWD>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
                            (const float*)nullptr, (int64_t)0, (const float*)nullptr, rowptr, col, N, H, indicator, out, ldo,
@@ -485,6 +611,33 @@ extern "C" int stin_edge_relu_mean_bwd_src_f32(const float* A, int64_t lda, cons
         hipLaunchKernelGGL((k_scalar<OP_EDGE_BWD_SRC>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
                            G, ldg, inv_deg, rowptr_src, col_src, N, H, 0, dB, lddb, (int32_t*)nullptr);
     }
+    return stin_launch_status();
+}
+
+extern "C" int stin_edge_relu_mean_bwd_dst_mask_f32(const float* G, int64_t ldg, const uint32_t* mask,
+                                                    const int32_t* rowptr, int64_t N, int H, float* dA, int64_t ldda,
+                                                    stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && ldda >= H, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(G && mask && rowptr && dA, STIN_E_NULL);
+    STIN_REQUIRE(H % 32 == 0 && vec_ok(H, {G, dA}, {ldg, ldda}), STIN_E_UNSUPPORTED);
+    STIN_DISPATCH(H, k_edge_bwd_dst_mask, 8, G, ldg, mask, rowptr, N, H, dA, ldda);
+    return stin_launch_status();
+}
+
+extern "C" int stin_edge_relu_mean_bwd_src_mask_f32(const float* G, int64_t ldg, const float* inv_deg,
+                                                    const uint32_t* mask, const int32_t* rowptr_src,
+                                                    const int32_t* col_src, const int32_t* xslot, int64_t N, int H,
+                                                    float* dB, int64_t lddb, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && lddb >= H, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(G && inv_deg && mask && rowptr_src && col_src && xslot && dB, STIN_E_NULL);
+    STIN_REQUIRE(H % 32 == 0 && vec_ok(H, {G, dB}, {ldg, lddb}), STIN_E_UNSUPPORTED);
+    STIN_DISPATCH(H, k_edge_bwd_src_mask, 8, G, ldg, inv_deg, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
     return stin_launch_status();
 }
 

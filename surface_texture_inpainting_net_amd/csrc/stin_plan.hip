@@ -89,7 +89,7 @@ __global__ void k_rank(const int64_t* __restrict__ a, const int64_t* __restrict_
                        const int32_t* __restrict__ tmp_id0, const int32_t* __restrict__ tmp_key0,
                        const int32_t* __restrict__ tmp_id1, const int32_t* __restrict__ tmp_key1,
                        int32_t* __restrict__ col0, int32_t* __restrict__ perm0, int32_t* __restrict__ col1,
-                       int32_t* __restrict__ perm1) {
+                       int32_t* __restrict__ perm1, int32_t* __restrict__ slot_of_edge) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int side = 0;
     if (t >= n_slots0) {
@@ -113,6 +113,15 @@ __global__ void k_rank(const int64_t* __restrict__ a, const int64_t* __restrict_
     const int64_t* other = side ? a : b;
     col[pos] = other != nullptr ? (int32_t)other[mine] : mine;
     if (perm != nullptr) perm[pos] = mine;
+    if (side == 0 && slot_of_edge != nullptr) slot_of_edge[mine] = pos;
+}
+
+// xslot[src-CSR slot] = dst-CSR slot of the same edge (slot_of_edge is the inverse of the dst-side perm)
+__global__ void k_xslot(const int32_t* __restrict__ perm_src, const int32_t* __restrict__ slot_of_edge, int64_t E,
+                        const int32_t* __restrict__ rowptr_src, int64_t N, int32_t* __restrict__ xslot) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E || t >= rowptr_src[N]) return;
+    xslot[t] = slot_of_edge[perm_src[t]];
 }
 
 __global__ void k_narrow(const int64_t* __restrict__ src, int64_t n, int64_t limit, int32_t* __restrict__ dst,
@@ -138,7 +147,7 @@ size_t scan_temp_bytes(int64_t n) {
 }
 
 struct Layout {
-    size_t cnt, cursor, id0, key0, id1, key1, scan, total;
+    size_t cnt, cursor, id0, key0, id1, key1, x0, x1, scan, total;
 };
 
 Layout layout(int64_t E, int64_t N, int pair) {
@@ -152,6 +161,8 @@ Layout layout(int64_t E, int64_t N, int pair) {
     L.key0 = off;   off += align_up(e * sizeof(int32_t));
     L.id1 = off;    off += pair ? align_up(e * sizeof(int32_t)) : 0;
     L.key1 = off;   off += pair ? align_up(e * sizeof(int32_t)) : 0;
+    L.x0 = off;     off += pair ? align_up(e * sizeof(int32_t)) : 0;
+    L.x1 = off;     off += pair ? align_up(e * sizeof(int32_t)) : 0;
     L.scan = off;   off += align_up(scan_temp_bytes((int64_t)(sides * N + 1)));
     L.total = off + 256;
     return L;
@@ -159,7 +170,7 @@ Layout layout(int64_t E, int64_t N, int pair) {
 
 int build(const int64_t* a, const int64_t* b, int64_t E, int64_t N, int64_t b_limit, int pair, int32_t* rowptr0,
           int32_t* col0, int32_t* perm0, float* inv_deg0, int32_t* rowptr1, int32_t* col1, int32_t* perm1,
-          float* inv_deg1, int32_t* bad, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+          float* inv_deg1, int32_t* xslot, int32_t* bad, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     const Layout L = layout(E, N, pair);
     STIN_REQUIRE(workspace_bytes >= L.total, STIN_E_WORKSPACE);
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
@@ -186,8 +197,20 @@ int build(const int64_t* a, const int64_t* b, int64_t E, int64_t N, int64_t b_li
         // out-of-range pairs were dropped, so the slot counts are the scanned totals; over-launch with E per side and
         // let the kernel stop at the true totals (read from rowptr[N] would need a sync): slots beyond the total
         // hold stale ids, so bound the grid by E and guard by row ranges instead.
+        // cross-slot map for the masked backward: reuse the (now dead) fill buffers key0 / key1 as
+        // slot_of_edge / perm_src
+        int32_t* slot_of_edge = xslot != nullptr ? key0 + 0 : nullptr;
+        int32_t* perm_src = xslot != nullptr ? key1 : perm1;
+        if (xslot != nullptr) {
+            // key0/key1 are still read by k_rank: use id-free scratch instead -> the cursor array (2N+2 ints) is too
+            // small, so take dedicated space appended to the workspace layout
+            slot_of_edge = reinterpret_cast<int32_t*>(ws + L.x0);
+            perm_src = reinterpret_cast<int32_t*>(ws + L.x1);
+        }
         hipLaunchKernelGGL(k_rank, dim3(grid_for(sides * E)), dim3(T), 0, stream, a, b, N, E, pair ? E : 0, rowptr0, rowptr1,
-                           id0, key0, id1, key1, col0, perm0, col1, perm1);
+                           id0, key0, id1, key1, col0, perm0, col1, perm_src, slot_of_edge);
+        if (xslot != nullptr)
+            hipLaunchKernelGGL(k_xslot, dim3(grid_for(E)), dim3(T), 0, stream, perm_src, slot_of_edge, E, rowptr1, N, xslot);
     }
     return stin_launch_status();
 }
@@ -206,20 +229,20 @@ extern "C" int stin_csr_from_coo_i64(const int64_t* key, const int64_t* val, int
     STIN_REQUIRE(E >= 0 && N >= 0 && N < ((int64_t)1 << 30) && E < ((int64_t)1 << 30), STIN_E_SIZE);
     STIN_REQUIRE(rowptr != nullptr && workspace != nullptr && (E == 0 || (key != nullptr && col != nullptr)), STIN_E_NULL);
     if (val != nullptr) STIN_REQUIRE(val_limit >= 0 && val_limit < ((int64_t)1 << 31), STIN_E_SIZE);
-    return build(key, val, E, N, val_limit, 0, rowptr, col, perm, inv_deg, nullptr, nullptr, nullptr, nullptr, bad,
-                 workspace, workspace_bytes, (hipStream_t)stream_);
+    return build(key, val, E, N, val_limit, 0, rowptr, col, perm, inv_deg, nullptr, nullptr, nullptr, nullptr, nullptr,
+                 bad, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 extern "C" int stin_csr_pair_from_edges_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N,
                                             int32_t* rowptr_dst, int32_t* col_dst, float* inv_deg_dst,
-                                            int32_t* rowptr_src, int32_t* col_src, int32_t* bad, void* workspace,
-                                            size_t workspace_bytes, stin_stream_t stream_) {
+                                            int32_t* rowptr_src, int32_t* col_src, int32_t* xslot, int32_t* bad,
+                                            void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
     stin_clear_stale_error();
     STIN_REQUIRE(E >= 0 && N >= 0 && N < ((int64_t)1 << 30) && E < ((int64_t)1 << 30), STIN_E_SIZE);
     STIN_REQUIRE(rowptr_dst && rowptr_src && workspace && (E == 0 || (src && dst && col_dst && col_src)), STIN_E_NULL);
     // side 0 groups by dst (value = src), side 1 groups by src (value = dst)
     return build(dst, src, E, N, N, 1, rowptr_dst, col_dst, nullptr, inv_deg_dst, rowptr_src, col_src, nullptr, nullptr,
-                 bad, workspace, workspace_bytes, (hipStream_t)stream_);
+                 xslot, bad, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 extern "C" int stin_narrow_i64_to_i32(const int64_t* src, int64_t n, int64_t limit, int32_t* dst, int32_t* bad,

@@ -13,6 +13,8 @@ from . import _lib
 from .plan import _ptr, _stream
 
 EPS = 1e-5
+# save the edge-stage ReLU decisions as a bit-mask in forward (STIN_EDGE_MASK=0: recompute them in backward)
+USE_EDGE_MASK = os.environ.get('STIN_EDGE_MASK', '1') != '0'
 RED_SUM, RED_CSQ, RED_DOT_ELU, RED_COEF_XC = 0, 1, 2, 3
 POST_NONE, POST_SCALE, POST_RSTD = 0, 1, 2
 
@@ -59,13 +61,34 @@ def _call(name, *args, tag=None):
 
 
 # ------------------------------------------------------------------ raw kernel wrappers
-def edge_relu_mean_fwd(A, B, csr, out, indicator=False):
+def edge_relu_mean_fwd(A, B, csr, out, indicator=False, mask=None):
     A, lda = _mat(A)
     B, ldb = _mat(B)
     H = A.shape[1]
     _call('stin_edge_relu_mean_fwd_f32', _ptr(A), lda, _ptr(B), ldb, _ptr(csr.rowptr), _ptr(csr.col), A.shape[0], H,
-          _ptr(out), out.stride(0), int(indicator), _stream(A), tag=(A.shape[0], csr.n_entries, H))
+          _ptr(out), out.stride(0), int(indicator), _ptr(mask), _stream(A), tag=(A.shape[0], csr.n_entries, H))
     return out
+
+
+def edge_mask_supported(H):
+    """The saved-ReLU-mask backward needs whole 32-bit mask words per lane octet."""
+    return H % 32 == 0 and H <= 2048
+
+
+def edge_relu_mean_bwd_dst_mask(G, mask, csr, dA):
+    G, ldg = _mat(G)
+    _call('stin_edge_relu_mean_bwd_dst_mask_f32', _ptr(G), ldg, _ptr(mask), _ptr(csr.rowptr), G.shape[0], G.shape[1],
+          _ptr(dA), dA.stride(0), _stream(G), tag=(G.shape[0], csr.n_entries, G.shape[1]))
+    return dA
+
+
+def edge_relu_mean_bwd_src_mask(G, mask, edges, dB):
+    G, ldg = _mat(G)
+    cs = edges.by_src
+    _call('stin_edge_relu_mean_bwd_src_mask_f32', _ptr(G), ldg, _ptr(edges.inv_deg), _ptr(mask), _ptr(cs.rowptr),
+          _ptr(cs.col), _ptr(edges.xslot), G.shape[0], G.shape[1], _ptr(dB), dB.stride(0), _stream(G),
+          tag=(G.shape[0], cs.n_entries, G.shape[1]))
+    return dB
 
 
 def edge_relu_mean_bwd_dst(A, B, G, csr, dA):
@@ -317,12 +340,16 @@ class EdgeConvBlockFn(torch.autograd.Function):
               int(has_shortcut), int(trans_inv), _ptr(wcat), _ptr(bcat), _ptr(wcatT), _ptr(w2T), _stream(x))
         Y = gemm_nt(x, wcat, bcat, precision=PREC_FWD)
         hE = torch.empty(N, H + 4, dtype=torch.float32, device=dev)
-        edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True)
+        # ReLU decisions as bits (E*H/8 bytes): backward then needs no recompute gathers
+        use_mask = USE_EDGE_MASK and edge_mask_supported(H) and Y.stride(0) % 4 == 0
+        mask = torch.empty(max(edges.n_edges, 1) * (H // 32), dtype=torch.int32, device=dev) if use_mask else None
+        edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True, mask=mask)
         agg = gemm_nt(hE[:, :H], W2c, b2, row_mask=hE[:, H], precision=PREC_FWD)
         mean, rstd = instance_stats(agg, groups)
         res = Y[:, 2 * H:] if has_shortcut else x
         out = norm_act_res_fwd(agg, mean, rstd, groups, res=res, act=True)
         ctx.save_for_backward(x, Y, hE, agg, mean, rstd, wcatT, w2T)
+        ctx.mask = mask
         ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut, ctx.trans_inv = edges, groups, H, has_shortcut, trans_inv
         ctx.has_b1, ctx.has_b2, ctx.has_bs = b1 is not None, b2 is not None, bs is not None
         ctx.w1_shape = tuple(W1.shape)
@@ -338,9 +365,14 @@ class EdgeConvBlockFn(torch.autograd.Function):
         dw2b = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H], precision=PREC_BWD)   # [Cout, H + 1] = dW2 | db2
         dhE = gemm_nt(dagg, w2T, precision=PREC_BWD)                                             # [N, H] = dagg W2
         dY = torch.empty_like(Y)
-        A, B = Y[:, :H], Y[:, H:2 * H]
-        edge_relu_mean_bwd_dst(A, B, dhE, edges.by_dst, dY[:, :H])
-        edge_relu_mean_bwd_src(A, B, dhE, edges.inv_deg, edges.by_src, dY[:, H:2 * H])
+        if ctx.mask is not None:
+            edge_relu_mean_bwd_dst_mask(dhE, ctx.mask, edges.by_dst, dY[:, :H])
+            edge_relu_mean_bwd_src_mask(dhE, ctx.mask, edges, dY[:, H:2 * H])
+            ctx.mask = None
+        else:
+            A, B = Y[:, :H], Y[:, H:2 * H]
+            edge_relu_mean_bwd_dst(A, B, dhE, edges.by_dst, dY[:, :H])
+            edge_relu_mean_bwd_src(A, B, dhE, edges.inv_deg, edges.by_src, dY[:, H:2 * H])
         if ctx.has_shortcut:
             dY[:, 2 * H:].copy_(g)
         dwb = gemm_tn(dY, x, ones_column=True, precision=PREC_BWD)           # [Yw, Cin + 1]: packed weight grad | bias grad

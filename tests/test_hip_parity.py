@@ -112,6 +112,37 @@ def test_edge_stage_forward_backward(H):
     assert float((Bd.grad.cpu() - B.grad).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize('H', [32, 64, 96, 128, 256, 512, 1024])
+def test_edge_stage_saved_mask_backward_equals_recompute(H):
+    """The forward's ReLU bit-mask (E*H/8 bytes) drives a backward that must equal the recompute form bit for bit."""
+    n, e = 1500, 9000
+    ei = _random_graph(n, e, seed=H + 1)
+    es = EdgeSet(ei.to(DEV), n, _bad())
+    g = torch.Generator().manual_seed(H)
+    Y = torch.randn(n, 2 * H + 8, generator=g).to(DEV)           # A and B as column slices of a wider matrix
+    A, B = Y[:, :H], Y[:, H:2 * H]
+    Gr = torch.randn(n, H, generator=g).to(DEV)
+    out0 = torch.empty(n, H + 4, device=DEV)
+    out1 = torch.empty(n, H + 4, device=DEV)
+    mask = torch.zeros(e * (H // 32), dtype=torch.int32, device=DEV)
+    SF.edge_relu_mean_fwd(A, B, es.by_dst, out0, indicator=True)
+    SF.edge_relu_mean_fwd(A, B, es.by_dst, out1, indicator=True, mask=mask)
+    assert torch.equal(out0, out1)
+    # the mask itself, against the definition (natural channel order, one H-bit row per destination-CSR slot)
+    dst = torch.repeat_interleave(torch.arange(n, device=DEV), (es.by_dst.rowptr[1:] - es.by_dst.rowptr[:-1]).long())
+    bits = (A[dst] + B[es.by_dst.col.long()] > 0)
+    words = mask.view(e, H // 32).long() & 0xFFFFFFFF
+    got_bits = ((words.unsqueeze(-1) >> torch.arange(32, device=DEV)) & 1).bool().view(e, H)
+    assert torch.equal(got_bits, bits)
+    dA0, dA1, dB0, dB1 = (torch.empty(n, H, device=DEV) for _ in range(4))
+    SF.edge_relu_mean_bwd_dst(A, B, Gr, es.by_dst, dA0)
+    SF.edge_relu_mean_bwd_dst_mask(Gr, mask, es.by_dst, dA1)
+    SF.edge_relu_mean_bwd_src(A, B, Gr, es.inv_deg, es.by_src, dB0)
+    SF.edge_relu_mean_bwd_src_mask(Gr, mask, es, dB1)
+    assert torch.equal(dA0, dA1)
+    assert torch.equal(dB0, dB1)
+
+
 def test_edge_stage_on_column_slices_and_indicator():
     n, H = 300, 32
     ei = _random_graph(n, 2000, seed=1)
