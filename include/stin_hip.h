@@ -74,11 +74,13 @@ int stin_csr_from_coo_i64(const int64_t* key, const int64_t* val, int64_t E, int
 /* Both CSRs of one directed edge set in the same launches: by destination (col = sources, inv_deg =
  * 1/max(1, in-degree)) for the forward gather and dA, by source (col = targets) for dB.
  * xslot[s] (may be NULL) = destination-CSR slot of the edge at source-CSR slot s: lets the backward
- * find an edge's saved ReLU mask (stored per destination-CSR slot) from the source side. */
+ * find an edge's saved ReLU mask (stored per destination-CSR slot) from the source side;
+ * w_src[s] (may be NULL; needs xslot and inv_deg_dst) = inv_deg_dst[col_src[s]], the mean weight of
+ * that edge's target, laid out sequentially for the dB pass. */
 int stin_csr_pair_from_edges_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N,
                                  int32_t* rowptr_dst, int32_t* col_dst, float* inv_deg_dst,
-                                 int32_t* rowptr_src, int32_t* col_src, int32_t* xslot, int32_t* bad,
-                                 void* workspace, size_t workspace_bytes, stin_stream_t stream);
+                                 int32_t* rowptr_src, int32_t* col_src, int32_t* xslot, float* w_src,
+                                 int32_t* bad, void* workspace, size_t workspace_bytes, stin_stream_t stream);
 /* dst[i] = (int32) src[i]; *bad set when a value is outside [0, limit). */
 int stin_narrow_i64_to_i32(const int64_t* src, int64_t n, int64_t limit, int32_t* dst, int32_t* bad,
                            stin_stream_t stream);
@@ -104,9 +106,11 @@ int stin_segment_sum_f32(const float* src, int64_t ld_src, const int32_t* rowptr
  *             H..H+3 of `out` = ([deg i > 0], 0, 0, 0) (needs ldo >= H+4): the following
  *             per-vertex GEMM against [W2 | b2 | 0 0 0] then yields W2 h + b2 [deg > 0],
  *             i.e. PyG's "vertices without in-edges aggregate to exactly 0".
- *             With mask != NULL (needs H % 32 == 0) it also stores, per destination-CSR edge slot e,
- *             the H-bit ReLU mask  bit c of mask[e * H/32 + c/32] = [A[i,c] + B[j,c] > 0]
- *             (E*H/8 bytes, 32x smaller than an fp32 [E,H] tensor) for the masked backward below.
+ *             With mask != NULL (needs H % 128 == 0) it also stores, per destination-CSR edge slot e,
+ *             the H ReLU decisions [A[i,c] + B[j,c] > 0] as H bits at mask[e * H/32 ...] (E*H/8 bytes,
+ *             32x smaller than an fp32 [E,H] tensor) for the masked backward below.  Bit order inside
+ *             a slot is the wave-ballot order of the kernel ([chunk][x,y,z,w][lane]); the three
+ *             kernels agree on it, it is not meant to be read elsewhere.
  *   bwd_dst : dA[i,:] = inv_deg[i] * G[i,:] * #{j in N(i) : A[i,:]+B[j,:] > 0}
  *   bwd_src : dB[j,:] = sum_{i : j in N(i)} inv_deg[i] * G[i,:] * [A[i,:]+B[j,:] > 0]
  *             (source CSR; the backward scatter-add becomes a gather, no atomics)
@@ -114,14 +118,14 @@ int stin_segment_sum_f32(const float* src, int64_t ld_src, const int32_t* rowptr
 int stin_edge_relu_mean_fwd_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
                                 const int32_t* rowptr, const int32_t* col, int64_t N, int H,
                                 float* out, int64_t ldo, int indicator, uint32_t* mask, stin_stream_t stream);
-/* Backward from the saved mask instead of recomputing it (H % 32 == 0):
+/* Backward from the saved mask instead of recomputing it (H % 128 == 0):
  *   bwd_dst_mask: dA[i,:] = inv_deg[i] * G[i,:] * popcount over the in-edge slots of i   (streams H/8 bytes
  *                 per edge instead of gathering a B row)
- *   bwd_src_mask: dB[j,:] = sum_{out-edges j->i} inv_deg[i] * G[i,:] * mask[xslot]        (gathers G rows and
+ *   bwd_src_mask: dB[j,:] = sum_{out-edge slots s: j->i} w_src[s] * G[i,:] * mask[xslot[s]] (gathers G rows and
  *                 mask words: half the bytes of the recompute form) */
 int stin_edge_relu_mean_bwd_dst_mask_f32(const float* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr,
                                          int64_t N, int H, float* dA, int64_t ldda, stin_stream_t stream);
-int stin_edge_relu_mean_bwd_src_mask_f32(const float* G, int64_t ldg, const float* inv_deg, const uint32_t* mask,
+int stin_edge_relu_mean_bwd_src_mask_f32(const float* G, int64_t ldg, const float* w_src, const uint32_t* mask,
                                          const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot,
                                          int64_t N, int H, float* dB, int64_t lddb, stin_stream_t stream);
 int stin_edge_relu_mean_bwd_dst_f32(const float* A, int64_t lda, const float* B, int64_t ldb,

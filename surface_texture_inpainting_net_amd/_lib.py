@@ -37,7 +37,7 @@ SIGNATURES = {
     'stin_csr_from_coo_i64': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                       c_size, c_ptr]),
     'stin_csr_pair_from_edges_i64': (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
-                                             c_ptr, c_size, c_ptr]),
+                                             c_ptr, c_ptr, c_size, c_ptr]),
     'stin_narrow_i64_to_i32': (c_int, [c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     'stin_segment_sum_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'stin_edge_relu_mean_fwd_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64,

@@ -32,11 +32,9 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd(const float* __restrict__ A,
                                                     float* __restrict__ out, int64_t ldo, int indicator,
                                                     uint32_t* __restrict__ mask) {
     Lane<G, VPL> L;
-    // With a mask output the 8-lane nibble gather below needs every lane of the wave alive: rows past N
-    // run on an empty segment instead of returning (G >= 8 on that path, so whole 8-lane sets share a row).
     const bool row_ok = L.row < N;
-    if (!row_ok && mask == nullptr) return;
-    const int beg = row_ok ? rowptr[L.row] : 0, end = row_ok ? rowptr[L.row + 1] : 0;
+    if (!row_ok) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
     float4 a[VPL], acc[VPL];
     bool on[VPL];
 #pragma unroll
@@ -66,21 +64,27 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd(const float* __restrict__ A,
                 acc[k].y += w * fmaxf(ty, 0.f);
                 acc[k].z += w * fmaxf(tz, 0.f);
                 acc[k].w += w * fmaxf(tw, 0.f);
-                if (G >= 8 && mask != nullptr) {
-                    // bit c of the slot's mask = [A_i[c] + B_j[c] > 0]; this lane owns channels chan(k)..+3 = one
-                    // nibble; 8 neighbouring lanes assemble one 32-bit word (3 xor-shuffles), lane%8 == 0 stores
-                    uint32_t nib = (tx > 0.f ? 1u : 0u) | (ty > 0.f ? 2u : 0u) | (tz > 0.f ? 4u : 0u) | (tw > 0.f ? 8u : 0u);
-                    uint32_t v = nib << (4 * (L.lg & 7));
-                    v |= __shfl_xor(v, 1);
-                    v |= __shfl_xor(v, 2);
-                    v |= __shfl_xor(v, 4);
-                    if ((L.lg & 7) == 0 && on[k] && e + u < end)
-                        mask[(int64_t)(e + u) * mwords + (L.chan(k) >> 5)] = v;
+                if (G >= 32 && mask != nullptr) {
+                    // Mask layout per destination-CSR slot (H bits): [k][component x,y,z,w][G lane bits]: exactly what
+                    // the wave ballots of the four compares deliver (the lane masks are already in SGPRs), so one lane
+                    // per row stores 16 bytes (G = 32) or 32 bytes (G = 64) per (slot, k) - no cross-lane shuffles.
+                    const unsigned long long bx = __ballot(tx > 0.f), by = __ballot(ty > 0.f);
+                    const unsigned long long bz = __ballot(tz > 0.f), bw = __ballot(tw > 0.f);
+                    if (L.lg == 0 && e + u < end) {
+                        uint32_t* m = mask + (int64_t)(e + u) * mwords + k * (G / 8);
+                        if (G == 32) {
+                            const int sh = (threadIdx.x & 32);            // which half of the wave this row lives in
+                            *reinterpret_cast<uint4*>(m) = make_uint4((uint32_t)(bx >> sh), (uint32_t)(by >> sh),
+                                                                       (uint32_t)(bz >> sh), (uint32_t)(bw >> sh));
+                        } else {
+                            reinterpret_cast<uint4*>(m)[0] = make_uint4((uint32_t)bx, (uint32_t)(bx >> 32), (uint32_t)by, (uint32_t)(by >> 32));
+                            reinterpret_cast<uint4*>(m)[1] = make_uint4((uint32_t)bz, (uint32_t)(bz >> 32), (uint32_t)bw, (uint32_t)(bw >> 32));
+                        }
+                    }
                 }
             }
         }
     }
-    if (!row_ok) return;
     const int deg = end - beg;
     const float s = (float)(deg > 0 ? deg : 1);      // true division, as torch_scatter's scatter_mean (sum / count)
 #pragma unroll
@@ -209,24 +213,33 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask(const float* __rest
         on[k] = L.chan(k) < H;
         cnt[k][0] = cnt[k][1] = cnt[k][2] = cnt[k][3] = 0;
     }
+    constexpr int WPC = G / 32;                          // 32-bit words per component
+    const int wsel = L.lg >> 5, bit = L.lg & 31;
     for (int e = beg; e < end; e += U) {
-        uint32_t wv[U][VPL];
+        uint32_t wv[U][VPL][4];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ee = min(e + u, end - 1);
 #pragma unroll
-            for (int k = 0; k < VPL; ++k) wv[u][k] = on[k] ? mask[(int64_t)ee * mwords + (L.chan(k) >> 5)] : 0u;
+            for (int k = 0; k < VPL; ++k) {
+                const uint32_t* m = mask + (int64_t)ee * mwords + k * (G / 8);
+                if (WPC == 1) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(m);     // all lanes of the row: same address
+                    wv[u][k][0] = q.x; wv[u][k][1] = q.y; wv[u][k][2] = q.z; wv[u][k][3] = q.w;
+                } else {
+                    const uint4 q0 = reinterpret_cast<const uint4*>(m)[0], q1 = reinterpret_cast<const uint4*>(m)[1];
+                    wv[u][k][0] = wsel ? q0.y : q0.x; wv[u][k][1] = wsel ? q0.w : q0.z;
+                    wv[u][k][2] = wsel ? q1.y : q1.x; wv[u][k][3] = wsel ? q1.w : q1.z;
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (e + u < end) {
 #pragma unroll
                 for (int k = 0; k < VPL; ++k) {
-                    const uint32_t nib = wv[u][k] >> (4 * (L.lg & 7));
-                    cnt[k][0] += nib & 1u;
-                    cnt[k][1] += (nib >> 1) & 1u;
-                    cnt[k][2] += (nib >> 2) & 1u;
-                    cnt[k][3] += (nib >> 3) & 1u;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) cnt[k][c] += (wv[u][k][c] >> bit) & 1u;
                 }
             }
         }
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask(const float* __rest
 // words (xslot = destination-CSR slot of the same edge), half the bytes of the recompute form.
 template <int G, int VPL, int U>
 __global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask(const float* __restrict__ Gr, int64_t ldg,
-                                                             const float* __restrict__ inv_deg,
+                                                             const float* __restrict__ w_slot,
                                                              const uint32_t* __restrict__ mask,
                                                              const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ col,
@@ -263,31 +276,40 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask(const float* __rest
         on[k] = L.chan(k) < H;
         acc[k] = f4zero();
     }
+    constexpr int WPC = G / 32;
+    const int wsel = L.lg >> 5, bit = L.lg & 31;
     for (int e = beg; e < end; e += U) {
         float4 g[U][VPL];
-        uint32_t wv[U][VPL];
+        uint32_t wv[U][VPL][4];
         float w[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ee = min(e + u, end - 1);
             const int64_t i = col[ee];
             const int64_t xs = xslot[ee];
-            w[u] = (e + u < end) ? inv_deg[i] : 0.f;
+            w[u] = (e + u < end) ? w_slot[ee] : 0.f;
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {
                 g[u][k] = on[k] ? ld4(Gr + i * ldg + L.chan(k)) : f4zero();
-                wv[u][k] = on[k] ? mask[xs * mwords + (L.chan(k) >> 5)] : 0u;
+                const uint32_t* m = mask + xs * mwords + k * (G / 8);
+                if (WPC == 1) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(m);
+                    wv[u][k][0] = q.x; wv[u][k][1] = q.y; wv[u][k][2] = q.z; wv[u][k][3] = q.w;
+                } else {
+                    const uint4 q0 = reinterpret_cast<const uint4*>(m)[0], q1 = reinterpret_cast<const uint4*>(m)[1];
+                    wv[u][k][0] = wsel ? q0.y : q0.x; wv[u][k][1] = wsel ? q0.w : q0.z;
+                    wv[u][k][2] = wsel ? q1.y : q1.x; wv[u][k][3] = wsel ? q1.w : q1.z;
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {
-                const uint32_t nib = wv[u][k] >> (4 * (L.lg & 7));
-                acc[k].x += (nib & 1u) ? w[u] * g[u][k].x : 0.f;
-                acc[k].y += (nib & 2u) ? w[u] * g[u][k].y : 0.f;
-                acc[k].z += (nib & 4u) ? w[u] * g[u][k].z : 0.f;
-                acc[k].w += (nib & 8u) ? w[u] * g[u][k].w : 0.f;
+                acc[k].x += ((wv[u][k][0] >> bit) & 1u) ? w[u] * g[u][k].x : 0.f;
+                acc[k].y += ((wv[u][k][1] >> bit) & 1u) ? w[u] * g[u][k].y : 0.f;
+                acc[k].z += ((wv[u][k][2] >> bit) & 1u) ? w[u] * g[u][k].z : 0.f;
+                acc[k].w += ((wv[u][k][3] >> bit) & 1u) ? w[u] * g[u][k].w : 0.f;
             }
         }
     }
@@ -516,6 +538,9 @@ inline bool vec_ok(int C, std::initializer_list<const void*> ptrs, std::initiali
     return true;
 }
 
+// full rows of 32 or 64 lanes (every lane live), so a slot is exactly H bits of ballot words
+inline bool mask_shape_ok(int H) { return H == 128 || H == 256 || H == 512 || H == 1024 || H == 2048; }
+
 inline unsigned grid_rows(int64_t N, int G) { return (unsigned)((N + (BLOCK / G) - 1) / (BLOCK / G)); }
 inline unsigned grid_elems(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
@@ -566,7 +591,7 @@ extern "C" int stin_edge_relu_mean_fwd_f32(const float* A, int64_t lda, const fl
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(N >= 0 && H > 0 && lda >= H && ldb >= H && ldo >= H + (indicator ? 4 : 0), STIN_E_SIZE);
     STIN_REQUIRE(!indicator || H >= 4, STIN_E_UNSUPPORTED);
-    STIN_REQUIRE(mask == nullptr || (H % 32 == 0 && vec_ok(H, {A, B, out}, {lda, ldb, ldo})), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(mask == nullptr || (mask_shape_ok(H) && vec_ok(H, {A, B, out}, {lda, ldb, ldo})), STIN_E_UNSUPPORTED);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(A && B && rowptr && out, STIN_E_NULL);
     if (vec_ok(H, {A, B, out}, {lda, ldb, ldo})) {
@@ -622,12 +647,12 @@ extern "C" int stin_edge_relu_mean_bwd_dst_mask_f32(const float* G, int64_t ldg,
     STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && ldda >= H, STIN_E_SIZE);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(G && mask && rowptr && dA, STIN_E_NULL);
-    STIN_REQUIRE(H % 32 == 0 && vec_ok(H, {G, dA}, {ldg, ldda}), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(mask_shape_ok(H) && vec_ok(H, {G, dA}, {ldg, ldda}), STIN_E_UNSUPPORTED);
     STIN_DISPATCH(H, k_edge_bwd_dst_mask, 8, G, ldg, mask, rowptr, N, H, dA, ldda);
     return stin_launch_status();
 }
 
-extern "C" int stin_edge_relu_mean_bwd_src_mask_f32(const float* G, int64_t ldg, const float* inv_deg,
+extern "C" int stin_edge_relu_mean_bwd_src_mask_f32(const float* G, int64_t ldg, const float* w_src,
                                                     const uint32_t* mask, const int32_t* rowptr_src,
                                                     const int32_t* col_src, const int32_t* xslot, int64_t N, int H,
                                                     float* dB, int64_t lddb, stin_stream_t stream_) {
@@ -635,9 +660,9 @@ extern "C" int stin_edge_relu_mean_bwd_src_mask_f32(const float* G, int64_t ldg,
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && lddb >= H, STIN_E_SIZE);
     if (N == 0) return STIN_OK;
-    STIN_REQUIRE(G && inv_deg && mask && rowptr_src && col_src && xslot && dB, STIN_E_NULL);
-    STIN_REQUIRE(H % 32 == 0 && vec_ok(H, {G, dB}, {ldg, lddb}), STIN_E_UNSUPPORTED);
-    STIN_DISPATCH(H, k_edge_bwd_src_mask, 8, G, ldg, inv_deg, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
+    STIN_REQUIRE(G && w_src && mask && rowptr_src && col_src && xslot && dB, STIN_E_NULL);
+    STIN_REQUIRE(mask_shape_ok(H) && vec_ok(H, {G, dB}, {ldg, lddb}), STIN_E_UNSUPPORTED);
+    STIN_DISPATCH(H, k_edge_bwd_src_mask, 8, G, ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
     return stin_launch_status();
 }
 

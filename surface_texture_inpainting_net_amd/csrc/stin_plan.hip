@@ -117,11 +117,15 @@ __global__ void k_rank(const int64_t* __restrict__ a, const int64_t* __restrict_
 }
 
 // xslot[src-CSR slot] = dst-CSR slot of the same edge (slot_of_edge is the inverse of the dst-side perm)
+// and w_src[src-CSR slot] = 1 / max(1, in-degree of that edge's target): sequential weights for the dB pass
 __global__ void k_xslot(const int32_t* __restrict__ perm_src, const int32_t* __restrict__ slot_of_edge, int64_t E,
-                        const int32_t* __restrict__ rowptr_src, int64_t N, int32_t* __restrict__ xslot) {
+                        const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ col_src,
+                        const float* __restrict__ inv_deg_dst, int64_t N, int32_t* __restrict__ xslot,
+                        float* __restrict__ w_src) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= E || t >= rowptr_src[N]) return;
     xslot[t] = slot_of_edge[perm_src[t]];
+    if (w_src != nullptr) w_src[t] = inv_deg_dst[col_src[t]];
 }
 
 __global__ void k_narrow(const int64_t* __restrict__ src, int64_t n, int64_t limit, int32_t* __restrict__ dst,
@@ -170,7 +174,8 @@ Layout layout(int64_t E, int64_t N, int pair) {
 
 int build(const int64_t* a, const int64_t* b, int64_t E, int64_t N, int64_t b_limit, int pair, int32_t* rowptr0,
           int32_t* col0, int32_t* perm0, float* inv_deg0, int32_t* rowptr1, int32_t* col1, int32_t* perm1,
-          float* inv_deg1, int32_t* xslot, int32_t* bad, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+          float* inv_deg1, int32_t* xslot, float* w_src, int32_t* bad, void* workspace, size_t workspace_bytes,
+          hipStream_t stream) {
     const Layout L = layout(E, N, pair);
     STIN_REQUIRE(workspace_bytes >= L.total, STIN_E_WORKSPACE);
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
@@ -210,7 +215,8 @@ int build(const int64_t* a, const int64_t* b, int64_t E, int64_t N, int64_t b_li
         hipLaunchKernelGGL(k_rank, dim3(grid_for(sides * E)), dim3(T), 0, stream, a, b, N, E, pair ? E : 0, rowptr0, rowptr1,
                            id0, key0, id1, key1, col0, perm0, col1, perm_src, slot_of_edge);
         if (xslot != nullptr)
-            hipLaunchKernelGGL(k_xslot, dim3(grid_for(E)), dim3(T), 0, stream, perm_src, slot_of_edge, E, rowptr1, N, xslot);
+            hipLaunchKernelGGL(k_xslot, dim3(grid_for(E)), dim3(T), 0, stream, perm_src, slot_of_edge, E, rowptr1, col1, inv_deg0, N,
+                               xslot, w_src);
     }
     return stin_launch_status();
 }
@@ -230,19 +236,21 @@ extern "C" int stin_csr_from_coo_i64(const int64_t* key, const int64_t* val, int
     STIN_REQUIRE(rowptr != nullptr && workspace != nullptr && (E == 0 || (key != nullptr && col != nullptr)), STIN_E_NULL);
     if (val != nullptr) STIN_REQUIRE(val_limit >= 0 && val_limit < ((int64_t)1 << 31), STIN_E_SIZE);
     return build(key, val, E, N, val_limit, 0, rowptr, col, perm, inv_deg, nullptr, nullptr, nullptr, nullptr, nullptr,
-                 bad, workspace, workspace_bytes, (hipStream_t)stream_);
+                 nullptr, bad, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 extern "C" int stin_csr_pair_from_edges_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N,
                                             int32_t* rowptr_dst, int32_t* col_dst, float* inv_deg_dst,
-                                            int32_t* rowptr_src, int32_t* col_src, int32_t* xslot, int32_t* bad,
-                                            void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+                                            int32_t* rowptr_src, int32_t* col_src, int32_t* xslot, float* w_src,
+                                            int32_t* bad, void* workspace, size_t workspace_bytes,
+                                            stin_stream_t stream_) {
     stin_clear_stale_error();
     STIN_REQUIRE(E >= 0 && N >= 0 && N < ((int64_t)1 << 30) && E < ((int64_t)1 << 30), STIN_E_SIZE);
     STIN_REQUIRE(rowptr_dst && rowptr_src && workspace && (E == 0 || (src && dst && col_dst && col_src)), STIN_E_NULL);
+    STIN_REQUIRE(w_src == nullptr || (xslot != nullptr && inv_deg_dst != nullptr), STIN_E_NULL);
     // side 0 groups by dst (value = src), side 1 groups by src (value = dst)
     return build(dst, src, E, N, N, 1, rowptr_dst, col_dst, nullptr, inv_deg_dst, rowptr_src, col_src, nullptr, nullptr,
-                 xslot, bad, workspace, workspace_bytes, (hipStream_t)stream_);
+                 xslot, w_src, bad, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 extern "C" int stin_narrow_i64_to_i32(const int64_t* src, int64_t n, int64_t limit, int32_t* dst, int32_t* bad,

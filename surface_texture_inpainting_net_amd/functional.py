@@ -71,8 +71,8 @@ def edge_relu_mean_fwd(A, B, csr, out, indicator=False, mask=None):
 
 
 def edge_mask_supported(H):
-    """The saved-ReLU-mask backward needs whole 32-bit mask words per lane octet."""
-    return H % 32 == 0 and H <= 2048
+    """The saved-ReLU-mask path stores wave-ballot words of full rows: H = 128, 256, 512, 1024 or 2048."""
+    return H in (128, 256, 512, 1024, 2048)
 
 
 def edge_relu_mean_bwd_dst_mask(G, mask, csr, dA):
@@ -85,7 +85,7 @@ def edge_relu_mean_bwd_dst_mask(G, mask, csr, dA):
 def edge_relu_mean_bwd_src_mask(G, mask, edges, dB):
     G, ldg = _mat(G)
     cs = edges.by_src
-    _call('stin_edge_relu_mean_bwd_src_mask_f32', _ptr(G), ldg, _ptr(edges.inv_deg), _ptr(mask), _ptr(cs.rowptr),
+    _call('stin_edge_relu_mean_bwd_src_mask_f32', _ptr(G), ldg, _ptr(edges.w_src), _ptr(mask), _ptr(cs.rowptr),
           _ptr(cs.col), _ptr(edges.xslot), G.shape[0], G.shape[1], _ptr(dB), dB.stride(0), _stream(G),
           tag=(G.shape[0], cs.n_entries, G.shape[1]))
     return dB

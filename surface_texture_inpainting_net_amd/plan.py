@@ -69,16 +69,18 @@ class EdgeSet:
         col_d = idx[2 * (n + 1):2 * (n + 1) + e1]
         col_s = idx[2 * (n + 1) + e1:2 * (n + 1) + 2 * e1]
         xslot = idx[2 * (n + 1) + 2 * e1:]
-        inv_deg = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        inv_deg = torch.empty(max(n, 1) + e1, dtype=torch.float32, device=dev)
+        w_src = inv_deg[max(n, 1):]
         ws_bytes = lib.stin_csr_workspace_bytes(E, n)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.stin_csr_pair_from_edges_i64(_ptr(src), _ptr(dst), E, n, _ptr(rp_d), _ptr(col_d), _ptr(inv_deg),
-                                                    _ptr(rp_s), _ptr(col_s), _ptr(xslot), _ptr(bad), _ptr(ws), ws_bytes,
+                                                    _ptr(rp_s), _ptr(col_s), _ptr(xslot), _ptr(w_src), _ptr(bad), _ptr(ws), ws_bytes,
                                                     _stream(src)),
                    'stin_csr_pair_from_edges_i64')
         self.by_dst = CSR(rp_d, col_d[:E], None, inv_deg[:n], n, E)     # rows = targets, col = sources
         self.by_src = CSR(rp_s, col_s[:E], None, None, n, E)            # rows = sources, col = targets
         self.inv_deg = self.by_dst.inv_deg                               # 1 / max(1, in-degree)
+        self.w_src = w_src[:E]                                           # 1/max(1, indeg(target)) per src-CSR slot
         self.xslot = xslot[:E]                                           # src-CSR slot -> dst-CSR slot of the same edge
         self.n_edges = E
 

