@@ -167,6 +167,7 @@ int stin_gather_i64(const int64_t* src, const int32_t* idx, int64_t n_out, int64
  *   STIN_RED_DOT_ELU : out0 = sum dY * xc, out1 = sum dY  with xc = x - mean[gid],
  *                      dY = gout * ELU'(xc * rstd[gid])
  *   STIN_RED_COEF_XC : sum coef[sid] * (x - mean[gid])
+ *   STIN_RED_MOMENTS : mean and rstd of each range in ONE pass over x (needs inv_cnt; ignores post)
  * `gid`/`sid` are per-row int32 group ids (NULL = 0).  They implement
  * FastInstanceNorm (models/modules/fastinstancenorm.py:42-107) including its
  * linspace-slice quirk (sums over `ptr` slices, centring through `gid`).
@@ -178,6 +179,7 @@ int stin_gather_i64(const int64_t* src, const int32_t* idx, int64_t n_out, int64
 #define STIN_RED_CSQ 1
 #define STIN_RED_DOT_ELU 2
 #define STIN_RED_COEF_XC 3
+#define STIN_RED_MOMENTS 4          /* one pass: out0 = mean, out1 = 1/sqrt(biased var + eps) from fp64 sum x, sum x^2 */
 #define STIN_POST_NONE 0            /* out = s                                  */
 #define STIN_POST_SCALE 1           /* out = s * inv_cnt[b]            (mean)    */
 #define STIN_POST_RSTD 2            /* out = 1/sqrt(s * inv_cnt[b] + eps)        */

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce(const float* __restrict__ x
                                                      const int32_t* __restrict__ sid, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ coef,
                                                      double* __restrict__ partial) {
-    constexpr int NOUT = (MODE == STIN_RED_DOT_ELU) ? 2 : 1;
+    constexpr int NOUT = (MODE == STIN_RED_DOT_ELU || MODE == STIN_RED_MOMENTS) ? 2 : 1;
     __shared__ double sm[NOUT][BLOCK][VW];
     const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
     const int64_t r0 = ptr != nullptr ? ptr[b] : 0;
@@ -52,6 +52,13 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce(const float* __restrict__ x
                 if (MODE == STIN_RED_SUM) {
 #pragma unroll
                     for (int i = 0; i < VW; ++i) acc0[i] += (double)xv.v[i];
+                } else if (MODE == STIN_RED_MOMENTS) {
+#pragma unroll
+                    for (int i = 0; i < VW; ++i) {
+                        const double d = (double)xv.v[i];
+                        acc0[i] += d;
+                        acc1[i] += d * d;
+                    }
                 } else {
                     const int g = gid != nullptr ? gid[r] : 0;
                     const V<VW> mu = V<VW>::load(mean + (int64_t)g * C + c);
@@ -134,6 +141,38 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce_final(const double* __restr
         if (post == STIN_POST_SCALE) r = r * inv_cnt[b];
         else if (post == STIN_POST_RSTD) r = 1.0f / sqrtf(r * inv_cnt[b] + eps);
         (o == 0 ? out0 : out1)[(int64_t)b * C + c] = r;
+    }
+}
+
+// (sum x, sum x^2) in fp64 -> mean and 1/sqrt(biased var + eps).  Exact to fp32 rounding: the fp64 sums carry
+// ~1e-16 relative error, so E[x^2] - mean^2 loses nothing visible unless mean^2/var exceeds ~1e8.
+__global__ void k_moments_final(const double* __restrict__ partial, int nch, int C, int B,
+                                const float* __restrict__ inv_cnt, float eps, float* __restrict__ mean,
+                                float* __restrict__ rstd) {
+    __shared__ double sm[2][FIN_KL][FIN_COLS + 1];
+    const int tx = threadIdx.x % FIN_COLS, ty = threadIdx.x / FIN_COLS;
+    const int c = blockIdx.x * FIN_COLS + tx, b = blockIdx.z;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        const double* p = partial + (int64_t)b * nch * 2 * C + c;
+        for (int k = ty; k < nch; k += FIN_KL) {
+            s1 += p[(int64_t)k * 2 * C];
+            s2 += p[(int64_t)k * 2 * C + C];
+        }
+    }
+    sm[0][ty][tx] = s1;
+    sm[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        double a = 0.0, q = 0.0;
+#pragma unroll
+        for (int k = 0; k < FIN_KL; ++k) { a += sm[0][k][tx]; q += sm[1][k][tx]; }
+        const double ic = (double)inv_cnt[b];
+        const double mu = a * ic;
+        double var = q * ic - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean[(int64_t)b * C + c] = (float)mu;
+        rstd[(int64_t)b * C + c] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
@@ -223,13 +262,14 @@ extern "C" int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const f
                                   stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
-    STIN_REQUIRE(mode >= STIN_RED_SUM && mode <= STIN_RED_COEF_XC, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(mode >= STIN_RED_SUM && mode <= STIN_RED_MOMENTS, STIN_E_UNSUPPORTED);
     STIN_REQUIRE(N >= 0 && C > 0 && B > 0 && ldx >= C, STIN_E_SIZE);
     STIN_REQUIRE((ptr != nullptr) || B == 1, STIN_E_SIZE);
     STIN_REQUIRE(x && out0 && workspace, STIN_E_NULL);
     STIN_REQUIRE(post >= STIN_POST_NONE && post <= STIN_POST_RSTD, STIN_E_UNSUPPORTED);
     STIN_REQUIRE(post == STIN_POST_NONE || inv_cnt != nullptr, STIN_E_NULL);
-    if (mode != STIN_RED_SUM) STIN_REQUIRE(mean != nullptr, STIN_E_NULL);
+    if (mode != STIN_RED_SUM && mode != STIN_RED_MOMENTS) STIN_REQUIRE(mean != nullptr, STIN_E_NULL);
+    if (mode == STIN_RED_MOMENTS) STIN_REQUIRE(out1 != nullptr && inv_cnt != nullptr, STIN_E_NULL);
     if (mode == STIN_RED_DOT_ELU) STIN_REQUIRE(gout && rstd && out1 && ldg >= C, STIN_E_NULL);
     if (mode == STIN_RED_COEF_XC) STIN_REQUIRE(coef != nullptr, STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_colreduce_workspace_bytes(C, B), STIN_E_WORKSPACE);
@@ -244,7 +284,7 @@ extern "C" int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const f
     int cap = MAX_SLABS / B;
     if (cap < 1) cap = 1;
     int nch = (int)(want < 1 ? 1 : (want > cap ? cap : want));
-    const int nout = mode == STIN_RED_DOT_ELU ? 2 : 1;
+    const int nout = (mode == STIN_RED_DOT_ELU || mode == STIN_RED_MOMENTS) ? 2 : 1;
     dim3 grid((unsigned)nch, (unsigned)B);
 #define STIN_RED_LAUNCH(M)                                                                                          \
     do {                                                                                                            \
@@ -255,9 +295,15 @@ extern "C" int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const f
         case STIN_RED_SUM: STIN_RED_LAUNCH(STIN_RED_SUM); break;
         case STIN_RED_CSQ: STIN_RED_LAUNCH(STIN_RED_CSQ); break;
         case STIN_RED_DOT_ELU: STIN_RED_LAUNCH(STIN_RED_DOT_ELU); break;
+        case STIN_RED_MOMENTS: STIN_RED_LAUNCH(STIN_RED_MOMENTS); break;
         default: STIN_RED_LAUNCH(STIN_RED_COEF_XC); break;
     }
 #undef STIN_RED_LAUNCH
+    if (mode == STIN_RED_MOMENTS) {
+        hipLaunchKernelGGL(k_moments_final, dim3((unsigned)((C + FIN_COLS - 1) / FIN_COLS), 1u, (unsigned)B), dim3(BLOCK), 0,
+                           stream, partial, nch, C, B, inv_cnt, eps, out0, out1);
+        return stin_launch_status();
+    }
     hipLaunchKernelGGL(k_colreduce_final, dim3((unsigned)((C + FIN_COLS - 1) / FIN_COLS), (unsigned)nout, (unsigned)B),
                        dim3(BLOCK), 0, stream, partial, nch, nout, C, B, post, inv_cnt, eps, out0, out1);
     return stin_launch_status();

@@ -15,7 +15,7 @@ from .plan import _ptr, _stream
 EPS = 1e-5
 # save the edge-stage ReLU decisions as a bit-mask in forward (STIN_EDGE_MASK=0: recompute them in backward)
 USE_EDGE_MASK = os.environ.get('STIN_EDGE_MASK', '1') != '0'
-RED_SUM, RED_CSQ, RED_DOT_ELU, RED_COEF_XC = 0, 1, 2, 3
+RED_SUM, RED_CSQ, RED_DOT_ELU, RED_COEF_XC, RED_MOMENTS = 0, 1, 2, 3, 4
 POST_NONE, POST_SCALE, POST_RSTD = 0, 1, 2
 
 
@@ -148,7 +148,7 @@ def colreduce(mode, x, groups, ptr, *, gout=None, mean=None, rstd=None, coef=Non
     N, C = x.shape
     B = groups.B
     out0 = torch.empty(B, C, dtype=torch.float32, device=x.device)
-    out1 = torch.empty(B, C, dtype=torch.float32, device=x.device) if mode == RED_DOT_ELU else None
+    out1 = torch.empty(B, C, dtype=torch.float32, device=x.device) if mode in (RED_DOT_ELU, RED_MOMENTS) else None
     ldg = 0
     if gout is not None:
         gout, ldg = _mat(gout)
@@ -173,6 +173,10 @@ def instance_stats(x, groups):
     if groups.gid is None and x.shape[0] == 1:   # F.instance_norm's own check on the batch=None branch
         raise ValueError('Expected more than 1 spatial element when training, got input size {}'.format(
             torch.Size([1, x.shape[1], 1])))
+    if not groups.quirk:
+        # one pass: fp64 sum x and sum x^2 over each graph's rows (slices == graphs here)
+        return colreduce(RED_MOMENTS, x, groups, groups.ptr_sum)
+    # linspace-slice quirk: sums over slices, centring through the graph id -> two passes as the reference does
     mean = colreduce(RED_SUM, x, groups, groups.ptr_sum, post=POST_SCALE)
     rstd = colreduce(RED_CSQ, x, groups, groups.ptr_sum, mean=mean, post=POST_RSTD)
     return mean, rstd
