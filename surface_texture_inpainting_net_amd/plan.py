@@ -15,7 +15,13 @@ import torch
 from . import _lib
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream(t):
+    """hipStream_t of torch's current stream on t's device (the fast C accessor when this torch has it)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

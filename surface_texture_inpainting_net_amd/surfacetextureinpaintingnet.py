@@ -84,7 +84,9 @@ class SurfaceTextureInpaintingNet(nn.Module):
         self.num_blocks_per_uncheckpointed_block = num_blocks_per_uncheckpointed_block  # blocks save only per-vertex
         self._use_embedding = use_label_embedding                   # tensors, so no recompute is needed
         self.dilations = list(dilations) if dilations is not None else [1] * n_blocks
-        # batched-norm compatibility switch: True reproduces the reference's linspace slices
+        # batched-norm compatibility switch: True reproduces the reference's linspace slices.  The
+        # plan's NormGroups carry the choice; blocks called directly with a raw batch tensor use their own
+        # FastInstanceNorm.linspace_quirk (default True).
         self.compat_linspace_norm = True
         inplace, use_bias = False, True
         if self._use_embedding:  # created but never used by forward, as in the reference (:277-278, :409-410)
@@ -148,9 +150,6 @@ class SurfaceTextureInpaintingNet(nn.Module):
 
     def forward(self, sample):
         plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm)
-        for m in self.modules():
-            if isinstance(m, M.FastInstanceNorm):
-                m.linspace_quirk = self.compat_linspace_norm
         num_levels = len(self.decoder_blocks) + 1
         out = sample.x
         e0 = plan.edges('edge_index', 0)
