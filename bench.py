@@ -167,7 +167,10 @@ def main():
     _lib.load()
 
     torch.manual_seed(49)                                   # reference config seed; identical replicas
-    net = S.define_G(**CONFIG_3D).to(device)
+    cfg = dict(CONFIG_3D)
+    if args.levels != 3:                                    # other hierarchy depths (configs 3 and 5): n_levels = levels - 1
+        cfg['n_levels'] = args.levels - 1
+    net = S.define_G(**cfg).to(device)
     step = TrainStep(net, lr=7e-5, amsgrad=True)
     sample = make_synthetic_mesh(args.vertices, args.levels, seed=rank).to(device)   # one scene per rank
     n0 = sample.x.shape[0]
@@ -234,11 +237,11 @@ def main():
             'value': total_vertices * args.steps / dt, 'unit': 'vertices/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'SurfaceTextureInpaintingNet 3-D config (ngf 64, n_levels 2, n_blocks 9, '
+            'config': {'workload': 'SurfaceTextureInpaintingNet 3-D config (ngf 64, n_levels %d, n_blocks 9, ' % cfg['n_levels'] +
                                    'edgeconvtransinv, instance norm, max pool, dilations 1-16), synthetic %d-vertex / '
                                    '%d-directed-edge %d-level mesh per GPU, fp32; step = CSR plan build + fwd + '
                                    'masked L1 + bwd + grad all-reduce + Adam(amsgrad)' % (n0, e0, args.levels),
-                       'vertices_per_gpu': n0, 'edges_per_gpu': e0, 'levels': args.levels, 'params': 4202051,
+                       'vertices_per_gpu': n0, 'edges_per_gpu': e0, 'levels': args.levels, 'params': sum(p.numel() for p in net.parameters()),
                        'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan},
             'loss': float(loss),
             'roofline': roofline,

@@ -118,3 +118,26 @@ def test_oracle_against_live_reference_random_config():
         warnings.simplefilter('ignore')
         a = ref(s)
     assert torch.equal(a, net(s))
+
+
+@pytest.mark.reference
+def test_seeded_init_equals_reference_for_product_and_oracle():
+    """Same torch seed -> the reference's define_G, the oracle's and the product's produce identical
+    parameters (same construction order), for the shipped 3-D config (4 202 051 parameters)."""
+    import warnings
+    from oracle import ref_import
+    from surface_texture_inpainting_net_amd import surfacetextureinpaintingnet as S
+    stin = ref_import.load_model_module()
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=9,
+               n_levels=2, pooling_type='max', dilations=[1, 1, 1, 2, 4, 8, 16, 1, 1], checkpoint_bottleneck=True)
+    nets = []
+    for mod in (stin, stin_oracle, S):
+        torch.manual_seed(49)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            nets.append(mod.define_G(**cfg))
+    ref_sd = nets[0].state_dict()
+    for other in nets[1:]:
+        sd = other.state_dict()
+        assert list(sd.keys()) == list(ref_sd.keys())
+        assert all(torch.equal(sd[k], ref_sd[k]) for k in sd)
