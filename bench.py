@@ -187,8 +187,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
     for _ in range(args.warmup):
         one_step()
+    gc.collect()
+    gc.disable()            # no cyclic-GC pause inside the timed region (collected again right after it)
     fence()
     SF.KernelTimer.start(['stin_edge_relu_mean_fwd_f32', 'stin_edge_relu_mean_bwd_dst_f32',
                           'stin_edge_relu_mean_bwd_src_f32', 'stin_edge_relu_mean_bwd_dst_mask_f32',
@@ -198,6 +201,7 @@ def main():
         loss = one_step()
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     ktimes = SF.KernelTimer.stop()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)

@@ -33,10 +33,11 @@ class KernelTimer:
     enabled = False
     names = ()
     records = []          # (name, tag, start_event, end_event)
+    max_records = 400     # thousands of outstanding timing events slow the HIP runtime down: sample, do not flood
 
     @classmethod
-    def start(cls, names):
-        cls.enabled, cls.names, cls.records = True, tuple(names), []
+    def start(cls, names, max_records=400):
+        cls.enabled, cls.names, cls.records, cls.max_records = True, tuple(names), [], max_records
 
     @classmethod
     def stop(cls):
@@ -56,6 +57,8 @@ def _call(name, *args, tag=None):
         _lib.check(getattr(_lib.load(), name)(*args), name)
         b.record()
         KernelTimer.records.append((name, tag, a, b))
+        if len(KernelTimer.records) >= KernelTimer.max_records:
+            KernelTimer.enabled = False          # the rest of the timed region runs un-instrumented
         return
     _lib.check(getattr(_lib.load(), name)(*args), name)
 
