@@ -195,7 +195,8 @@ def main():
     fence()
     SF.KernelTimer.start(['stin_edge_relu_mean_fwd_f32', 'stin_edge_relu_mean_bwd_dst_f32',
                           'stin_edge_relu_mean_bwd_src_f32', 'stin_edge_relu_mean_bwd_dst_mask_f32',
-                          'stin_edge_relu_mean_bwd_src_mask_f32'] + (['stin_gemm_nt_f32', 'stin_gemm_tn_f32'] if args.time_gemms else []))
+                          'stin_edge_relu_mean_bwd_src_mask_f32'] + (['stin_gemm_nt_f32', 'stin_gemm_tn_f32'] if args.time_gemms else []),
+                         max_records=1_000_000 if args.time_gemms else 400)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
