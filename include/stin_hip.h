@@ -206,7 +206,7 @@ int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_
  * restructure leaves (reference: the per-EDGE aten::addmm of Lin1/Lin2 in
  * models/modules/edge_conv_filter.py:47-52, the shortcut Linear at
  * models/surfacetextureinpaintingnet.py:515-516 and the tail Linears :464,:467).
- *   nt: C[M, Nc] = A[M, K] . W[Nc, K]^T + bias[Nc] * (row_mask ? row_mask[m * ld_mask] : 1)
+ *   nt: C[M, Nc] = A[M, K] . W[Nc, K]^T + bias[Nc] * (row_mask ? row_mask[m * ld_mask] : 1) (+ residual[M, Nc])
  *       forward, and dgrad with W := W^T.  row_mask = the [deg > 0] indicator gives PyG's
  *       "no in-edges -> exactly 0" (bias only where a vertex aggregated something).
  *       `precision` picks the matrix-core path: exact fp32 MFMA, or the bf16 cores (16x the fp32
@@ -219,8 +219,8 @@ int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_
 #define STIN_GEMM_BF16X3 2   /* fp32 operands split into 2 bf16 pieces, 3 bf16 MFMAs, ~2^-17 / product */
 #define STIN_GEMM_BF16X6 3   /* 3 pieces (exact split), 6 bf16 MFMAs, ~2^-22 / product                 */
 int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
-                     const float* row_mask, int64_t ld_mask, int64_t M, int Nc, int K, float* C, int64_t ldc,
-                     int precision, stin_stream_t stream);
+                     const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
+                     int Nc, int K, float* C, int64_t ldc, int precision, stin_stream_t stream);
 size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int ones_column);
 int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
                      int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
@@ -231,15 +231,17 @@ int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, i
  * (or [H, Cin] for EdgeConvTransInv), first_filter.nn.2.weight = W2 [Cout, H], shortcut.{weight,bias})
  * -> the per-vertex GEMM operands  wcat [Yw, Cin] = [Wa-Wb ; Wb ; Ws] (trans_inv: [-W1 ; W1 ; Ws]),
  * bcat [Yw] = [b1 ; 0 ; bs], wcatT = wcat^T, w2T = W2^T; Yw = 2H (+ Cout).
- * unpack: dwb [Yw, Cin+1] (gemm_tn output: weight grad | bias grad) -> dW1, db1, dWs, dbs.
+ * unpack: dwb [Yw, Cin+1] (gemm_tn output: weight grad | bias grad) -> dW1, db1, dWs, dbs; and
+ *   dw2b [Cout, H+1] (optional) -> contiguous dW2 [Cout, H], db2 [Cout].
  * (models/modules/edge_conv_filter.py:46-52, models/surfacetextureinpaintingnet.py:505-506)
  * norm_bwd_coef: k = -rstd^3 T1 inv_cnt, m = -rstd S0 inv_cnt for stin_norm_act_bwd_f32.
  */
 int stin_edgeconv_pack_f32(const float* W1, const float* b1, const float* Ws, const float* bs, const float* W2,
                            int Cin, int H, int Cout, int has_shortcut, int trans_inv, float* wcat, float* bcat,
                            float* wcatT, float* w2T, stin_stream_t stream);
-int stin_edgeconv_unpack_grads_f32(const float* dwb, int Cin, int H, int Cout, int has_shortcut, int trans_inv,
-                                   float* dW1, float* db1, float* dWs, float* dbs, stin_stream_t stream);
+int stin_edgeconv_unpack_grads_f32(const float* dwb, const float* dw2b, int Cin, int H, int Cout, int has_shortcut,
+                                   int trans_inv, float* dW1, float* db1, float* dWs, float* dbs, float* dW2,
+                                   float* db2, stin_stream_t stream);
 int stin_norm_bwd_coef_f32(const float* T1, const float* S0, const float* rstd, const float* inv_cnt, int B, int C,
                            float* k, float* m, stin_stream_t stream);
 

@@ -25,7 +25,8 @@ template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_gemm_nt(const float* __restrict__ A, int64_t lda,
                                                    const float* __restrict__ W, int64_t ldw,
                                                    const float* __restrict__ bias,
-                                                   const float* __restrict__ row_mask, int64_t ld_mask, int64_t M,
+                                                   const float* __restrict__ row_mask, int64_t ld_mask,
+                                                   const float* __restrict__ res, int64_t ld_res, int64_t M,
                                                    int Nc, int K, float* __restrict__ C, int64_t ldc) {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
     constexpr int A_F4 = BM * BK / 4 / BLOCK, W_F4 = BN * BK / 4 / BLOCK;   // float4 per thread per tile
@@ -138,7 +139,9 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt(const float* __restrict__ A, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < M) C[row * ldc + col] = acc[i][j][r] + (row_mask != nullptr ? bv * row_mask[row * ld_mask] : bv);
+                if (row < M)
+                    C[row * ldc + col] = acc[i][j][r] + (row_mask != nullptr ? bv * row_mask[row * ld_mask] : bv) +
+                                         (res != nullptr ? res[row * ld_res + col] : 0.f);
             }
         }
     }
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
                                                          const float* __restrict__ W, int64_t ldw,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ row_mask, int64_t ld_mask,
+                                                         const float* __restrict__ res, int64_t ld_res,
                                                          int64_t M, int Nc, int K, float* __restrict__ C,
                                                          int64_t ldc) {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
@@ -291,7 +295,9 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < M) C[row * ldc + col] = acc[i][j][r] + (row_mask != nullptr ? bv * row_mask[row * ld_mask] : bv);
+                if (row < M)
+                    C[row * ldc + col] = acc[i][j][r] + (row_mask != nullptr ? bv * row_mask[row * ld_mask] : bv) +
+                                         (res != nullptr ? res[row * ld_res + col] : 0.f);
             }
         }
     }
@@ -680,11 +686,12 @@ inline int tn_rows_per_chunk(int64_t M, int tiles) {
 }  // namespace
 
 extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
-                                const float* row_mask, int64_t ld_mask, int64_t M, int Nc, int K, float* C, int64_t ldc,
-                                int precision, stin_stream_t stream_) {
+                                const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
+                                int Nc, int K, float* C, int64_t ldc, int precision, stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
+    STIN_REQUIRE(residual == nullptr || ld_res >= Nc, STIN_E_SIZE);
     STIN_REQUIRE(precision == STIN_GEMM_F32 || precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6,
                  STIN_E_UNSUPPORTED);
     if (M == 0) return STIN_OK;
@@ -693,7 +700,7 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     // Tile choice: the largest tile that still leaves >= ~6 blocks per CU (256 CUs), so that the tail
     // wave of blocks does not idle half the chip on the M ~ 2e4 levels.
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Nc + bn - 1) / bn); };
-#define STIN_NT_ARGS A, lda, W, ldw, bias, row_mask, ld_mask, M, Nc, K, C, ldc
+#define STIN_NT_ARGS A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc
 #define STIN_NT(KERNEL, BM_, BN_, WM_, WN_, ...)                                                                  \
     do {                                                                                                          \
         dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((Nc + BN_ - 1) / BN_));                             \

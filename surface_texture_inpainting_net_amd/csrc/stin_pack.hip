@@ -34,13 +34,22 @@ __global__ void k_pack(const float* __restrict__ W1, const float* __restrict__ b
 
 // dwb [Yw, Cin + 1] (weight grad | bias grad of the packed operand) -> grads of the reference-layout
 // parameters: dW1 [H, Cin or 2Cin], db1 [H], dWs [Cout, Cin], dbs [Cout].
-__global__ void k_unpack(const float* __restrict__ dwb, int Cin, int H, int Cout, int has_shortcut, int trans_inv,
-                         float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dWs,
-                         float* __restrict__ dbs) {
+__global__ void k_unpack(const float* __restrict__ dwb, const float* __restrict__ dw2b, int Cin, int H, int Cout,
+                         int has_shortcut, int trans_inv, float* __restrict__ dW1, float* __restrict__ db1,
+                         float* __restrict__ dWs, float* __restrict__ dbs, float* __restrict__ dW2,
+                         float* __restrict__ db2) {
     const int ld = Cin + 1;
     const int ld1 = trans_inv ? Cin : 2 * Cin;
     const int64_t n1 = (int64_t)H * ld1, ns = has_shortcut ? (int64_t)Cout * Cin : 0;
+    const int64_t n2 = dw2b != nullptr ? (int64_t)Cout * H : 0;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n1 + ns && t < n1 + ns + n2) {          // dw2b [Cout, H + 1] = dW2 | db2 -> contiguous dW2, db2
+        const int64_t u = t - n1 - ns;
+        const int r = (int)(u / H), c = (int)(u % H);
+        dW2[u] = dw2b[(int64_t)r * (H + 1) + c];
+        if (c == 0 && db2 != nullptr) db2[r] = dw2b[(int64_t)r * (H + 1) + H];
+        return;
+    }
     if (t < n1) {
         const int r = (int)(t / ld1), c = (int)(t % ld1);
         float v;
@@ -82,15 +91,16 @@ extern "C" int stin_edgeconv_pack_f32(const float* W1, const float* b1, const fl
     return stin_launch_status();
 }
 
-extern "C" int stin_edgeconv_unpack_grads_f32(const float* dwb, int Cin, int H, int Cout, int has_shortcut,
-                                              int trans_inv, float* dW1, float* db1, float* dWs, float* dbs,
-                                              stin_stream_t stream_) {
+extern "C" int stin_edgeconv_unpack_grads_f32(const float* dwb, const float* dw2b, int Cin, int H, int Cout,
+                                              int has_shortcut, int trans_inv, float* dW1, float* db1, float* dWs,
+                                              float* dbs, float* dW2, float* db2, stin_stream_t stream_) {
     stin_clear_stale_error();
     STIN_REQUIRE(Cin > 0 && H > 0 && Cout > 0, STIN_E_SIZE);
-    STIN_REQUIRE(dwb && dW1 && (!has_shortcut || dWs), STIN_E_NULL);
-    const int64_t n = (int64_t)H * (trans_inv ? Cin : 2 * Cin) + (has_shortcut ? (int64_t)Cout * Cin : 0);
-    hipLaunchKernelGGL(k_unpack, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream_, dwb, Cin,
-                       H, Cout, has_shortcut, trans_inv, dW1, db1, dWs, dbs);
+    STIN_REQUIRE(dwb && dW1 && (!has_shortcut || dWs) && (dw2b == nullptr || dW2 != nullptr), STIN_E_NULL);
+    const int64_t n = (int64_t)H * (trans_inv ? Cin : 2 * Cin) + (has_shortcut ? (int64_t)Cout * Cin : 0) +
+                      (dw2b != nullptr ? (int64_t)Cout * H : 0);
+    hipLaunchKernelGGL(k_unpack, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream_, dwb, dw2b,
+                       Cin, H, Cout, has_shortcut, trans_inv, dW1, db1, dWs, dbs, dW2, db2);
     return stin_launch_status();
 }
 

@@ -238,7 +238,7 @@ PREC_FWD = int(os.environ.get('STIN_GEMM_FWD', GEMM_BF16X6))
 PREC_BWD = int(os.environ.get('STIN_GEMM_BWD', GEMM_BF16X3))
 
 
-def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32):
+def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32, residual=None):
     """A[M, K] . W[Nc, K]^T + bias * row_mask -> [M, Nc]  (hand-written fp32 MFMA kernel).
     row_mask: optional [M] column view (stride = its row pitch) multiplying the bias per row."""
     if _GEMM_BLAS_NT:
@@ -248,6 +248,8 @@ def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32):
             r = torch.addmm(bias, A, W.t())
         else:
             r = torch.mm(A, W.t()) + row_mask.reshape(-1, 1) * bias
+        if residual is not None:
+            r = r + residual
         if out is not None:
             out.copy_(r)
             return out
@@ -259,8 +261,11 @@ def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32):
     assert W.shape[1] == K
     if out is None:
         out = torch.empty(M, Nc, dtype=torch.float32, device=A.device)
+    ld_res = 0
+    if residual is not None:
+        residual, ld_res = _mat(residual)
     _call('stin_gemm_nt_f32', _ptr(A), lda, _ptr(W), ldw, _ptr(bias), _ptr(row_mask),
-          row_mask.stride(0) if row_mask is not None else 0, M, Nc, K, _ptr(out),
+          row_mask.stride(0) if row_mask is not None else 0, _ptr(residual), ld_res, M, Nc, K, _ptr(out),
           out.stride(0) if M > 1 else max(Nc, out.stride(0)), int(precision), _stream(A), tag=(M, Nc, K))
     return out
 
@@ -308,7 +313,7 @@ class LinearFn(torch.autograd.Function):
         dwb = gemm_tn(g, x, ones_column=ctx.has_bias, precision=PREC_BWD)
         dx = gemm_nt(g, weight.t().contiguous(), precision=PREC_BWD)
         if ctx.has_bias:
-            return dx, dwb[:, :-1], dwb[:, -1]
+            return dx, dwb[:, :-1].contiguous(), dwb[:, -1].contiguous()
         return dx, dwb, None
 
 
@@ -383,17 +388,17 @@ class EdgeConvBlockFn(torch.autograd.Function):
         if ctx.has_shortcut:
             dY[:, 2 * H:].copy_(g)
         dwb = gemm_tn(dY, x, ones_column=True, precision=PREC_BWD)           # [Yw, Cin + 1]: packed weight grad | bias grad
-        dx = gemm_nt(dY, wcatT, precision=PREC_BWD)                            # dY Wcat
-        if not ctx.has_shortcut:
-            dx.add_(g)
-        dW1 = torch.empty(ctx.w1_shape, dtype=torch.float32, device=x.device)
-        db1 = torch.empty(H, dtype=torch.float32, device=x.device) if ctx.has_b1 else None
-        dWs = torch.empty(Cout, Cin, dtype=torch.float32, device=x.device) if ctx.has_shortcut else None
-        dbs = torch.empty(Cout, dtype=torch.float32, device=x.device) if ctx.has_bs else None
-        _call('stin_edgeconv_unpack_grads_f32', _ptr(dwb), Cin, H, Cout, int(ctx.has_shortcut), int(ctx.trans_inv),
-              _ptr(dW1), _ptr(db1), _ptr(dWs), _ptr(dbs), _stream(x))
-        dW2 = dw2b[:, :H]
-        db2 = dw2b[:, H] if ctx.has_b2 else None
+        # dx = dY Wcat (+ g: the identity-residual path, added in the GEMM epilogue)
+        dx = gemm_nt(dY, wcatT, precision=PREC_BWD, residual=None if ctx.has_shortcut else g)
+        dev = x.device
+        dW1 = torch.empty(ctx.w1_shape, dtype=torch.float32, device=dev)
+        db1 = torch.empty(H, dtype=torch.float32, device=dev) if ctx.has_b1 else None
+        dWs = torch.empty(Cout, Cin, dtype=torch.float32, device=dev) if ctx.has_shortcut else None
+        dbs = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bs else None
+        dW2 = torch.empty(Cout, H, dtype=torch.float32, device=dev)
+        db2 = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b2 else None
+        _call('stin_edgeconv_unpack_grads_f32', _ptr(dwb), _ptr(dw2b), Cin, H, Cout, int(ctx.has_shortcut),
+              int(ctx.trans_inv), _ptr(dW1), _ptr(db1), _ptr(dWs), _ptr(dbs), _ptr(dW2), _ptr(db2), _stream(x))
         return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None
 
 
