@@ -8,6 +8,7 @@
 // library GEMMs pick poor tiles.  Fragment maps (cdna_hip_programming.md §3): A operand lane l holds
 // A[i = l&31][k = l>>5], B operand B[k = l>>5][j = l&31]; C/D reg r of lane l is
 // row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+#include <cstdlib>
 #include "stin_common.h"
 
 namespace {
@@ -674,8 +675,9 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_slabs(const float* __restrict_
 inline int tn_tile(int n) { return n > 64 ? 128 : 64; }
 
 inline int tn_rows_per_chunk(int64_t M, int tiles) {
-    // ~768 blocks in flight (2 per CU resident, 3 rounds), chunks a multiple of the LDS slab
-    int64_t chunks = (768 + tiles - 1) / tiles;
+    // ~512 blocks (2 resident per CU, one round; measured best of 256..1536), chunks a multiple of the LDS slab
+    static const int target = getenv("STIN_TN_BLOCKS") ? atoi(getenv("STIN_TN_BLOCKS")) : 512;   // tuning aid
+    int64_t chunks = (target + tiles - 1) / tiles;
     int64_t rows = (M + chunks - 1) / chunks;
     if (rows < 4 * TN_R) rows = 4 * TN_R;
     if (rows > 128 * TN_R) rows = 128 * TN_R;
@@ -700,6 +702,7 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     // Tile choice: the largest tile that still leaves >= ~6 blocks per CU (256 CUs), so that the tail
     // wave of blocks does not idle half the chip on the M ~ 2e4 levels.
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Nc + bn - 1) / bn); };
+    static const int64_t min_blocks = getenv("STIN_NT_MINBLOCKS") ? atoi(getenv("STIN_NT_MINBLOCKS")) : 1536;   // tuning aid
 #define STIN_NT_ARGS A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc
 #define STIN_NT(KERNEL, BM_, BN_, WM_, WN_, ...)                                                                  \
     do {                                                                                                          \
@@ -710,8 +713,8 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
 #define STIN_NT_PICK(KERNEL, ...)                                                              \
     do {                                                                                       \
         if (Nc <= 32) STIN_NT(KERNEL, 128, 32, 4, 1, ##__VA_ARGS__);                           \
-        else if (Nc % 128 == 0 && blocks(128, 128) >= 1536) STIN_NT(KERNEL, 128, 128, 2, 2, ##__VA_ARGS__); \
-        else if (blocks(128, 64) >= 1536) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);       \
+        else if (Nc % 128 == 0 && blocks(128, 128) >= min_blocks) STIN_NT(KERNEL, 128, 128, 2, 2, ##__VA_ARGS__); \
+        else if (blocks(128, 64) >= min_blocks) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);  \
         else STIN_NT(KERNEL, 64, 64, 2, 2, ##__VA_ARGS__);                                     \
     } while (0)
     if (precision == STIN_GEMM_BF16X3) STIN_NT_PICK(k_gemm_nt_bf16s, 2);
