@@ -168,3 +168,23 @@ def test_synthetic_mesh_invariants():
     assert 0.15 < float((s.mask > 0).float().mean()) < 0.35
     big = make_synthetic_mesh(200_000, 1, seed=0, dilations=())
     assert big.x.shape[0] == 200_704 and big.edge_index.shape[1] == 1_200_642
+
+
+def test_scene_io_round_trip_in_reference_schema(tmp_path):
+    """Write a synthetic scene in the reference's graphs/<scene>.pt + masks/...npz schema and read it back the way
+    ScanNetGraphColorDataSet.__getitem__ assembles a sample (feature layout, key names, dilation fall-back)."""
+    from surface_texture_inpainting_net_amd.scene_io import load_scene, save_scene_like_reference
+    s = make_synthetic_mesh(400, 3, seed=9, dilations=(2, 4))
+    gp, mp = str(tmp_path / 'scene0000_00.pt'), str(tmp_path / '0.npz')
+    save_scene_like_reference(s, gp, mp, dilation_dists=(2, 4, 8))      # dist 8 is empty -> falls back to dist 4
+    t = load_scene(gp, mp, end_level=3)
+    assert t['name'] == 'scene0000_00'
+    for k in ('edge_index', 'hierarchy_edge_index_1', 'hierarchy_edge_index_2', 'hierarchy_trace_index_1',
+              'hierarchy_trace_index_2', 'hierarchy_dil_2_edge_index_2', 'hierarchy_dil_4_edge_index_2', 'mask', 'batch'):
+        assert torch.equal(t[k], s[k]), k
+    assert torch.equal(t['hierarchy_dil_8_edge_index_2'], s['hierarchy_dil_4_edge_index_2'])
+    assert torch.equal(t.num_vertices, s.num_vertices) and t.num_vertices.dtype == torch.int32
+    assert torch.allclose(t.color, s.color, atol=1e-6)
+    assert torch.allclose(t.x, s.x, atol=1e-6)          # [rgb*known, normal, pos/1.5, known]
+    t2 = load_scene(gp, mp, end_level=2)
+    assert t2.num_vertices.shape == (1, 2) and 'hierarchy_trace_index_2' not in t2
