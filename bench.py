@@ -145,6 +145,8 @@ def main():
     ap.add_argument('--vertices', type=int, default=200_000)
     ap.add_argument('--levels', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to smoke-test "
+                    "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--time-gemms', action='store_true', help='also bracket every MFMA GEMM launch with HIP events')
     ap.add_argument('--cache-plan', action='store_true', help='reuse the CSR plan across steps (NOT the headline)')
     args = ap.parse_args()
@@ -153,11 +155,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from surface_texture_inpainting_net_amd import _lib
     from surface_texture_inpainting_net_amd import functional as SF
