@@ -154,12 +154,11 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt(const float* __restrict__ A, 
 //   NS = 2: A0 B0 + A0 B1 + A1 B0                     (3 MFMAs, ~2^-17 per-product error: backward GEMMs)
 //   NS = 3: + A0 B2 + A2 B0 + A1 B1                   (6 MFMAs, x0+x1+x2 is exact, dropped terms 2^-24)
 // fp32 accumulation inside the MFMA.  LDS tiles are [rows][BK] bf16 with K contiguous (as in global
-// memory, no transpose), row pitch 80 B = conflict-free ds_read_b128 fragments
+// memory, no transpose), XOR-swizzled 64-byte rows = conflict-free staging stores and ds_read_b128 fragments
 // (lane l: row l&31, k = 8*(l>>5) .. +7 of a 16-wide k-step).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BKH = 32;          // k per LDS tile (two MFMA k-steps of 16)
-constexpr int PITCH = BKH + 8;   // bf16 elements per LDS row (80 bytes)
 
 template <int NS>
 __device__ __forceinline__ void split_store(float4 v, __bf16* dst, int plane_stride) {
@@ -187,8 +186,11 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
     constexpr int A_F4 = BM * BKH / 4 / BLOCK, W_F4 = BN * BKH / 4 / BLOCK;
     static_assert(A_F4 >= 1 && W_F4 >= 1, "tile too small for 256 threads");
-    __shared__ __attribute__((aligned(16))) __bf16 As[NS][BM][PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Ws[NS][BN][PITCH];
+    // 64-byte rows (32 bf16), the 16-byte chunk c of row r stored at chunk position c ^ ((r >> 2) & 3): conflict-free for
+    // the 8-byte staging stores (two consecutive rows tile one 128-byte bank span) AND for the ds_read_b128 fragment
+    // reads (any 16 rows of one read group land on 16 distinct 16-byte slots) - no padding.
+    __shared__ __attribute__((aligned(16))) __bf16 As[NS][BM][BKH];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[NS][BN][BKH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
     const int n0 = blockIdx.y * BN;
     const int kq = tid % (BKH / 4), r0 = tid / (BKH / 4);
     constexpr int RSTEP = BLOCK / (BKH / 4);
+    auto swz = [](int row, int chunk) { return ((chunk ^ ((row >> 2) & 3)) << 3); };   // bf16 offset of a 16-byte chunk
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -245,9 +248,15 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
     };
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int s = 0; s < A_F4; ++s) split_store<NS>(ra[s], &As[0][r0 + s * RSTEP][kq * 4], BM * PITCH);
+        for (int s = 0; s < A_F4; ++s) {
+            const int row = r0 + s * RSTEP;
+            split_store<NS>(ra[s], &As[0][row][swz(row, kq >> 1) + (kq & 1) * 4], BM * BKH);
+        }
 #pragma unroll
-        for (int s = 0; s < W_F4; ++s) split_store<NS>(rw[s], &Ws[0][r0 + s * RSTEP][kq * 4], BN * PITCH);
+        for (int s = 0; s < W_F4; ++s) {
+            const int row = r0 + s * RSTEP;
+            split_store<NS>(rw[s], &Ws[0][row][swz(row, kq >> 1) + (kq & 1) * 4], BN * BKH);
+        }
     };
 
     const int kh = lane >> 5, li = lane & 31;
@@ -263,11 +272,15 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
 #pragma unroll
             for (int p = 0; p < NS; ++p) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    a[p][i] = *reinterpret_cast<const bf16x8*>(&As[p][wm * TM + i * 32 + li][ks + 8 * kh]);
+                for (int i = 0; i < MT; ++i) {
+                    const int row = wm * TM + i * 32 + li;
+                    a[p][i] = *reinterpret_cast<const bf16x8*>(&As[p][row][swz(row, (ks >> 3) + kh)]);
+                }
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    b[p][j] = *reinterpret_cast<const bf16x8*>(&Ws[p][wn * TN + j * 32 + li][ks + 8 * kh]);
+                for (int j = 0; j < NT; ++j) {
+                    const int row = wn * TN + j * 32 + li;
+                    b[p][j] = *reinterpret_cast<const bf16x8*>(&Ws[p][row][swz(row, (ks >> 3) + kh)]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)

@@ -43,9 +43,10 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd(const float* __restrict__ A,
         a[k] = on[k] ? ld4(A + L.row * lda + L.chan(k)) : f4zero();
         acc[k] = f4zero();
     }
-    const int mwords = H >> 5;                            // mask words per edge slot (natural channel order)
+    const int mwords = H >> 5;                            // mask words per edge slot
     for (int e = beg; e < end; e += U) {
         float4 b[U][VPL];
+        uint4 mw[VPL];                                    // this lane's share of the U neighbours' ReLU masks
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ee = min(e + u, end - 1);          // clamped: branch-free, always a valid row
@@ -66,21 +67,29 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd(const float* __restrict__ A,
                 acc[k].w += w * fmaxf(tw, 0.f);
                 if (G >= 32 && mask != nullptr) {
                     // Mask layout per destination-CSR slot (H bits): [k][component x,y,z,w][G lane bits]: exactly what
-                    // the wave ballots of the four compares deliver (the lane masks are already in SGPRs), so one lane
-                    // per row stores 16 bytes (G = 32) or 32 bytes (G = 64) per (slot, k) - no cross-lane shuffles.
+                    // the wave ballots of the four compares deliver (the lane masks are already in SGPRs).  Lane u of
+                    // the row keeps neighbour u's words; after the u-loop lanes 0..U-1 store them with ONE instruction
+                    // (U consecutive slots = U*16 contiguous bytes for G = 32).
                     const unsigned long long bx = __ballot(tx > 0.f), by = __ballot(ty > 0.f);
                     const unsigned long long bz = __ballot(tz > 0.f), bw = __ballot(tw > 0.f);
-                    if (L.lg == 0 && e + u < end) {
-                        uint32_t* m = mask + (int64_t)(e + u) * mwords + k * (G / 8);
-                        if (G == 32) {
-                            const int sh = (threadIdx.x & 32);            // which half of the wave this row lives in
-                            *reinterpret_cast<uint4*>(m) = make_uint4((uint32_t)(bx >> sh), (uint32_t)(by >> sh),
-                                                                       (uint32_t)(bz >> sh), (uint32_t)(bw >> sh));
-                        } else {
-                            reinterpret_cast<uint4*>(m)[0] = make_uint4((uint32_t)bx, (uint32_t)(bx >> 32), (uint32_t)by, (uint32_t)(by >> 32));
-                            reinterpret_cast<uint4*>(m)[1] = make_uint4((uint32_t)bz, (uint32_t)(bz >> 32), (uint32_t)bw, (uint32_t)(bw >> 32));
-                        }
+                    if (G == 32) {
+                        const int sh = (threadIdx.x & 32);            // which half of the wave this row lives in
+                        if (L.lg == u) mw[k] = make_uint4((uint32_t)(bx >> sh), (uint32_t)(by >> sh), (uint32_t)(bz >> sh), (uint32_t)(bw >> sh));
+                    } else {
+                        if (L.lg == 2 * u) mw[k] = make_uint4((uint32_t)bx, (uint32_t)(bx >> 32), (uint32_t)by, (uint32_t)(by >> 32));
+                        if (L.lg == 2 * u + 1) mw[k] = make_uint4((uint32_t)bz, (uint32_t)(bz >> 32), (uint32_t)bw, (uint32_t)(bw >> 32));
                     }
+                }
+            }
+        }
+        if (G >= 32 && mask != nullptr) {
+            // G = 32: lane u -> slot e+u, 16 bytes per k.  G = 64: lanes 2u, 2u+1 -> the two 16-byte halves of slot e+u.
+            const int uu = (G == 32) ? L.lg : (L.lg >> 1);
+            if (uu < U && e + uu < end) {
+#pragma unroll
+                for (int k = 0; k < VPL; ++k) {
+                    uint32_t* m = mask + (int64_t)(e + uu) * mwords + k * (G / 8) + ((G == 32) ? 0 : (L.lg & 1) * 4);
+                    *reinterpret_cast<uint4*>(m) = mw[k];
                 }
             }
         }
