@@ -155,10 +155,21 @@ __global__ void k_moments_final(const double* __restrict__ partial, int nch, int
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
         const double* p = partial + (int64_t)b * nch * 2 * C + c;
-        for (int k = ty; k < nch; k += FIN_KL) {
-            s1 += p[(int64_t)k * 2 * C];
-            s2 += p[(int64_t)k * 2 * C + C];
+        const int64_t st = (int64_t)2 * C;
+        double t1 = 0.0, t2 = 0.0;
+        int k = ty;
+        for (; k + FIN_KL < nch; k += 2 * FIN_KL) {       // two independent loads in flight
+            s1 += p[k * st];
+            s2 += p[k * st + C];
+            t1 += p[(k + FIN_KL) * st];
+            t2 += p[(k + FIN_KL) * st + C];
         }
+        for (; k < nch; k += FIN_KL) {
+            s1 += p[k * st];
+            s2 += p[k * st + C];
+        }
+        s1 += t1;
+        s2 += t2;
     }
     sm[0][ty][tx] = s1;
     sm[1][ty][tx] = s2;

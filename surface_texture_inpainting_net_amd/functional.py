@@ -388,8 +388,11 @@ class EdgeConvBlockFn(torch.autograd.Function):
         if ctx.has_shortcut:
             dY[:, 2 * H:].copy_(g)
         dwb = gemm_tn(dY, x, ones_column=True, precision=PREC_BWD)           # [Yw, Cin + 1]: packed weight grad | bias grad
-        # dx = dY Wcat (+ g: the identity-residual path, added in the GEMM epilogue)
-        dx = gemm_nt(dY, wcatT, precision=PREC_BWD, residual=None if ctx.has_shortcut else g)
+        # dx = dY Wcat (+ g: the identity-residual path, added in the GEMM epilogue); skipped when the block input
+        # needs no gradient (the network input of the first block)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_nt(dY, wcatT, precision=PREC_BWD, residual=None if ctx.has_shortcut else g)
         dev = x.device
         dW1 = torch.empty(ctx.w1_shape, dtype=torch.float32, device=dev)
         db1 = torch.empty(H, dtype=torch.float32, device=dev) if ctx.has_b1 else None
