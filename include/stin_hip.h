@@ -230,18 +230,19 @@ int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, i
  * pack: the reference-layout EdgeConv parameters (first_filter.nn.0.{weight,bias} = W1 [H, 2Cin]
  * (or [H, Cin] for EdgeConvTransInv), first_filter.nn.2.weight = W2 [Cout, H], shortcut.{weight,bias})
  * -> the per-vertex GEMM operands  wcat [Yw, Cin] = [Wa-Wb ; Wb ; Ws] (trans_inv: [-W1 ; W1 ; Ws]),
- * bcat [Yw] = [b1 ; 0 ; bs], wcatT = wcat^T, w2T = W2^T; Yw = 2H (+ Cout).
+ * bcat [Yw] = [b1 ; 0 ; bs], wcatT = wcat^T, w2T = W2^T; Yw = 2H (+ Cout).  The inner dimension may be zero-padded
+ * from Cin to Cp (a multiple of 4) so that a 10-channel network input still takes the 16-byte GEMM paths.
  * unpack: dwb [Yw, Cin+1] (gemm_tn output: weight grad | bias grad) -> dW1, db1, dWs, dbs; and
  *   dw2b [Cout, H+1] (optional) -> contiguous dW2 [Cout, H], db2 [Cout].
  * (models/modules/edge_conv_filter.py:46-52, models/surfacetextureinpaintingnet.py:505-506)
  * norm_bwd_coef: k = -rstd^3 T1 inv_cnt, m = -rstd S0 inv_cnt for stin_norm_act_bwd_f32.
  */
 int stin_edgeconv_pack_f32(const float* W1, const float* b1, const float* Ws, const float* bs, const float* W2,
-                           int Cin, int H, int Cout, int has_shortcut, int trans_inv, float* wcat, float* bcat,
-                           float* wcatT, float* w2T, stin_stream_t stream);
-int stin_edgeconv_unpack_grads_f32(const float* dwb, const float* dw2b, int Cin, int H, int Cout, int has_shortcut,
-                                   int trans_inv, float* dW1, float* db1, float* dWs, float* dbs, float* dW2,
-                                   float* db2, stin_stream_t stream);
+                           int Cin, int Cp, int H, int Cout, int has_shortcut, int trans_inv, float* wcat,
+                           float* bcat, float* wcatT, float* w2T, stin_stream_t stream);
+int stin_edgeconv_unpack_grads_f32(const float* dwb, const float* dw2b, int Cin, int Cp, int H, int Cout,
+                                   int has_shortcut, int trans_inv, float* dW1, float* db1, float* dWs, float* dbs,
+                                   float* dW2, float* db2, stin_stream_t stream);
 int stin_norm_bwd_coef_f32(const float* T1, const float* S0, const float* rstd, const float* inv_cnt, int B, int C,
                            float* k, float* m, stin_stream_t stream);
 

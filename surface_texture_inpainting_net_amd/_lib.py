@@ -66,10 +66,10 @@ SIGNATURES = {
     'stin_gemm_tn_workspace_bytes': (c_size, [c_i64, c_int, c_int, c_int]),
     'stin_gemm_tn_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64,
                                  c_int, c_ptr, c_size, c_ptr]),
-    'stin_edgeconv_pack_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr,
-                                       c_ptr, c_ptr, c_ptr]),
-    'stin_edgeconv_unpack_grads_f32': (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
-                                               c_ptr, c_ptr, c_ptr]),
+    'stin_edgeconv_pack_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr,
+                                       c_ptr, c_ptr, c_ptr, c_ptr]),
+    'stin_edgeconv_unpack_grads_f32': (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr,
+                                               c_ptr, c_ptr, c_ptr, c_ptr]),
     'stin_norm_bwd_coef_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr]),
 }
 

@@ -342,15 +342,21 @@ class EdgeConvBlockFn(torch.autograd.Function):
         has_shortcut = Ws is not None
         Yw = 2 * H + (Cout if has_shortcut else 0)
         dev = x.device
-        pack = torch.empty(Yw * Cin * 2 + Yw + H * Cout, dtype=torch.float32, device=dev)
-        wcat = pack[:Yw * Cin].view(Yw, Cin)
-        wcatT = pack[Yw * Cin:2 * Yw * Cin].view(Cin, Yw)
-        w2T = pack[2 * Yw * Cin:2 * Yw * Cin + H * Cout].view(H, Cout)
-        bcat = pack[2 * Yw * Cin + H * Cout:]
+        Cp = (Cin + 3) // 4 * 4                                   # inner dimension padded for the 16-byte GEMM paths
+        if Cp != Cin:                                             # (the 10-channel network input -> 12)
+            xp = x.new_zeros(N, Cp)
+            xp[:, :Cin] = x
+        else:
+            xp = x
+        pack = torch.empty(Yw * Cp * 2 + Yw + H * Cout, dtype=torch.float32, device=dev)
+        wcat = pack[:Yw * Cp].view(Yw, Cp)
+        wcatT = pack[Yw * Cp:2 * Yw * Cp].view(Cp, Yw)
+        w2T = pack[2 * Yw * Cp:2 * Yw * Cp + H * Cout].view(H, Cout)
+        bcat = pack[2 * Yw * Cp + H * Cout:]
         W1c, W2c = W1.contiguous(), W2.contiguous()
-        _call('stin_edgeconv_pack_f32', _ptr(W1c), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2c), Cin, H, Cout,
+        _call('stin_edgeconv_pack_f32', _ptr(W1c), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2c), Cin, Cp, H, Cout,
               int(has_shortcut), int(trans_inv), _ptr(wcat), _ptr(bcat), _ptr(wcatT), _ptr(w2T), _stream(x))
-        Y = gemm_nt(x, wcat, bcat, precision=PREC_FWD)
+        Y = gemm_nt(xp, wcat, bcat, precision=PREC_FWD)
         hE = torch.empty(N, H + 4, dtype=torch.float32, device=dev)
         # ReLU decisions as bits (E*H/8 bytes): backward then needs no recompute gathers
         use_mask = USE_EDGE_MASK and edge_mask_supported(H) and Y.stride(0) % 4 == 0
@@ -360,8 +366,9 @@ class EdgeConvBlockFn(torch.autograd.Function):
         mean, rstd = instance_stats(agg, groups)
         res = Y[:, 2 * H:] if has_shortcut else x
         out = norm_act_res_fwd(agg, mean, rstd, groups, res=res, act=True)
-        ctx.save_for_backward(x, Y, hE, agg, mean, rstd, wcatT, w2T)
+        ctx.save_for_backward(xp, Y, hE, agg, mean, rstd, wcatT, w2T)
         ctx.mask = mask
+        ctx.cin = Cin
         ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut, ctx.trans_inv = edges, groups, H, has_shortcut, trans_inv
         ctx.has_b1, ctx.has_b2, ctx.has_bs = b1 is not None, b2 is not None, bs is not None
         ctx.w1_shape = tuple(W1.shape)
@@ -369,9 +376,9 @@ class EdgeConvBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        x, Y, hE, agg, mean, rstd, wcatT, w2T = ctx.saved_tensors
+        x, Y, hE, agg, mean, rstd, wcatT, w2T = ctx.saved_tensors          # x: the (possibly channel-padded) block input
         edges, groups, H = ctx.edges, ctx.groups, ctx.H
-        Cin, Cout = x.shape[1], agg.shape[1]
+        Cin, Cp, Cout = ctx.cin, x.shape[1], agg.shape[1]
         g, _ = _mat(g)
         dagg = instance_norm_act_bwd(agg, g, mean, rstd, groups, act=True)
         dw2b = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H], precision=PREC_BWD)   # [Cout, H + 1] = dW2 | db2
@@ -393,6 +400,8 @@ class EdgeConvBlockFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = gemm_nt(dY, wcatT, precision=PREC_BWD, residual=None if ctx.has_shortcut else g)
+            if Cp != Cin:
+                dx = dx[:, :Cin]
         dev = x.device
         dW1 = torch.empty(ctx.w1_shape, dtype=torch.float32, device=dev)
         db1 = torch.empty(H, dtype=torch.float32, device=dev) if ctx.has_b1 else None
@@ -400,7 +409,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         dbs = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bs else None
         dW2 = torch.empty(Cout, H, dtype=torch.float32, device=dev)
         db2 = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b2 else None
-        _call('stin_edgeconv_unpack_grads_f32', _ptr(dwb), _ptr(dw2b), Cin, H, Cout, int(ctx.has_shortcut),
+        _call('stin_edgeconv_unpack_grads_f32', _ptr(dwb), _ptr(dw2b), Cin, Cp, H, Cout, int(ctx.has_shortcut),
               int(ctx.trans_inv), _ptr(dW1), _ptr(db1), _ptr(dWs), _ptr(dbs), _ptr(dW2), _ptr(db2), _stream(x))
         return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None
 
