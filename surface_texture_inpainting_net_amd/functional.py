@@ -2,8 +2,9 @@
 the nn.Modules in surfacetextureinpaintingnet.py are written on.
 
 Every function here runs on GPU tensors only and calls through the C ABI
-(include/stin_hip.h); there is no eager/CPU fallback.  Dense per-vertex GEMMs use
-torch.mm / addmm (rocBLAS / hipBLASLt) - plain library GEMMs.
+(include/stin_hip.h); there is no eager/CPU fallback.  The dense per-vertex GEMMs are
+the hand-written MFMA kernels too (gemm_nt / gemm_tn); STIN_GEMM_BACKEND=blas swaps in
+torch.mm purely as an A/B numerics aid.
 """
 import os
 
@@ -21,7 +22,9 @@ POST_NONE, POST_SCALE, POST_RSTD = 0, 1, 2
 
 def _mat(t):
     """2-D fp32 GPU tensor with unit inner stride -> (tensor, ld)."""
-    assert t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda, (t.shape, t.dtype, t.device)
+    if not (t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda):
+        raise TypeError('the STINet HIP path takes 2-D float32 CUDA tensors (no CPU / eager fallback exists); got '
+                        'shape %s dtype %s device %s' % (tuple(t.shape), t.dtype, t.device))
     if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
         t = t.contiguous()
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))

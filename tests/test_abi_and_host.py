@@ -188,3 +188,12 @@ def test_scene_io_round_trip_in_reference_schema(tmp_path):
     assert torch.allclose(t.x, s.x, atol=1e-6)          # [rgb*known, normal, pos/1.5, known]
     t2 = load_scene(gp, mp, end_level=2)
     assert t2.num_vertices.shape == (1, 2) and 'hierarchy_trace_index_2' not in t2
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    """No CPU / eager fallback: a CPU sample must fail loudly, never produce an answer."""
+    s = make_synthetic_mesh(100, 2, seed=3, dilations=())
+    net = S.define_G(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconv', norm='instance', n_blocks=1, n_levels=1,
+                     pooling_type='max')
+    with pytest.raises((AssertionError, TypeError)):
+        net(s)
