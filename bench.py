@@ -59,12 +59,13 @@ def pmc_traffic_bytes(kernel, n, e, h):
     while g < c4 and g < 64:
         g *= 2
     vpl = (c4 + g - 1) // g
-    base = 4 if kernel.endswith('bwd_src_f32') else 8
+    table = {1: 4, 2: 4, 4: 4, 8: 4, 16: 4, 32: 6}.get(g, {1: 4, 2: 2, 4: 2}.get(vpl, 1))
+    u = max(1, table // (2 if kernel.endswith('bwd_src_f32') else 1))
     short = {'stin_edge_relu_mean_fwd_f32': 'k_edge_fwd', 'stin_edge_relu_mean_bwd_dst_f32': 'k_edge_bwd_dst',
              'stin_edge_relu_mean_bwd_src_f32': 'k_edge_bwd_src',
              'stin_edge_relu_mean_bwd_dst_mask_f32': 'k_edge_bwd_dst_mask',
              'stin_edge_relu_mean_bwd_src_mask_f32': 'k_edge_bwd_src_mask'}[kernel]
-    key = '%s<%d, %d, %d>' % (short, g, vpl, max(1, (base + vpl - 1) // vpl))
+    key = '%s<%d, %d, %d>' % (short, g, vpl, u)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
     if not files:
         return None

@@ -553,24 +553,27 @@ inline bool mask_shape_ok(int H) { return H == 128 || H == 256 || H == 512 || H 
 inline unsigned grid_rows(int64_t N, int G) { return (unsigned)((N + (BLOCK / G) - 1) / (BLOCK / G)); }
 inline unsigned grid_elems(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
-// Dispatch on (G, VPL) for a channel count C (C % 4 == 0, C <= 2048).  U_ is chosen per VPL so that
-// roughly 8 float4 gathers per lane are in flight.
-#define STIN_DISPATCH(C_, KERNEL, UBASE, ...)                                                                \
+// Dispatch on (G, VPL) for a channel count C (C % 4 == 0, C <= 2048).  U = neighbour rows requested per loop trip,
+// tuned on MI355X at mean degree ~6 (level-0/1/2 edge kernels and the standalone scatter-add, U in {8, 6, 4}):
+// rows of <= 256 B: 4; 512-B rows (G = 32): 6 - one trip for a typical mesh vertex; 1-KB rows (G = 64): 4; then 2, 2, 1
+// as a lane holds 2, 4, 8 chunks.  DIV halves it for kernels that gather two rows per neighbour.
+#define STIN_U(base, DIV) (((base) / (DIV)) > 0 ? ((base) / (DIV)) : 1)
+#define STIN_DISPATCH(C_, KERNEL, DIV, ...)                                                                  \
     do {                                                                                                     \
         const int c4_ = (C_) / 4;                                                                            \
         const int g_ = stin_group_lanes(c4_);                                                                \
         const int vpl_ = (c4_ + g_ - 1) / g_;                                                                \
         const unsigned grid_ = grid_rows(N, g_);                                                             \
-        if (g_ == 1) hipLaunchKernelGGL((KERNEL<1, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);        \
-        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<2, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<4, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<8, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<16, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<32, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<64, 1, UBASE>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<64, 2, (UBASE + 1) / 2>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<64, 4, (UBASE + 3) / 4>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<64, 8, (UBASE + 7) / 8>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);     \
+        if (g_ == 1) hipLaunchKernelGGL((KERNEL<1, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);        \
+        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<2, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<4, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<8, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<16, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<32, 1, STIN_U(6, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<64, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<64, 2, STIN_U(2, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<64, 4, STIN_U(2, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<64, 8, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);       \
     } while (0)
 
 #define STIN_DISPATCH_NOU(C_, KERNEL, ...)                                                                   \
@@ -604,7 +607,7 @@ extern "C" int stin_edge_relu_mean_fwd_f32(const float* A, int64_t lda, const fl
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(A && B && rowptr && out, STIN_E_NULL);
     if (vec_ok(H, {A, B, out}, {lda, ldb, ldo})) {
-        STIN_DISPATCH(H, k_edge_fwd, 8, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+        STIN_DISPATCH(H, k_edge_fwd, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
     } else {
         hipLaunchKernelGGL((k_scalar<OP_EDGE_FWD>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
                            (const float*)nullptr, (int64_t)0, (const float*)nullptr, rowptr, col, N, H, indicator, out, ldo,
@@ -622,7 +625,7 @@ extern "C" int stin_edge_relu_mean_bwd_dst_f32(const float* A, int64_t lda, cons
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(A && B && G && rowptr && dA, STIN_E_NULL);
     if (vec_ok(H, {A, B, G, dA}, {lda, ldb, ldg, ldda})) {
-        STIN_DISPATCH(H, k_edge_bwd_dst, 8, A, lda, B, ldb, G, ldg, rowptr, col, N, H, dA, ldda);
+        STIN_DISPATCH(H, k_edge_bwd_dst, 1, A, lda, B, ldb, G, ldg, rowptr, col, N, H, dA, ldda);
     } else {
         hipLaunchKernelGGL((k_scalar<OP_EDGE_BWD_DST>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
                            G, ldg, (const float*)nullptr, rowptr, col, N, H, 0, dA, ldda, (int32_t*)nullptr);
@@ -640,7 +643,7 @@ extern "C" int stin_edge_relu_mean_bwd_src_f32(const float* A, int64_t lda, cons
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(A && B && G && inv_deg && rowptr_src && dB, STIN_E_NULL);
     if (vec_ok(H, {A, B, G, dB}, {lda, ldb, ldg, lddb})) {
-        STIN_DISPATCH(H, k_edge_bwd_src, 4, A, lda, B, ldb, G, ldg, inv_deg, rowptr_src, col_src, N, H, dB, lddb);
+        STIN_DISPATCH(H, k_edge_bwd_src, 2, A, lda, B, ldb, G, ldg, inv_deg, rowptr_src, col_src, N, H, dB, lddb);
     } else {
         hipLaunchKernelGGL((k_scalar<OP_EDGE_BWD_SRC>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
                            G, ldg, inv_deg, rowptr_src, col_src, N, H, 0, dB, lddb, (int32_t*)nullptr);
@@ -657,7 +660,7 @@ extern "C" int stin_edge_relu_mean_bwd_dst_mask_f32(const float* G, int64_t ldg,
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(G && mask && rowptr && dA, STIN_E_NULL);
     STIN_REQUIRE(mask_shape_ok(H) && vec_ok(H, {G, dA}, {ldg, ldda}), STIN_E_UNSUPPORTED);
-    STIN_DISPATCH(H, k_edge_bwd_dst_mask, 8, G, ldg, mask, rowptr, N, H, dA, ldda);
+    STIN_DISPATCH(H, k_edge_bwd_dst_mask, 1, G, ldg, mask, rowptr, N, H, dA, ldda);
     return stin_launch_status();
 }
 
@@ -671,7 +674,7 @@ extern "C" int stin_edge_relu_mean_bwd_src_mask_f32(const float* G, int64_t ldg,
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(G && w_src && mask && rowptr_src && col_src && xslot && dB, STIN_E_NULL);
     STIN_REQUIRE(mask_shape_ok(H) && vec_ok(H, {G, dB}, {ldg, lddb}), STIN_E_UNSUPPORTED);
-    STIN_DISPATCH(H, k_edge_bwd_src_mask, 8, G, ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
+    STIN_DISPATCH(H, k_edge_bwd_src_mask, 1, G, ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
     return stin_launch_status();
 }
 
@@ -683,7 +686,7 @@ extern "C" int stin_segment_sum_f32(const float* src, int64_t ld_src, const int3
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(src && rowptr && out, STIN_E_NULL);
     if (vec_ok(C, {src, out}, {ld_src, ld_out})) {
-        STIN_DISPATCH(C, k_segment_sum, 8, src, ld_src, rowptr, col, N, C, mean, out, ld_out);
+        STIN_DISPATCH(C, k_segment_sum, 1, src, ld_src, rowptr, col, N, C, mean, out, ld_out);
     } else {
         hipLaunchKernelGGL((k_scalar<OP_SEG_SUM>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, src, ld_src,
                            (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
@@ -700,7 +703,7 @@ extern "C" int stin_pool_max_fwd_f32(const float* x, int64_t ldx, const int32_t*
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(x && rowptr && col && out && arg, STIN_E_NULL);
     if (vec_ok(C, {x, out, arg}, {ldx, ldo})) {
-        STIN_DISPATCH(C, k_pool_max_fwd, 4, x, ldx, rowptr, col, N, C, out, ldo, arg);
+        STIN_DISPATCH(C, k_pool_max_fwd, 1, x, ldx, rowptr, col, N, C, out, ldo, arg);
     } else {
         hipLaunchKernelGGL((k_scalar<OP_POOL_MAX>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, x, ldx,
                            (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
