@@ -246,6 +246,21 @@ int stin_edgeconv_unpack_grads_f32(const float* dwb, const float* dw2b, int Cin,
 int stin_norm_bwd_coef_f32(const float* T1, const float* S0, const float* rstd, const float* inv_cnt, int B, int C,
                            float* k, float* m, stin_stream_t stream);
 
+/* ----------------------------------------------------------- train-step epilogues --
+ * masked_l1_loss: the trainer's loss and its gradient in one pass
+ * (trainers/inpainting3d_trainer.py:127-137): pred = mask > 0 ? out : color,
+ * loss = mean |pred - color| * 0.99^mask (use_weight = trainer.use_mask_weighted_loss),
+ * grad = dloss/dout.  fp64 block partials summed in a fixed order.  mask: int64 [N].
+ * adam: torch.optim.Adam(amsgrad) on ONE flat parameter/gradient/state buffer (the reference's
+ * optimizer, experiments/3d_inpainting/config/...json:95-102), step = 1-based update count.
+ */
+size_t stin_masked_l1_workspace_bytes(int64_t N, int C);
+int stin_masked_l1_loss_f32(const float* out, const float* color, const int64_t* mask, int64_t N, int C,
+                            int use_weight, float* loss, float* grad, void* workspace, size_t workspace_bytes,
+                            stin_stream_t stream);
+int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, int amsgrad, stin_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,10 @@ SIGNATURES = {
     'stin_edgeconv_unpack_grads_f32': (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr,
                                                c_ptr, c_ptr, c_ptr, c_ptr]),
     'stin_norm_bwd_coef_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    'stin_masked_l1_workspace_bytes': (c_size, [c_i64, c_int]),
+    'stin_masked_l1_loss_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    'stin_adam_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int,
+                              c_ptr]),
 }
 
 _lib = None

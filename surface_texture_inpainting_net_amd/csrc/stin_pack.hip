@@ -115,3 +115,113 @@ extern "C" int stin_norm_bwd_coef_f32(const float* T1, const float* S0, const fl
                        S0, rstd, inv_cnt, B, C, k, m);
     return stin_launch_status();
 }
+
+// ------------------------------------------------------------------ train-step epilogues
+// Masked, distance-weighted L1 loss of the inpainting trainer and its gradient in one pass
+// (reference trainers/inpainting3d_trainer.py:127-137):
+//   pred = mask > 0 ? out : color ; loss = mean_{v,c} |pred - color| * 0.99^mask_v
+//   dloss/dout[v,c] = mask_v > 0 ? sign(out - color) * 0.99^mask_v / (N*C) : 0
+// partial[block] holds each block's fp64 sum (fixed order); k_loss_final adds them.
+namespace {
+__global__ __launch_bounds__(256) void k_masked_l1(const float* __restrict__ out, const float* __restrict__ color,
+                                                   const int64_t* __restrict__ mask, int64_t N, int C, int use_weight,
+                                                   float inv_count, float* __restrict__ grad,
+                                                   double* __restrict__ partial) {
+    __shared__ double sm[256];
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    if (t < N * C) {
+        const int64_t v = t / C;
+        const int64_t m = mask[v];
+        const float w = use_weight ? powf(0.99f, (float)m) : 1.f;
+        float d = 0.f, g = 0.f;
+        if (m > 0) {
+            d = out[t] - color[t];
+            g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w * inv_count;
+        }
+        grad[t] = g;
+        acc = (double)(fabsf(d) * w);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
+__global__ __launch_bounds__(256) void k_loss_final(const double* __restrict__ partial, int n, float inv_count,
+                                                    float* __restrict__ loss) {
+    __shared__ double sm[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(sm[0] * (double)inv_count);
+}
+
+// Adam with amsgrad over one flat parameter buffer (torch.optim.Adam semantics, weight_decay added to the gradient):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; vmax = max(vmax, v)
+//   p -= lr / (1 - b1^t) * m / (sqrt(vmax) / sqrt(1 - b2^t) + eps)
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, float* __restrict__ vmax, int64_t n, float lr,
+                                              float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                              int amsgrad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float vh = vi;
+    if (amsgrad) {
+        vh = fmaxf(vmax[i], vi);
+        vmax[i] = vh;
+    }
+    const float denom = sqrtf(vh) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+}  // namespace
+
+extern "C" size_t stin_masked_l1_workspace_bytes(int64_t N, int C) {
+    if (N < 0 || C <= 0) return 0;
+    return (size_t)((N * C + 255) / 256 + 1) * sizeof(double) + 256;
+}
+
+extern "C" int stin_masked_l1_loss_f32(const float* out, const float* color, const int64_t* mask, int64_t N, int C,
+                                       int use_weight, float* loss, float* grad, void* workspace, size_t workspace_bytes,
+                                       stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N > 0 && C > 0, STIN_E_SIZE);
+    STIN_REQUIRE(out && color && mask && loss && grad && workspace, STIN_E_NULL);
+    STIN_REQUIRE(workspace_bytes >= stin_masked_l1_workspace_bytes(N, C), STIN_E_WORKSPACE);
+    double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int64_t n = N * C;
+    const int blocks = (int)((n + 255) / 256);
+    const float inv = 1.0f / (float)n;
+    hipLaunchKernelGGL(k_masked_l1, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, out, color, mask, N, C,
+                       use_weight, inv, grad, partial);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, (hipStream_t)stream_, partial, blocks, inv, loss);
+    return stin_launch_status();
+}
+
+extern "C" int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int step, int amsgrad, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(n >= 0 && step >= 1, STIN_E_SIZE);
+    if (n == 0) return STIN_OK;
+    STIN_REQUIRE(p && g && m && v && (!amsgrad || vmax), STIN_E_NULL);
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, vmax, n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2s, amsgrad);
+    return stin_launch_status();
+}

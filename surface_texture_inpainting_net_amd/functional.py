@@ -536,6 +536,46 @@ class InstanceNormActResFn(torch.autograd.Function):
         return dx, (g if ctx.has_res else None), None, None
 
 
+class MaskedL1LossFn(torch.autograd.Function):
+    """The inpainting trainer's loss in one kernel: pred = where(mask > 0, out, color);
+    loss = mean(|pred - color| * 0.99^mask) (reference trainers/inpainting3d_trainer.py:127-137).  The gradient
+    w.r.t. `out` is produced by the same pass and only scaled in backward."""
+
+    @staticmethod
+    def forward(ctx, out, color, mask, use_weight):
+        lib = _lib.load()
+        out, _ = _mat(out)
+        color, _ = _mat(color)
+        out, color = out.contiguous(), color.contiguous()
+        N, C = out.shape
+        m = mask.reshape(-1).contiguous()
+        if m.dtype != torch.int64:
+            m = m.long()
+        loss = torch.empty((), dtype=torch.float32, device=out.device)
+        grad = torch.empty_like(out)
+        ws_bytes = lib.stin_masked_l1_workspace_bytes(N, C)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out.device)
+        _call('stin_masked_l1_loss_f32', _ptr(out), _ptr(color), _ptr(m), N, C, int(use_weight), _ptr(loss), _ptr(grad),
+              _ptr(ws), ws_bytes, _stream(out))
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+def masked_l1_loss(out, color, mask, use_weight=True):
+    return MaskedL1LossFn.apply(out, color, mask, use_weight)
+
+
+def adam_step(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step, amsgrad=True):
+    """torch.optim.Adam(amsgrad) on flat fp32 buffers, one launch."""
+    _call('stin_adam_f32', _ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), p.numel(), float(lr), float(beta1), float(beta2),
+          float(eps), float(weight_decay), int(step), int(amsgrad), _stream(p))
+
+
 class SliceSumFn(torch.autograd.Function):
     """[N, C] -> [B, C] sums over contiguous row ranges (SingleBatchGraphNorm statistics)."""
 

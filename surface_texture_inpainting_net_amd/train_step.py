@@ -90,9 +90,42 @@ def broadcast_parameters(model, src=0, group=None):
         off += p.numel()
 
 
+class FlatAdam:
+    """Adam(amsgrad) over ONE flat parameter buffer: the parameters are re-pointed at views of `flat_p`, the moments
+    live in flat buffers of the same size, and the update is a single HIP launch (stin_adam_f32) on the bucket's
+    flat gradient - instead of torch's ~15 multi-tensor kernels per step.  Same arithmetic as
+    torch.optim.Adam(lr, betas, eps, weight_decay, amsgrad)."""
+
+    def __init__(self, bucket, lr=7e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=True):
+        self.bucket = bucket
+        self.lr, self.betas, self.eps, self.weight_decay, self.amsgrad = lr, betas, eps, weight_decay, amsgrad
+        self.flat_p = torch.empty_like(bucket.flat)
+        off = 0
+        for p in bucket.params:
+            n = p.numel()
+            self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + n].view_as(p)
+            off += n
+        self.exp_avg = torch.zeros_like(bucket.flat)
+        self.exp_avg_sq = torch.zeros_like(bucket.flat)
+        self.max_exp_avg_sq = torch.zeros_like(bucket.flat)
+        self.step_count = 0
+
+    def step(self):
+        from . import functional as SF
+        self.step_count += 1
+        SF.adam_step(self.flat_p, self.bucket.flat, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, self.lr,
+                     self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, self.amsgrad)
+
+    def state_dict(self):
+        return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
+                'max_exp_avg_sq': self.max_exp_avg_sq, 'lr': self.lr}
+
+
 class TrainStep:
     """model + Adam(amsgrad) + flat-bucket gradient all-reduce; ``step(sample) -> loss`` (a 0-dim
-    tensor, no host sync)."""
+    tensor, no host sync).  On the GPU the loss (+ its gradient) and the optimizer update are one HIP
+    kernel each; on the CPU (the gloo tests of the harness) the same arithmetic runs through torch."""
 
     def __init__(self, model, lr=7e-5, weight_decay=0.0, amsgrad=True, use_mask_weighted_loss=True, group=None):
         self.model = model
@@ -100,12 +133,20 @@ class TrainStep:
         self.use_mask_weighted_loss = use_mask_weighted_loss
         broadcast_parameters(model, 0, group)
         self.bucket = FlatGradBucket(model.parameters())
-        self.optimizer = torch.optim.Adam(self.bucket.params, lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
+        self.on_gpu = self.bucket.flat.is_cuda
+        if self.on_gpu:
+            self.optimizer = FlatAdam(self.bucket, lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
+        else:
+            self.optimizer = torch.optim.Adam(self.bucket.params, lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
 
     def forward_backward(self, sample):
         self.bucket.detach_grads()
-        pred = graph_forward(self.model, sample)
-        loss = compute_loss(pred, sample.color, sample.mask if self.use_mask_weighted_loss else None)
+        if self.on_gpu:
+            from . import functional as SF
+            loss = SF.masked_l1_loss(self.model(sample), sample.color, sample.mask, self.use_mask_weighted_loss)
+        else:
+            pred = graph_forward(self.model, sample)
+            loss = compute_loss(pred, sample.color, sample.mask if self.use_mask_weighted_loss else None)
         loss.backward()
         self.bucket.gather_grads()
         return loss.detach()

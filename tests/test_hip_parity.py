@@ -467,6 +467,40 @@ def test_train_step_against_reference_fixture():
         assert torch.allclose(v.cpu()[ok], fx.state_dict_after[k][ok], rtol=0, atol=5e-7), k
 
 
+def test_fused_masked_l1_loss_matches_trainer_formula():
+    g = torch.Generator().manual_seed(5)
+    n = 5000
+    out = (torch.rand(n, 3, generator=g) * 2 - 1).requires_grad_(True)
+    color = torch.rand(n, 3, generator=g) * 2 - 1
+    mask = torch.where(torch.rand(n, 1, generator=g) < 0.3, torch.randint(1, 17, (n, 1), generator=g), torch.zeros(n, 1, dtype=torch.long))
+    out.data[7] = color[7]                                         # exact zeros: |.|' = 0 there, as torch's abs backward
+    for use_w in (True, False):
+        out.grad = None
+        want = stin_oracle.compute_loss(torch.where((mask > 0).expand_as(color), out, color), color, mask if use_w else None)
+        want.backward()
+        od = out.detach().to(DEV).requires_grad_(True)
+        got = SF.masked_l1_loss(od, color.to(DEV), mask.to(DEV), use_w)
+        (got * 3.0).backward()
+        assert abs(float(got) - float(want)) <= 2e-7
+        assert float((od.grad.cpu() / 3.0 - out.grad).abs().max()) <= 1e-9 + 1e-6 * float(out.grad.abs().max())
+
+
+@pytest.mark.parametrize('amsgrad,wd', [(True, 0.0), (False, 0.0), (True, 0.01)])
+def test_flat_adam_matches_torch_adam(amsgrad, wd):
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(10_001, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=7e-5, weight_decay=wd, amsgrad=amsgrad)
+    p = p0.clone().to(DEV)
+    m, v, vm = (torch.zeros_like(p) for _ in range(3))
+    for step in range(1, 6):
+        grad = torch.randn(10_001, generator=g) * (0.1 if step != 3 else 10.0)     # a spike: amsgrad's max matters
+        ref.grad = grad.clone()
+        opt.step()
+        SF.adam_step(p, grad.to(DEV), m, v, vm, 7e-5, 0.9, 0.999, 1e-8, wd, step, amsgrad)
+        assert float((p.cpu() - ref.detach()).abs().max()) <= 2e-7, step
+
+
 def test_model_batched_true_per_graph_mode_equals_separate_graphs():
     """compat_linspace_norm=False: correct segmented statistics; the encoder/bottleneck/decoder
     blocks then treat each graph of the batch independently (io blocks still share statistics, Q1)."""
