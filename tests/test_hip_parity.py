@@ -498,7 +498,7 @@ def test_flat_adam_matches_torch_adam(amsgrad, wd):
         ref.grad = grad.clone()
         opt.step()
         SF.adam_step(p, grad.to(DEV), m, v, vm, 7e-5, 0.9, 0.999, 1e-8, wd, step, amsgrad)
-        assert float((p.cpu() - ref.detach()).abs().max()) <= 2e-7, step
+        assert float((p.cpu() - ref.detach()).abs().max()) <= 5e-7, step          # 1-2 ulp of |p| ~ 4
 
 
 def test_model_batched_true_per_graph_mode_equals_separate_graphs():
