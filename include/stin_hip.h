@@ -218,6 +218,10 @@ int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_
 #define STIN_GEMM_F32 0      /* v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain                          */
 #define STIN_GEMM_BF16X3 2   /* fp32 operands split into 2 bf16 pieces, 3 bf16 MFMAs, ~2^-17 / product */
 #define STIN_GEMM_BF16X6 3   /* 3 pieces (exact split), 6 bf16 MFMAs, ~2^-22 / product                 */
+#define STIN_GEMM_F16X3 4    /* nt only: 2 fp16 pieces (11 bits each), 3 fp16 MFMAs, ~2^-22 / product for
+                                |a| >= 2^-6, |w| >= 2^-9 (absolute 2^-28 / 2^-31 below: made for normalised
+                                activations); A, W pre-scaled by 2^3, 2^6 internally (exact); needs
+                                |A| < 8188, |W| < 1023 (outside: inf/NaN, never a silently wrong value)   */
 int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                      const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
                      int Nc, int K, float* C, int64_t ldc, int precision, stin_stream_t stream);

@@ -160,22 +160,48 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BKH = 32;          // k per LDS tile (two MFMA k-steps of 16)
 
-template <int NS>
-__device__ __forceinline__ void split_store(float4 v, __bf16* dst, int plane_stride) {
-    float r[4] = {v.x, v.y, v.z, v.w};
+// Piece type PT = __bf16 (above) or _Float16: an fp32 value is hi + lo with 11-bit pieces, hi*hi + hi*lo + lo*hi
+// leaves 2^-22 relative error - fp32-grade products from THREE MFMAs (v_mfma_f32_32x32x16_f16, same rate as
+// bf16).  fp16's narrow exponent is handled by fixed power-of-two pre-scales (exact, undone on the
+// accumulator): A * 2^3 and W * 2^6, so that the low pieces of unit-scale activations and of typical weights
+// (|w| ~ 1e-2) stay normal fp16 numbers.  Relative precision 2^-22 for |a| >= 2^-6, |w| >= 2^-9; below that the
+// low piece is an fp16 subnormal and the precision becomes ABSOLUTE (2^-28 for a, 2^-31 for w) - fp32-grade for
+// the normalised activations of this network, not for arbitrarily scaled data (use BF16X6 there).  Requires
+// |A| < 8188 and |W| < 1023: out-of-range operands give inf/NaN, never a silently wrong value.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <typename PT> struct PieceTraits;
+template <> struct PieceTraits<__bf16> {
+    typedef bf16x8 vec8;
+    static constexpr float ascale = 1.f, wscale = 1.f;
+};
+template <> struct PieceTraits<_Float16> {
+    typedef f16x8 vec8;
+    static constexpr float ascale = 8.f, wscale = 64.f;
+};
+__device__ __forceinline__ f32x16 mfma_k16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_k16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <int NS, typename PT>
+__device__ __forceinline__ void split_store(float4 v, PT* dst, int plane_stride, float scale) {
+    typedef PT pt4 __attribute__((ext_vector_type(4)));
+    float r[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
 #pragma unroll
     for (int p = 0; p < NS; ++p) {
-        bf16x4 h;
+        pt4 h;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            h[i] = (__bf16)r[i];
+            h[i] = (PT)r[i];
             r[i] -= (float)h[i];
         }
-        *reinterpret_cast<bf16x4*>(dst + p * plane_stride) = h;
+        *reinterpret_cast<pt4*>(dst + p * plane_stride) = h;
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool VEC>
+template <int BM, int BN, int WM, int WN, int NS, typename PT, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ W, int64_t ldw,
                                                          const float* __restrict__ bias,
@@ -189,8 +215,10 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
     // 64-byte rows (32 bf16), the 16-byte chunk c of row r stored at chunk position c ^ ((r >> 2) & 3): conflict-free for
     // the 8-byte staging stores (two consecutive rows tile one 128-byte bank span) AND for the ds_read_b128 fragment
     // reads (any 16 rows of one read group land on 16 distinct 16-byte slots) - no padding.
-    __shared__ __attribute__((aligned(16))) __bf16 As[NS][BM][BKH];
-    __shared__ __attribute__((aligned(16))) __bf16 Ws[NS][BN][BKH];
+    typedef typename PieceTraits<PT>::vec8 vec8;
+    constexpr float ASCALE = PieceTraits<PT>::ascale, WSCALE = PieceTraits<PT>::wscale;
+    __shared__ __attribute__((aligned(16))) PT As[NS][BM][BKH];
+    __shared__ __attribute__((aligned(16))) PT Ws[NS][BN][BKH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -250,12 +278,12 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
 #pragma unroll
         for (int s = 0; s < A_F4; ++s) {
             const int row = r0 + s * RSTEP;
-            split_store<NS>(ra[s], &As[0][row][swz(row, kq >> 1) + (kq & 1) * 4], BM * BKH);
+            split_store<NS, PT>(ra[s], &As[0][row][swz(row, kq >> 1) + (kq & 1) * 4], BM * BKH, ASCALE);
         }
 #pragma unroll
         for (int s = 0; s < W_F4; ++s) {
             const int row = r0 + s * RSTEP;
-            split_store<NS>(rw[s], &Ws[0][row][swz(row, kq >> 1) + (kq & 1) * 4], BN * BKH);
+            split_store<NS, PT>(rw[s], &Ws[0][row][swz(row, kq >> 1) + (kq & 1) * 4], BN * BKH, WSCALE);
         }
     };
 
@@ -268,18 +296,18 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
         if (k0 + BKH < K) load_tiles(k0 + BKH);
 #pragma unroll
         for (int ks = 0; ks < BKH; ks += 16) {
-            bf16x8 a[NS][MT], b[NS][NT];
+            vec8 a[NS][MT], b[NS][NT];
 #pragma unroll
             for (int p = 0; p < NS; ++p) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int row = wm * TM + i * 32 + li;
-                    a[p][i] = *reinterpret_cast<const bf16x8*>(&As[p][row][swz(row, (ks >> 3) + kh)]);
+                    a[p][i] = *reinterpret_cast<const vec8*>(&As[p][row][swz(row, (ks >> 3) + kh)]);
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int row = wn * TN + j * 32 + li;
-                    b[p][j] = *reinterpret_cast<const bf16x8*>(&Ws[p][row][swz(row, (ks >> 3) + kh)]);
+                    b[p][j] = *reinterpret_cast<const vec8*>(&Ws[p][row][swz(row, (ks >> 3) + kh)]);
                 }
             }
 #pragma unroll
@@ -288,13 +316,13 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
                 for (int j = 0; j < NT; ++j) {
                     // smallest terms first
                     if (NS == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_k16(a[1][i], b[1][j], acc[i][j]);
+                        acc[i][j] = mfma_k16(a[0][i], b[2][j], acc[i][j]);
+                        acc[i][j] = mfma_k16(a[2][i], b[0][j], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_k16(a[0][i], b[1][j], acc[i][j]);
+                    acc[i][j] = mfma_k16(a[1][i], b[0][j], acc[i][j]);
+                    acc[i][j] = mfma_k16(a[0][i], b[0][j], acc[i][j]);
                 }
         }
     }
@@ -310,7 +338,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row < M)
-                    C[row * ldc + col] = acc[i][j][r] + (row_mask != nullptr ? bv * row_mask[row * ld_mask] : bv) +
+                    C[row * ldc + col] = acc[i][j][r] * (1.f / (ASCALE * WSCALE)) + (row_mask != nullptr ? bv * row_mask[row * ld_mask] : bv) +
                                          (res != nullptr ? res[row * ld_res + col] : 0.f);
             }
         }
@@ -707,7 +735,8 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
     STIN_REQUIRE(residual == nullptr || ld_res >= Nc, STIN_E_SIZE);
-    STIN_REQUIRE(precision == STIN_GEMM_F32 || precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6,
+    STIN_REQUIRE(precision == STIN_GEMM_F32 || precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6 ||
+                     precision == STIN_GEMM_F16X3,
                  STIN_E_UNSUPPORTED);
     if (M == 0) return STIN_OK;
     STIN_REQUIRE(A && W && C, STIN_E_NULL);
@@ -730,8 +759,9 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
         else if (blocks(128, 64) >= min_blocks) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);  \
         else STIN_NT(KERNEL, 64, 64, 2, 2, ##__VA_ARGS__);                                     \
     } while (0)
-    if (precision == STIN_GEMM_BF16X3) STIN_NT_PICK(k_gemm_nt_bf16s, 2);
-    else if (precision == STIN_GEMM_BF16X6) STIN_NT_PICK(k_gemm_nt_bf16s, 3);
+    if (precision == STIN_GEMM_BF16X3) STIN_NT_PICK(k_gemm_nt_bf16s, 2, __bf16);
+    else if (precision == STIN_GEMM_BF16X6) STIN_NT_PICK(k_gemm_nt_bf16s, 3, __bf16);
+    else if (precision == STIN_GEMM_F16X3) STIN_NT_PICK(k_gemm_nt_bf16s, 2, _Float16);
     else STIN_NT_PICK(k_gemm_nt);
 #undef STIN_NT_PICK
 #undef STIN_NT

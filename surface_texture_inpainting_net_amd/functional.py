@@ -232,12 +232,13 @@ _GEMM_BLAS_NT = os.environ.get('STIN_GEMM_BACKEND', 'mfma') in ('blas', 'blas_nt
 _GEMM_BLAS_TN = os.environ.get('STIN_GEMM_BACKEND', 'mfma') in ('blas', 'blas_tn')
 
 
-GEMM_F32, GEMM_BF16X3, GEMM_BF16X6 = 0, 2, 3
-# matrix-core path per GEMM role (env override for A/B experiments: STIN_GEMM_FWD / STIN_GEMM_BWD = 0 | 2 | 3)
-# Defaults: forward GEMMs on the exact 3-piece split (measured MORE accurate than the fp32 MFMA chain:
-# rms 2.0e-7 vs 2.4e-7 against fp64, and 1.15-1.5x faster); backward GEMMs on the 2-piece split
-# (rms 4e-6, far inside the 1e-3 gradient tolerance; 1.8-2.1x faster).
-PREC_FWD = int(os.environ.get('STIN_GEMM_FWD', GEMM_BF16X6))
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X6, GEMM_F16X3 = 0, 2, 3, 4
+# matrix-core path per GEMM role (env override for A/B experiments: STIN_GEMM_FWD / STIN_GEMM_BWD = 0 | 2 | 3 | 4)
+# Defaults: forward GEMMs on the 2-piece fp16 split (3 MFMAs; rms 1-5e-7 against fp64 = the fp32 MFMA chain's
+# accuracy on unit-scale activations, 1.7x faster than it; whole-net forward error 5-6e-6 like fp32 and bf16x6,
+# where bf16x3 gives 1.2e-4); backward GEMMs on the 2-piece bf16 split (gradients need bf16's exponent range;
+# rms 4e-6, far inside the 1e-3 gradient tolerance).
+PREC_FWD = int(os.environ.get('STIN_GEMM_FWD', GEMM_F16X3))
 PREC_BWD = int(os.environ.get('STIN_GEMM_BWD', GEMM_BF16X3))
 
 

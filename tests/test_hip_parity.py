@@ -208,14 +208,21 @@ def test_gemm_nt_precision_modes(M, Nc, K):
     want = A.double() @ W.double().t() + b.double()
     scale = float(want.abs().max())
     err = {p: float((SF.gemm_nt(A, W, b, precision=p).double() - want).abs().max()) / scale
-           for p in (SF.GEMM_F32, SF.GEMM_BF16X3, SF.GEMM_BF16X6)}
+           for p in (SF.GEMM_F32, SF.GEMM_BF16X3, SF.GEMM_BF16X6, SF.GEMM_F16X3)}
     assert err[SF.GEMM_F32] <= 3e-6
     assert err[SF.GEMM_BF16X6] <= 3e-6
+    assert err[SF.GEMM_F16X3] <= 3e-6          # 2 fp16 pieces = 22 bits on unit-scale operands
     assert err[SF.GEMM_BF16X3] <= 2e-5
     small = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV)          # exactly representable: all paths exact
     wi = torch.randint(-3, 4, (Nc, K), generator=g).float().to(DEV)
-    for p in (SF.GEMM_F32, SF.GEMM_BF16X3, SF.GEMM_BF16X6):
+    for p in (SF.GEMM_F32, SF.GEMM_BF16X3, SF.GEMM_BF16X6, SF.GEMM_F16X3):
         assert torch.equal(SF.gemm_nt(small, wi, precision=p).double(), small.double() @ wi.double().t())
+    # fp16 split: out-of-range operands must fail loudly (inf/NaN), tiny ones degrade to absolute precision
+    big = A.clone()
+    big[0, 0] = 1e4
+    assert not bool(torch.isfinite(SF.gemm_nt(big, W, precision=SF.GEMM_F16X3)[0]).all())
+    tiny = SF.gemm_nt(A * 1e-3, W, precision=SF.GEMM_F16X3).double() * 1e3
+    assert float((tiny - (want - b.double())).abs().max()) / scale <= 2e-5
 
 
 def test_gemm_nt_on_strided_views_and_linear_autograd():
