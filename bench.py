@@ -33,18 +33,20 @@ CONFIG_3D = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv
 
 def edge_bytes(kernel, n, e, h):
     """Algorithmic bytes per launch: gathered rows are charged once
-    per edge (no cache credit), fp32, int32 indices."""
+    per edge (no cache credit), s = 4 (fp32) or 2 (bf16 storage) bytes per element, int32 indices."""
     idx = 4 * e + 4 * (n + 1)
+    s = 2 if kernel.endswith('_bf16') else 4
+    kernel = kernel.replace('_bf16', '_f32')
     if kernel == 'stin_edge_relu_mean_fwd_f32':      # gather B per edge, read A, write h
-        return (e * h + 2 * n * h) * 4 + idx
+        return (e * h + 2 * n * h) * s + idx
     if kernel == 'stin_edge_relu_mean_bwd_dst_f32':  # gather B per edge, read A and G, write dA
-        return (e * h + 3 * n * h) * 4 + idx
+        return (e * h + 3 * n * h) * s + idx
     if kernel == 'stin_edge_relu_mean_bwd_src_f32':  # gather A and G per edge, read B, write dB, inv_deg per edge
-        return (2 * e * h + 2 * n * h) * 4 + idx + 4 * e
+        return (2 * e * h + 2 * n * h) * s + idx + 4 * e
     if kernel == 'stin_edge_relu_mean_bwd_dst_mask_f32':  # stream the H-bit masks of the in-edges, read G, write dA
-        return e * h // 8 + 2 * n * h * 4 + 4 * (n + 1)
+        return e * h // 8 + 2 * n * h * s + 4 * (n + 1)
     if kernel == 'stin_edge_relu_mean_bwd_src_mask_f32':  # gather G per edge + its mask words, col/xslot/inv_deg, write dB
-        return e * h * 4 + e * h // 8 + 12 * e + n * h * 4 + 4 * (n + 1)
+        return e * h * s + e * h // 8 + 12 * e + n * h * s + 4 * (n + 1)
     raise KeyError(kernel)
 
 
@@ -52,7 +54,7 @@ def pmc_traffic_bytes(kernel, n, e, h):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json, collected at
     the headline level-0 shape with profiles/pmc_kernels.py; FETCH_SIZE doubled per the gfx950 correction)."""
     import glob
-    if (n, e) != (200704, 1200642):
+    if (n, e) != (200704, 1200642) or kernel.endswith('_bf16'):
         return None
     c4 = h // 4
     g = 1
@@ -150,6 +152,9 @@ def main():
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--time-gemms', action='store_true', help='also bracket every MFMA GEMM launch with HIP events')
     ap.add_argument('--cache-plan', action='store_true', help='reuse the CSR plan across steps (NOT the headline)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="activation storage: f32 = the headline (reference numerics); bf16 = the build's "
+                         "mixed-precision mode of BASELINE configs 3/5 (NOT the headline, stated tolerance)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -178,6 +183,8 @@ def main():
     if args.levels != 3:                                    # other hierarchy depths (configs 3 and 5): n_levels = levels - 1
         cfg['n_levels'] = args.levels - 1
     net = S.define_G(**cfg).to(device)
+    if args.dtype == 'bf16':
+        net.set_activation_dtype(torch.bfloat16)
     step = TrainStep(net, lr=7e-5, amsgrad=True)
     sample = make_synthetic_mesh(args.vertices, args.levels, seed=rank).to(device)   # one scene per rank
     n0 = sample.x.shape[0]
@@ -200,9 +207,10 @@ def main():
     gc.collect()
     gc.disable()            # no cyclic-GC pause inside the timed region (collected again right after it)
     fence()
-    SF.KernelTimer.start(['stin_edge_relu_mean_fwd_f32', 'stin_edge_relu_mean_bwd_dst_f32',
-                          'stin_edge_relu_mean_bwd_src_f32', 'stin_edge_relu_mean_bwd_dst_mask_f32',
-                          'stin_edge_relu_mean_bwd_src_mask_f32'] + (['stin_gemm_nt_f32', 'stin_gemm_tn_f32'] if args.time_gemms else []),
+    sfx = '_' + args.dtype
+    SF.KernelTimer.start(['stin_edge_relu_mean_fwd' + sfx, 'stin_edge_relu_mean_bwd_dst_f32',
+                          'stin_edge_relu_mean_bwd_src_f32', 'stin_edge_relu_mean_bwd_dst_mask' + sfx,
+                          'stin_edge_relu_mean_bwd_src_mask' + sfx] + (['stin_gemm_nt' + sfx, 'stin_gemm_tn' + sfx] if args.time_gemms else []),
                          max_records=1_000_000 if args.time_gemms else 400)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -229,7 +237,7 @@ def main():
                 avg = sum(ts) / len(ts)
                 gemms.append({'kernel': name, 'M': m, 'Nc': nc, 'K': k, 'launches': len(ts), 'avg_us': avg * 1e6,
                               'total_ms': sum(ts) * 1e3, 'TFLOPs': 2.0 * m * nc * k / avg / 1e12,
-                              'GBps_min_traffic': 4.0 * (m * nc + m * k + nc * k) / avg / 1e9})
+                              'GBps_min_traffic': (2.0 if args.dtype == 'bf16' else 4.0) * (m * nc + m * k + nc * k) / avg / 1e9})
                 continue
             n, e, h = tag
             nbytes = edge_bytes(name, n, e, h)
@@ -248,11 +256,13 @@ def main():
             'metric': 'vertices/sec forward+backward on 200k-vert ScanNet mesh; scatter-add GB/s vs HBM roofline',
             'value': total_vertices * args.steps / dt, 'unit': 'vertices/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'SurfaceTextureInpaintingNet 3-D config (ngf 64, n_levels %d, n_blocks 9, ' % cfg['n_levels'] +
                                    'edgeconvtransinv, instance norm, max pool, dilations 1-16), synthetic %d-vertex / '
-                                   '%d-directed-edge %d-level mesh per GPU, fp32; step = CSR plan build + fwd + '
-                                   'masked L1 + bwd + grad all-reduce + Adam(amsgrad)' % (n0, e0, args.levels),
+                                   '%d-directed-edge %d-level mesh per GPU, %s; step = CSR plan build + fwd + '
+                                   'masked L1 + bwd + grad all-reduce + Adam(amsgrad)'
+                                   % (n0, e0, args.levels, 'fp32' if args.dtype == 'f32' else 'bf16 activation storage '
+                                      '(fp32 accumulate / statistics / weights)'),
                        'vertices_per_gpu': n0, 'edges_per_gpu': e0, 'levels': args.levels, 'params': sum(p.numel() for p in net.parameters()),
                        'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan},
             'loss': float(loss),

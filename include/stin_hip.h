@@ -43,6 +43,13 @@ extern "C" {
 #define STIN_E_UNSUPPORTED (-5)    /* shape outside what this build supports */
 
 typedef void* stin_stream_t;
+/* bf16 STORAGE variants (*_bf16): the same operation on row-major bfloat16 matrices (raw 16-bit patterns, the
+ * upper half of an fp32).  Every kernel widens to fp32 on load, computes and accumulates in fp32 and rounds to
+ * nearest-even on store; statistics, weights, biases, index plans and weight gradients stay fp32.  Halves the HBM
+ * bytes of the streaming/gather kernels and puts the GEMMs on one bf16 MFMA per k-step.  The reference is
+ * fp32-only: this is the build's mixed-precision extension for BASELINE configs 3 and 5 (stated tolerance, not
+ * the 1e-4 fp32 bar).  bf16 rows must be 4-channel vectorisable: C % 4 == 0, ld % 4 == 0, 8-byte aligned. */
+typedef uint16_t stin_bf16_t;
 
 int stin_version(void);
 /* Static, NUL-terminated description of a return code (host pointer). */
@@ -264,6 +271,52 @@ int stin_masked_l1_loss_f32(const float* out, const float* color, const int64_t*
                             stin_stream_t stream);
 int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, int amsgrad, stin_stream_t stream);
+
+/* --------------------------------------------------- bf16-storage variants of the path --
+ * Same semantics, argument order and reference call sites as the *_f32 entry points above, on bf16 rows
+ * (stin_bf16_t, see the typedef).  What stays fp32: instance-norm statistics (fp64 accumulation), inv_deg / w_src /
+ * row_scale, the weight operand W and bias of the GEMMs, the weight gradients dW and every index plan.
+ * Vector kernels only: C % 4 == 0, ld % 4 == 0, 8-byte aligned rows, else STIN_E_UNSUPPORTED; the edge stage
+ * needs the saved ReLU mask (H in {128, 256, 512, 1024, 2048}) in backward.
+ * gemm_nt_bf16: A, row_mask, residual bf16; W, bias fp32 (W is rounded to bf16 while staged); one
+ *   v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate, bias/mask/residual added in fp32, one rounding;
+ *   C is bf16 (c_is_f32 = 0) or fp32 (c_is_f32 = 1: the network's final [N, 3] output).
+ * gemm_tn_bf16: G, X, row_weight bf16 -> fp32 dW; workspace = stin_gemm_tn_workspace_bytes.
+ */
+int stin_segment_sum_bf16(const stin_bf16_t* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col,
+                          int64_t n_rows, int C, int mean, stin_bf16_t* out, int64_t ld_out, stin_stream_t stream);
+int stin_edge_relu_mean_fwd_bf16(const stin_bf16_t* A, int64_t lda, const stin_bf16_t* B, int64_t ldb,
+                                 const int32_t* rowptr, const int32_t* col, int64_t N, int H, stin_bf16_t* out,
+                                 int64_t ldo, int indicator, uint32_t* mask, stin_stream_t stream);
+int stin_edge_relu_mean_bwd_dst_mask_bf16(const stin_bf16_t* G, int64_t ldg, const uint32_t* mask,
+                                          const int32_t* rowptr, int64_t N, int H, stin_bf16_t* dA, int64_t ldda,
+                                          stin_stream_t stream);
+int stin_edge_relu_mean_bwd_src_mask_bf16(const stin_bf16_t* G, int64_t ldg, const float* w_src, const uint32_t* mask,
+                                          const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot,
+                                          int64_t N, int H, stin_bf16_t* dB, int64_t lddb, stin_stream_t stream);
+int stin_pool_max_fwd_bf16(const stin_bf16_t* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                           int64_t n_coarse, int C, stin_bf16_t* out, int64_t ldo, int32_t* arg, stin_stream_t stream);
+int stin_pool_max_bwd_bf16(const stin_bf16_t* g, int64_t ldg, const int32_t* arg, const int32_t* trace,
+                           int64_t n_fine, int C, stin_bf16_t* gx, int64_t ldgx, stin_stream_t stream);
+int stin_gather_rows_bf16(const stin_bf16_t* src, int64_t ld_src, const int32_t* idx, const float* row_scale,
+                          int64_t n_out, int C, stin_bf16_t* out, int64_t ldo, stin_stream_t stream);
+int stin_colreduce_bf16(int mode, const stin_bf16_t* x, int64_t ldx, const stin_bf16_t* gout, int64_t ldg, int64_t N,
+                        int C, const int32_t* ptr, int B, const int32_t* gid, const int32_t* sid, const float* mean,
+                        const float* rstd, const float* coef, int post, const float* inv_cnt, float eps, float* out0,
+                        float* out1, void* workspace, size_t workspace_bytes, stin_stream_t stream);
+int stin_norm_act_res_fwd_bf16(const stin_bf16_t* x, int64_t ldx, const float* mean, const float* rstd,
+                               const int32_t* gid, const stin_bf16_t* res, int64_t ldres, int64_t N, int C, int act,
+                               stin_bf16_t* y, int64_t ldy, stin_stream_t stream);
+int stin_norm_act_bwd_bf16(const stin_bf16_t* x, int64_t ldx, const stin_bf16_t* gout, int64_t ldg, const float* mean,
+                           const float* rstd, const float* a, const float* k, const float* m, const int32_t* gid,
+                           const int32_t* sid, int64_t N, int C, int act, stin_bf16_t* dx, int64_t lddx,
+                           stin_stream_t stream);
+int stin_gemm_nt_bf16(const stin_bf16_t* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                      const stin_bf16_t* row_mask, int64_t ld_mask, const stin_bf16_t* residual, int64_t ld_res,
+                      int64_t M, int Nc, int K, void* C, int64_t ldc, int c_is_f32, stin_stream_t stream);
+int stin_gemm_tn_bf16(const stin_bf16_t* G, int64_t ldg, const stin_bf16_t* X, int64_t ldx, int64_t M, int Nc, int K,
+                      int ones_column, const stin_bf16_t* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
+                      void* workspace, size_t workspace_bytes, stin_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -31,3 +31,26 @@ static inline int stin_group_lanes(int c4) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// bf16 STORAGE (the *_bf16 entry points): rows of __bf16 in HBM, every kernel widens to fp32 on load, computes and
+// accumulates in fp32 and rounds to nearest-even on store.  A 4-channel chunk is 8 bytes.
+typedef __bf16 stin_bf16;
+typedef __bf16 stin_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const stin_bf16* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(stin_bf16* p, float4 v) {
+    stin_bf16x4 h = {(stin_bf16)v.x, (stin_bf16)v.y, (stin_bf16)v.z, (stin_bf16)v.w};
+    *reinterpret_cast<stin_bf16x4*>(p) = h;
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const stin_bf16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(stin_bf16* p, float v) { *p = (stin_bf16)v; }
+
+// 4-channel vector access needs 16-byte (fp32) / 8-byte (bf16) aligned rows
+template <typename T> static inline bool stin_aligned_vec4(const void* p) {
+    return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0;
+}

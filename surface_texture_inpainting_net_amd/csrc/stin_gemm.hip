@@ -684,6 +684,366 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
     }
 }
 
+// =================================================================== bf16-STORAGE GEMMs
+// Operands already live in HBM as bf16 rows (the *_bf16 pipeline): no split, ONE v_mfma_f32_32x32x16_bf16 per
+// k-step, fp32 accumulation.  The weight operand W stays fp32 in memory (it is tiny) and is rounded to bf16 while
+// it is staged.  LDS tiles are [rows][64 bf16] = 128-byte rows, the 16-byte chunk c of row r stored at chunk
+// position c ^ ((r >> 1) & 7): conflict-free ds_write_b128 staging (8 lanes = one row) and ds_read_b128 fragments
+// (the 16-lane read groups {0-3,12-15,20-27}, {4-11,16-19,28-31} hit 16 distinct 16-byte slots of the 256-byte
+// bank span).  bf16 output tiles go through LDS so that the global stores are 16 bytes per lane, row-contiguous.
+constexpr int BKB = 64;
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 h = {(__bf16)lo, (__bf16)hi};
+    return *reinterpret_cast<uint32_t*>(&h);
+}
+__device__ __forceinline__ uint4 f8_to_bf16x8(float4 a, float4 b) {
+    return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+}
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <int BM, int BN, int WM, int WN, typename OUT, bool VEC>
+__global__ __launch_bounds__(BLOCK) void k_gemm_nt_b16(const stin_bf16* __restrict__ A, int64_t lda,
+                                                       const float* __restrict__ W, int64_t ldw,
+                                                       const float* __restrict__ bias,
+                                                       const stin_bf16* __restrict__ row_mask, int64_t ld_mask,
+                                                       const stin_bf16* __restrict__ res, int64_t ld_res, int64_t M,
+                                                       int Nc, int K, OUT* __restrict__ C, int64_t ldc, int vec_out) {
+    constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
+    constexpr int A_CH = BM * 8 / BLOCK, W_CH = BN * 8 / BLOCK;   // 16-byte (8 x bf16) chunks per thread per tile
+    static_assert(A_CH >= 1 && W_CH >= 1, "tile too small for 256 threads");
+    constexpr int CPITCH = BN + 32;                               // output staging pitch (bf16): rows r, r+1 on disjoint banks
+    constexpr int TILE_BYTES = (BM + BN) * BKB * 2, OUT_BYTES = BM * CPITCH * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES > OUT_BYTES ? TILE_BYTES : OUT_BYTES];
+    stin_bf16(*As)[BKB] = reinterpret_cast<stin_bf16(*)[BKB]>(smem);
+    stin_bf16(*Ws)[BKB] = reinterpret_cast<stin_bf16(*)[BKB]>(smem + BM * BKB * 2);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int ch = tid & 7, r0 = tid >> 3;                       // staging: chunk along k, first row (32 rows per pass)
+    auto swz = [](int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 3; };   // bf16 offset of a 16-byte chunk
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[A_CH], rw[W_CH];
+    auto load_tiles = [&](int k0) {
+        const int k = k0 + ch * 8;
+#pragma unroll
+        for (int s = 0; s < A_CH; ++s) {
+            const int64_t row = m0 + r0 + s * 32;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (row < M) {
+                const stin_bf16* p = A + row * lda + k;
+                if (VEC) {
+                    if (k < K) v = *reinterpret_cast<const uint4*>(p);
+                } else {
+                    uint32_t h[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (k + e < K) ? (uint32_t)*reinterpret_cast<const uint16_t*>(p + e) : 0u;
+                    v = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                }
+            }
+            ra[s] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < W_CH; ++s) {
+            const int row = n0 + r0 + s * 32;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (row < Nc) {
+                const float* p = W + (int64_t)row * ldw + k;
+                if (VEC) {
+                    if (k < K) {
+                        a = ld4(p);
+                        b = ld4(p + 4);
+                    }
+                } else {
+                    if (k + 0 < K) a.x = p[0];
+                    if (k + 1 < K) a.y = p[1];
+                    if (k + 2 < K) a.z = p[2];
+                    if (k + 3 < K) a.w = p[3];
+                    if (k + 4 < K) b.x = p[4];
+                    if (k + 5 < K) b.y = p[5];
+                    if (k + 6 < K) b.z = p[6];
+                    if (k + 7 < K) b.w = p[7];
+                }
+            }
+            rw[s] = f8_to_bf16x8(a, b);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int s = 0; s < A_CH; ++s) {
+            const int row = r0 + s * 32;
+            *reinterpret_cast<uint4*>(&As[row][swz(row, ch)]) = ra[s];
+        }
+#pragma unroll
+        for (int s = 0; s < W_CH; ++s) {
+            const int row = r0 + s * 32;
+            *reinterpret_cast<uint4*>(&Ws[row][swz(row, ch)]) = rw[s];
+        }
+    };
+
+    const int kh = lane >> 5, li = lane & 31;
+    load_tiles(0);
+    for (int k0 = 0; k0 < K; k0 += BKB) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (k0 + BKB < K) load_tiles(k0 + BKB);
+#pragma unroll
+        for (int ks = 0; ks < BKB / 16; ++ks) {
+            bf16x8 a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = wm * TM + i * 32 + li;
+                a[i] = *reinterpret_cast<const bf16x8*>(&As[row][swz(row, 2 * ks + kh)]);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int row = wn * TN + j * 32 + li;
+                b[j] = *reinterpret_cast<const bf16x8*>(&Ws[row][swz(row, 2 * ks + kh)]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: + bias * row_mask + residual in fp32, one rounding
+    constexpr bool OUT_BF16 = sizeof(OUT) == 2;
+    const bool staged = OUT_BF16 && vec_out;
+    if (staged) __syncthreads();                                  // every wave is done with the operand tiles
+    stin_bf16(*Cs)[CPITCH] = reinterpret_cast<stin_bf16(*)[CPITCH]>(smem);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int lcol = wn * TN + j * 32 + li;
+        const int col = n0 + lcol;
+        const bool col_ok = col < Nc;
+        const float bv = (bias != nullptr && col_ok) ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int64_t row = m0 + lrow;
+                float t = acc[i][j][r];
+                if (row < M && col_ok) {
+                    if (bias != nullptr) t += row_mask != nullptr ? bv * (float)row_mask[row * ld_mask] : bv;
+                    if (res != nullptr) t += (float)res[row * ld_res + col];
+                }
+                v[r] = t;
+            }
+            if (staged) {
+                // lanes (li, li^1) trade one value per register pair so that each writes two adjacent columns of ONE row
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool odd = li & 1;
+                    const float got = __shfl_xor(odd ? v[2 * q] : v[2 * q + 1], 1);
+                    const int lrow = wm * TM + i * 32 + ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * kh + (odd ? 1 : 0);
+                    const uint32_t pr = odd ? pack_bf16x2(got, v[2 * q + 1]) : pack_bf16x2(v[2 * q], got);
+                    *reinterpret_cast<uint32_t*>(&Cs[lrow][lcol & ~1]) = pr;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (row < M && col_ok) st1(C + row * ldc + col, v[r]);
+                }
+            }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        constexpr int CHUNKS = BM * BN / 8;                       // 16-byte chunks of the output tile
+#pragma unroll
+        for (int s = 0; s < CHUNKS / BLOCK; ++s) {
+            const int c = tid + s * BLOCK;
+            const int lrow = c / (BN / 8), lc = (c % (BN / 8)) * 8;
+            const int64_t row = m0 + lrow;
+            const int col = n0 + lc;
+            if (row < M && col < Nc)
+                *reinterpret_cast<uint4*>(reinterpret_cast<stin_bf16*>(C) + row * ldc + col) =
+                    *reinterpret_cast<const uint4*>(&Cs[lrow][lc]);
+        }
+    }
+}
+
+// dW[Nc, K(+1)] = G^T [X | w] with G, X (and the optional row weight w) stored as bf16; fp32 slabs as k_gemm_tn.
+// The reduction index is the ROW m: each staging thread loads a 4(rows) x 8(cols) bf16 patch (4 x 16-byte loads),
+// transposes it in registers (v_perm byte selects) and writes one 8-byte run (4 consecutive m) per column into
+// Gt[col][m] / Xt[col][m] (row pitch 144 B: conflict-free ds_write_b64 across 16 row groups and ds_read_b128).
+constexpr int TNK_R = 64;                  // rows (m) per LDS slab = four MFMA k-steps
+constexpr int TNK_PITCH = TNK_R + 8;
+
+template <int TI, int TJ, bool VEC>
+__global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restrict__ G, int64_t ldg,
+                                                       const stin_bf16* __restrict__ X, int64_t ldx, int64_t M, int Nc,
+                                                       int K, int Kp, const stin_bf16* __restrict__ row_w, int64_t ld_w,
+                                                       int rows_per_chunk, int tiles_i, int tiles_j, int64_t chunks,
+                                                       float* __restrict__ slab) {
+    constexpr int MT = TI / 64, NT = TJ / 64;
+    constexpr int ITEMS = 2 * (TI + TJ);                           // 4x8 patches per 64-row slab (G then X): 16 row groups x T/8
+    constexpr int NPASS = (ITEMS + BLOCK - 1) / BLOCK;
+    __shared__ __attribute__((aligned(16))) stin_bf16 Gt[TI][TNK_PITCH];
+    __shared__ __attribute__((aligned(16))) stin_bf16 Xt[TJ][TNK_PITCH];
+    __shared__ float bsum[16][TI + 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int tiles = tiles_i * tiles_j;
+    const int64_t b = blockIdx.x;
+    const int64_t xcd = b % 8, q = b / 8;
+    const int64_t chunk = (q / tiles) * 8 + xcd;
+    const int tile = (int)(q % tiles);
+    if (chunk >= chunks) return;
+    const int tj = tile % tiles_j, ti = tile / tiles_j;
+    const int i0 = ti * TI, j0 = tj * TJ;
+    const int64_t mb = chunk * rows_per_chunk;
+    const int64_t me = (mb + rows_per_chunk < M) ? mb + rows_per_chunk : M;
+    const bool want_bias = (Kp > K) && (tj == 0);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    float bs[8];                                                    // bias-gradient partial: the 8 columns of this thread's G patches
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+
+    uint4 patch[NPASS][4];
+    float pw[NPASS][4];
+    auto load_slab = [&](int64_t m0) {
+#pragma unroll
+        for (int s = 0; s < NPASS; ++s) {
+            const int item = tid + s * BLOCK;
+            const bool isG = item < 2 * TI;
+            const int it = isG ? item : item - 2 * TI;
+            const int rg = it % 16, c8 = it / 16;
+            const bool live = item < ITEMS;
+            const stin_bf16* base = isG ? G : X;
+            const int64_t ld = isG ? ldg : ldx;
+            const int col = (isG ? i0 : j0) + c8 * 8;
+            const int lim = isG ? Nc : K;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = m0 + rg * 4 + r;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (live && row < me) {
+                    const stin_bf16* p = base + row * ld + col;
+                    if (VEC) {
+                        if (col < lim) v = *reinterpret_cast<const uint4*>(p);
+                    } else {
+                        uint32_t h[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = (col + e < lim) ? (uint32_t)*reinterpret_cast<const uint16_t*>(p + e) : 0u;
+                        v = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                    }
+                }
+                patch[s][r] = v;
+                pw[s][r] = (want_bias && isG && live && row < me) ? (row_w != nullptr ? (float)row_w[row * ld_w] : 1.f) : 0.f;
+            }
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int s = 0; s < NPASS; ++s) {
+            const int item = tid + s * BLOCK;
+            if (item >= ITEMS) continue;
+            const bool isG = item < 2 * TI;
+            const int it = isG ? item : item - 2 * TI;
+            const int rg = it % 16, c8 = it / 16;
+            if (isG && want_bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint4 v = patch[s][r];
+                    bs[0] += pw[s][r] * bf16_lo(v.x); bs[1] += pw[s][r] * bf16_hi(v.x);
+                    bs[2] += pw[s][r] * bf16_lo(v.y); bs[3] += pw[s][r] * bf16_hi(v.y);
+                    bs[4] += pw[s][r] * bf16_lo(v.z); bs[5] += pw[s][r] * bf16_hi(v.z);
+                    bs[6] += pw[s][r] * bf16_lo(v.w); bs[7] += pw[s][r] * bf16_hi(v.w);
+                }
+            }
+            stin_bf16* dst = isG ? &Gt[c8 * 8][rg * 4] : &Xt[c8 * 8][rg * 4];
+            const uint32_t w[4][4] = {{patch[s][0].x, patch[s][0].y, patch[s][0].z, patch[s][0].w},
+                                      {patch[s][1].x, patch[s][1].y, patch[s][1].z, patch[s][1].w},
+                                      {patch[s][2].x, patch[s][2].y, patch[s][2].z, patch[s][2].w},
+                                      {patch[s][3].x, patch[s][3].y, patch[s][3].z, patch[s][3].w}};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {                          // dword d of a row = columns 2d, 2d+1
+                // column 2d: low halves of rows 0..3; column 2d+1: high halves
+                const uint32_t lo01 = __builtin_amdgcn_perm(w[1][d], w[0][d], 0x05040100u);
+                const uint32_t lo23 = __builtin_amdgcn_perm(w[3][d], w[2][d], 0x05040100u);
+                const uint32_t hi01 = __builtin_amdgcn_perm(w[1][d], w[0][d], 0x07060302u);
+                const uint32_t hi23 = __builtin_amdgcn_perm(w[3][d], w[2][d], 0x07060302u);
+                *reinterpret_cast<uint2*>(dst + (2 * d) * TNK_PITCH) = make_uint2(lo01, lo23);
+                *reinterpret_cast<uint2*>(dst + (2 * d + 1) * TNK_PITCH) = make_uint2(hi01, hi23);
+            }
+        }
+    };
+
+    const int kh = lane >> 5, li = lane & 31;
+    for (int64_t m0 = mb; m0 < me; m0 += TNK_R) {
+        load_slab(m0);
+        __syncthreads();                                           // previous slab's fragment reads are done
+        store_slab();
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < TNK_R; ks += 16) {
+            bf16x8 a[MT], c[NT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const bf16x8*>(&Gt[wi * (TI / 2) + t * 32 + li][ks + 8 * kh]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) c[t] = *reinterpret_cast<const bf16x8*>(&Xt[wj * (TJ / 2) + t * 32 + li][ks + 8 * kh]);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], c[u], acc[t][u], 0, 0, 0);
+        }
+    }
+
+    float* out = slab + chunk * (int64_t)Nc * Kp;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int col = j0 + wj * (TJ / 2) + u * 32 + li;
+        if (col >= K) continue;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wi * (TI / 2) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < Nc) out[(int64_t)row * Kp + col] = acc[t][u][r];
+            }
+    }
+    if (want_bias) {                                              // block-uniform
+        // G patches are items [0, 2*TI): item = tid (2*TI <= 256), row group tid % 16, column group tid / 16
+        if (tid < 2 * TI) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum[tid % 16][(tid / 16) * 8 + e] = bs[e];
+        }
+        __syncthreads();
+        if (tid < TI) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += bsum[r][tid];
+            if (i0 + tid < Nc) out[(int64_t)(i0 + tid) * Kp + K] = t;
+        }
+    }
+}
+
 // out[t] = sum_c slab[c][t]: 16 chunk-lanes x 16 consecutive elements per block, each chunk-lane walks
 // the chunk list with stride 16 (4 loads in flight), then a fixed-order LDS reduction -> deterministic.
 constexpr int RS_COLS = 16, RS_KL = 16;
@@ -823,6 +1183,82 @@ extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int
 #undef STIN_TN_PICK
 #undef STIN_TNB
 #undef STIN_TN
+    }
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, chunks,
+                       n, Kp, dW, lddw);
+    return stin_launch_status();
+}
+
+// ------------------------------------------------------------------ bf16-storage entry points
+extern "C" int stin_gemm_nt_bf16(const stin_bf16_t* A_, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                                 const stin_bf16_t* row_mask_, int64_t ld_mask, const stin_bf16_t* residual_,
+                                 int64_t ld_res, int64_t M, int Nc, int K, void* C, int64_t ldc, int c_is_f32,
+                                 stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    const stin_bf16* A = reinterpret_cast<const stin_bf16*>(A_);
+    const stin_bf16* row_mask = reinterpret_cast<const stin_bf16*>(row_mask_);
+    const stin_bf16* residual = reinterpret_cast<const stin_bf16*>(residual_);
+    STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
+    STIN_REQUIRE(residual == nullptr || ld_res >= Nc, STIN_E_SIZE);
+    if (M == 0) return STIN_OK;
+    STIN_REQUIRE(A && W && C, STIN_E_NULL);
+    const bool vec = (K % 8 == 0) && (lda % 8 == 0) && (ldw % 4 == 0) && stin_aligned16(A) && stin_aligned16(W);
+    const int vec_out = (!c_is_f32 && Nc % 8 == 0 && ldc % 8 == 0 && stin_aligned16(C)) ? 1 : 0;
+    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Nc + bn - 1) / bn); };
+    static const int64_t min_blocks = getenv("STIN_NT_MINBLOCKS") ? atoi(getenv("STIN_NT_MINBLOCKS")) : 1536;
+#define STIN_NTB(BM_, BN_, WM_, WN_, OUT_)                                                                             \
+    do {                                                                                                               \
+        dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((Nc + BN_ - 1) / BN_));                                  \
+        if (vec) hipLaunchKernelGGL((k_gemm_nt_b16<BM_, BN_, WM_, WN_, OUT_, true>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (OUT_*)C, ldc, vec_out); \
+        else hipLaunchKernelGGL((k_gemm_nt_b16<BM_, BN_, WM_, WN_, OUT_, false>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (OUT_*)C, ldc, vec_out);    \
+    } while (0)
+#define STIN_NTB_PICK(OUT_)                                                                          \
+    do {                                                                                             \
+        if (Nc <= 32) STIN_NTB(128, 32, 4, 1, OUT_);                                                 \
+        else if (Nc % 128 == 0 && blocks(128, 128) >= min_blocks) STIN_NTB(128, 128, 2, 2, OUT_);    \
+        else if (blocks(128, 64) >= min_blocks) STIN_NTB(128, 64, 2, 2, OUT_);                       \
+        else STIN_NTB(64, 64, 2, 2, OUT_);                                                           \
+    } while (0)
+    if (c_is_f32) STIN_NTB_PICK(float);
+    else STIN_NTB_PICK(stin_bf16);
+#undef STIN_NTB_PICK
+#undef STIN_NTB
+    return stin_launch_status();
+}
+
+extern "C" int stin_gemm_tn_bf16(const stin_bf16_t* G_, int64_t ldg, const stin_bf16_t* X_, int64_t ldx, int64_t M, int Nc,
+                                 int K, int ones_column, const stin_bf16_t* row_weight_, int64_t ld_weight, float* dW,
+                                 int64_t lddw, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    const stin_bf16* G = reinterpret_cast<const stin_bf16*>(G_);
+    const stin_bf16* X = reinterpret_cast<const stin_bf16*>(X_);
+    const stin_bf16* row_weight = reinterpret_cast<const stin_bf16*>(row_weight_);
+    const int Kp = K + (ones_column ? 1 : 0);
+    STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && ldg >= Nc && ldx >= K && lddw >= Kp, STIN_E_SIZE);
+    STIN_REQUIRE(dW && workspace && (M == 0 || (G && X)), STIN_E_NULL);
+    STIN_REQUIRE(workspace_bytes >= stin_gemm_tn_workspace_bytes(M, Nc, K, ones_column), STIN_E_WORKSPACE);
+    float* slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int TI = tn_tile(Nc), TJ = tn_tile(K);
+    const int tiles_i = (Nc + TI - 1) / TI, tiles_j = (K + TJ - 1) / TJ;
+    const int rows = tn_rows_per_chunk(M, tiles_i * tiles_j);
+    const int64_t chunks = M > 0 ? (M + rows - 1) / rows : 0;
+    const int64_t n = (int64_t)Nc * Kp;
+    if (chunks > 0) {
+        const bool vec = (Nc % 8 == 0) && (K % 8 == 0) && (ldg % 8 == 0) && (ldx % 8 == 0) && stin_aligned16(G) &&
+                         stin_aligned16(X);
+        const int64_t blocks = ((chunks + 7) / 8) * 8 * (int64_t)tiles_i * tiles_j;
+#define STIN_TNK(TI_, TJ_)                                                                                            \
+    do {                                                                                                              \
+        if (vec) hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
+        else hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
+    } while (0)
+        if (TI == 128 && TJ == 128) STIN_TNK(128, 128);
+        else if (TI == 128) STIN_TNK(128, 64);
+        else if (TJ == 128) STIN_TNK(64, 128);
+        else STIN_TNK(64, 64);
+#undef STIN_TNK
     }
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, chunks,
                        n, Kp, dW, lddw);

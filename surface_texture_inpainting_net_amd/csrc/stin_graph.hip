@@ -24,12 +24,12 @@ struct Lane {
 };
 
 // ------------------------------------------------------------------ edge stage, forward
-template <int G, int VPL, int U>
-__global__ __launch_bounds__(BLOCK) void k_edge_fwd(const float* __restrict__ A, int64_t lda,
-                                                    const float* __restrict__ B, int64_t ldb,
+template <typename T, int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_fwd(const T* __restrict__ A, int64_t lda,
+                                                    const T* __restrict__ B, int64_t ldb,
                                                     const int32_t* __restrict__ rowptr,
                                                     const int32_t* __restrict__ col, int64_t N, int H,
-                                                    float* __restrict__ out, int64_t ldo, int indicator,
+                                                    T* __restrict__ out, int64_t ldo, int indicator,
                                                     uint32_t* __restrict__ mask) {
     Lane<G, VPL> L;
     const bool row_ok = L.row < N;
@@ -103,13 +103,13 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd(const float* __restrict__ A,
 }
 
 // ------------------------------------------ edge stage, backward w.r.t. A (destination CSR)
-template <int G, int VPL, int U>
-__global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst(const float* __restrict__ A, int64_t lda,
-                                                        const float* __restrict__ B, int64_t ldb,
-                                                        const float* __restrict__ Gr, int64_t ldg,
+template <typename T, int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst(const T* __restrict__ A, int64_t lda,
+                                                        const T* __restrict__ B, int64_t ldb,
+                                                        const T* __restrict__ Gr, int64_t ldg,
                                                         const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col, int64_t N, int H,
-                                                        float* __restrict__ dA, int64_t ldda) {
+                                                        T* __restrict__ dA, int64_t ldda) {
     Lane<G, VPL> L;
     if (L.row >= N) return;
     const int beg = rowptr[L.row], end = rowptr[L.row + 1];
@@ -154,14 +154,14 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst(const float* __restrict_
 }
 
 // ----------------------------------------------- edge stage, backward w.r.t. B (source CSR)
-template <int G, int VPL, int U>
-__global__ __launch_bounds__(BLOCK) void k_edge_bwd_src(const float* __restrict__ A, int64_t lda,
-                                                        const float* __restrict__ B, int64_t ldb,
-                                                        const float* __restrict__ Gr, int64_t ldg,
+template <typename T, int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_src(const T* __restrict__ A, int64_t lda,
+                                                        const T* __restrict__ B, int64_t ldb,
+                                                        const T* __restrict__ Gr, int64_t ldg,
                                                         const float* __restrict__ inv_deg,
                                                         const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col, int64_t N, int H,
-                                                        float* __restrict__ dB, int64_t lddb) {
+                                                        T* __restrict__ dB, int64_t lddb) {
     Lane<G, VPL> L;
     if (L.row >= N) return;
     const int beg = rowptr[L.row], end = rowptr[L.row + 1];
@@ -206,11 +206,11 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_src(const float* __restrict_
 // ----------------------------- edge stage backward from the saved ReLU bit-mask (no recompute)
 // dA[i,c] = G[i,c]/deg_i * popcount_e mask[e][c] over the in-edge slots e of i: a pure streaming kernel
 // (reads H/8 bytes per edge instead of gathering a B row).
-template <int G, int VPL, int U>
-__global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask(const float* __restrict__ Gr, int64_t ldg,
+template <typename T, int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask(const T* __restrict__ Gr, int64_t ldg,
                                                              const uint32_t* __restrict__ mask,
                                                              const int32_t* __restrict__ rowptr, int64_t N, int H,
-                                                             float* __restrict__ dA, int64_t ldda) {
+                                                             T* __restrict__ dA, int64_t ldda) {
     Lane<G, VPL> L;
     if (L.row >= N) return;
     const int beg = rowptr[L.row], end = rowptr[L.row + 1];
@@ -266,14 +266,14 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask(const float* __rest
 
 // dB[j,c] = sum over out-edges (j -> i) of inv_deg[i] * G[i,c] * mask[xslot][c]: gathers G rows and 32-bit mask
 // words (xslot = destination-CSR slot of the same edge), half the bytes of the recompute form.
-template <int G, int VPL, int U>
-__global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask(const float* __restrict__ Gr, int64_t ldg,
+template <typename T, int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask(const T* __restrict__ Gr, int64_t ldg,
                                                              const float* __restrict__ w_slot,
                                                              const uint32_t* __restrict__ mask,
                                                              const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ col,
                                                              const int32_t* __restrict__ xslot, int64_t N, int H,
-                                                             float* __restrict__ dB, int64_t lddb) {
+                                                             T* __restrict__ dB, int64_t lddb) {
     Lane<G, VPL> L;
     if (L.row >= N) return;
     const int beg = rowptr[L.row], end = rowptr[L.row + 1];
@@ -328,11 +328,11 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask(const float* __rest
 }
 
 // --------------------------------------------------------------- segment sum / mean
-template <int G, int VPL, int U>
-__global__ __launch_bounds__(BLOCK) void k_segment_sum(const float* __restrict__ src, int64_t lds_,
+template <typename T, int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_segment_sum(const T* __restrict__ src, int64_t lds_,
                                                        const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ col, int64_t N, int C,
-                                                       int mean, float* __restrict__ out, int64_t ldo) {
+                                                       int mean, T* __restrict__ out, int64_t ldo) {
     Lane<G, VPL> L;
     if (L.row >= N) return;
     const int beg = rowptr[L.row], end = rowptr[L.row + 1];
@@ -375,11 +375,11 @@ __global__ __launch_bounds__(BLOCK) void k_segment_sum(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------- max pool
-template <int G, int VPL, int U>
-__global__ __launch_bounds__(BLOCK) void k_pool_max_fwd(const float* __restrict__ x, int64_t ldx,
+template <typename T, int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_pool_max_fwd(const T* __restrict__ x, int64_t ldx,
                                                         const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col, int64_t N, int C,
-                                                        float* __restrict__ out, int64_t ldo,
+                                                        T* __restrict__ out, int64_t ldo,
                                                         int32_t* __restrict__ arg) {
     Lane<G, VPL> L;
     if (L.row >= N) return;
@@ -425,11 +425,11 @@ __global__ __launch_bounds__(BLOCK) void k_pool_max_fwd(const float* __restrict_
         }
 }
 
-template <int G, int VPL>
-__global__ __launch_bounds__(BLOCK) void k_pool_max_bwd(const float* __restrict__ g, int64_t ldg,
+template <typename T, int G, int VPL>
+__global__ __launch_bounds__(BLOCK) void k_pool_max_bwd(const T* __restrict__ g, int64_t ldg,
                                                         const int32_t* __restrict__ arg,
                                                         const int32_t* __restrict__ trace, int64_t N, int C,
-                                                        float* __restrict__ gx, int64_t ldgx) {
+                                                        T* __restrict__ gx, int64_t ldgx) {
     Lane<G, VPL> L;
     if (L.row >= N) return;
     const int64_t t = trace[L.row];
@@ -444,11 +444,11 @@ __global__ __launch_bounds__(BLOCK) void k_pool_max_bwd(const float* __restrict_
         }
 }
 
-template <int G, int VPL>
-__global__ __launch_bounds__(BLOCK) void k_gather_rows(const float* __restrict__ src, int64_t lds_,
+template <typename T, int G, int VPL>
+__global__ __launch_bounds__(BLOCK) void k_gather_rows(const T* __restrict__ src, int64_t lds_,
                                                        const int32_t* __restrict__ idx,
                                                        const float* __restrict__ row_scale, int64_t N, int C,
-                                                       float* __restrict__ out, int64_t ldo) {
+                                                       T* __restrict__ out, int64_t ldo) {
     Lane<G, VPL> L;
     if (L.row >= N) return;
     const int64_t t = idx[L.row];
@@ -538,10 +538,11 @@ __global__ void k_gather_i64(const int64_t* __restrict__ src, const int32_t* __r
     if (r < N) out[r] = src[idx[r]];
 }
 
+template <typename T>
 inline bool vec_ok(int C, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
     if (C % 4 != 0 || C > 64 * 8 * 4) return false;
     for (const void* p : ptrs)
-        if (p != nullptr && !stin_aligned16(p)) return false;
+        if (p != nullptr && !stin_aligned_vec4<T>(p)) return false;
     for (int64_t ld : lds)
         if (ld % 4 != 0) return false;
     return true;
@@ -564,16 +565,16 @@ inline unsigned grid_elems(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOC
         const int g_ = stin_group_lanes(c4_);                                                                \
         const int vpl_ = (c4_ + g_ - 1) / g_;                                                                \
         const unsigned grid_ = grid_rows(N, g_);                                                             \
-        if (g_ == 1) hipLaunchKernelGGL((KERNEL<1, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);        \
-        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<2, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<4, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<8, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<16, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<32, 1, STIN_U(6, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<64, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<64, 2, STIN_U(2, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<64, 4, STIN_U(2, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<64, 8, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);       \
+        if (g_ == 1) hipLaunchKernelGGL((KERNEL<T, 1, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);        \
+        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<T, 2, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<T, 4, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<T, 8, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<T, 16, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<T, 32, 1, STIN_U(6, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<T, 64, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<T, 64, 2, STIN_U(2, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<T, 64, 4, STIN_U(2, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<T, 64, 8, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);       \
     } while (0)
 
 #define STIN_DISPATCH_NOU(C_, KERNEL, ...)                                                                   \
@@ -582,49 +583,170 @@ inline unsigned grid_elems(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOC
         const int g_ = stin_group_lanes(c4_);                                                                \
         const int vpl_ = (c4_ + g_ - 1) / g_;                                                                \
         const unsigned grid_ = grid_rows(N, g_);                                                             \
-        if (g_ == 1) hipLaunchKernelGGL((KERNEL<1, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<2, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<4, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<8, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<16, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<32, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<64, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<64, 2>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<64, 4>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<64, 8>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);          \
+        if (g_ == 1) hipLaunchKernelGGL((KERNEL<T, 1, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<T, 2, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<T, 4, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<T, 8, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<T, 16, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<T, 32, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<T, 64, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<T, 64, 2>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<T, 64, 4>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<T, 64, 8>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);          \
     } while (0)
+
+constexpr bool is_f32(const float*) { return true; }
+constexpr bool is_f32(const stin_bf16*) { return false; }
+
+// ------------------------------------------------------------- host side, one implementation per element type
+// (fp32 rows: every shape, scalar kernels when C % 4 != 0 or rows are not 16-byte aligned;
+//  bf16 rows: the 4-channel vector kernels only -> STIN_E_UNSUPPORTED otherwise)
+template <typename T>
+int edge_fwd_impl(const T* A, int64_t lda, const T* B, int64_t ldb, const int32_t* rowptr, const int32_t* col, int64_t N,
+                  int H, T* out, int64_t ldo, int indicator, uint32_t* mask, hipStream_t stream) {
+    STIN_REQUIRE(N >= 0 && H > 0 && lda >= H && ldb >= H && ldo >= H + (indicator ? 4 : 0), STIN_E_SIZE);
+    STIN_REQUIRE(!indicator || H >= 4, STIN_E_UNSUPPORTED);
+    const bool vec = vec_ok<T>(H, {A, B, out}, {lda, ldb, ldo});
+    STIN_REQUIRE(mask == nullptr || (mask_shape_ok(H) && vec), STIN_E_UNSUPPORTED);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(A && B && rowptr && out, STIN_E_NULL);
+    if (vec) {
+        STIN_DISPATCH(H, k_edge_fwd, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+    } else if constexpr (is_f32((const T*)nullptr)) {
+        hipLaunchKernelGGL((k_scalar<OP_EDGE_FWD>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
+                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, rowptr, col, N, H, indicator, out, ldo,
+                           (int32_t*)nullptr);
+    } else {
+        return STIN_E_UNSUPPORTED;
+    }
+    return stin_launch_status();
+}
+
+template <typename T>
+int edge_bwd_dst_mask_impl(const T* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr, int64_t N, int H, T* dA,
+                           int64_t ldda, hipStream_t stream) {
+    STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && ldda >= H, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(G && mask && rowptr && dA, STIN_E_NULL);
+    STIN_REQUIRE(mask_shape_ok(H) && vec_ok<T>(H, {G, dA}, {ldg, ldda}), STIN_E_UNSUPPORTED);
+    STIN_DISPATCH(H, k_edge_bwd_dst_mask, 1, G, ldg, mask, rowptr, N, H, dA, ldda);
+    return stin_launch_status();
+}
+
+template <typename T>
+int edge_bwd_src_mask_impl(const T* G, int64_t ldg, const float* w_src, const uint32_t* mask, const int32_t* rowptr_src,
+                           const int32_t* col_src, const int32_t* xslot, int64_t N, int H, T* dB, int64_t lddb,
+                           hipStream_t stream) {
+    STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && lddb >= H, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(G && w_src && mask && rowptr_src && col_src && xslot && dB, STIN_E_NULL);
+    STIN_REQUIRE(mask_shape_ok(H) && vec_ok<T>(H, {G, dB}, {ldg, lddb}), STIN_E_UNSUPPORTED);
+    STIN_DISPATCH(H, k_edge_bwd_src_mask, 1, G, ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
+    return stin_launch_status();
+}
+
+template <typename T>
+int segment_sum_impl(const T* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col, int64_t N, int C, int mean,
+                     T* out, int64_t ld_out, hipStream_t stream) {
+    STIN_REQUIRE(N >= 0 && C > 0 && ld_src >= C && ld_out >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(src && rowptr && out, STIN_E_NULL);
+    if (vec_ok<T>(C, {src, out}, {ld_src, ld_out})) {
+        STIN_DISPATCH(C, k_segment_sum, 1, src, ld_src, rowptr, col, N, C, mean, out, ld_out);
+    } else if constexpr (is_f32((const T*)nullptr)) {
+        hipLaunchKernelGGL((k_scalar<OP_SEG_SUM>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, src, ld_src,
+                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
+                           rowptr, col, N, C, mean, out, ld_out, (int32_t*)nullptr);
+    } else {
+        return STIN_E_UNSUPPORTED;
+    }
+    return stin_launch_status();
+}
+
+template <typename T>
+int pool_max_fwd_impl(const T* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, int64_t N, int C, T* out,
+                      int64_t ldo, int32_t* arg, hipStream_t stream) {
+    STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldo >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(x && rowptr && col && out && arg, STIN_E_NULL);
+    if (vec_ok<T>(C, {x, out}, {ldx, ldo}) && stin_aligned16(arg)) {
+        STIN_DISPATCH(C, k_pool_max_fwd, 1, x, ldx, rowptr, col, N, C, out, ldo, arg);
+    } else if constexpr (is_f32((const T*)nullptr)) {
+        hipLaunchKernelGGL((k_scalar<OP_POOL_MAX>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, x, ldx,
+                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
+                           rowptr, col, N, C, 0, out, ldo, arg);
+    } else {
+        return STIN_E_UNSUPPORTED;
+    }
+    return stin_launch_status();
+}
+
+template <typename T>
+int pool_max_bwd_impl(const T* g, int64_t ldg, const int32_t* arg, const int32_t* trace, int64_t N, int C, T* gx,
+                      int64_t ldgx, hipStream_t stream) {
+    STIN_REQUIRE(N >= 0 && C > 0 && ldg >= C && ldgx >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(g && arg && trace && gx, STIN_E_NULL);
+    if (vec_ok<T>(C, {g, gx}, {ldg, ldgx}) && stin_aligned16(arg)) {
+        STIN_DISPATCH_NOU(C, k_pool_max_bwd, g, ldg, arg, trace, N, C, gx, ldgx);
+    } else if constexpr (is_f32((const T*)nullptr)) {
+        hipLaunchKernelGGL((k_scalar<OP_POOL_MAX_BWD>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, g, ldg,
+                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
+                           (const int32_t*)nullptr, trace, N, C, 0, gx, ldgx, const_cast<int32_t*>(arg));
+    } else {
+        return STIN_E_UNSUPPORTED;
+    }
+    return stin_launch_status();
+}
+
+template <typename T>
+int gather_rows_impl(const T* src, int64_t ld_src, const int32_t* idx, const float* row_scale, int64_t N, int C, T* out,
+                     int64_t ldo, hipStream_t stream) {
+    STIN_REQUIRE(N >= 0 && C > 0 && ld_src >= C && ldo >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(src && idx && out, STIN_E_NULL);
+    if (vec_ok<T>(C, {src, out}, {ld_src, ldo})) {
+        STIN_DISPATCH_NOU(C, k_gather_rows, src, ld_src, idx, row_scale, N, C, out, ldo);
+    } else if constexpr (is_f32((const T*)nullptr)) {
+        hipLaunchKernelGGL((k_scalar<OP_GATHER>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, src, ld_src,
+                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, row_scale,
+                           (const int32_t*)nullptr, idx, N, C, 0, out, ldo, (int32_t*)nullptr);
+    } else {
+        return STIN_E_UNSUPPORTED;
+    }
+    return stin_launch_status();
+}
+
+inline const stin_bf16* b16(const stin_bf16_t* p) { return reinterpret_cast<const stin_bf16*>(p); }
+inline stin_bf16* b16(stin_bf16_t* p) { return reinterpret_cast<stin_bf16*>(p); }
 
 }  // namespace
 
 extern "C" int stin_edge_relu_mean_fwd_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
                                            const int32_t* rowptr, const int32_t* col, int64_t N, int H, float* out,
-                                           int64_t ldo, int indicator, uint32_t* mask, stin_stream_t stream_) {
+                                           int64_t ldo, int indicator, uint32_t* mask, stin_stream_t stream) {
     stin_clear_stale_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    STIN_REQUIRE(N >= 0 && H > 0 && lda >= H && ldb >= H && ldo >= H + (indicator ? 4 : 0), STIN_E_SIZE);
-    STIN_REQUIRE(!indicator || H >= 4, STIN_E_UNSUPPORTED);
-    STIN_REQUIRE(mask == nullptr || (mask_shape_ok(H) && vec_ok(H, {A, B, out}, {lda, ldb, ldo})), STIN_E_UNSUPPORTED);
-    if (N == 0) return STIN_OK;
-    STIN_REQUIRE(A && B && rowptr && out, STIN_E_NULL);
-    if (vec_ok(H, {A, B, out}, {lda, ldb, ldo})) {
-        STIN_DISPATCH(H, k_edge_fwd, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
-    } else {
-        hipLaunchKernelGGL((k_scalar<OP_EDGE_FWD>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
-                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, rowptr, col, N, H, indicator, out, ldo,
-                           (int32_t*)nullptr);
-    }
-    return stin_launch_status();
+    return edge_fwd_impl<float>(A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask, (hipStream_t)stream);
+}
+extern "C" int stin_edge_relu_mean_fwd_bf16(const stin_bf16_t* A, int64_t lda, const stin_bf16_t* B, int64_t ldb,
+                                            const int32_t* rowptr, const int32_t* col, int64_t N, int H,
+                                            stin_bf16_t* out, int64_t ldo, int indicator, uint32_t* mask,
+                                            stin_stream_t stream) {
+    stin_clear_stale_error();
+    return edge_fwd_impl<stin_bf16>(b16(A), lda, b16(B), ldb, rowptr, col, N, H, b16(out), ldo, indicator, mask,
+                                    (hipStream_t)stream);
 }
 
 extern "C" int stin_edge_relu_mean_bwd_dst_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* G,
                                                int64_t ldg, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
                                                float* dA, int64_t ldda, stin_stream_t stream_) {
+    typedef float T;
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(N >= 0 && H > 0 && lda >= H && ldb >= H && ldg >= H && ldda >= H, STIN_E_SIZE);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(A && B && G && rowptr && dA, STIN_E_NULL);
-    if (vec_ok(H, {A, B, G, dA}, {lda, ldb, ldg, ldda})) {
+    if (vec_ok<T>(H, {A, B, G, dA}, {lda, ldb, ldg, ldda})) {
         STIN_DISPATCH(H, k_edge_bwd_dst, 1, A, lda, B, ldb, G, ldg, rowptr, col, N, H, dA, ldda);
     } else {
         hipLaunchKernelGGL((k_scalar<OP_EDGE_BWD_DST>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
@@ -637,12 +759,13 @@ extern "C" int stin_edge_relu_mean_bwd_src_f32(const float* A, int64_t lda, cons
                                                int64_t ldg, const float* inv_deg, const int32_t* rowptr_src,
                                                const int32_t* col_src, int64_t N, int H, float* dB, int64_t lddb,
                                                stin_stream_t stream_) {
+    typedef float T;
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(N >= 0 && H > 0 && lda >= H && ldb >= H && ldg >= H && lddb >= H, STIN_E_SIZE);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(A && B && G && inv_deg && rowptr_src && dB, STIN_E_NULL);
-    if (vec_ok(H, {A, B, G, dB}, {lda, ldb, ldg, lddb})) {
+    if (vec_ok<T>(H, {A, B, G, dB}, {lda, ldb, ldg, lddb})) {
         STIN_DISPATCH(H, k_edge_bwd_src, 2, A, lda, B, ldb, G, ldg, inv_deg, rowptr_src, col_src, N, H, dB, lddb);
     } else {
         hipLaunchKernelGGL((k_scalar<OP_EDGE_BWD_SRC>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
@@ -653,97 +776,77 @@ extern "C" int stin_edge_relu_mean_bwd_src_f32(const float* A, int64_t lda, cons
 
 extern "C" int stin_edge_relu_mean_bwd_dst_mask_f32(const float* G, int64_t ldg, const uint32_t* mask,
                                                     const int32_t* rowptr, int64_t N, int H, float* dA, int64_t ldda,
-                                                    stin_stream_t stream_) {
+                                                    stin_stream_t stream) {
     stin_clear_stale_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && ldda >= H, STIN_E_SIZE);
-    if (N == 0) return STIN_OK;
-    STIN_REQUIRE(G && mask && rowptr && dA, STIN_E_NULL);
-    STIN_REQUIRE(mask_shape_ok(H) && vec_ok(H, {G, dA}, {ldg, ldda}), STIN_E_UNSUPPORTED);
-    STIN_DISPATCH(H, k_edge_bwd_dst_mask, 1, G, ldg, mask, rowptr, N, H, dA, ldda);
-    return stin_launch_status();
+    return edge_bwd_dst_mask_impl<float>(G, ldg, mask, rowptr, N, H, dA, ldda, (hipStream_t)stream);
+}
+extern "C" int stin_edge_relu_mean_bwd_dst_mask_bf16(const stin_bf16_t* G, int64_t ldg, const uint32_t* mask,
+                                                     const int32_t* rowptr, int64_t N, int H, stin_bf16_t* dA,
+                                                     int64_t ldda, stin_stream_t stream) {
+    stin_clear_stale_error();
+    return edge_bwd_dst_mask_impl<stin_bf16>(b16(G), ldg, mask, rowptr, N, H, b16(dA), ldda, (hipStream_t)stream);
 }
 
 extern "C" int stin_edge_relu_mean_bwd_src_mask_f32(const float* G, int64_t ldg, const float* w_src,
                                                     const uint32_t* mask, const int32_t* rowptr_src,
                                                     const int32_t* col_src, const int32_t* xslot, int64_t N, int H,
-                                                    float* dB, int64_t lddb, stin_stream_t stream_) {
+                                                    float* dB, int64_t lddb, stin_stream_t stream) {
     stin_clear_stale_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && lddb >= H, STIN_E_SIZE);
-    if (N == 0) return STIN_OK;
-    STIN_REQUIRE(G && w_src && mask && rowptr_src && col_src && xslot && dB, STIN_E_NULL);
-    STIN_REQUIRE(mask_shape_ok(H) && vec_ok(H, {G, dB}, {ldg, lddb}), STIN_E_UNSUPPORTED);
-    STIN_DISPATCH(H, k_edge_bwd_src_mask, 1, G, ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
-    return stin_launch_status();
+    return edge_bwd_src_mask_impl<float>(G, ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, dB, lddb,
+                                         (hipStream_t)stream);
+}
+extern "C" int stin_edge_relu_mean_bwd_src_mask_bf16(const stin_bf16_t* G, int64_t ldg, const float* w_src,
+                                                     const uint32_t* mask, const int32_t* rowptr_src,
+                                                     const int32_t* col_src, const int32_t* xslot, int64_t N, int H,
+                                                     stin_bf16_t* dB, int64_t lddb, stin_stream_t stream) {
+    stin_clear_stale_error();
+    return edge_bwd_src_mask_impl<stin_bf16>(b16(G), ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, b16(dB), lddb,
+                                             (hipStream_t)stream);
 }
 
 extern "C" int stin_segment_sum_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col,
-                                    int64_t N, int C, int mean, float* out, int64_t ld_out, stin_stream_t stream_) {
+                                    int64_t N, int C, int mean, float* out, int64_t ld_out, stin_stream_t stream) {
     stin_clear_stale_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    STIN_REQUIRE(N >= 0 && C > 0 && ld_src >= C && ld_out >= C, STIN_E_SIZE);
-    if (N == 0) return STIN_OK;
-    STIN_REQUIRE(src && rowptr && out, STIN_E_NULL);
-    if (vec_ok(C, {src, out}, {ld_src, ld_out})) {
-        STIN_DISPATCH(C, k_segment_sum, 1, src, ld_src, rowptr, col, N, C, mean, out, ld_out);
-    } else {
-        hipLaunchKernelGGL((k_scalar<OP_SEG_SUM>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, src, ld_src,
-                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
-                           rowptr, col, N, C, mean, out, ld_out, (int32_t*)nullptr);
-    }
-    return stin_launch_status();
+    return segment_sum_impl<float>(src, ld_src, rowptr, col, N, C, mean, out, ld_out, (hipStream_t)stream);
+}
+extern "C" int stin_segment_sum_bf16(const stin_bf16_t* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col,
+                                     int64_t N, int C, int mean, stin_bf16_t* out, int64_t ld_out, stin_stream_t stream) {
+    stin_clear_stale_error();
+    return segment_sum_impl<stin_bf16>(b16(src), ld_src, rowptr, col, N, C, mean, b16(out), ld_out, (hipStream_t)stream);
 }
 
 extern "C" int stin_pool_max_fwd_f32(const float* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
-                                     int64_t N, int C, float* out, int64_t ldo, int32_t* arg, stin_stream_t stream_) {
+                                     int64_t N, int C, float* out, int64_t ldo, int32_t* arg, stin_stream_t stream) {
     stin_clear_stale_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldo >= C, STIN_E_SIZE);
-    if (N == 0) return STIN_OK;
-    STIN_REQUIRE(x && rowptr && col && out && arg, STIN_E_NULL);
-    if (vec_ok(C, {x, out, arg}, {ldx, ldo})) {
-        STIN_DISPATCH(C, k_pool_max_fwd, 1, x, ldx, rowptr, col, N, C, out, ldo, arg);
-    } else {
-        hipLaunchKernelGGL((k_scalar<OP_POOL_MAX>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, x, ldx,
-                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
-                           rowptr, col, N, C, 0, out, ldo, arg);
-    }
-    return stin_launch_status();
+    return pool_max_fwd_impl<float>(x, ldx, rowptr, col, N, C, out, ldo, arg, (hipStream_t)stream);
+}
+extern "C" int stin_pool_max_fwd_bf16(const stin_bf16_t* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
+                                      int64_t N, int C, stin_bf16_t* out, int64_t ldo, int32_t* arg,
+                                      stin_stream_t stream) {
+    stin_clear_stale_error();
+    return pool_max_fwd_impl<stin_bf16>(b16(x), ldx, rowptr, col, N, C, b16(out), ldo, arg, (hipStream_t)stream);
 }
 
 extern "C" int stin_pool_max_bwd_f32(const float* g, int64_t ldg, const int32_t* arg, const int32_t* trace,
-                                     int64_t N, int C, float* gx, int64_t ldgx, stin_stream_t stream_) {
+                                     int64_t N, int C, float* gx, int64_t ldgx, stin_stream_t stream) {
     stin_clear_stale_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    STIN_REQUIRE(N >= 0 && C > 0 && ldg >= C && ldgx >= C, STIN_E_SIZE);
-    if (N == 0) return STIN_OK;
-    STIN_REQUIRE(g && arg && trace && gx, STIN_E_NULL);
-    if (vec_ok(C, {g, gx, arg}, {ldg, ldgx})) {
-        STIN_DISPATCH_NOU(C, k_pool_max_bwd, g, ldg, arg, trace, N, C, gx, ldgx);
-    } else {
-        hipLaunchKernelGGL((k_scalar<OP_POOL_MAX_BWD>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, g, ldg,
-                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr,
-                           (const int32_t*)nullptr, trace, N, C, 0, gx, ldgx, const_cast<int32_t*>(arg));
-    }
-    return stin_launch_status();
+    return pool_max_bwd_impl<float>(g, ldg, arg, trace, N, C, gx, ldgx, (hipStream_t)stream);
+}
+extern "C" int stin_pool_max_bwd_bf16(const stin_bf16_t* g, int64_t ldg, const int32_t* arg, const int32_t* trace,
+                                      int64_t N, int C, stin_bf16_t* gx, int64_t ldgx, stin_stream_t stream) {
+    stin_clear_stale_error();
+    return pool_max_bwd_impl<stin_bf16>(b16(g), ldg, arg, trace, N, C, b16(gx), ldgx, (hipStream_t)stream);
 }
 
 extern "C" int stin_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, const float* row_scale,
-                                    int64_t N, int C, float* out, int64_t ldo, stin_stream_t stream_) {
+                                    int64_t N, int C, float* out, int64_t ldo, stin_stream_t stream) {
     stin_clear_stale_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    STIN_REQUIRE(N >= 0 && C > 0 && ld_src >= C && ldo >= C, STIN_E_SIZE);
-    if (N == 0) return STIN_OK;
-    STIN_REQUIRE(src && idx && out, STIN_E_NULL);
-    if (vec_ok(C, {src, out}, {ld_src, ldo})) {
-        STIN_DISPATCH_NOU(C, k_gather_rows, src, ld_src, idx, row_scale, N, C, out, ldo);
-    } else {
-        hipLaunchKernelGGL((k_scalar<OP_GATHER>), dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, src, ld_src,
-                           (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, row_scale,
-                           (const int32_t*)nullptr, idx, N, C, 0, out, ldo, (int32_t*)nullptr);
-    }
-    return stin_launch_status();
+    return gather_rows_impl<float>(src, ld_src, idx, row_scale, N, C, out, ldo, (hipStream_t)stream);
+}
+extern "C" int stin_gather_rows_bf16(const stin_bf16_t* src, int64_t ld_src, const int32_t* idx, const float* row_scale,
+                                     int64_t N, int C, stin_bf16_t* out, int64_t ldo, stin_stream_t stream) {
+    stin_clear_stale_error();
+    return gather_rows_impl<stin_bf16>(b16(src), ld_src, idx, row_scale, N, C, b16(out), ldo, (hipStream_t)stream);
 }
 
 extern "C" int stin_batch_pool_i64(const int64_t* batch, const int32_t* rowptr, const int32_t* col, int64_t N,

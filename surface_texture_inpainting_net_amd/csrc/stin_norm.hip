@@ -12,21 +12,21 @@ constexpr int MAX_SLABS = 1024;  // B * chunks-per-segment upper bound (workspac
 template <int VW> struct V;
 template <> struct V<4> {
     float v[4];
-    __device__ __forceinline__ static V load(const float* p) { V r; float4 t = ld4(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r; }
-    __device__ __forceinline__ void store(float* p) const { st4(p, make_float4(v[0], v[1], v[2], v[3])); }
+    template <typename T> __device__ __forceinline__ static V load(const T* p) { V r; float4 t = ld4(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r; }
+    template <typename T> __device__ __forceinline__ void store(T* p) const { st4(p, make_float4(v[0], v[1], v[2], v[3])); }
 };
 template <> struct V<1> {
     float v[1];
-    __device__ __forceinline__ static V load(const float* p) { V r; r.v[0] = *p; return r; }
-    __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
+    template <typename T> __device__ __forceinline__ static V load(const T* p) { V r; r.v[0] = ld1(p); return r; }
+    template <typename T> __device__ __forceinline__ void store(T* p) const { st1(p, v[0]); }
 };
 
 __device__ __forceinline__ float elu_grad_from_pre(float n) { return n > 0.f ? 1.f : __expf(n); }
 
 // grid = (chunks, B). partial layout: [b][chunk][o][C] doubles, o in {0,1}.
-template <int MODE, int VW>
-__global__ __launch_bounds__(BLOCK) void k_colreduce(const float* __restrict__ x, int64_t ldx,
-                                                     const float* __restrict__ gout, int64_t ldg, int64_t N, int C,
+template <typename T, int MODE, int VW>
+__global__ __launch_bounds__(BLOCK) void k_colreduce(const T* __restrict__ x, int64_t ldx,
+                                                     const T* __restrict__ gout, int64_t ldg, int64_t N, int C,
                                                      const int32_t* __restrict__ ptr, const int32_t* __restrict__ gid,
                                                      const int32_t* __restrict__ sid, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ coef,
@@ -187,11 +187,11 @@ __global__ void k_moments_final(const double* __restrict__ partial, int nch, int
     }
 }
 
-template <int VW>
-__global__ __launch_bounds__(BLOCK) void k_norm_fwd(const float* __restrict__ x, int64_t ldx,
+template <typename T, int VW>
+__global__ __launch_bounds__(BLOCK) void k_norm_fwd(const T* __restrict__ x, int64_t ldx,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                    const int32_t* __restrict__ gid, const float* __restrict__ res,
-                                                    int64_t ldres, int64_t N, int C, int act, float* __restrict__ y,
+                                                    const int32_t* __restrict__ gid, const T* __restrict__ res,
+                                                    int64_t ldres, int64_t N, int C, int act, T* __restrict__ y,
                                                     int64_t ldy) {
     const int CV = C / VW;
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -217,14 +217,14 @@ __global__ __launch_bounds__(BLOCK) void k_norm_fwd(const float* __restrict__ x,
     o.store(y + r * ldy + c);
 }
 
-template <int VW>
-__global__ __launch_bounds__(BLOCK) void k_norm_bwd(const float* __restrict__ x, int64_t ldx,
-                                                    const float* __restrict__ gout, int64_t ldg,
+template <typename T, int VW>
+__global__ __launch_bounds__(BLOCK) void k_norm_bwd(const T* __restrict__ x, int64_t ldx,
+                                                    const T* __restrict__ gout, int64_t ldg,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ a, const float* __restrict__ kk,
                                                     const float* __restrict__ m, const int32_t* __restrict__ gid,
                                                     const int32_t* __restrict__ sid, int64_t N, int C, int act,
-                                                    float* __restrict__ dx, int64_t lddx) {
+                                                    T* __restrict__ dx, int64_t lddx) {
     const int CV = C / VW;
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= N * CV) return;
@@ -249,30 +249,29 @@ __global__ __launch_bounds__(BLOCK) void k_norm_bwd(const float* __restrict__ x,
     o.store(dx + r * lddx + c);
 }
 
-inline bool vec4_ok(int C, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+template <typename T>
+inline bool vec4_ok(int C, std::initializer_list<const void*> data, std::initializer_list<const void*> stats,
+                    std::initializer_list<int64_t> lds) {
     if (C % 4 != 0) return false;
-    for (const void* p : ptrs)
+    for (const void* p : data)
+        if (p != nullptr && !stin_aligned_vec4<T>(p)) return false;
+    for (const void* p : stats)
         if (p != nullptr && !stin_aligned16(p)) return false;
     for (int64_t ld : lds)
         if (ld % 4 != 0) return false;
     return true;
 }
 
-}  // namespace
+constexpr bool is_f32(const float*) { return true; }
+constexpr bool is_f32(const stin_bf16*) { return false; }
+inline const stin_bf16* b16(const stin_bf16_t* p) { return reinterpret_cast<const stin_bf16*>(p); }
+inline stin_bf16* b16(stin_bf16_t* p) { return reinterpret_cast<stin_bf16*>(p); }
 
-extern "C" size_t stin_colreduce_workspace_bytes(int C, int B) {
-    if (C <= 0 || B <= 0) return 0;
-    const size_t slabs = (size_t)(B > MAX_SLABS ? B : MAX_SLABS);
-    return slabs * 2 * (size_t)C * sizeof(double) + 256;
-}
-
-extern "C" int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const float* gout, int64_t ldg, int64_t N, int C,
-                                  const int32_t* ptr, int B, const int32_t* gid, const int32_t* sid, const float* mean,
-                                  const float* rstd, const float* coef, int post, const float* inv_cnt, float eps,
-                                  float* out0, float* out1, void* workspace, size_t workspace_bytes,
-                                  stin_stream_t stream_) {
-    stin_clear_stale_error();
-    hipStream_t stream = (hipStream_t)stream_;
+template <typename T>
+int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg, int64_t N, int C, const int32_t* ptr,
+                   int B, const int32_t* gid, const int32_t* sid, const float* mean, const float* rstd,
+                   const float* coef, int post, const float* inv_cnt, float eps, float* out0, float* out1,
+                   void* workspace, size_t workspace_bytes, hipStream_t stream) {
     STIN_REQUIRE(mode >= STIN_RED_SUM && mode <= STIN_RED_MOMENTS, STIN_E_UNSUPPORTED);
     STIN_REQUIRE(N >= 0 && C > 0 && B > 0 && ldx >= C, STIN_E_SIZE);
     STIN_REQUIRE((ptr != nullptr) || B == 1, STIN_E_SIZE);
@@ -286,7 +285,8 @@ extern "C" int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const f
     STIN_REQUIRE(workspace_bytes >= stin_colreduce_workspace_bytes(C, B), STIN_E_WORKSPACE);
     double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
 
-    const bool vec = vec4_ok(C, {x, gout, mean, rstd, coef}, {ldx, gout ? ldg : 0});
+    const bool vec = vec4_ok<T>(C, {x, gout}, {mean, rstd, coef}, {ldx, gout ? ldg : 0});
+    if (!vec && !is_f32((const T*)nullptr)) return STIN_E_UNSUPPORTED;
     const int VW = vec ? 4 : 1;
     const int CV = C / VW;
     const int CG = CV < BLOCK ? CV : BLOCK;
@@ -299,8 +299,8 @@ extern "C" int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const f
     dim3 grid((unsigned)nch, (unsigned)B);
 #define STIN_RED_LAUNCH(M)                                                                                          \
     do {                                                                                                            \
-        if (vec) hipLaunchKernelGGL((k_colreduce<M, 4>), grid, dim3(BLOCK), 0, stream, x, ldx, gout, ldg, N, C, ptr, gid, sid, mean, rstd, coef, partial); \
-        else hipLaunchKernelGGL((k_colreduce<M, 1>), grid, dim3(BLOCK), 0, stream, x, ldx, gout, ldg, N, C, ptr, gid, sid, mean, rstd, coef, partial);     \
+        if (vec) hipLaunchKernelGGL((k_colreduce<T, M, 4>), grid, dim3(BLOCK), 0, stream, x, ldx, gout, ldg, N, C, ptr, gid, sid, mean, rstd, coef, partial); \
+        else if constexpr (is_f32((const T*)nullptr)) hipLaunchKernelGGL((k_colreduce<T, M, 1>), grid, dim3(BLOCK), 0, stream, x, ldx, gout, ldg, N, C, ptr, gid, sid, mean, rstd, coef, partial);     \
     } while (0)
     switch (mode) {
         case STIN_RED_SUM: STIN_RED_LAUNCH(STIN_RED_SUM); break;
@@ -320,43 +320,99 @@ extern "C" int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const f
     return stin_launch_status();
 }
 
-extern "C" int stin_norm_act_res_fwd_f32(const float* x, int64_t ldx, const float* mean, const float* rstd,
-                                         const int32_t* gid, const float* res, int64_t ldres, int64_t N, int C, int act,
-                                         float* y, int64_t ldy, stin_stream_t stream_) {
-    stin_clear_stale_error();
-    hipStream_t stream = (hipStream_t)stream_;
+template <typename T>
+int norm_fwd_impl(const T* x, int64_t ldx, const float* mean, const float* rstd, const int32_t* gid, const T* res,
+                  int64_t ldres, int64_t N, int C, int act, T* y, int64_t ldy, hipStream_t stream) {
     STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldy >= C && (res == nullptr || ldres >= C), STIN_E_SIZE);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(x && mean && rstd && y, STIN_E_NULL);
-    if (vec4_ok(C, {x, mean, rstd, res, y}, {ldx, ldy, res ? ldres : 0})) {
+    if (vec4_ok<T>(C, {x, res, y}, {mean, rstd}, {ldx, ldy, res ? ldres : 0})) {
         const int64_t n = N * (C / 4);
-        hipLaunchKernelGGL((k_norm_fwd<4>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, mean,
-                           rstd, gid, res, ldres, N, C, act, y, ldy);
-    } else {
+        hipLaunchKernelGGL((k_norm_fwd<T, 4>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx,
+                           mean, rstd, gid, res, ldres, N, C, act, y, ldy);
+    } else if constexpr (is_f32((const T*)nullptr)) {
         const int64_t n = N * C;
-        hipLaunchKernelGGL((k_norm_fwd<1>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, mean,
-                           rstd, gid, res, ldres, N, C, act, y, ldy);
+        hipLaunchKernelGGL((k_norm_fwd<T, 1>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx,
+                           mean, rstd, gid, res, ldres, N, C, act, y, ldy);
+    } else {
+        return STIN_E_UNSUPPORTED;
     }
     return stin_launch_status();
+}
+
+template <typename T>
+int norm_bwd_impl(const T* x, int64_t ldx, const T* gout, int64_t ldg, const float* mean, const float* rstd,
+                  const float* a, const float* k, const float* m, const int32_t* gid, const int32_t* sid, int64_t N, int C,
+                  int act, T* dx, int64_t lddx, hipStream_t stream) {
+    STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldg >= C && lddx >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(x && gout && mean && rstd && a && k && m && dx, STIN_E_NULL);
+    if (vec4_ok<T>(C, {x, gout, dx}, {mean, rstd, a, k, m}, {ldx, ldg, lddx})) {
+        const int64_t n = N * (C / 4);
+        hipLaunchKernelGGL((k_norm_bwd<T, 4>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx,
+                           gout, ldg, mean, rstd, a, k, m, gid, sid, N, C, act, dx, lddx);
+    } else if constexpr (is_f32((const T*)nullptr)) {
+        const int64_t n = N * C;
+        hipLaunchKernelGGL((k_norm_bwd<T, 1>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx,
+                           gout, ldg, mean, rstd, a, k, m, gid, sid, N, C, act, dx, lddx);
+    } else {
+        return STIN_E_UNSUPPORTED;
+    }
+    return stin_launch_status();
+}
+
+}  // namespace
+
+extern "C" size_t stin_colreduce_workspace_bytes(int C, int B) {
+    if (C <= 0 || B <= 0) return 0;
+    const size_t slabs = (size_t)(B > MAX_SLABS ? B : MAX_SLABS);
+    return slabs * 2 * (size_t)C * sizeof(double) + 256;
+}
+
+extern "C" int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const float* gout, int64_t ldg, int64_t N, int C,
+                                  const int32_t* ptr, int B, const int32_t* gid, const int32_t* sid, const float* mean,
+                                  const float* rstd, const float* coef, int post, const float* inv_cnt, float eps,
+                                  float* out0, float* out1, void* workspace, size_t workspace_bytes, stin_stream_t stream) {
+    stin_clear_stale_error();
+    return colreduce_impl<float>(mode, x, ldx, gout, ldg, N, C, ptr, B, gid, sid, mean, rstd, coef, post, inv_cnt, eps, out0,
+                                 out1, workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int stin_colreduce_bf16(int mode, const stin_bf16_t* x, int64_t ldx, const stin_bf16_t* gout, int64_t ldg,
+                                   int64_t N, int C, const int32_t* ptr, int B, const int32_t* gid, const int32_t* sid,
+                                   const float* mean, const float* rstd, const float* coef, int post, const float* inv_cnt,
+                                   float eps, float* out0, float* out1, void* workspace, size_t workspace_bytes,
+                                   stin_stream_t stream) {
+    stin_clear_stale_error();
+    return colreduce_impl<stin_bf16>(mode, b16(x), ldx, b16(gout), ldg, N, C, ptr, B, gid, sid, mean, rstd, coef, post,
+                                     inv_cnt, eps, out0, out1, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int stin_norm_act_res_fwd_f32(const float* x, int64_t ldx, const float* mean, const float* rstd,
+                                         const int32_t* gid, const float* res, int64_t ldres, int64_t N, int C, int act,
+                                         float* y, int64_t ldy, stin_stream_t stream) {
+    stin_clear_stale_error();
+    return norm_fwd_impl<float>(x, ldx, mean, rstd, gid, res, ldres, N, C, act, y, ldy, (hipStream_t)stream);
+}
+extern "C" int stin_norm_act_res_fwd_bf16(const stin_bf16_t* x, int64_t ldx, const float* mean, const float* rstd,
+                                          const int32_t* gid, const stin_bf16_t* res, int64_t ldres, int64_t N, int C,
+                                          int act, stin_bf16_t* y, int64_t ldy, stin_stream_t stream) {
+    stin_clear_stale_error();
+    return norm_fwd_impl<stin_bf16>(b16(x), ldx, mean, rstd, gid, b16(res), ldres, N, C, act, b16(y), ldy,
+                                    (hipStream_t)stream);
 }
 
 extern "C" int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_t ldg, const float* mean,
                                      const float* rstd, const float* a, const float* k, const float* m,
                                      const int32_t* gid, const int32_t* sid, int64_t N, int C, int act, float* dx,
-                                     int64_t lddx, stin_stream_t stream_) {
+                                     int64_t lddx, stin_stream_t stream) {
     stin_clear_stale_error();
-    hipStream_t stream = (hipStream_t)stream_;
-    STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldg >= C && lddx >= C, STIN_E_SIZE);
-    if (N == 0) return STIN_OK;
-    STIN_REQUIRE(x && gout && mean && rstd && a && k && m && dx, STIN_E_NULL);
-    if (vec4_ok(C, {x, gout, mean, rstd, a, k, m, dx}, {ldx, ldg, lddx})) {
-        const int64_t n = N * (C / 4);
-        hipLaunchKernelGGL((k_norm_bwd<4>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, gout,
-                           ldg, mean, rstd, a, k, m, gid, sid, N, C, act, dx, lddx);
-    } else {
-        const int64_t n = N * C;
-        hipLaunchKernelGGL((k_norm_bwd<1>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, gout,
-                           ldg, mean, rstd, a, k, m, gid, sid, N, C, act, dx, lddx);
-    }
-    return stin_launch_status();
+    return norm_bwd_impl<float>(x, ldx, gout, ldg, mean, rstd, a, k, m, gid, sid, N, C, act, dx, lddx, (hipStream_t)stream);
+}
+extern "C" int stin_norm_act_bwd_bf16(const stin_bf16_t* x, int64_t ldx, const stin_bf16_t* gout, int64_t ldg,
+                                      const float* mean, const float* rstd, const float* a, const float* k, const float* m,
+                                      const int32_t* gid, const int32_t* sid, int64_t N, int C, int act, stin_bf16_t* dx,
+                                      int64_t lddx, stin_stream_t stream) {
+    stin_clear_stale_error();
+    return norm_bwd_impl<stin_bf16>(b16(x), ldx, b16(gout), ldg, mean, rstd, a, k, m, gid, sid, N, C, act, b16(dx), lddx,
+                                    (hipStream_t)stream);
 }

@@ -21,13 +21,25 @@ POST_NONE, POST_SCALE, POST_RSTD = 0, 1, 2
 
 
 def _mat(t):
-    """2-D fp32 GPU tensor with unit inner stride -> (tensor, ld)."""
-    if not (t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda):
-        raise TypeError('the STINet HIP path takes 2-D float32 CUDA tensors (no CPU / eager fallback exists); got '
-                        'shape %s dtype %s device %s' % (tuple(t.shape), t.dtype, t.device))
+    """2-D fp32 (or bf16-storage) GPU tensor with unit inner stride -> (tensor, ld)."""
+    if not (t.dim() == 2 and t.dtype in (torch.float32, torch.bfloat16) and t.is_cuda):
+        raise TypeError('the STINet HIP path takes 2-D float32 (or bfloat16-storage) CUDA tensors (no CPU / eager '
+                        'fallback exists); got shape %s dtype %s device %s' % (tuple(t.shape), t.dtype, t.device))
     if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
         t = t.contiguous()
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+def _sfx(t):
+    """C-ABI suffix of the kernel family for a tensor's storage type."""
+    return '_bf16' if t.dtype == torch.bfloat16 else '_f32'
+
+
+def _same(ref, *ts):
+    """The optional operands of a kernel must share the storage type of its main operand."""
+    for t in ts:
+        if t is not None and t.dtype != ref.dtype:
+            raise TypeError('mixed storage types in one kernel call: %s vs %s' % (ref.dtype, t.dtype))
 
 
 class KernelTimer:
@@ -70,8 +82,9 @@ def _call(name, *args, tag=None):
 def edge_relu_mean_fwd(A, B, csr, out, indicator=False, mask=None):
     A, lda = _mat(A)
     B, ldb = _mat(B)
+    _same(A, B, out)
     H = A.shape[1]
-    _call('stin_edge_relu_mean_fwd_f32', _ptr(A), lda, _ptr(B), ldb, _ptr(csr.rowptr), _ptr(csr.col), A.shape[0], H,
+    _call('stin_edge_relu_mean_fwd' + _sfx(A), _ptr(A), lda, _ptr(B), ldb, _ptr(csr.rowptr), _ptr(csr.col), A.shape[0], H,
           _ptr(out), out.stride(0), int(indicator), _ptr(mask), _stream(A), tag=(A.shape[0], csr.n_entries, H))
     return out
 
@@ -83,7 +96,8 @@ def edge_mask_supported(H):
 
 def edge_relu_mean_bwd_dst_mask(G, mask, csr, dA):
     G, ldg = _mat(G)
-    _call('stin_edge_relu_mean_bwd_dst_mask_f32', _ptr(G), ldg, _ptr(mask), _ptr(csr.rowptr), G.shape[0], G.shape[1],
+    _same(G, dA)
+    _call('stin_edge_relu_mean_bwd_dst_mask' + _sfx(G), _ptr(G), ldg, _ptr(mask), _ptr(csr.rowptr), G.shape[0], G.shape[1],
           _ptr(dA), dA.stride(0), _stream(G), tag=(G.shape[0], csr.n_entries, G.shape[1]))
     return dA
 
@@ -91,7 +105,8 @@ def edge_relu_mean_bwd_dst_mask(G, mask, csr, dA):
 def edge_relu_mean_bwd_src_mask(G, mask, edges, dB):
     G, ldg = _mat(G)
     cs = edges.by_src
-    _call('stin_edge_relu_mean_bwd_src_mask_f32', _ptr(G), ldg, _ptr(edges.w_src), _ptr(mask), _ptr(cs.rowptr),
+    _same(G, dB)
+    _call('stin_edge_relu_mean_bwd_src_mask' + _sfx(G), _ptr(G), ldg, _ptr(edges.w_src), _ptr(mask), _ptr(cs.rowptr),
           _ptr(cs.col), _ptr(edges.xslot), G.shape[0], G.shape[1], _ptr(dB), dB.stride(0), _stream(G),
           tag=(G.shape[0], cs.n_entries, G.shape[1]))
     return dB
@@ -118,8 +133,8 @@ def edge_relu_mean_bwd_src(A, B, G, inv_deg, csr_src, dB):
 
 def segment_sum(src, rowptr, col, n_rows, mean=False):
     src, ld = _mat(src)
-    out = torch.empty(n_rows, src.shape[1], dtype=torch.float32, device=src.device)
-    _call('stin_segment_sum_f32', _ptr(src), ld, _ptr(rowptr), _ptr(col), n_rows, src.shape[1], int(mean), _ptr(out),
+    out = torch.empty(n_rows, src.shape[1], dtype=src.dtype, device=src.device)
+    _call('stin_segment_sum' + _sfx(src), _ptr(src), ld, _ptr(rowptr), _ptr(col), n_rows, src.shape[1], int(mean), _ptr(out),
           out.stride(0) if n_rows > 1 else src.shape[1], _stream(src))
     return out
 
@@ -127,8 +142,8 @@ def segment_sum(src, rowptr, col, n_rows, mean=False):
 def gather_rows(src, idx, row_scale=None):
     src, ld = _mat(src)
     n = idx.numel()
-    out = torch.empty(n, src.shape[1], dtype=torch.float32, device=src.device)
-    _call('stin_gather_rows_f32', _ptr(src), ld, _ptr(idx), _ptr(row_scale), n, src.shape[1], _ptr(out), src.shape[1],
+    out = torch.empty(n, src.shape[1], dtype=src.dtype, device=src.device)
+    _call('stin_gather_rows' + _sfx(src), _ptr(src), ld, _ptr(idx), _ptr(row_scale), n, src.shape[1], _ptr(out), src.shape[1],
           _stream(src))
     return out
 
@@ -158,9 +173,10 @@ def colreduce(mode, x, groups, ptr, *, gout=None, mean=None, rstd=None, coef=Non
     ldg = 0
     if gout is not None:
         gout, ldg = _mat(gout)
+        _same(x, gout)
     ws_bytes = lib.stin_colreduce_workspace_bytes(C, B)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-    _call('stin_colreduce_f32', mode, _ptr(x), ldx, _ptr(gout), ldg, N, C, _ptr(ptr), B, _ptr(groups.gid),
+    _call('stin_colreduce' + _sfx(x), mode, _ptr(x), ldx, _ptr(gout), ldg, N, C, _ptr(ptr), B, _ptr(groups.gid),
           _ptr(groups.sid if use_sid else None), _ptr(mean), _ptr(rstd), _ptr(coef), post, _ptr(groups.inv_cnt),
           float(eps), _ptr(out0), _ptr(out1), _ptr(ws), ws_bytes, _stream(x))
     return (out0, out1) if out1 is not None else out0
@@ -194,8 +210,9 @@ def norm_act_res_fwd(x, mean, rstd, groups, res=None, act=True):
     ldres = 0
     if res is not None:
         res, ldres = _mat(res)
-    y = torch.empty(N, C, dtype=torch.float32, device=x.device)
-    _call('stin_norm_act_res_fwd_f32', _ptr(x), ldx, _ptr(mean), _ptr(rstd), _ptr(groups.gid), _ptr(res), ldres, N, C,
+        _same(x, res)
+    y = torch.empty(N, C, dtype=x.dtype, device=x.device)
+    _call('stin_norm_act_res_fwd' + _sfx(x), _ptr(x), ldx, _ptr(mean), _ptr(rstd), _ptr(groups.gid), _ptr(res), ldres, N, C,
           int(act), _ptr(y), C, _stream(x))
     return y
 
@@ -205,6 +222,7 @@ def instance_norm_act_bwd(x, gout, mean, rstd, groups, act=True, out=None):
     (incl. the linspace-slice quirk: sums over slices sigma, centring through g)."""
     x, ldx = _mat(x)
     gout, ldg = _mat(gout)
+    _same(x, gout, out)
     N, C = x.shape
     if act:
         T1, S0 = colreduce(RED_DOT_ELU, x, groups, groups.ptr_true, gout=gout, mean=mean, rstd=rstd)
@@ -221,8 +239,8 @@ def instance_norm_act_bwd(x, gout, mean, rstd, groups, act=True, out=None):
         k = -(rstd * rstd * rstd) * T1 * inv_cnt                   # indexed by the SUM slice (sid)
         U = colreduce(RED_COEF_XC, x, groups, groups.ptr_true, mean=mean, coef=k, use_sid=True)
         m = -(rstd * S0 + U) * inv_cnt
-    dx = out if out is not None else torch.empty(N, C, dtype=torch.float32, device=x.device)
-    _call('stin_norm_act_bwd_f32', _ptr(x), ldx, _ptr(gout), ldg, _ptr(mean), _ptr(rstd), _ptr(rstd), _ptr(k.contiguous()),
+    dx = out if out is not None else torch.empty(N, C, dtype=x.dtype, device=x.device)
+    _call('stin_norm_act_bwd' + _sfx(x), _ptr(x), ldx, _ptr(gout), ldg, _ptr(mean), _ptr(rstd), _ptr(rstd), _ptr(k.contiguous()),
           _ptr(m.contiguous()), _ptr(groups.gid), _ptr(groups.sid), N, C, int(act), _ptr(dx), dx.stride(0), _stream(x))
     return dx
 
@@ -242,9 +260,13 @@ PREC_FWD = int(os.environ.get('STIN_GEMM_FWD', GEMM_F16X3))
 PREC_BWD = int(os.environ.get('STIN_GEMM_BWD', GEMM_BF16X3))
 
 
-def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32, residual=None):
-    """A[M, K] . W[Nc, K]^T + bias * row_mask -> [M, Nc]  (hand-written fp32 MFMA kernel).
-    row_mask: optional [M] column view (stride = its row pitch) multiplying the bias per row."""
+def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32, residual=None, out_dtype=None):
+    """A[M, K] . W[Nc, K]^T + bias * row_mask -> [M, Nc]  (hand-written MFMA kernels).
+    row_mask: optional [M] column view (stride = its row pitch) multiplying the bias per row.
+    A in bf16 storage: W and bias stay fp32, one bf16 MFMA per k-step (`precision` is ignored), the result is bf16
+    unless out_dtype=torch.float32."""
+    if A.dtype == torch.bfloat16:
+        return _gemm_nt_bf16(A, W, bias, out, row_mask, residual, out_dtype)
     if _GEMM_BLAS_NT:
         if bias is None:
             r = torch.mm(A, W.t())
@@ -274,9 +296,45 @@ def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32, residu
     return out
 
 
+def _gemm_nt_bf16(A, W, bias, out, row_mask, residual, out_dtype):
+    A, lda = _mat(A)
+    W, ldw = _mat(W)
+    if W.dtype != torch.float32:
+        raise TypeError('gemm_nt on bf16 activations takes the fp32 master weights')
+    _same(A, row_mask, residual)
+    M, K = A.shape
+    Nc = W.shape[0]
+    assert W.shape[1] == K
+    if out is None:
+        out = torch.empty(M, Nc, dtype=out_dtype or torch.bfloat16, device=A.device)
+    ld_res = 0
+    if residual is not None:
+        residual, ld_res = _mat(residual)
+    _call('stin_gemm_nt_bf16', _ptr(A), lda, _ptr(W), ldw, _ptr(bias), _ptr(row_mask),
+          row_mask.stride(0) if row_mask is not None else 0, _ptr(residual), ld_res, M, Nc, K, _ptr(out),
+          out.stride(0) if M > 1 else max(Nc, out.stride(0)), int(out.dtype == torch.float32), _stream(A), tag=(M, Nc, K))
+    return out
+
+
 def gemm_tn(G, X, ones_column=False, row_weight=None, precision=GEMM_F32):
     """G[M, Nc]^T . [X[M, K] | w] -> [Nc, K (+1)]  (weight gradient; last column = bias gradient
-    sum_m w[m] G[m, :], w = row_weight (an [M] column view) or 1)."""
+    sum_m w[m] G[m, :], w = row_weight (an [M] column view) or 1).  bf16-storage operands -> fp32 result."""
+    if G.dtype == torch.bfloat16:
+        lib = _lib.load()
+        G, ldg = _mat(G)
+        X, ldx = _mat(X)
+        _same(G, X, row_weight)
+        M, Nc = G.shape
+        K = X.shape[1]
+        assert X.shape[0] == M
+        Kp = K + int(ones_column)
+        out = torch.empty(Nc, Kp, dtype=torch.float32, device=G.device)
+        ws_bytes = lib.stin_gemm_tn_workspace_bytes(M, Nc, K, int(ones_column))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)
+        _call('stin_gemm_tn_bf16', _ptr(G), ldg, _ptr(X), ldx, M, Nc, K, int(ones_column), _ptr(row_weight),
+              row_weight.stride(0) if row_weight is not None else 0, _ptr(out), Kp, _ptr(ws), ws_bytes, _stream(G),
+              tag=(M, Nc, K))
+        return out
     if _GEMM_BLAS_TN:
         r = torch.mm(G.t(), X)
         if not ones_column:
@@ -304,25 +362,28 @@ class LinearFn(torch.autograd.Function):
     """y = x W^T + b on the MFMA kernels (the tail Linears and the generic filter paths)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, out_fp32=False):
         x, _ = _mat(x)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return gemm_nt(x, weight, bias, precision=PREC_FWD)
+        return gemm_nt(x, weight, bias, precision=PREC_FWD, out_dtype=torch.float32 if out_fp32 else None)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
+        if g.dtype != x.dtype:                     # fp32 network output on bf16-storage activations
+            g = g.to(x.dtype)
         g, _ = _mat(g)
         dwb = gemm_tn(g, x, ones_column=ctx.has_bias, precision=PREC_BWD)
         dx = gemm_nt(g, weight.t().contiguous(), precision=PREC_BWD)
         if ctx.has_bias:
-            return dx, dwb[:, :-1].contiguous(), dwb[:, -1].contiguous()
-        return dx, dwb, None
+            return dx, dwb[:, :-1].contiguous(), dwb[:, -1].contiguous(), None
+        return dx, dwb, None, None
 
 
-def linear(x, weight, bias=None):
-    return LinearFn.apply(x, weight, bias)
+def linear(x, weight, bias=None, out_fp32=False):
+    """x W^T + b.  out_fp32: fp32 result from bf16-storage activations (the network's final output)."""
+    return LinearFn.apply(x, weight, bias, out_fp32)
 
 
 # ----------------------------------------------------------------------- autograd ops
@@ -346,8 +407,10 @@ class EdgeConvBlockFn(torch.autograd.Function):
         has_shortcut = Ws is not None
         Yw = 2 * H + (Cout if has_shortcut else 0)
         dev = x.device
-        Cp = (Cin + 3) // 4 * 4                                   # inner dimension padded for the 16-byte GEMM paths
-        if Cp != Cin:                                             # (the 10-channel network input -> 12)
+        b16 = x.dtype == torch.bfloat16
+        pad = 8 if b16 else 4
+        Cp = (Cin + pad - 1) // pad * pad                         # inner dimension padded for the 16-byte GEMM paths
+        if Cp != Cin:                                             # (the 10-channel network input -> 12; bf16: 16)
             xp = x.new_zeros(N, Cp)
             xp[:, :Cin] = x
         else:
@@ -361,9 +424,12 @@ class EdgeConvBlockFn(torch.autograd.Function):
         _call('stin_edgeconv_pack_f32', _ptr(W1c), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2c), Cin, Cp, H, Cout,
               int(has_shortcut), int(trans_inv), _ptr(wcat), _ptr(bcat), _ptr(wcatT), _ptr(w2T), _stream(x))
         Y = gemm_nt(xp, wcat, bcat, precision=PREC_FWD)
-        hE = torch.empty(N, H + 4, dtype=torch.float32, device=dev)
+        hE = torch.empty(N, H + pad, dtype=x.dtype, device=dev)     # [h | (deg > 0) | pad]: rows stay 16-byte multiples
         # ReLU decisions as bits (E*H/8 bytes): backward then needs no recompute gathers
         use_mask = USE_EDGE_MASK and edge_mask_supported(H) and Y.stride(0) % 4 == 0
+        if b16 and not use_mask:
+            raise NotImplementedError('bf16 storage needs the saved ReLU mask: hidden width %d not in '
+                                      '{128, 256, 512, 1024, 2048} (or STIN_EDGE_MASK=0)' % H)
         mask = torch.empty(max(edges.n_edges, 1) * (H // 32), dtype=torch.int32, device=dev) if use_mask else None
         edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True, mask=mask)
         agg = gemm_nt(hE[:, :H], W2c, b2, row_mask=hE[:, H], precision=PREC_FWD)
@@ -476,9 +542,9 @@ class PoolMaxFn(torch.autograd.Function):
     def forward(ctx, x, pool):
         x, ldx = _mat(x)
         C = x.shape[1]
-        out = torch.empty(pool.n_coarse, C, dtype=torch.float32, device=x.device)
+        out = torch.empty(pool.n_coarse, C, dtype=x.dtype, device=x.device)
         arg = torch.empty(pool.n_coarse, C, dtype=torch.int32, device=x.device)
-        _call('stin_pool_max_fwd_f32', _ptr(x), ldx, _ptr(pool.children.rowptr), _ptr(pool.children.col), pool.n_coarse, C,
+        _call('stin_pool_max_fwd' + _sfx(x), _ptr(x), ldx, _ptr(pool.children.rowptr), _ptr(pool.children.col), pool.n_coarse, C,
               _ptr(out), C, _ptr(arg), _stream(x))
         ctx.save_for_backward(arg)
         ctx.pool = pool
@@ -490,8 +556,8 @@ class PoolMaxFn(torch.autograd.Function):
         pool = ctx.pool
         g, ldg = _mat(g)
         C = g.shape[1]
-        gx = torch.empty(pool.n_fine, C, dtype=torch.float32, device=g.device)
-        _call('stin_pool_max_bwd_f32', _ptr(g), ldg, _ptr(arg), _ptr(pool.trace), pool.n_fine, C, _ptr(gx), C, _stream(g))
+        gx = torch.empty(pool.n_fine, C, dtype=g.dtype, device=g.device)
+        _call('stin_pool_max_bwd' + _sfx(g), _ptr(g), ldg, _ptr(arg), _ptr(pool.trace), pool.n_fine, C, _ptr(gx), C, _stream(g))
         return gx, None
 
 

@@ -88,6 +88,11 @@ class SurfaceTextureInpaintingNet(nn.Module):
         # plan's NormGroups carry the choice; blocks called directly with a raw batch tensor use their own
         # FastInstanceNorm.linspace_quirk (default True).
         self.compat_linspace_norm = True
+        # storage type of the per-vertex activations and their gradients (parameters, statistics and weight
+        # gradients are always fp32): torch.float32 = the reference's numerics (1e-4 bar); torch.bfloat16 = the
+        # build's mixed-precision extension for BASELINE configs 3/5 (see set_activation_dtype)
+        self.activation_dtype = torch.float32
+        self._filter_type, self._norm_type = filter_type, norm_type
         inplace, use_bias = False, True
         if self._use_embedding:  # created but never used by forward, as in the reference (:277-278, :409-410)
             self.label_embedding = nn.Embedding(num_classes, num_embedding, padding_idx=0)
@@ -129,6 +134,20 @@ class SurfaceTextureInpaintingNet(nn.Module):
             if isinstance(m, nn.Linear) and m.bias is not None:
                 nn.init.zeros_(m.bias)
 
+    def set_activation_dtype(self, dtype):
+        """torch.float32 (default) or torch.bfloat16: bf16 STORAGE of activations / activation gradients with fp32
+        accumulation, fp32 statistics, fp32 master weights and weight gradients.  The reference has no such mode
+        (fp32 only, no autocast): results then agree with the fp32 path to ~1e-2 on the tanh output, not 1e-4."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError('activation dtype must be torch.float32 or torch.bfloat16')
+        if dtype == torch.bfloat16 and not (self._filter_type in ('edgeconv', 'edgeconvtransinv')
+                                            and self._norm_type == 'instance'):
+            raise NotImplementedError('bf16 storage is implemented for the EdgeConv + instance-norm network '
+                                      '(the shipped configs), not for filter %s / norm %s'
+                                      % (self._filter_type, self._norm_type))
+        self.activation_dtype = dtype
+        return self
+
     # -- pooling ------------------------------------------------------------------------
     def _pooling(self, vertex_features, pool_map):
         if self._pooling_type == 'mean':
@@ -152,6 +171,8 @@ class SurfaceTextureInpaintingNet(nn.Module):
         plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm)
         num_levels = len(self.decoder_blocks) + 1
         out = sample.x
+        if self.activation_dtype != out.dtype:
+            out = out.to(self.activation_dtype)
         e0 = plan.edges('edge_index', 0)
         for blk in self.input_blocks:                               # norm over the WHOLE batch (reference :406-407)
             out = blk(out, e0, self._norm_arg(plan, 0, whole_batch=True))
@@ -180,7 +201,7 @@ class SurfaceTextureInpaintingNet(nn.Module):
             out = SF.InstanceNormActResFn.apply(out, None, plan.norm_groups(0), True)
         else:
             out = F.elu(self.final_norm1(out, batch=sample.batch))
-        out = torch.tanh(SF.linear(out, self.final_linear2.weight, self.final_linear2.bias))
+        out = torch.tanh(SF.linear(out, self.final_linear2.weight, self.final_linear2.bias, out_fp32=True))
         plan.validate()
         return out
 
