@@ -1075,6 +1075,12 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_slabs(const float* __restrict_
 
 inline int tn_tile(int n) { return n > 64 ? 128 : 64; }
 
+// tuning aid (profiles/gemm_tiles.py): STIN_NT_TILE is re-read on every call so that one process can sweep the tiles
+inline int stin_nt_force_tile() {
+    const char* e = getenv("STIN_NT_TILE");
+    return e ? atoi(e) : 0;
+}
+
 inline int tn_rows_per_chunk(int64_t M, int tiles) {
     // ~512 blocks (2 resident per CU, one round; measured best of 256..1536), chunks a multiple of the LDS slab
     static const int target = getenv("STIN_TN_BLOCKS") ? atoi(getenv("STIN_TN_BLOCKS")) : 512;   // tuning aid
@@ -1101,10 +1107,13 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     if (M == 0) return STIN_OK;
     STIN_REQUIRE(A && W && C, STIN_E_NULL);
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldw % 4 == 0) && stin_aligned16(A) && stin_aligned16(W);
-    // Tile choice: the largest tile that still leaves >= ~6 blocks per CU (256 CUs), so that the tail
-    // wave of blocks does not idle half the chip on the M ~ 2e4 levels.
+    // Tile choice, from a per-shape sweep on MI355X (profiles/gemm_tiles.py) and whole-step A/B runs: these skinny GEMMs
+    // are latency-bound, so the 64x64 tile (4x the blocks in flight) wins nearly everywhere.  128x128 is 6-22 % faster
+    // in isolation (operands warm in L2) for Nc % 128 == 0, K >= 256, M >= 6e4, but slower inside the training step,
+    // where A arrives from HBM - so it stays opt-in (STIN_NT_MINBLOCKS / STIN_NT_TILE).
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Nc + bn - 1) / bn); };
-    static const int64_t min_blocks = getenv("STIN_NT_MINBLOCKS") ? atoi(getenv("STIN_NT_MINBLOCKS")) : 1536;   // tuning aid
+    static const int64_t min_blocks = getenv("STIN_NT_MINBLOCKS") ? atoi(getenv("STIN_NT_MINBLOCKS")) : (int64_t)1 << 40;   // tuning aid
+    const int force_tile = stin_nt_force_tile();   // tuning aid: 0 = rule above, 1 = 128x128, 2 = 128x64, 3 = 64x64
 #define STIN_NT_ARGS A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc
 #define STIN_NT(KERNEL, BM_, BN_, WM_, WN_, ...)                                                                  \
     do {                                                                                                          \
@@ -1115,8 +1124,8 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
 #define STIN_NT_PICK(KERNEL, ...)                                                              \
     do {                                                                                       \
         if (Nc <= 32) STIN_NT(KERNEL, 128, 32, 4, 1, ##__VA_ARGS__);                           \
-        else if (Nc % 128 == 0 && blocks(128, 128) >= min_blocks) STIN_NT(KERNEL, 128, 128, 2, 2, ##__VA_ARGS__); \
-        else if (blocks(128, 64) >= min_blocks) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);  \
+        else if (force_tile == 1 || (force_tile == 0 && Nc % 128 == 0 && K >= 256 && blocks(128, 128) >= min_blocks)) STIN_NT(KERNEL, 128, 128, 2, 2, ##__VA_ARGS__); \
+        else if (force_tile == 2) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);  \
         else STIN_NT(KERNEL, 64, 64, 2, 2, ##__VA_ARGS__);                                     \
     } while (0)
     if (precision == STIN_GEMM_BF16X3) STIN_NT_PICK(k_gemm_nt_bf16s, 2, __bf16);
@@ -1205,8 +1214,7 @@ extern "C" int stin_gemm_nt_bf16(const stin_bf16_t* A_, int64_t lda, const float
     STIN_REQUIRE(A && W && C, STIN_E_NULL);
     const bool vec = (K % 8 == 0) && (lda % 8 == 0) && (ldw % 4 == 0) && stin_aligned16(A) && stin_aligned16(W);
     const int vec_out = (!c_is_f32 && Nc % 8 == 0 && ldc % 8 == 0 && stin_aligned16(C)) ? 1 : 0;
-    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Nc + bn - 1) / bn); };
-    static const int64_t min_blocks = getenv("STIN_NT_MINBLOCKS") ? atoi(getenv("STIN_NT_MINBLOCKS")) : 1536;
+    const int force_tile = stin_nt_force_tile();   // 64x64 is the best tile for every network shape (profiles/gemm_tiles.py)
 #define STIN_NTB(BM_, BN_, WM_, WN_, OUT_)                                                                             \
     do {                                                                                                               \
         dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((Nc + BN_ - 1) / BN_));                                  \
@@ -1216,8 +1224,8 @@ extern "C" int stin_gemm_nt_bf16(const stin_bf16_t* A_, int64_t lda, const float
 #define STIN_NTB_PICK(OUT_)                                                                          \
     do {                                                                                             \
         if (Nc <= 32) STIN_NTB(128, 32, 4, 1, OUT_);                                                 \
-        else if (Nc % 128 == 0 && blocks(128, 128) >= min_blocks) STIN_NTB(128, 128, 2, 2, OUT_);    \
-        else if (blocks(128, 64) >= min_blocks) STIN_NTB(128, 64, 2, 2, OUT_);                       \
+        else if (force_tile == 1) STIN_NTB(128, 128, 2, 2, OUT_);                                    \
+        else if (force_tile == 2) STIN_NTB(128, 64, 2, 2, OUT_);                                     \
         else STIN_NTB(64, 64, 2, 2, OUT_);                                                           \
     } while (0)
     if (c_is_f32) STIN_NTB_PICK(float);
