@@ -8,6 +8,12 @@ import sys
 
 
 def short(n):
+    m = re.match(r'_ZN12_GLOBAL__N_1\d+(k_\w+?)I(.*?)EEv', n)        # names the profiler left mangled (_Float16 args)
+    if m:
+        args = re.findall(r'Li(\d+)E|Lb([01])E|(DF16_|DF16b|f)', m.group(2))
+        pretty = [a or ('true' if b == '1' else 'false' if b else {'DF16_': '_Float16', 'DF16b': '__bf16', 'f': 'float'}[c])
+                  for a, b, c in args]
+        return '%s<%s>' % (m.group(1), ', '.join(pretty))
     n = re.sub(r'\(anonymous namespace\)::', '', n)
     n = re.sub(r'^void ', '', n)
     if n.startswith('Cijk_'):
