@@ -318,6 +318,27 @@ int stin_gemm_tn_bf16(const stin_bf16_t* G, int64_t ldg, const stin_bf16_t* X, i
                       int ones_column, const stin_bf16_t* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
                       void* workspace, size_t workspace_bytes, stin_stream_t stream);
 
+/* ------------------------------------------------- offline preprocessing on the GPU --
+ * The dilated-edge walk of preprocessing/graph_dilation.py:85-137 (`compute_dilated_edges`), one thread per
+ * directed adjacency entry (centre c = row_of[e], one-hop h = col[e]) of the COALESCED adjacency CSR
+ * (`rowptr`/`col`: neighbours of every vertex sorted by id, duplicates removed - pyg.utils.coalesce, :53-56):
+ * from h the walker repeatedly moves to the neighbour whose direction, pushed through the reference's
+ * plane_projection (:27-28) with the current vertex normal, has the largest cosine with the running direction
+ * (candidates adjacent to c or equal to the previous vertex excluded, similarity must be >= 0, the last maximum in
+ * adjacency order wins, :104-118) and records the vertex reached after d hops for every requested d.
+ *   dilations: HOST array of n_dil ascending ints in [2, 63];
+ *   out[i * E + e] = vertex reached for dilations[i] (the edge is [out, c]), -1 where the walk ended earlier.
+ * pos / nrm: [N, 3] row-major in the arithmetic type of the call (the pipeline passes float64,
+ * preprocessing/graph_level_generation.py:463-465; the reference's dil_test float32).  Bit-identical to
+ * oracle/dilation_oracle.py (fixed operation order, IEEE divide / sqrt, no FMA).
+ */
+int stin_dilated_walk_f32(const int32_t* rowptr, const int32_t* col, const int32_t* row_of, const float* pos,
+                          const float* nrm, int64_t N, int64_t E, const int32_t* dilations, int n_dil, int32_t* out,
+                          stin_stream_t stream);
+int stin_dilated_walk_f64(const int32_t* rowptr, const int32_t* col, const int32_t* row_of, const double* pos,
+                          const double* nrm, int64_t N, int64_t E, const int32_t* dilations, int n_dil, int32_t* out,
+                          stin_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

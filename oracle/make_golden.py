@@ -260,6 +260,63 @@ def g8_metrics():
     np.savez_compressed(os.path.join(OUT, 'g8_metrics.npz'), **d)
 
 
+def _jittered_mesh(n_side, seed):
+    """Small triangulated grid with jittered positions, noisy unit normals, permuted ids and shuffled edge order."""
+    rng = np.random.default_rng(seed)
+    idx = np.arange(n_side * n_side).reshape(n_side, n_side)
+    e = list(zip(idx[:, :-1].ravel(), idx[:, 1:].ravel())) + list(zip(idx[:-1, :].ravel(), idx[1:, :].ravel())) + \
+        list(zip(idx[:-1, :-1].ravel(), idx[1:, 1:].ravel()))
+    e = np.array(e).T
+    e = np.concatenate([e, e[::-1]], axis=1)
+    perm = rng.permutation(n_side * n_side)
+    e = perm[e]
+    gx, gy = np.meshgrid(np.arange(n_side), np.arange(n_side), indexing='ij')
+    pos = np.stack([gx.ravel(), gy.ravel(), np.zeros(n_side * n_side)], 1).astype(np.float64) + rng.normal(0, 0.2, (n_side * n_side, 3))
+    p = np.empty_like(pos)
+    p[perm] = pos
+    nrm = rng.normal(0, 0.3, pos.shape)
+    nrm[:, 2] += 1.0
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return e[:, rng.permutation(e.shape[1])].astype(np.int64), p, nrm
+
+
+def g9_preprocessing():
+    """Offline preprocessing either side of the path, outputs of the reference's OWN functions:
+    graph_dilation.compute_all_node_dilated_edges on its dil_test toy graph (float32, the only known-answer candidate
+    the reference holds) and on a jittered mesh (float64, as the pipeline calls it), and
+    graph_level_generation.vertex_clustering on the same mesh."""
+    gd, gl = ref_import.load_preprocessing()
+    d = {}
+    toy_e = np.array([[10, 9], [9, 10], [9, 6], [6, 9], [9, 7], [7, 9], [0, 7], [7, 0], [0, 8], [8, 0], [10, 0], [0, 10],
+                      [10, 3], [3, 10], [3, 1], [1, 3], [10, 11], [11, 10], [11, 2], [2, 11], [11, 5], [5, 11], [5, 4], [4, 5],
+                      [6, 4], [4, 6], [8, 12], [12, 8], [12, 13], [13, 12], [6, 14], [14, 6], [7, 14], [14, 7], [2, 15], [15, 2],
+                      [5, 15], [15, 5], [2, 16], [16, 2], [1, 16], [16, 1], [2, 3], [3, 2], [3, 0], [0, 3], [4, 17], [17, 4],
+                      [11, 17], [17, 11], [9, 17], [17, 9], [8, 13], [13, 8]], dtype=np.int64).T       # the toy graph of dil_test
+    toy_x = np.array([[2, -1], [-2, -4], [-5, -1], [-2, -1.5], [0, 3], [-4, 3], [3, 3], [4, 3], [4, -3], [2, 2], [1, 1], [-3, 1],
+                      [6, -2], [8, -3], [5, 4], [-7, 1], [-6, -4], [1, 2]], dtype=np.float32)
+    toy_x = np.concatenate([toy_x, np.zeros((toy_x.shape[0], 1), np.float32)], 1)
+    toy_n = np.zeros_like(toy_x)
+    toy_n[:, 2] = 1.0
+    d['toy_edge_index'], d['toy_pos'], d['toy_nrm'] = toy_e, toy_x, toy_n
+    d['toy_dilations'] = np.array([2, 4, 6])
+    for dil, out in zip((2, 4, 6), gd.compute_all_node_dilated_edges(toy_e, toy_x, toy_n, dilation=[2, 4, 6])):
+        d['toy_d%d' % dil] = out.numpy()
+    e, p, nrm = _jittered_mesh(16, 9)
+    d['mesh_edge_index'], d['mesh_pos'], d['mesh_nrm'] = e, p, nrm
+    d['mesh_dilations'] = np.array([2, 4, 8, 16])
+    for dil, out in zip((2, 4, 8, 16), gd.compute_all_node_dilated_edges(e, p, nrm, dilation=[2, 4, 8, 16])):
+        d['mesh_d%d' % dil] = out.numpy()
+    adj = [[] for _ in range(p.shape[0])]
+    for s, t in e.T:
+        adj[s].append(int(t))
+    nc, trace, _, edge_out = gl.vertex_clustering(p, adj, 2.5)
+    d['vc_voxel'] = np.array(2.5)
+    d['vc_coords'], d['vc_trace'] = nc, np.asarray(trace, dtype=np.int64)
+    d['vc_edges'] = np.array(sorted(map(tuple, edge_out)), dtype=np.int64)       # the reference's order is a set order
+    np.savez_compressed(os.path.join(OUT, 'g9_preprocessing.npz'), **d)
+    print('g9_preprocessing', {k: v.shape for k, v in d.items() if k.startswith(('toy_d', 'mesh_d', 'vc_'))})
+
+
 def param_counts(stin):
     """The structural constants SURVEY.md §8(c) records."""
     out = {}
@@ -288,6 +345,7 @@ def main():
     g6_graphnorm(stin, trainer_mod)
     g7_train_step(stin, trainer_mod)
     g8_metrics()
+    g9_preprocessing()
     param_counts(stin)
 
 

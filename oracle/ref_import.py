@@ -69,6 +69,19 @@ def load_module(name):
     return importlib.import_module(name)
 
 
+def load_preprocessing():
+    """-> (preprocessing.graph_dilation, preprocessing.graph_level_generation) with the mesh-IO libraries they import
+    but the graph functions do not need (open3d, plyfile) stubbed and tqdm silenced."""
+    setup()
+    _stub('open3d')
+    _stub('plyfile', PlyData=object)
+    _stub('termcolor', colored=lambda s, *a, **k: s)
+    _stub('git', Repo=object)
+    gd = importlib.import_module('preprocessing.graph_dilation')
+    gd.tqdm = lambda it: it
+    return gd, importlib.import_module('preprocessing.graph_level_generation')
+
+
 def load_imagegraph_dataset_class():
     """-> datasets.imagegraph_dataloader.ImageGraphTextureDataSet under stubs for the
     image libraries it imports but does not need for the index maps."""

@@ -84,6 +84,8 @@ for _n in ('stin_segment_sum', 'stin_edge_relu_mean_fwd', 'stin_edge_relu_mean_b
 SIGNATURES['stin_gemm_nt_bf16'] = SIGNATURES['stin_gemm_nt_f32']          # last int = c_is_f32 instead of precision
 SIGNATURES['stin_gemm_tn_bf16'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr,
                                            c_i64, c_ptr, c_size, c_ptr])
+for _n in ('stin_dilated_walk_f32', 'stin_dilated_walk_f64'):
+    SIGNATURES[_n] = (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.POINTER(c_i32), c_int, c_ptr, c_ptr])
 
 _lib = None
 
