@@ -229,6 +229,12 @@ int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_
                                 |a| >= 2^-6, |w| >= 2^-9 (absolute 2^-28 / 2^-31 below: made for normalised
                                 activations); A, W pre-scaled by 2^3, 2^6 internally (exact); needs
                                 |A| < 8188, |W| < 1023 (outside: inf/NaN, never a silently wrong value)   */
+#define STIN_GEMM_W_PRESPLIT 0x100 /* nt, OR-ed into BF16X3 / F16X3: W already holds its two 16-bit pieces, per 4-wide
+                                      k-group [hi x 4 | lo x 4] in the 16 bytes of the fp32 values it replaces (same
+                                      shape / ld / footprint; made by stin_gemm_split_weights_f32 or the pack kernel) -
+                                      the weight split is then done once per step instead of once per block    */
+int stin_gemm_split_weights_f32(const float* W, int64_t ldw, int Nc, int K, int precision, float* out, int64_t ldo,
+                                stin_stream_t stream);
 int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                      const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
                      int Nc, int K, float* C, int64_t ldc, int precision, stin_stream_t stream);
@@ -247,10 +253,13 @@ int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, i
  *   dw2b [Cout, H+1] (optional) -> contiguous dW2 [Cout, H], db2 [Cout].
  * (models/modules/edge_conv_filter.py:46-52, models/surfacetextureinpaintingnet.py:505-506)
  * norm_bwd_coef: k = -rstd^3 T1 inv_cnt, m = -rstd S0 inv_cnt for stin_norm_act_bwd_f32.
+ * fwd_split / bwd_split (0, STIN_GEMM_F16X3 or STIN_GEMM_BF16X3): write the forward operands (wcat, and a copy w2s
+ * [Cout, H] of W2) / the backward operands (wcatT, w2T) directly in the STIN_GEMM_W_PRESPLIT form of that precision.
  */
 int stin_edgeconv_pack_f32(const float* W1, const float* b1, const float* Ws, const float* bs, const float* W2,
                            int Cin, int Cp, int H, int Cout, int has_shortcut, int trans_inv, float* wcat,
-                           float* bcat, float* wcatT, float* w2T, stin_stream_t stream);
+                           float* bcat, float* wcatT, float* w2T, float* w2s, int fwd_split, int bwd_split,
+                           stin_stream_t stream);
 int stin_edgeconv_unpack_grads_f32(const float* dwb, const float* dw2b, int Cin, int Cp, int H, int Cout,
                                    int has_shortcut, int trans_inv, float* dW1, float* db1, float* dWs, float* dbs,
                                    float* dW2, float* db2, stin_stream_t stream);

@@ -18,6 +18,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BLOCK = 256;
 constexpr int BK = 32;
 
+// NT block -> output tile, XCD-aware: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own
+// 4 MB L2.  Row tile r lives on XCD r % 8 and its column blocks get CONSECUTIVE slots of that XCD, so the A rows of a tile
+// are fetched across the fabric once and then re-read from that L2 by the other column blocks (a 2-D grid dispatches
+// x-fastest: the column blocks of one row tile would start thousands of workgroups apart, on different XCDs).
+__device__ __forceinline__ bool nt_block_tile(int64_t M, int Nc, int BM, int BN, int64_t& m0, int& n0) {
+    const int64_t L = blockIdx.x;
+    const int64_t j = L >> 3;
+    const int ncol = (Nc + BN - 1) / BN;
+    const int64_t rt = (j / ncol) * 8 + (L & 7);
+    if (rt * BM >= M) return false;
+    m0 = rt * BM;
+    n0 = (int)(j % ncol) * BN;
+    return true;
+}
+inline unsigned nt_grid(int64_t M, int Nc, int BM, int BN) {
+    const int64_t nrow = (M + BM - 1) / BM, ncol = (Nc + BN - 1) / BN;
+    return (unsigned)(((nrow + 7) / 8) * 8 * ncol);
+}
+
 // ----------------------------------------------------------------------------- NT
 // Block tile BM x BN, 4 waves as WM x WN, each wave (BM/WM) x (BN/WN) = MT x NT MFMA tiles of 32x32.
 // A and W tiles are staged K-major in LDS ([BK][rows + 1]: conflict-free transposed stores and
@@ -37,8 +56,9 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt(const float* __restrict__ A, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int64_t m0;
+    int n0;
+    if (!nt_block_tile(M, Nc, BM, BN, m0, n0)) return;                 // block-uniform
     const int kq = tid % (BK / 4), r0 = tid / (BK / 4);   // staging: float4 index along k, first row
     constexpr int RSTEP = BLOCK / (BK / 4);                // rows covered per staging pass (32)
 
@@ -201,7 +221,7 @@ __device__ __forceinline__ void split_store(float4 v, PT* dst, int plane_stride,
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, typename PT, bool VEC>
+template <int BM, int BN, int WM, int WN, int NS, typename PT, bool VEC, bool WPRE = false>
 __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict__ A, int64_t lda,
                                                          const float* __restrict__ W, int64_t ldw,
                                                          const float* __restrict__ bias,
@@ -222,8 +242,9 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int64_t m0;
+    int n0;
+    if (!nt_block_tile(M, Nc, BM, BN, m0, n0)) return;                 // block-uniform
     const int kq = tid % (BKH / 4), r0 = tid / (BKH / 4);
     constexpr int RSTEP = BLOCK / (BKH / 4);
     auto swz = [](int row, int chunk) { return ((chunk ^ ((row >> 2) & 3)) << 3); };   // bf16 offset of a 16-byte chunk
@@ -283,7 +304,13 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
 #pragma unroll
         for (int s = 0; s < W_F4; ++s) {
             const int row = r0 + s * RSTEP;
-            split_store<NS, PT>(rw[s], &Ws[0][row][swz(row, kq >> 1) + (kq & 1) * 4], BN * BKH, WSCALE);
+            PT* dst = &Ws[0][row][swz(row, kq >> 1) + (kq & 1) * 4];
+            if (WPRE) {          // W arrives pre-split: [hi x 4 | lo x 4] per k-group (stin_pack.hip put_weight) - no VALU work
+                *reinterpret_cast<float2*>(dst) = make_float2(rw[s].x, rw[s].y);
+                *reinterpret_cast<float2*>(dst + BN * BKH) = make_float2(rw[s].z, rw[s].w);
+            } else {
+                split_store<NS, PT>(rw[s], dst, BN * BKH, WSCALE);
+            }
         }
     };
 
@@ -722,8 +749,9 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_b16(const stin_bf16* __restri
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int64_t m0;
+    int n0;
+    if (!nt_block_tile(M, Nc, BM, BN, m0, n0)) return;                 // block-uniform
     const int ch = tid & 7, r0 = tid >> 3;                       // staging: chunk along k, first row (32 rows per pass)
     auto swz = [](int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 3; };   // bf16 offset of a 16-byte chunk
 
@@ -1101,9 +1129,12 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
     STIN_REQUIRE(residual == nullptr || ld_res >= Nc, STIN_E_SIZE);
+    const bool wpre = (precision & STIN_GEMM_W_PRESPLIT) != 0;
+    precision &= ~STIN_GEMM_W_PRESPLIT;
     STIN_REQUIRE(precision == STIN_GEMM_F32 || precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6 ||
                      precision == STIN_GEMM_F16X3,
                  STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(!wpre || precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_F16X3, STIN_E_UNSUPPORTED);
     if (M == 0) return STIN_OK;
     STIN_REQUIRE(A && W && C, STIN_E_NULL);
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldw % 4 == 0) && stin_aligned16(A) && stin_aligned16(W);
@@ -1117,7 +1148,7 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
 #define STIN_NT_ARGS A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc
 #define STIN_NT(KERNEL, BM_, BN_, WM_, WN_, ...)                                                                  \
     do {                                                                                                          \
-        dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((Nc + BN_ - 1) / BN_));                             \
+        dim3 grid(nt_grid(M, Nc, BM_, BN_));                                                                      \
         if (vec) hipLaunchKernelGGL((KERNEL<BM_, BN_, WM_, WN_, ##__VA_ARGS__, true>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS); \
         else hipLaunchKernelGGL((KERNEL<BM_, BN_, WM_, WN_, ##__VA_ARGS__, false>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS);    \
     } while (0)
@@ -1128,7 +1159,15 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
         else if (force_tile == 2) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);  \
         else STIN_NT(KERNEL, 64, 64, 2, 2, ##__VA_ARGS__);                                     \
     } while (0)
-    if (precision == STIN_GEMM_BF16X3) STIN_NT_PICK(k_gemm_nt_bf16s, 2, __bf16);
+    if (wpre) {
+        // pre-split W: the 16-byte vector path only (K % 4 == 0, aligned rows) - one tile shape, the data is per-network
+        STIN_REQUIRE(vec, STIN_E_ALIGN);
+        dim3 grid(nt_grid(M, Nc, 64, 64));
+        if (precision == STIN_GEMM_BF16X3)
+            hipLaunchKernelGGL((k_gemm_nt_bf16s<64, 64, 2, 2, 2, __bf16, true, true>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS);
+        else
+            hipLaunchKernelGGL((k_gemm_nt_bf16s<64, 64, 2, 2, 2, _Float16, true, true>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS);
+    } else if (precision == STIN_GEMM_BF16X3) STIN_NT_PICK(k_gemm_nt_bf16s, 2, __bf16);
     else if (precision == STIN_GEMM_BF16X6) STIN_NT_PICK(k_gemm_nt_bf16s, 3, __bf16);
     else if (precision == STIN_GEMM_F16X3) STIN_NT_PICK(k_gemm_nt_bf16s, 2, _Float16);
     else STIN_NT_PICK(k_gemm_nt);
@@ -1217,7 +1256,7 @@ extern "C" int stin_gemm_nt_bf16(const stin_bf16_t* A_, int64_t lda, const float
     const int force_tile = stin_nt_force_tile();   // 64x64 is the best tile for every network shape (profiles/gemm_tiles.py)
 #define STIN_NTB(BM_, BN_, WM_, WN_, OUT_)                                                                             \
     do {                                                                                                               \
-        dim3 grid((unsigned)((M + BM_ - 1) / BM_), (unsigned)((Nc + BN_ - 1) / BN_));                                  \
+        dim3 grid(nt_grid(M, Nc, BM_, BN_));                                                                           \
         if (vec) hipLaunchKernelGGL((k_gemm_nt_b16<BM_, BN_, WM_, WN_, OUT_, true>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (OUT_*)C, ldc, vec_out); \
         else hipLaunchKernelGGL((k_gemm_nt_b16<BM_, BN_, WM_, WN_, OUT_, false>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (OUT_*)C, ldc, vec_out);    \
     } while (0)

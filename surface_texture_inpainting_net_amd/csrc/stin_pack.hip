@@ -6,12 +6,47 @@
 namespace {
 constexpr int BLOCK = 256;
 
+// Weight operand of stin_gemm_nt_f32 in PRE-SPLIT form (precision | STIN_GEMM_W_PRESPLIT): the two 16-bit pieces the
+// kernel would otherwise compute for every block that stages the tile.  Same footprint as fp32: the 16 bytes of the
+// k-group 4g..4g+3 of a row hold [hi x 4 | lo x 4]; piece type / pre-scale as in stin_gemm.hip (fp16: x 64, bf16: x 1).
+// mode 0 = plain fp32.
+__device__ __forceinline__ void put_weight(float* __restrict__ base, int64_t row_off, int c, float v, int mode) {
+    if (mode == 0) {
+        base[row_off + c] = v;
+        return;
+    }
+    uint16_t* h = reinterpret_cast<uint16_t*>(base + row_off + (c & ~3)) + (c & 3);
+    if (mode == STIN_GEMM_F16X3) {
+        const float s = v * 64.f;
+        const _Float16 hi = (_Float16)s;
+        const _Float16 lo = (_Float16)(s - (float)hi);
+        h[0] = *reinterpret_cast<const uint16_t*>(&hi);
+        h[4] = *reinterpret_cast<const uint16_t*>(&lo);
+    } else {
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        h[0] = *reinterpret_cast<const uint16_t*>(&hi);
+        h[4] = *reinterpret_cast<const uint16_t*>(&lo);
+    }
+}
+
+__global__ void k_split_weights(const float* __restrict__ W, int64_t ldw, int Nc, int K, int mode, float* __restrict__ out,
+                                int64_t ldo) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)Nc * K) return;
+    const int r = (int)(t / K), c = (int)(t % K);
+    put_weight(out, (int64_t)r * ldo, c, W[(int64_t)r * ldw + c], mode);
+}
+
 // wcat [Yw, Cin] = [Wa - Wb ; Wb ; Ws]   (trans_inv: [-W1 ; W1 ; Ws]),  bcat [Yw] = [b1 ; 0 ; bs],
-// wcatT [Cin, Yw] = wcat^T,  w2T [H, Cout] = W2^T.   Yw = 2H (+ Cout with a shortcut).
+// wcatT [Cin, Yw] = wcat^T,  w2T [H, Cout] = W2^T,  w2s [Cout, H] = W2 (only when pre-split).  Yw = 2H (+ Cout with a
+// shortcut).  fwd_mode / bwd_mode: the storage form (put_weight) of the forward operands (wcat, w2s) and of the
+// backward operands (wcatT, w2T).
 __global__ void k_pack(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ Ws,
                        const float* __restrict__ bs, const float* __restrict__ W2, int Cin, int Cp, int H, int Cout,
                        int has_shortcut, int trans_inv, float* __restrict__ wcat, float* __restrict__ bcat,
-                       float* __restrict__ wcatT, float* __restrict__ w2T) {
+                       float* __restrict__ wcatT, float* __restrict__ w2T, float* __restrict__ w2s, int fwd_mode,
+                       int bwd_mode) {
     const int Yw = 2 * H + (has_shortcut ? Cout : 0);
     const int ld1 = trans_inv ? Cin : 2 * Cin;
     const int64_t n_w = (int64_t)Yw * Cp, n_2 = (int64_t)H * Cout;
@@ -24,13 +59,15 @@ __global__ void k_pack(const float* __restrict__ W1, const float* __restrict__ b
             else if (r < 2 * H) v = trans_inv ? W1[(int64_t)(r - H) * ld1 + c] : W1[(int64_t)(r - H) * ld1 + Cin + c];
             else v = Ws[(int64_t)(r - 2 * H) * Cin + c];
         }
-        wcat[t] = v;
-        wcatT[(int64_t)c * Yw + r] = v;
+        put_weight(wcat, (int64_t)r * Cp, c, v, fwd_mode);
+        put_weight(wcatT, (int64_t)c * Yw, r, v, bwd_mode);
         if (c == 0) bcat[r] = r < H ? (b1 != nullptr ? b1[r] : 0.f) : (r < 2 * H ? 0.f : (bs != nullptr ? bs[r - 2 * H] : 0.f));
     } else if (t < n_w + n_2) {
         const int64_t u = t - n_w;
         const int k = (int)(u / Cout), o = (int)(u % Cout);      // w2T[k][o] = W2[o][k]
-        w2T[u] = W2[(int64_t)o * H + k];
+        const float v = W2[(int64_t)o * H + k];
+        put_weight(w2T, (int64_t)k * Cout, o, v, bwd_mode);
+        if (w2s != nullptr) put_weight(w2s, (int64_t)o * H, k, v, fwd_mode);
     }
 }
 
@@ -80,16 +117,35 @@ __global__ void k_norm_coef(const float* __restrict__ T1, const float* __restric
 }
 }  // namespace
 
+static inline bool split_mode_ok(int m) { return m == 0 || m == STIN_GEMM_BF16X3 || m == STIN_GEMM_F16X3; }
+
+extern "C" int stin_gemm_split_weights_f32(const float* W, int64_t ldw, int Nc, int K, int precision, float* out, int64_t ldo,
+                                           stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(Nc > 0 && K > 0 && ldw >= K && ldo >= K, STIN_E_SIZE);
+    STIN_REQUIRE(W && out, STIN_E_NULL);
+    STIN_REQUIRE(split_mode_ok(precision) && precision != 0, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(K % 4 == 0 && ldo % 4 == 0 && stin_aligned16(out), STIN_E_ALIGN);
+    const int64_t n = (int64_t)Nc * K;
+    hipLaunchKernelGGL(k_split_weights, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream_, W, ldw,
+                       Nc, K, precision, out, ldo);
+    return stin_launch_status();
+}
+
 extern "C" int stin_edgeconv_pack_f32(const float* W1, const float* b1, const float* Ws, const float* bs, const float* W2,
                                       int Cin, int Cp, int H, int Cout, int has_shortcut, int trans_inv, float* wcat,
-                                      float* bcat, float* wcatT, float* w2T, stin_stream_t stream_) {
+                                      float* bcat, float* wcatT, float* w2T, float* w2s, int fwd_split, int bwd_split,
+                                      stin_stream_t stream_) {
     stin_clear_stale_error();
     STIN_REQUIRE(Cin > 0 && Cp >= Cin && H > 0 && Cout > 0, STIN_E_SIZE);
     STIN_REQUIRE(W1 && W2 && wcat && bcat && wcatT && w2T && (!has_shortcut || Ws), STIN_E_NULL);
+    STIN_REQUIRE(split_mode_ok(fwd_split) && split_mode_ok(bwd_split), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(fwd_split == 0 || (w2s != nullptr && Cp % 4 == 0 && H % 4 == 0), STIN_E_ALIGN);
+    STIN_REQUIRE(bwd_split == 0 || (Cout % 4 == 0 && H % 2 == 0), STIN_E_ALIGN);     // Yw = 2H (+ Cout) must be a multiple of 4
     const int Yw = 2 * H + (has_shortcut ? Cout : 0);
     const int64_t n = (int64_t)Yw * Cp + (int64_t)H * Cout;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream_, W1, b1, Ws,
-                       bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T);
+                       bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T, w2s, fwd_split, bwd_split);
     return stin_launch_status();
 }
 

@@ -258,6 +258,8 @@ GEMM_F32, GEMM_BF16X3, GEMM_BF16X6, GEMM_F16X3 = 0, 2, 3, 4
 # rms 4e-6, far inside the 1e-3 gradient tolerance).
 PREC_FWD = int(os.environ.get('STIN_GEMM_FWD', GEMM_F16X3))
 PREC_BWD = int(os.environ.get('STIN_GEMM_BWD', GEMM_BF16X3))
+GEMM_W_PRESPLIT = 0x100            # nt: the weight operand already holds its two 16-bit pieces (stin_hip.h)
+WEIGHT_PRESPLIT = os.environ.get('STIN_WEIGHT_PRESPLIT', '1') != '0' and not _GEMM_BLAS_NT
 
 
 def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32, residual=None, out_dtype=None):
@@ -313,6 +315,15 @@ def _gemm_nt_bf16(A, W, bias, out, row_mask, residual, out_dtype):
     _call('stin_gemm_nt_bf16', _ptr(A), lda, _ptr(W), ldw, _ptr(bias), _ptr(row_mask),
           row_mask.stride(0) if row_mask is not None else 0, _ptr(residual), ld_res, M, Nc, K, _ptr(out),
           out.stride(0) if M > 1 else max(Nc, out.stride(0)), int(out.dtype == torch.float32), _stream(A), tag=(M, Nc, K))
+    return out
+
+
+def split_weights(W, precision):
+    """fp32 W [Nc, K] -> the STIN_GEMM_W_PRESPLIT form for `precision` (GEMM_BF16X3 or GEMM_F16X3), same shape."""
+    W, ldw = _mat(W)
+    out = torch.empty_like(W, memory_format=torch.contiguous_format)
+    _call('stin_gemm_split_weights_f32', _ptr(W), ldw, W.shape[0], W.shape[1], int(precision), _ptr(out), W.shape[1],
+          _stream(W))
     return out
 
 
@@ -415,15 +426,22 @@ class EdgeConvBlockFn(torch.autograd.Function):
             xp[:, :Cin] = x
         else:
             xp = x
-        pack = torch.empty(Yw * Cp * 2 + Yw + H * Cout, dtype=torch.float32, device=dev)
+        # forward / backward weight operands, pre-split once here into the two 16-bit pieces the split GEMMs use
+        # (instead of once per GEMM block); plain fp32 for the other precisions and for bf16-storage activations
+        fsp = PREC_FWD if (not b16 and PREC_FWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT) else 0
+        bsp = PREC_BWD if (not b16 and PREC_BWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT and Cout % 4 == 0) else 0
+        pack = torch.empty(Yw * Cp * 2 + 2 * H * Cout + Yw, dtype=torch.float32, device=dev)
         wcat = pack[:Yw * Cp].view(Yw, Cp)
         wcatT = pack[Yw * Cp:2 * Yw * Cp].view(Cp, Yw)
         w2T = pack[2 * Yw * Cp:2 * Yw * Cp + H * Cout].view(H, Cout)
-        bcat = pack[2 * Yw * Cp + H * Cout:]
+        w2s = pack[2 * Yw * Cp + H * Cout:2 * Yw * Cp + 2 * H * Cout].view(Cout, H)
+        bcat = pack[2 * Yw * Cp + 2 * H * Cout:]
         W1c, W2c = W1.contiguous(), W2.contiguous()
         _call('stin_edgeconv_pack_f32', _ptr(W1c), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2c), Cin, Cp, H, Cout,
-              int(has_shortcut), int(trans_inv), _ptr(wcat), _ptr(bcat), _ptr(wcatT), _ptr(w2T), _stream(x))
-        Y = gemm_nt(xp, wcat, bcat, precision=PREC_FWD)
+              int(has_shortcut), int(trans_inv), _ptr(wcat), _ptr(bcat), _ptr(wcatT), _ptr(w2T), _ptr(w2s) if fsp else None,
+              fsp, bsp, _stream(x))
+        pf = (PREC_FWD | GEMM_W_PRESPLIT) if fsp else PREC_FWD
+        Y = gemm_nt(xp, wcat, bcat, precision=pf)
         hE = torch.empty(N, H + pad, dtype=x.dtype, device=dev)     # [h | (deg > 0) | pad]: rows stay 16-byte multiples
         # ReLU decisions as bits (E*H/8 bytes): backward then needs no recompute gathers
         use_mask = USE_EDGE_MASK and edge_mask_supported(H) and Y.stride(0) % 4 == 0
@@ -432,7 +450,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
                                       '{128, 256, 512, 1024, 2048} (or STIN_EDGE_MASK=0)' % H)
         mask = torch.empty(max(edges.n_edges, 1) * (H // 32), dtype=torch.int32, device=dev) if use_mask else None
         edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True, mask=mask)
-        agg = gemm_nt(hE[:, :H], W2c, b2, row_mask=hE[:, H], precision=PREC_FWD)
+        agg = gemm_nt(hE[:, :H], w2s if fsp else W2c, b2, row_mask=hE[:, H], precision=pf)
         mean, rstd = instance_stats(agg, groups)
         res = Y[:, 2 * H:] if has_shortcut else x
         out = norm_act_res_fwd(agg, mean, rstd, groups, res=res, act=True)
@@ -442,6 +460,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut, ctx.trans_inv = edges, groups, H, has_shortcut, trans_inv
         ctx.has_b1, ctx.has_b2, ctx.has_bs = b1 is not None, b2 is not None, bs is not None
         ctx.w1_shape = tuple(W1.shape)
+        ctx.prec_bwd_nt = (PREC_BWD | GEMM_W_PRESPLIT) if bsp else PREC_BWD
         return out
 
     @staticmethod
@@ -452,7 +471,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         g, _ = _mat(g)
         dagg = instance_norm_act_bwd(agg, g, mean, rstd, groups, act=True)
         dw2b = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H], precision=PREC_BWD)   # [Cout, H + 1] = dW2 | db2
-        dhE = gemm_nt(dagg, w2T, precision=PREC_BWD)                                             # [N, H] = dagg W2
+        dhE = gemm_nt(dagg, w2T, precision=ctx.prec_bwd_nt)                                             # [N, H] = dagg W2
         dY = torch.empty_like(Y)
         if ctx.mask is not None:
             edge_relu_mean_bwd_dst_mask(dhE, ctx.mask, edges.by_dst, dY[:, :H])
@@ -469,7 +488,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         # needs no gradient (the network input of the first block)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = gemm_nt(dY, wcatT, precision=PREC_BWD, residual=None if ctx.has_shortcut else g)
+            dx = gemm_nt(dY, wcatT, precision=ctx.prec_bwd_nt, residual=None if ctx.has_shortcut else g)
             if Cp != Cin:
                 dx = dx[:, :Cin]
         dev = x.device

@@ -217,6 +217,11 @@ def test_gemm_nt_precision_modes(M, Nc, K):
     wi = torch.randint(-3, 4, (Nc, K), generator=g).float().to(DEV)
     for p in (SF.GEMM_F32, SF.GEMM_BF16X3, SF.GEMM_BF16X6, SF.GEMM_F16X3):
         assert torch.equal(SF.gemm_nt(small, wi, precision=p).double(), small.double() @ wi.double().t())
+    # pre-split weight operand (split once per step by the pack kernel): the very same arithmetic
+    if K % 4 == 0:
+        for p in (SF.GEMM_BF16X3, SF.GEMM_F16X3):
+            assert torch.equal(SF.gemm_nt(A, SF.split_weights(W, p), b, precision=p | SF.GEMM_W_PRESPLIT),
+                               SF.gemm_nt(A, W, b, precision=p)), p
     # fp16 split: out-of-range operands must fail loudly (inf/NaN), tiny ones degrade to absolute precision
     big = A.clone()
     big[0, 0] = 1e4
