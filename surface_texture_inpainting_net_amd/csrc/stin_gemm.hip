@@ -1101,7 +1101,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_slabs(const float* __restrict_
     }
 }
 
-inline int tn_tile(int n) { return n > 64 ? 128 : 64; }
+inline int tn_tile(int n) {
+    static const int cap = getenv("STIN_TN_TILE") ? atoi(getenv("STIN_TN_TILE")) : 128;   // tuning aid: 64 forces 64x64 tiles
+    return (n > 64 && cap >= 128) ? 128 : 64;    // (measured: 64x64 wgrad tiles are 2-5 % slower end to end at any slab count)
+}
 
 // tuning aid (profiles/gemm_tiles.py): STIN_NT_TILE is re-read on every call so that one process can sweep the tiles
 inline int stin_nt_force_tile() {
