@@ -54,8 +54,10 @@ def pmc_traffic_bytes(kernel, n, e, h):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json, collected at
     the headline level-0 shape with profiles/pmc_kernels.py; FETCH_SIZE doubled per the gfx950 correction)."""
     import glob
-    if (n, e) != (200704, 1200642) or kernel.endswith('_bf16'):
+    if (n, e) != (200704, 1200642):
         return None
+    elem = '__bf16' if kernel.endswith('_bf16') else 'float'
+    kernel = kernel.replace('_bf16', '_f32')
     c4 = h // 4
     g = 1
     while g < c4 and g < 64:
@@ -67,7 +69,7 @@ def pmc_traffic_bytes(kernel, n, e, h):
              'stin_edge_relu_mean_bwd_src_f32': 'k_edge_bwd_src',
              'stin_edge_relu_mean_bwd_dst_mask_f32': 'k_edge_bwd_dst_mask',
              'stin_edge_relu_mean_bwd_src_mask_f32': 'k_edge_bwd_src_mask'}[kernel]
-    key = '%s<%d, %d, %d>' % (short, g, vpl, u)
+    key = '%s<%s, %d, %d, %d>' % (short, elem, g, vpl, u)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
     if not files:
         return None
@@ -211,7 +213,7 @@ def main():
     SF.KernelTimer.start(['stin_edge_relu_mean_fwd' + sfx, 'stin_edge_relu_mean_bwd_dst_f32',
                           'stin_edge_relu_mean_bwd_src_f32', 'stin_edge_relu_mean_bwd_dst_mask' + sfx,
                           'stin_edge_relu_mean_bwd_src_mask' + sfx] + (['stin_gemm_nt' + sfx, 'stin_gemm_tn' + sfx] if args.time_gemms else []),
-                         max_records=1_000_000 if args.time_gemms else 400)
+                         max_records=1_000_000 if args.time_gemms else 150)   # ~3 steps' worth of edge launches: event pairs are not free
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()

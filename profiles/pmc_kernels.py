@@ -30,6 +30,13 @@ for _ in range(5):
     SF.edge_relu_mean_bwd_src_mask(G, mask, e, out)
     SF.edge_relu_mean_bwd_dst(A, B, G, e.by_dst, out)               # recompute forms (STIN_EDGE_MASK=0)
     SF.edge_relu_mean_bwd_src(A, B, G, e.inv_deg, e.by_src, out)
+# bf16-storage twins of the training-step kernels
+A16, B16, G16 = A.bfloat16(), B.bfloat16(), G.bfloat16()
+out16 = torch.empty(n, H, dtype=torch.bfloat16, device=dev)
+for _ in range(5):
+    SF.edge_relu_mean_fwd(A16, B16, e.by_dst, out16, mask=mask)
+    SF.edge_relu_mean_bwd_dst_mask(G16, mask, e.by_dst, out16)
+    SF.edge_relu_mean_bwd_src_mask(G16, mask, e, out16)
 # standalone scatter-add: src[E, 64] -> out[N, 64], index in arbitrary edge order
 g = torch.Generator().manual_seed(0)
 idx = torch.randint(0, 200_000, (1_200_000,), generator=g).to(dev)

@@ -14,7 +14,13 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r.get('Counter_Name') != counter:
             continue
-        name = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
+        name = r['Kernel_Name']
+        m = re.match(r'_ZN12_GLOBAL__N_1\d+(k_\w+?)I(.*?)EEv', name)          # names the profiler left mangled (__bf16 / _Float16)
+        if m:
+            args = re.findall(r'Li(\d+)E|Lb([01])E|(DF16_|DF16b|f)', m.group(2))
+            name = '%s<%s>' % (m.group(1), ', '.join(a or ('true' if b == '1' else 'false' if b else
+                                                            {'DF16_': '_Float16', 'DF16b': '__bf16', 'f': 'float'}[c]) for a, b, c in args))
+        name = re.sub(r'\(anonymous namespace\)::', '', name)
         name = re.sub(r'^void ', '', name)
         name = re.sub(r'\(.*', '', name)
         acc[name].append(float(r['Counter_Value']))
