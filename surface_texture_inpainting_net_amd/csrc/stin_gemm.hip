@@ -579,6 +579,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
 
     float4 patch[NPASS][4];
     float pw[4];
+    bool pv[4];
     auto load_slab = [&](int64_t m0) {
 #pragma unroll
         for (int s = 0; s < NPASS; ++s) {
@@ -607,7 +608,14 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
                     }
                 }
                 patch[s][r] = v;
-                if (s == 0) pw[r] = (want_bias && row < me) ? (row_w != nullptr ? row_w[row * ld_w] : 1.f) : 0.f;
+                // row weight of the bias-gradient column: a PLAIN load (clamped row, no select on the loaded value), so that
+                // the compiler does not have to drain the prefetched patch loads before the MFMAs; masked in store_slab
+                if (s == 0) {
+                    const int64_t rc = row < me ? row : me - 1;
+                    const float* wp = (want_bias && row_w != nullptr) ? row_w + rc * ld_w : G;   // always a valid address
+                    pw[r] = *wp;
+                    pv[r] = row < me;
+                }
             }
         }
     };
@@ -623,10 +631,11 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
             if (s == 0 && isG) {                                   // 2*TI >= 128: pass 0 holds every G patch of TI=128; see below for TI=64
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    bs.x += pw[r] * patch[s][r].x;
-                    bs.y += pw[r] * patch[s][r].y;
-                    bs.z += pw[r] * patch[s][r].z;
-                    bs.w += pw[r] * patch[s][r].w;
+                    const float w = (want_bias && pv[r]) ? (row_w != nullptr ? pw[r] : 1.f) : 0.f;
+                    bs.x += w * patch[s][r].x;
+                    bs.y += w * patch[s][r].y;
+                    bs.z += w * patch[s][r].z;
+                    bs.w += w * patch[s][r].w;
                 }
             }
             __bf16* dst = isG ? &Gt[0][c4 * 4][rg * 4] : &Xt[0][c4 * 4][rg * 4];
@@ -652,11 +661,12 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
     };
 
     const int kh = lane >> 5, li = lane & 31;
+    load_slab(mb);
     for (int64_t m0 = mb; m0 < me; m0 += TNB_R) {
-        load_slab(m0);
         __syncthreads();                                           // previous slab's fragment reads are done
         store_slab(0);
         __syncthreads();
+        if (m0 + TNB_R < me) load_slab(m0 + TNB_R);                // next slab's global loads in flight during the MFMAs
 #pragma unroll
         for (int ks = 0; ks < TNB_R; ks += 16) {
             bf16x8 a[NS][MT], c[NS][NT];
@@ -954,7 +964,8 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restri
     for (int e = 0; e < 8; ++e) bs[e] = 0.f;
 
     uint4 patch[NPASS][4];
-    float pw[NPASS][4];
+    uint16_t pw[NPASS][4];
+    bool pv[NPASS][4];
     auto load_slab = [&](int64_t m0) {
 #pragma unroll
         for (int s = 0; s < NPASS; ++s) {
@@ -983,7 +994,10 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restri
                     }
                 }
                 patch[s][r] = v;
-                pw[s][r] = (want_bias && isG && live && row < me) ? (row_w != nullptr ? (float)row_w[row * ld_w] : 1.f) : 0.f;
+                const int64_t rc = row < me ? row : me - 1;        // plain load, masked in store_slab (see k_gemm_tn_bf16s)
+                const stin_bf16* wp = (want_bias && row_w != nullptr) ? row_w + rc * ld_w : G;   // always a valid address
+                pw[s][r] = *reinterpret_cast<const uint16_t*>(wp);   // raw bits: widened in store_slab, no use of the value here
+                pv[s][r] = isG && live && row < me;
             }
         }
     };
@@ -999,10 +1013,11 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const uint4 v = patch[s][r];
-                    bs[0] += pw[s][r] * bf16_lo(v.x); bs[1] += pw[s][r] * bf16_hi(v.x);
-                    bs[2] += pw[s][r] * bf16_lo(v.y); bs[3] += pw[s][r] * bf16_hi(v.y);
-                    bs[4] += pw[s][r] * bf16_lo(v.z); bs[5] += pw[s][r] * bf16_hi(v.z);
-                    bs[6] += pw[s][r] * bf16_lo(v.w); bs[7] += pw[s][r] * bf16_hi(v.w);
+                    const float w = pv[s][r] ? (row_w != nullptr ? bf16_lo(pw[s][r]) : 1.f) : 0.f;
+                    bs[0] += w * bf16_lo(v.x); bs[1] += w * bf16_hi(v.x);
+                    bs[2] += w * bf16_lo(v.y); bs[3] += w * bf16_hi(v.y);
+                    bs[4] += w * bf16_lo(v.z); bs[5] += w * bf16_hi(v.z);
+                    bs[6] += w * bf16_lo(v.w); bs[7] += w * bf16_hi(v.w);
                 }
             }
             stin_bf16* dst = isG ? &Gt[c8 * 8][rg * 4] : &Xt[c8 * 8][rg * 4];
@@ -1024,11 +1039,12 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restri
     };
 
     const int kh = lane >> 5, li = lane & 31;
+    load_slab(mb);
     for (int64_t m0 = mb; m0 < me; m0 += TNK_R) {
-        load_slab(m0);
         __syncthreads();                                           // previous slab's fragment reads are done
         store_slab();
         __syncthreads();
+        if (m0 + TNK_R < me) load_slab(m0 + TNK_R);                // next slab's global loads in flight during the MFMAs
 #pragma unroll
         for (int ks = 0; ks < TNK_R; ks += 16) {
             bf16x8 a[MT], c[NT];
