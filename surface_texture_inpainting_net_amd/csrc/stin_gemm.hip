@@ -379,15 +379,19 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
 // slab's loads in flight during the MFMAs) and the MFMA fragments are stride-1 ds_read_b32:
 // A[i][k] = Gs[k][i], B[k][j] = Xs[k][j] with k = the row inside the slab.  4 waves as 2 x 2, each
 // (TI/2) x (TJ/2).  The bias gradient sum_m w[m] G[m, :] is accumulated on the VALU by the staging
-// threads of the j-tile-0 blocks.  Partial tiles go to slab[chunk][Nc][Kp]; k_reduce_slabs adds them
+// threads of the j-tile-0 blocks.  Partial tiles go to the chunk block of the slab workspace (tn_chunk_stride); k_reduce_slabs adds them
 // in a fixed order.  Blocks are numbered so that all tiles of one row chunk share an XCD
 // (blockIdx % 8 is the observed XCD round-robin): the chunk's rows are re-read from that L2.
 constexpr int TN_R = 32;   // rows per LDS slab
+// One chunk's partial result in the slab workspace: the weight block [Nc][Kq] (Kq = K rounded up to 4: rows stay
+// 16-byte aligned, and 128-byte aligned for the usual K % 32 == 0, so the tile stores are whole cache lines) followed
+// by the bias-gradient partials [Nc] - NOT an odd-pitched [Nc][K + 1] matrix.
+__host__ __device__ __forceinline__ int64_t tn_chunk_stride(int Nc, int Kq) { return (int64_t)Nc * Kq + ((Nc + 3) & ~3); }
 
 template <int TI, int TJ, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, int64_t ldg,
                                                    const float* __restrict__ X, int64_t ldx, int64_t M, int Nc,
-                                                   int K, int Kp, const float* __restrict__ row_w, int64_t ld_w,
+                                                   int K, int Kq, int has_bias, const float* __restrict__ row_w, int64_t ld_w,
                                                    int rows_per_chunk, int tiles_i, int tiles_j, int64_t chunks,
                                                    float* __restrict__ slab) {
     constexpr int MT = TI / 64, NT = TJ / 64;                    // 32x32 MFMA tiles per wave
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, 
     const int i0 = ti * TI, j0 = tj * TJ;
     const int64_t mb = chunk * rows_per_chunk;
     const int64_t me = (mb + rows_per_chunk < M) ? mb + rows_per_chunk : M;
-    const bool want_bias = (Kp > K) && (tj == 0);
+    const bool want_bias = has_bias && (tj == 0);
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, 
         buf ^= 1;
     }
 
-    float* out = slab + chunk * (int64_t)Nc * Kp;
+    float* out = slab + chunk * tn_chunk_stride(Nc, Kq);
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         const int col = j0 + wj * (TJ / 2) + u * 32 + li;
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wi * (TI / 2) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < Nc) out[(int64_t)row * Kp + col] = acc[t][u][r];
+                if (row < Nc) out[(int64_t)row * Kq + col] = acc[t][u][r];
             }
     }
     if (want_bias) {                                              // block-uniform branch
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, 
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < BLOCK / GC4; ++r) t += bsum[r][tid];
-            if (i0 + tid < Nc) out[(int64_t)(i0 + tid) * Kp + K] = t;
+            if (i0 + tid < Nc) out[(int64_t)Nc * Kq + i0 + tid] = t;
         }
     }
 }
@@ -542,7 +546,7 @@ constexpr int TNB_PITCH = TNB_R + 8;       // bf16 per LDS row (80 bytes)
 template <int TI, int TJ, int NS, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict__ G, int64_t ldg,
                                                          const float* __restrict__ X, int64_t ldx, int64_t M,
-                                                         int Nc, int K, int Kp, const float* __restrict__ row_w,
+                                                         int Nc, int K, int Kq, int has_bias, const float* __restrict__ row_w,
                                                          int64_t ld_w, int rows_per_chunk, int tiles_i, int tiles_j,
                                                          int64_t chunks, float* __restrict__ slab) {
     constexpr int MT = TI / 64, NT = TJ / 64;
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
     const int i0 = ti * TI, j0 = tj * TJ;
     const int64_t mb = chunk * rows_per_chunk;
     const int64_t me = (mb + rows_per_chunk < M) ? mb + rows_per_chunk : M;
-    const bool want_bias = (Kp > K) && (tj == 0);
+    const bool want_bias = has_bias && (tj == 0);
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
         }
     }
 
-    float* out = slab + chunk * (int64_t)Nc * Kp;
+    float* out = slab + chunk * tn_chunk_stride(Nc, Kq);
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         const int col = j0 + wj * (TJ / 2) + u * 32 + li;
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wi * (TI / 2) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < Nc) out[(int64_t)row * Kp + col] = acc[t][u][r];
+                if (row < Nc) out[(int64_t)row * Kq + col] = acc[t][u][r];
             }
     }
     if (want_bias) {                                              // block-uniform
@@ -716,7 +720,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) t += bsum[r][tid];
-            if (i0 + tid < Nc) out[(int64_t)(i0 + tid) * Kp + K] = t;
+            if (i0 + tid < Nc) out[(int64_t)Nc * Kq + i0 + tid] = t;
         }
     }
 }
@@ -928,7 +932,7 @@ constexpr int TNK_PITCH = TNK_R + 8;
 template <int TI, int TJ, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restrict__ G, int64_t ldg,
                                                        const stin_bf16* __restrict__ X, int64_t ldx, int64_t M, int Nc,
-                                                       int K, int Kp, const stin_bf16* __restrict__ row_w, int64_t ld_w,
+                                                       int K, int Kq, int has_bias, const stin_bf16* __restrict__ row_w, int64_t ld_w,
                                                        int rows_per_chunk, int tiles_i, int tiles_j, int64_t chunks,
                                                        float* __restrict__ slab) {
     constexpr int MT = TI / 64, NT = TJ / 64;
@@ -950,7 +954,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restri
     const int i0 = ti * TI, j0 = tj * TJ;
     const int64_t mb = chunk * rows_per_chunk;
     const int64_t me = (mb + rows_per_chunk < M) ? mb + rows_per_chunk : M;
-    const bool want_bias = (Kp > K) && (tj == 0);
+    const bool want_bias = has_bias && (tj == 0);
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -1059,7 +1063,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restri
         }
     }
 
-    float* out = slab + chunk * (int64_t)Nc * Kp;
+    float* out = slab + chunk * tn_chunk_stride(Nc, Kq);
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         const int col = j0 + wj * (TJ / 2) + u * 32 + li;
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wi * (TI / 2) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < Nc) out[(int64_t)row * Kp + col] = acc[t][u][r];
+                if (row < Nc) out[(int64_t)row * Kq + col] = acc[t][u][r];
             }
     }
     if (want_bias) {                                              // block-uniform
@@ -1083,37 +1087,57 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restri
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) t += bsum[r][tid];
-            if (i0 + tid < Nc) out[(int64_t)(i0 + tid) * Kp + K] = t;
+            if (i0 + tid < Nc) out[(int64_t)Nc * Kq + i0 + tid] = t;
         }
     }
 }
 
-// out[t] = sum_c slab[c][t]: 16 chunk-lanes x 16 consecutive elements per block, each chunk-lane walks
-// the chunk list with stride 16 (4 loads in flight), then a fixed-order LDS reduction -> deterministic.
+// dW[row][col] = sum_c slab[c][row][col] (and the bias column from the chunk's bias block): 16 chunk-lanes x 16 float4
+// groups per block, each chunk-lane walks the chunk list with stride 16 (4 x 16-byte loads in flight), then a
+// fixed-order LDS reduction over the chunk-lanes -> deterministic.
 constexpr int RS_COLS = 16, RS_KL = 16;
-__global__ __launch_bounds__(BLOCK) void k_reduce_slabs(const float* __restrict__ slab, int64_t chunks, int64_t n,
-                                                        int Kp, float* __restrict__ out, int64_t ldo) {
-    __shared__ float sm[RS_KL][RS_COLS + 1];
+__device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__global__ __launch_bounds__(BLOCK) void k_reduce_slabs(const float* __restrict__ slab, int64_t chunks, int Nc, int K, int Kq,
+                                                        int has_bias, float* __restrict__ out, int64_t ldo) {
+    __shared__ float4 sm[RS_KL][RS_COLS + 1];
     const int tx = threadIdx.x % RS_COLS, ty = threadIdx.x / RS_COLS;
-    const int64_t t = (int64_t)blockIdx.x * RS_COLS + tx;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (t < n) {
+    const int64_t cs = tn_chunk_stride(Nc, Kq);
+    const int64_t nw4 = (int64_t)Nc * Kq / 4, nb4 = has_bias ? (Nc + 3) / 4 : 0;
+    const int64_t g = (int64_t)blockIdx.x * RS_COLS + tx;          // float4 group: weight block first, then the bias block
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    if (g < nw4 + nb4) {
+        const float* p = slab + 4 * g;
         int64_t c = ty;
         for (; c + 3 * RS_KL < chunks; c += 4 * RS_KL) {
-            s0 += slab[c * n + t];
-            s1 += slab[(c + RS_KL) * n + t];
-            s2 += slab[(c + 2 * RS_KL) * n + t];
-            s3 += slab[(c + 3 * RS_KL) * n + t];
+            add4(s0, ld4(p + c * cs));
+            add4(s1, ld4(p + (c + RS_KL) * cs));
+            add4(s2, ld4(p + (c + 2 * RS_KL) * cs));
+            add4(s3, ld4(p + (c + 3 * RS_KL) * cs));
         }
-        for (; c < chunks; c += RS_KL) s0 += slab[c * n + t];
+        for (; c < chunks; c += RS_KL) add4(s0, ld4(p + c * cs));
     }
-    sm[ty][tx] = (s0 + s1) + (s2 + s3);
+    add4(s0, s1);
+    add4(s2, s3);
+    add4(s0, s2);
+    sm[ty][tx] = s0;
     __syncthreads();
-    if (ty == 0 && t < n) {
-        float s = 0.f;
+    if (ty == 0 && g < nw4 + nb4) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < RS_KL; ++k) s += sm[k][tx];
-        out[(t / Kp) * ldo + (t % Kp)] = s;
+        for (int k = 0; k < RS_KL; ++k) add4(s, sm[k][tx]);
+        const float v[4] = {s.x, s.y, s.z, s.w};
+        if (g < nw4) {
+            const int64_t row = (4 * g) / Kq;
+            const int col = (int)((4 * g) % Kq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < K) out[row * ldo + col + e] = v[e];
+        } else {
+            const int64_t i = 4 * (g - nw4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i + e < Nc) out[(i + e) * ldo + K] = v[e];
+        }
     }
 }
 
@@ -1198,12 +1222,12 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
 
 extern "C" size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int ones_column) {
     if (M < 0 || Nc <= 0 || K <= 0) return 0;
-    const int Kp = K + (ones_column ? 1 : 0);
+    (void)ones_column;
     const int TI = tn_tile(Nc), TJ = tn_tile(K);
     const int tiles = ((Nc + TI - 1) / TI) * ((K + TJ - 1) / TJ);
     const int rows = tn_rows_per_chunk(M, tiles);
     const int64_t chunks = (M + rows - 1) / rows;
-    return (size_t)(chunks > 0 ? chunks : 1) * Nc * Kp * sizeof(float) + 256;
+    return (size_t)(chunks > 0 ? chunks : 1) * (size_t)tn_chunk_stride(Nc, (K + 3) & ~3) * sizeof(float) + 256;
 }
 
 extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
@@ -1222,20 +1246,21 @@ extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int
     const int tiles_i = (Nc + TI - 1) / TI, tiles_j = (K + TJ - 1) / TJ;
     const int rows = tn_rows_per_chunk(M, tiles_i * tiles_j);
     const int64_t chunks = M > 0 ? (M + rows - 1) / rows : 0;
-    const int64_t n = (int64_t)Nc * Kp;
+    const int Kq = (K + 3) & ~3, has_bias = ones_column ? 1 : 0;
+    const int64_t n4 = (int64_t)Nc * Kq / 4 + (has_bias ? (Nc + 3) / 4 : 0);
     if (chunks > 0) {
         const bool vec = (Nc % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldx % 4 == 0) && stin_aligned16(G) &&
                          stin_aligned16(X);
         const int64_t blocks = ((chunks + 7) / 8) * 8 * (int64_t)tiles_i * tiles_j;   // 8 chunks (one per XCD) per round
 #define STIN_TN(TI_, TJ_)                                                                                            \
     do {                                                                                                             \
-        if (vec) hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
-        else hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
+        if (vec) hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
+        else hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
     } while (0)
 #define STIN_TNB(TI_, TJ_, NS_)                                                                                      \
     do {                                                                                                             \
-        if (vec) hipLaunchKernelGGL((k_gemm_tn_bf16s<TI_, TJ_, NS_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
-        else hipLaunchKernelGGL((k_gemm_tn_bf16s<TI_, TJ_, NS_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
+        if (vec) hipLaunchKernelGGL((k_gemm_tn_bf16s<TI_, TJ_, NS_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
+        else hipLaunchKernelGGL((k_gemm_tn_bf16s<TI_, TJ_, NS_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
     } while (0)
 #define STIN_TN_PICK(LAUNCH, ...)                                   \
     do {                                                            \
@@ -1251,8 +1276,8 @@ extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int
 #undef STIN_TNB
 #undef STIN_TN
     }
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, chunks,
-                       n, Kp, dW, lddw);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n4 + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, chunks, Nc, K,
+                       Kq, has_bias, dW, lddw);
     return stin_launch_status();
 }
 
@@ -1310,15 +1335,16 @@ extern "C" int stin_gemm_tn_bf16(const stin_bf16_t* G_, int64_t ldg, const stin_
     const int tiles_i = (Nc + TI - 1) / TI, tiles_j = (K + TJ - 1) / TJ;
     const int rows = tn_rows_per_chunk(M, tiles_i * tiles_j);
     const int64_t chunks = M > 0 ? (M + rows - 1) / rows : 0;
-    const int64_t n = (int64_t)Nc * Kp;
+    const int Kq = (K + 3) & ~3, has_bias = ones_column ? 1 : 0;
+    const int64_t n4 = (int64_t)Nc * Kq / 4 + (has_bias ? (Nc + 3) / 4 : 0);
     if (chunks > 0) {
         const bool vec = (Nc % 8 == 0) && (K % 8 == 0) && (ldg % 8 == 0) && (ldx % 8 == 0) && stin_aligned16(G) &&
                          stin_aligned16(X);
         const int64_t blocks = ((chunks + 7) / 8) * 8 * (int64_t)tiles_i * tiles_j;
 #define STIN_TNK(TI_, TJ_)                                                                                            \
     do {                                                                                                              \
-        if (vec) hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
-        else hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kp, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
+        if (vec) hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
+        else hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
     } while (0)
         if (TI == 128 && TJ == 128) STIN_TNK(128, 128);
         else if (TI == 128) STIN_TNK(128, 64);
@@ -1326,7 +1352,7 @@ extern "C" int stin_gemm_tn_bf16(const stin_bf16_t* G_, int64_t ldg, const stin_
         else STIN_TNK(64, 64);
 #undef STIN_TNK
     }
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, chunks,
-                       n, Kp, dW, lddw);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n4 + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, chunks, Nc, K,
+                       Kq, has_bias, dW, lddw);
     return stin_launch_status();
 }
