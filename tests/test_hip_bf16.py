@@ -241,3 +241,27 @@ def test_bf16_mode_is_refused_for_unsupported_variants():
         net.set_activation_dtype(BF)
     with pytest.raises(ValueError):
         net.set_activation_dtype(torch.float16)
+
+
+def test_bf16_batch_of_unequal_crops_four_levels():
+    """BASELINE config 3 in miniature: a batch of 8 unequal crops, 4 graph levels, bf16 storage, full channel widths
+    (ngf 64 -> 512 at the coarsest level).  Batched instance norm (per-graph statistics incl. the linspace-slice quirk)
+    and the bit-exact integer batch propagation are shared with the fp32 path; the values carry the bf16 tolerance."""
+    from surface_texture_inpainting_net_amd.data import collate
+    graphs = [make_synthetic_mesh(n, 4, seed=60 + i, dilations=(2,)) for i, n in enumerate((1200, 2800, 1900, 1500, 2400, 2000, 1300, 2600))]
+    batch = collate(graphs)
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=3,
+               pooling_type='max', dilations=[1, 2, 1])
+    ref, net = _net_pair(cfg, seed=7)
+    net.set_activation_dtype(BF)
+    want = ref(batch)
+    loss_ref = stin_oracle.compute_loss(stin_oracle.graph_forward(ref, batch), batch.color, batch.mask)
+    bd = batch.to(DEV)
+    got = net(bd)
+    loss = stin_oracle.compute_loss(torch.where((bd.mask > 0).expand_as(bd.color), got, bd.color), bd.color, bd.mask)
+    d = (got.detach().cpu() - want.detach()).abs()
+    print('bf16 crops: fwd max-abs %.3e mean-abs %.3e, loss %.6f vs %.6f' % (float(d.max()), float(d.mean()), float(loss.detach()), float(loss_ref.detach())))
+    assert float(d.max()) <= 0.15 and float(d.mean()) <= 2e-2
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-2 * float(loss_ref.detach())
+    loss.backward()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
