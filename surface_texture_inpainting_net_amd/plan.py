@@ -29,6 +29,18 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n=4):
+    """A small per-device pool of HIP streams for building the independent CSR structures of a sample side by side
+    (each build is a chain of ~13 short, latency-bound kernels)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _SIDE_STREAMS[key]
+
+
 class CSR:
     __slots__ = ('rowptr', 'col', 'perm', 'inv_deg', 'n_rows', 'n_entries')
 
@@ -89,6 +101,11 @@ class EdgeSet:
         self.w_src = w_src[:E]                                           # 1/max(1, indeg(target)) per src-CSR slot
         self.xslot = xslot[:E]                                           # src-CSR slot -> dst-CSR slot of the same edge
         self.n_edges = E
+        self._storage = (idx, inv_deg)
+
+    def tensors(self):
+        """The allocations behind this edge set (for record_stream when built on a side stream)."""
+        return self._storage
 
 
 class PoolMap:
@@ -104,6 +121,10 @@ class PoolMap:
         self.trace = torch.empty(max(n_fine, 1), dtype=torch.int32, device=trace.device)[:n_fine]
         _lib.check(lib.stin_narrow_i64_to_i32(_ptr(trace), n_fine, n_coarse, _ptr(self.trace), _ptr(bad),
                                               _stream(trace)), 'stin_narrow_i64_to_i32')
+
+    def tensors(self):
+        c = self.children
+        return tuple(t for t in (c.rowptr, c.col, c.perm, c.inv_deg, self.trace) if t is not None)
 
 
 class NormGroups:
@@ -157,13 +178,56 @@ class GraphPlan:
         self.level_sizes = [int(v) for v in nv.sum(dim=0)]
         self.num_graphs = int(nv.shape[0])
         self._sample = sample
-        self._bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # out-of-range flag, zeroed on a side stream so that side-stream builds (prefetch) never have to wait for the
+        # compute still queued on the main stream; the main stream joins it here (one event wait)
+        main = torch.cuda.current_stream(self.device)
+        s0 = _side_streams(self.device)[0]
+        with torch.cuda.stream(s0):
+            self._bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._bad.record_stream(main)
+        self._bad_ready = s0.record_event()
+        main.wait_event(self._bad_ready)
         self._edges = {}
         self._pools = {}
         self._norms = {}
         self._batch = {}
         self._validate = validate
         self._validated = False
+
+    def prefetch(self, edge_items=(), pool_levels=(), inputs_ready=False):
+        """Build the listed edge sets [(key, level), ...] and pool maps [level, ...] NOW, side by side on a pool of HIP
+        streams, instead of one after the other at first use on the compute stream.  The compute stream then waits
+        for them once.  inputs_ready=True asserts that the sample's index tensors are already complete in memory (a
+        loader handed over resident tensors): the builds then do not wait for work still queued on the compute stream
+        and overlap with it (the previous step's tail); otherwise they start after everything queued so far."""
+        todo = [('e', k, l) for (k, l) in edge_items if k not in self._edges]
+        todo += [('p', l, l) for l in pool_levels if l not in self._pools]
+        if not todo:
+            return self
+        main = torch.cuda.current_stream(self.device)
+        streams = _side_streams(self.device)
+        used = []
+        for i, (kind, key, level) in enumerate(todo):
+            s = streams[i % len(streams)]
+            if s not in used:
+                used.append(s)
+                if inputs_ready:
+                    s.wait_event(self._bad_ready)
+                else:
+                    s.wait_stream(main)
+            with torch.cuda.stream(s):
+                if kind == 'e':
+                    ei = self._sample.edge_index if key == 'edge_index' else self._sample[key]
+                    obj = self._edges[key] = EdgeSet(ei, self.level_sizes[level], self._bad)
+                else:
+                    trace = self._sample['hierarchy_trace_index_%d' % level]
+                    obj = self._pools[level] = PoolMap(trace, self.level_sizes[level - 1], self.level_sizes[level], self._bad)
+            for t in obj.tensors():
+                t.record_stream(main)            # allocated on s, consumed on the compute stream: defer reuse accordingly
+        for s in used:
+            main.wait_stream(s)
+        self._validated = False
+        return self
 
     # ---- lazily built pieces ------------------------------------------------------
     def edges(self, key, level):

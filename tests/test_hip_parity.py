@@ -611,3 +611,28 @@ def test_mid_size_full_width_model_vs_oracle():
         num += float(d.double().pow(2).sum())
         den += float(q.grad.double().pow(2).sum())
     assert (num / den) ** 0.5 <= 3e-3
+
+
+def test_plan_prefetch_on_side_streams_equals_lazy_build():
+    """GraphPlan.prefetch builds the CSR pieces side by side on side streams; results and the model output must be
+    identical to the lazy build on the compute stream, also when the sample's plan is rebuilt while earlier work is
+    still queued (record_stream keeps freed plan memory from being reused too early)."""
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 4])
+    torch.manual_seed(5)
+    net = S.define_G(**cfg).to(DEV)
+    s = make_synthetic_mesh(30_000, 3, seed=11, dilations=(2, 4)).to(DEV)
+    with torch.no_grad():
+        want = net(s)
+        lazy = s._plan_cache
+        for ready in (False, True, True, True):
+            s._plan_cache = None
+            plan = net.prefetch_plan(s, inputs_ready=ready)
+            got = net(s)
+            assert torch.equal(got, want)
+        for key, es in plan._edges.items():
+            ref = lazy._edges[key]
+            assert torch.equal(es.by_dst.rowptr, ref.by_dst.rowptr) and torch.equal(es.by_dst.col, ref.by_dst.col)
+            assert torch.equal(es.by_src.col, ref.by_src.col) and torch.equal(es.xslot, ref.xslot)
+        for lvl, pm in plan._pools.items():
+            assert torch.equal(pm.trace, lazy._pools[lvl].trace) and torch.equal(pm.children.col, lazy._pools[lvl].children.col)
