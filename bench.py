@@ -219,8 +219,16 @@ def main():
         loss = one_step()
     fence()
     dt = time.perf_counter() - t0
-    gc.enable()
     ktimes = SF.KernelTimer.stop()
+    # secondary figure, BASELINE's literal metric definition (fwd + loss + bwd of one scene; CSR plan reused, no
+    # all-reduce, no optimizer) - reported beside the headline, never instead of it
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step.forward_backward(sample)
+    fence()
+    dt_fb = time.perf_counter() - t1
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -268,6 +276,8 @@ def main():
                        'vertices_per_gpu': n0, 'edges_per_gpu': e0, 'levels': args.levels, 'params': sum(p.numel() for p in net.parameters()),
                        'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan},
             'loss': float(loss),
+            'fwd_loss_bwd_only': {'ms_per_step': dt_fb / args.steps * 1e3, 'vertices_per_s_per_gpu': n0 * args.steps / dt_fb,
+                                  'note': 'same scene, CSR plan reused, no gradient all-reduce, no optimizer step (rank 0)'},
             'roofline': roofline,
             'edge_stage_ms_per_step': edge_total_ms,
             'edge_kernels': table[:6],

@@ -327,6 +327,39 @@ int stin_gemm_tn_bf16(const stin_bf16_t* G, int64_t ldg, const stin_bf16_t* X, i
                       int ones_column, const stin_bf16_t* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
                       void* workspace, size_t workspace_bytes, stin_stream_t stream);
 
+/* ------------------------------------------------------ whole-block launch sequences --
+ * One GraphResnetBlock (EdgeConv(mean) -> instance norm -> ELU -> + residual,
+ * models/surfacetextureinpaintingnet.py:507-521) per call: these functions only ENQUEUE the entry points above in the
+ * order of the fused block (pack -> Y GEMM -> edge stage -> agg GEMM -> moments -> norm/ELU/residual; and its
+ * backward), so the arithmetic is identical to calling them one by one - what they remove is ~9 / ~16 host-side
+ * foreign calls per block and direction.  storage: 0 = fp32 rows, 1 = bf16 rows (x, Y, hE, agg, out, g, dx).
+ * Fast-path preconditions (callers fall back to the individual entry points otherwise): H supports the saved ReLU mask,
+ * norm statistics over the true per-graph row ranges (no linspace-slice quirk).
+ *   fwd: x [N, Cp] (input zero-padded to Cp columns), reference-layout parameters, destination CSR, norm groups
+ *        (ptr_sum/gid may be NULL for one graph; inv_cnt [B]); writes what backward needs - wcatT [Cp, Yw], w2T [H, Cout]
+ *        (fp32 or pre-split per bwd_split), Y [N, Yw], hE [N, H + pad] (column H = [deg > 0]), mask [E * H / 32],
+ *        agg [N, Cout], mean / rstd [B, Cout] - and out [N, Cout].  Yw = 2 H (+ Cout with a shortcut).
+ *   bwd: g = dL/dout; dx [N, Cp] may be NULL; parameter gradients in the reference layout (NULL where the parameter
+ *        does not exist).  All temporaries live in the caller's workspace.
+ */
+size_t stin_edgeconv_block_fwd_workspace_bytes(int Cin, int Cp, int H, int Cout, int has_shortcut, int B);
+int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, int64_t N, int Cin, int Cp, int H, int Cout,
+                            int has_shortcut, int trans_inv, const float* W1, const float* b1, const float* W2,
+                            const float* b2, const float* Ws, const float* bs, const int32_t* rowptr_dst,
+                            const int32_t* col_dst, const int32_t* ptr_sum, int B, const int32_t* gid, const float* inv_cnt,
+                            float eps, int prec_fwd, int fwd_split, int bwd_split, float* wcatT, float* w2T, void* Y,
+                            int64_t ldy, void* hE, int64_t ldh, uint32_t* mask, void* agg, float* mean, float* rstd, void* out,
+                            int64_t ldo, void* workspace, size_t workspace_bytes, stin_stream_t stream);
+size_t stin_edgeconv_block_bwd_workspace_bytes(int64_t N, int Cp, int H, int Cout, int has_shortcut, int B, int storage);
+int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, const void* x, int64_t ldx, int64_t N, int Cin, int Cp,
+                            int H, int Cout, int has_shortcut, int trans_inv, const void* Y, int64_t ldy, const void* hE,
+                            int64_t ldh, const uint32_t* mask, const void* agg, const float* mean, const float* rstd,
+                            const float* wcatT, const float* w2T, const int32_t* rowptr_dst, const int32_t* rowptr_src,
+                            const int32_t* col_src, const int32_t* xslot, const float* w_src, const int32_t* ptr_true, int B,
+                            const int32_t* gid, const float* inv_cnt, int prec_bwd, int bwd_split, void* dx, int64_t lddx,
+                            float* dW1, float* db1, float* dW2, float* db2, float* dWs, float* dbs, void* workspace,
+                            size_t workspace_bytes, stin_stream_t stream);
+
 /* ------------------------------------------------- offline preprocessing on the GPU --
  * The dilated-edge walk of preprocessing/graph_dilation.py:85-137 (`compute_dilated_edges`), one thread per
  * directed adjacency entry (centre c = row_of[e], one-hop h = col[e]) of the COALESCED adjacency CSR

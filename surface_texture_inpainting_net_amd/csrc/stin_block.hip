@@ -1,0 +1,217 @@
+// One GraphResnetBlock (EdgeConv(mean) -> instance norm -> ELU -> + residual) per C call: the launch SEQUENCE of the
+// fused block, forward and backward, enqueued from native code instead of ~9 / ~16 Python-level ctypes calls.  The
+// arithmetic is exactly that of the individual entry points (this file only calls them, in the order
+// functional.EdgeConvBlockFn used to); what it removes is host time - at 200k vertices the training step was
+// launch-bound on the Python side in its backward half, at 20k vertices entirely.
+// Reference composition: models/surfacetextureinpaintingnet.py:507-521 (GraphResnetBlock.forward).
+#include "stin_common.h"
+
+namespace {
+
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline char* carve(char*& p, size_t bytes) {
+    char* r = p;
+    p += up256(bytes);
+    return r;
+}
+#define STIN_TRY(expr)            \
+    do {                          \
+        const int rc_ = (expr);   \
+        if (rc_ != STIN_OK) return rc_; \
+    } while (0)
+
+// element-size aware column offset
+inline const void* col_off(const void* base, int64_t cols, int storage) {
+    return static_cast<const char*>(base) + cols * (storage ? 2 : 4);
+}
+inline void* col_off(void* base, int64_t cols, int storage) { return static_cast<char*>(base) + cols * (storage ? 2 : 4); }
+
+}  // namespace
+
+extern "C" size_t stin_edgeconv_block_fwd_workspace_bytes(int Cin, int Cp, int H, int Cout, int has_shortcut, int B) {
+    if (Cp <= 0 || H <= 0 || Cout <= 0 || B <= 0) return 0;
+    const size_t Yw = 2 * (size_t)H + (has_shortcut ? Cout : 0);
+    (void)Cin;
+    // wcat [Yw, Cp] + w2s [Cout, H] + bcat [Yw] (forward-only weight operands) + column-reduction workspace
+    return up256(Yw * Cp * 4) + up256((size_t)Cout * H * 4) + up256(Yw * 4) + up256(stin_colreduce_workspace_bytes(Cout, B)) + 256;
+}
+
+// Forward.  storage: 0 = fp32 rows, 1 = bf16 rows (x, Y, hE, agg, out).  Saved for backward by the caller: x, Y, hE,
+// mask, agg, mean, rstd, wcatT, w2T.  Requirements of this fast path (the caller falls back to the individual entry
+// points otherwise): saved ReLU mask supported for H, statistics over true per-graph ranges (no linspace-slice quirk).
+extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, int64_t N, int Cin, int Cp, int H, int Cout,
+                                       int has_shortcut, int trans_inv, const float* W1, const float* b1, const float* W2,
+                                       const float* b2, const float* Ws, const float* bs, const int32_t* rowptr_dst,
+                                       const int32_t* col_dst, const int32_t* ptr_sum, int B, const int32_t* gid,
+                                       const float* inv_cnt, float eps, int prec_fwd, int fwd_split, int bwd_split,
+                                       float* wcatT, float* w2T, void* Y, int64_t ldy, void* hE, int64_t ldh, uint32_t* mask,
+                                       void* agg, float* mean, float* rstd, void* out, int64_t ldo, void* workspace,
+                                       size_t workspace_bytes, stin_stream_t stream) {
+    STIN_REQUIRE(storage == 0 || storage == 1, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(N >= 0 && Cin > 0 && Cp >= Cin && H > 0 && Cout > 0 && B > 0, STIN_E_SIZE);
+    STIN_REQUIRE(x && W1 && W2 && rowptr_dst && wcatT && w2T && Y && hE && mask && agg && mean && rstd && out && workspace,
+                 STIN_E_NULL);
+    STIN_REQUIRE(workspace_bytes >= stin_edgeconv_block_fwd_workspace_bytes(Cin, Cp, H, Cout, has_shortcut, B), STIN_E_WORKSPACE);
+    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+    char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    float* wcat = reinterpret_cast<float*>(carve(p, (size_t)Yw * Cp * 4));
+    float* w2s = reinterpret_cast<float*>(carve(p, (size_t)Cout * H * 4));
+    float* bcat = reinterpret_cast<float*>(carve(p, (size_t)Yw * 4));
+    void* red_ws = p;
+    const size_t red_bytes = stin_colreduce_workspace_bytes(Cout, B);
+
+    STIN_TRY(stin_edgeconv_pack_f32(W1, b1, Ws, bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T,
+                                    fwd_split ? w2s : nullptr, fwd_split, bwd_split, stream));
+    const float* w2_op = fwd_split ? w2s : W2;
+    const int pf = fwd_split ? (prec_fwd | STIN_GEMM_W_PRESPLIT) : prec_fwd;
+    const void* res = has_shortcut ? col_off(static_cast<const void*>(Y), 2 * (int64_t)H, storage) : x;
+    const int64_t ld_res = has_shortcut ? ldy : ldx;
+    if (storage == 0) {
+        float* Yf = static_cast<float*>(Y);
+        float* hf = static_cast<float*>(hE);
+        STIN_TRY(stin_gemm_nt_f32(static_cast<const float*>(x), ldx, wcat, Cp, bcat, nullptr, 0, nullptr, 0, N, Yw, Cp, Yf, ldy,
+                                  pf, stream));
+        STIN_TRY(stin_edge_relu_mean_fwd_f32(Yf, ldy, Yf + H, ldy, rowptr_dst, col_dst, N, H, hf, ldh, 1, mask, stream));
+        STIN_TRY(stin_gemm_nt_f32(hf, ldh, w2_op, H, b2, hf + H, ldh, nullptr, 0, N, Cout, H, static_cast<float*>(agg), Cout,
+                                  pf, stream));
+        STIN_TRY(stin_colreduce_f32(STIN_RED_MOMENTS, static_cast<const float*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum, B, gid,
+                                    nullptr, nullptr, nullptr, nullptr, STIN_POST_NONE, inv_cnt, eps, mean, rstd, red_ws,
+                                    red_bytes, stream));
+        STIN_TRY(stin_norm_act_res_fwd_f32(static_cast<const float*>(agg), Cout, mean, rstd, gid, static_cast<const float*>(res),
+                                           ld_res, N, Cout, 1, static_cast<float*>(out), ldo, stream));
+    } else {
+        stin_bf16_t* Yh = static_cast<stin_bf16_t*>(Y);
+        stin_bf16_t* hh = static_cast<stin_bf16_t*>(hE);
+        STIN_TRY(stin_gemm_nt_bf16(static_cast<const stin_bf16_t*>(x), ldx, wcat, Cp, bcat, nullptr, 0, nullptr, 0, N, Yw, Cp, Yh,
+                                   ldy, 0, stream));
+        STIN_TRY(stin_edge_relu_mean_fwd_bf16(Yh, ldy, Yh + H, ldy, rowptr_dst, col_dst, N, H, hh, ldh, 1, mask, stream));
+        STIN_TRY(stin_gemm_nt_bf16(hh, ldh, w2_op, H, b2, hh + H, ldh, nullptr, 0, N, Cout, H, agg, Cout, 0, stream));
+        STIN_TRY(stin_colreduce_bf16(STIN_RED_MOMENTS, static_cast<const stin_bf16_t*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum, B,
+                                     gid, nullptr, nullptr, nullptr, nullptr, STIN_POST_NONE, inv_cnt, eps, mean, rstd, red_ws,
+                                     red_bytes, stream));
+        STIN_TRY(stin_norm_act_res_fwd_bf16(static_cast<const stin_bf16_t*>(agg), Cout, mean, rstd, gid,
+                                            static_cast<const stin_bf16_t*>(res), ld_res, N, Cout, 1,
+                                            static_cast<stin_bf16_t*>(out), ldo, stream));
+    }
+    return STIN_OK;
+}
+
+extern "C" size_t stin_edgeconv_block_bwd_workspace_bytes(int64_t N, int Cp, int H, int Cout, int has_shortcut, int B,
+                                                          int storage) {
+    if (N < 0 || Cp <= 0 || H <= 0 || Cout <= 0 || B <= 0) return 0;
+    const size_t Yw = 2 * (size_t)H + (has_shortcut ? Cout : 0);
+    const size_t es = storage ? 2 : 4;
+    size_t tn = stin_gemm_tn_workspace_bytes(N, Cout, H, 1);
+    const size_t tn2 = stin_gemm_tn_workspace_bytes(N, (int)Yw, Cp, 1);
+    if (tn2 > tn) tn = tn2;
+    return up256((size_t)N * Cout * es)      /* dagg */
+           + up256((size_t)N * H * es)       /* dhE  */
+           + up256((size_t)N * Yw * es)      /* dY   */
+           + up256((size_t)Cout * (H + 1) * 4) + up256(Yw * (size_t)(Cp + 1) * 4) /* dw2b, dwb */
+           + 4 * up256((size_t)B * Cout * 4) /* T1, S0, k, m */
+           + up256(stin_colreduce_workspace_bytes(Cout, B)) + up256(tn) + 256;
+}
+
+// Backward of the same block.  g = dL/dout [N, Cout]; dx may be NULL (block input needs no gradient).  Gradients of the
+// reference-layout parameters are written to dW1 [H, Cin or 2 Cin], db1 [H], dW2 [Cout, H], db2 [Cout], dWs [Cout, Cin],
+// dbs [Cout] (bias / shortcut outputs may be NULL when the parameter does not exist).
+extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, const void* x, int64_t ldx, int64_t N, int Cin,
+                                       int Cp, int H, int Cout, int has_shortcut, int trans_inv, const void* Y, int64_t ldy,
+                                       const void* hE, int64_t ldh, const uint32_t* mask, const void* agg, const float* mean,
+                                       const float* rstd, const float* wcatT, const float* w2T, const int32_t* rowptr_dst,
+                                       const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot,
+                                       const float* w_src, const int32_t* ptr_true, int B, const int32_t* gid,
+                                       const float* inv_cnt, int prec_bwd, int bwd_split, void* dx, int64_t lddx, float* dW1,
+                                       float* db1, float* dW2, float* db2, float* dWs, float* dbs, void* workspace,
+                                       size_t workspace_bytes, stin_stream_t stream) {
+    (void)Y;
+    (void)ldy;
+    STIN_REQUIRE(storage == 0 || storage == 1, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(N >= 0 && Cin > 0 && Cp >= Cin && H > 0 && Cout > 0 && B > 0, STIN_E_SIZE);
+    STIN_REQUIRE(g && x && hE && mask && agg && mean && rstd && wcatT && w2T && rowptr_dst && rowptr_src && col_src && xslot &&
+                     w_src && inv_cnt && dW1 && dW2 && workspace && (!has_shortcut || dWs),
+                 STIN_E_NULL);
+    STIN_REQUIRE(workspace_bytes >= stin_edgeconv_block_bwd_workspace_bytes(N, Cp, H, Cout, has_shortcut, B, storage),
+                 STIN_E_WORKSPACE);
+    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+    const size_t es = storage ? 2 : 4;
+    char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    void* dagg = carve(p, (size_t)N * Cout * es);
+    void* dhE = carve(p, (size_t)N * H * es);
+    void* dY = carve(p, (size_t)N * Yw * es);
+    float* dw2b = reinterpret_cast<float*>(carve(p, (size_t)Cout * (H + 1) * 4));
+    float* dwb = reinterpret_cast<float*>(carve(p, (size_t)Yw * (Cp + 1) * 4));
+    float* T1 = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
+    float* S0 = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
+    float* kk = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
+    float* mm = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
+    const size_t red_bytes = stin_colreduce_workspace_bytes(Cout, B);
+    void* red_ws = carve(p, red_bytes);
+    void* tn_ws = p;
+    const size_t tn_bytes = workspace_bytes - (size_t)(p - static_cast<char*>(workspace));
+    const int pb = bwd_split ? (prec_bwd | STIN_GEMM_W_PRESPLIT) : prec_bwd;
+    hipStream_t hs = (hipStream_t)stream;
+
+    if (storage == 0) {
+        const float* gf = static_cast<const float*>(g);
+        const float* hf = static_cast<const float*>(hE);
+        float* dYf = static_cast<float*>(dY);
+        // instance norm + ELU backward: two column sums, their coefficients, one elementwise pass
+        STIN_TRY(stin_colreduce_f32(STIN_RED_DOT_ELU, static_cast<const float*>(agg), Cout, gf, ldg, N, Cout, ptr_true, B, gid,
+                                    nullptr, mean, rstd, nullptr, STIN_POST_NONE, inv_cnt, 0.f, T1, S0, red_ws, red_bytes, stream));
+        STIN_TRY(stin_norm_bwd_coef_f32(T1, S0, rstd, inv_cnt, B, Cout, kk, mm, stream));
+        STIN_TRY(stin_norm_act_bwd_f32(static_cast<const float*>(agg), Cout, gf, ldg, mean, rstd, rstd, kk, mm, gid, gid, N, Cout,
+                                       1, static_cast<float*>(dagg), Cout, stream));
+        // second Linear: weight gradient (+ masked bias gradient) and input gradient
+        STIN_TRY(stin_gemm_tn_f32(static_cast<const float*>(dagg), Cout, hf, ldh, N, Cout, H, 1, hf + H, ldh, dw2b, H + 1,
+                                  prec_bwd, tn_ws, tn_bytes, stream));
+        STIN_TRY(stin_gemm_nt_f32(static_cast<const float*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H, Cout,
+                                  static_cast<float*>(dhE), H, pb, stream));
+        // edge stage backward from the saved ReLU mask -> dY = [dA | dB | g]
+        STIN_TRY(stin_edge_relu_mean_bwd_dst_mask_f32(static_cast<const float*>(dhE), H, mask, rowptr_dst, N, H, dYf, Yw, stream));
+        STIN_TRY(stin_edge_relu_mean_bwd_src_mask_f32(static_cast<const float*>(dhE), H, w_src, mask, rowptr_src, col_src, xslot, N,
+                                                      H, dYf + H, Yw, stream));
+        if (has_shortcut && N > 0) {
+            hipError_t e = hipMemcpy2DAsync(dYf + 2 * H, (size_t)Yw * 4, gf, (size_t)ldg * 4, (size_t)Cout * 4, (size_t)N,
+                                            hipMemcpyDeviceToDevice, hs);
+            if (e != hipSuccess) return (int)e;
+        }
+        // first Linear (+ shortcut): packed weight gradient and the block-input gradient (+ identity residual)
+        STIN_TRY(stin_gemm_tn_f32(dYf, Yw, static_cast<const float*>(x), ldx, N, Yw, Cp, 1, nullptr, 0, dwb, Cp + 1, prec_bwd,
+                                  tn_ws, tn_bytes, stream));
+        if (dx != nullptr)
+            STIN_TRY(stin_gemm_nt_f32(dYf, Yw, wcatT, Yw, nullptr, nullptr, 0, has_shortcut ? nullptr : gf, ldg, N, Cp, Yw,
+                                      static_cast<float*>(dx), lddx, pb, stream));
+    } else {
+        const stin_bf16_t* gh = static_cast<const stin_bf16_t*>(g);
+        const stin_bf16_t* hh = static_cast<const stin_bf16_t*>(hE);
+        stin_bf16_t* dYh = static_cast<stin_bf16_t*>(dY);
+        STIN_TRY(stin_colreduce_bf16(STIN_RED_DOT_ELU, static_cast<const stin_bf16_t*>(agg), Cout, gh, ldg, N, Cout, ptr_true, B,
+                                     gid, nullptr, mean, rstd, nullptr, STIN_POST_NONE, inv_cnt, 0.f, T1, S0, red_ws, red_bytes,
+                                     stream));
+        STIN_TRY(stin_norm_bwd_coef_f32(T1, S0, rstd, inv_cnt, B, Cout, kk, mm, stream));
+        STIN_TRY(stin_norm_act_bwd_bf16(static_cast<const stin_bf16_t*>(agg), Cout, gh, ldg, mean, rstd, rstd, kk, mm, gid, gid, N,
+                                        Cout, 1, static_cast<stin_bf16_t*>(dagg), Cout, stream));
+        STIN_TRY(stin_gemm_tn_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, hh, ldh, N, Cout, H, 1, hh + H, ldh, dw2b, H + 1,
+                                   tn_ws, tn_bytes, stream));
+        STIN_TRY(stin_gemm_nt_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H,
+                                   Cout, dhE, H, 0, stream));
+        STIN_TRY(stin_edge_relu_mean_bwd_dst_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, mask, rowptr_dst, N, H, dYh, Yw,
+                                                       stream));
+        STIN_TRY(stin_edge_relu_mean_bwd_src_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, w_src, mask, rowptr_src, col_src,
+                                                       xslot, N, H, dYh + H, Yw, stream));
+        if (has_shortcut && N > 0) {
+            hipError_t e = hipMemcpy2DAsync(dYh + 2 * H, (size_t)Yw * 2, gh, (size_t)ldg * 2, (size_t)Cout * 2, (size_t)N,
+                                            hipMemcpyDeviceToDevice, hs);
+            if (e != hipSuccess) return (int)e;
+        }
+        STIN_TRY(stin_gemm_tn_bf16(dYh, Yw, static_cast<const stin_bf16_t*>(x), ldx, N, Yw, Cp, 1, nullptr, 0, dwb, Cp + 1, tn_ws,
+                                   tn_bytes, stream));
+        if (dx != nullptr)
+            STIN_TRY(stin_gemm_nt_bf16(dYh, Yw, wcatT, Yw, nullptr, nullptr, 0, has_shortcut ? nullptr : gh, ldg, N, Cp, Yw, dx,
+                                       lddx, 0, stream));
+    }
+    STIN_TRY(stin_edgeconv_unpack_grads_f32(dwb, dw2b, Cin, Cp, H, Cout, has_shortcut, trans_inv, dW1, db1, dWs, dbs, dW2, db2,
+                                            stream));
+    return STIN_OK;
+}

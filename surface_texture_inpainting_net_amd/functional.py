@@ -260,6 +260,9 @@ PREC_FWD = int(os.environ.get('STIN_GEMM_FWD', GEMM_F16X3))
 PREC_BWD = int(os.environ.get('STIN_GEMM_BWD', GEMM_BF16X3))
 GEMM_W_PRESPLIT = 0x100            # nt: the weight operand already holds its two 16-bit pieces (stin_hip.h)
 WEIGHT_PRESPLIT = os.environ.get('STIN_WEIGHT_PRESPLIT', '1') != '0' and not _GEMM_BLAS_NT
+# one C call per GraphResnetBlock and direction (stin_edgeconv_block_fwd/bwd enqueue the same kernels in the same order
+# as the per-kernel path below): removes ~25 Python-level foreign calls per block.  STIN_BLOCK_CALL=0 = per-kernel path.
+USE_BLOCK_CALL = os.environ.get('STIN_BLOCK_CALL', '1') != '0' and not (_GEMM_BLAS_NT or _GEMM_BLAS_TN)
 
 
 def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32, residual=None, out_dtype=None):
@@ -430,6 +433,38 @@ class EdgeConvBlockFn(torch.autograd.Function):
         # (instead of once per GEMM block); plain fp32 for the other precisions and for bf16-storage activations
         fsp = PREC_FWD if (not b16 and PREC_FWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT) else 0
         bsp = PREC_BWD if (not b16 and PREC_BWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT and Cout % 4 == 0) else 0
+        fast = (USE_BLOCK_CALL and USE_EDGE_MASK and edge_mask_supported(H) and not groups.quirk and N > 1
+                and not KernelTimer.enabled)          # (the bench's per-kernel HIP-event brackets need the per-kernel path)
+        ctx.fast = fast
+        if fast:
+            lib = _lib.load()
+            B = groups.B
+            wts = torch.empty(Yw * Cp + H * Cout, dtype=torch.float32, device=dev)       # backward weight operands
+            wcatT, w2T = wts[:Yw * Cp].view(Cp, Yw), wts[Yw * Cp:].view(H, Cout)
+            Y = torch.empty(N, Yw, dtype=x.dtype, device=dev)
+            hE = torch.empty(N, H + pad, dtype=x.dtype, device=dev)
+            mask = torch.empty(max(edges.n_edges, 1) * (H // 32), dtype=torch.int32, device=dev)
+            agg = torch.empty(N, Cout, dtype=x.dtype, device=dev)
+            stats = torch.empty(2, B, Cout, dtype=torch.float32, device=dev)
+            mean, rstd = stats[0], stats[1]
+            out = torch.empty(N, Cout, dtype=x.dtype, device=dev)
+            ws_bytes = lib.stin_edgeconv_block_fwd_workspace_bytes(Cin, Cp, H, Cout, int(has_shortcut), B)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            W1c, W2c = W1.contiguous(), W2.contiguous()
+            cd = edges.by_dst
+            _call('stin_edgeconv_block_fwd', int(b16), _ptr(xp), xp.stride(0), N, Cin, Cp, H, Cout, int(has_shortcut),
+                  int(trans_inv), _ptr(W1c), _ptr(b1), _ptr(W2c), _ptr(b2), _ptr(Ws), _ptr(bs), _ptr(cd.rowptr), _ptr(cd.col),
+                  _ptr(groups.ptr_sum), B, _ptr(groups.gid), _ptr(groups.inv_cnt), float(EPS), int(PREC_FWD), fsp, bsp,
+                  _ptr(wcatT), _ptr(w2T), _ptr(Y), Yw, _ptr(hE), H + pad, _ptr(mask), _ptr(agg), _ptr(mean), _ptr(rstd),
+                  _ptr(out), Cout, _ptr(ws), ws_bytes, _stream(x))
+            ctx.save_for_backward(xp, Y, hE, agg, mean, rstd, wcatT, w2T)
+            ctx.mask = mask
+            ctx.cin = Cin
+            ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut, ctx.trans_inv = edges, groups, H, has_shortcut, trans_inv
+            ctx.has_b1, ctx.has_b2, ctx.has_bs = b1 is not None, b2 is not None, bs is not None
+            ctx.w1_shape = tuple(W1.shape)
+            ctx.bsp = bsp
+            return out
         pack = torch.empty(Yw * Cp * 2 + 2 * H * Cout + Yw, dtype=torch.float32, device=dev)
         wcat = pack[:Yw * Cp].view(Yw, Cp)
         wcatT = pack[Yw * Cp:2 * Yw * Cp].view(Cp, Yw)
@@ -461,6 +496,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         ctx.has_b1, ctx.has_b2, ctx.has_bs = b1 is not None, b2 is not None, bs is not None
         ctx.w1_shape = tuple(W1.shape)
         ctx.prec_bwd_nt = (PREC_BWD | GEMM_W_PRESPLIT) if bsp else PREC_BWD
+        ctx.bsp = bsp
         return out
 
     @staticmethod
@@ -468,7 +504,31 @@ class EdgeConvBlockFn(torch.autograd.Function):
         x, Y, hE, agg, mean, rstd, wcatT, w2T = ctx.saved_tensors          # x: the (possibly channel-padded) block input
         edges, groups, H = ctx.edges, ctx.groups, ctx.H
         Cin, Cp, Cout = ctx.cin, x.shape[1], agg.shape[1]
-        g, _ = _mat(g)
+        g, ldg = _mat(g)
+        if ctx.fast:
+            lib = _lib.load()
+            dev, N, b16 = x.device, x.shape[0], x.dtype == torch.bfloat16
+            _same(x, g)
+            dx = torch.empty(N, Cp, dtype=x.dtype, device=dev) if ctx.needs_input_grad[0] else None
+            dW1 = torch.empty(ctx.w1_shape, dtype=torch.float32, device=dev)
+            db1 = torch.empty(H, dtype=torch.float32, device=dev) if ctx.has_b1 else None
+            dWs = torch.empty(Cout, Cin, dtype=torch.float32, device=dev) if ctx.has_shortcut else None
+            dbs = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bs else None
+            dW2 = torch.empty(Cout, H, dtype=torch.float32, device=dev)
+            db2 = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b2 else None
+            ws_bytes = lib.stin_edgeconv_block_bwd_workspace_bytes(N, Cp, H, Cout, int(ctx.has_shortcut), groups.B, int(b16))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            cs = edges.by_src
+            _call('stin_edgeconv_block_bwd', int(b16), _ptr(g), ldg, _ptr(x), x.stride(0), N, Cin, Cp, H, Cout,
+                  int(ctx.has_shortcut), int(ctx.trans_inv), _ptr(Y), Y.stride(0), _ptr(hE), hE.stride(0), _ptr(ctx.mask),
+                  _ptr(agg), _ptr(mean), _ptr(rstd), _ptr(wcatT), _ptr(w2T), _ptr(edges.by_dst.rowptr), _ptr(cs.rowptr),
+                  _ptr(cs.col), _ptr(edges.xslot), _ptr(edges.w_src), _ptr(groups.ptr_true), groups.B, _ptr(groups.gid),
+                  _ptr(groups.inv_cnt), int(PREC_BWD), ctx.bsp, _ptr(dx), Cp, _ptr(dW1), _ptr(db1), _ptr(dW2), _ptr(db2),
+                  _ptr(dWs), _ptr(dbs), _ptr(ws), ws_bytes, _stream(x))
+            ctx.mask = None
+            if dx is not None and Cp != Cin:
+                dx = dx[:, :Cin]
+            return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None
         dagg = instance_norm_act_bwd(agg, g, mean, rstd, groups, act=True)
         dw2b = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H], precision=PREC_BWD)   # [Cout, H + 1] = dW2 | db2
         dhE = gemm_nt(dagg, w2T, precision=ctx.prec_bwd_nt)                                             # [N, H] = dagg W2
