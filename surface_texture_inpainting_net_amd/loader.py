@@ -1,0 +1,221 @@
+"""Scene loader for the data path in front of the hot path.
+
+The reference feeds the model through a torch DataLoader with 8 worker processes, pin_memory and the PyG collate of
+``HierarchicalData`` (datasets/scannetcolorgraph_dataloader.py:190-208, utils/data_utils.py:11-42), one scene (3-D
+training) or a batch of crops per step.  This module is the MI355X-side equivalent, designed around 288 GB of HBM:
+
+* a background thread reads / collates / pins the NEXT batches while the GPU trains (``prefetch`` deep);
+* host->device copies run on their own HIP stream; the compute stream only waits for the copy event;
+* the graph part of a scene (int64 index tensors AND the CSR plan built from them) never changes between epochs or
+  between masks, so it is kept RESIDENT in HBM in an LRU cache bounded in bytes - a revisited scene uploads only its
+  per-vertex features (x, color, mask) and skips the plan build entirely (~1.4 ms of a 10 ms step at 200k vertices);
+* scenes are sharded over data-parallel ranks like a DistributedSampler (seeded permutation per epoch, padded so that
+  every rank runs the same number of steps - the gradient all-reduce needs that).
+
+Items are ``(graph_path, mask_path)`` pairs in the reference's on-disk schema (scene_io.load_scene), already built CPU
+``HierarchicalBatch`` objects, or zero-argument callables returning one.
+"""
+import collections
+import queue
+import threading
+
+import torch
+
+from . import plan as _plan
+from .data import HierarchicalBatch, collate
+from .scene_io import load_scene
+
+_FEATURE_KEYS = ('x', 'color', 'mask', 'batch', 'name')
+
+
+def shard_indices(n, epoch, seed=0, shuffle=True, rank=0, world_size=1):
+    """The item order of one epoch for one rank: seeded permutation of range(n), padded by wrap-around to a multiple of
+    world_size, every world_size-th element starting at rank (torch.utils.data.DistributedSampler semantics)."""
+    if shuffle:
+        g = torch.Generator().manual_seed(int(seed) + int(epoch))
+        order = torch.randperm(n, generator=g).tolist()
+    else:
+        order = list(range(n))
+    if world_size > 1 and n > 0:
+        total = (n + world_size - 1) // world_size * world_size
+        order = order + order[:total - n]
+    return order[rank::world_size]
+
+
+def _tensor_bytes(obj):
+    seen, total = set(), 0
+    stack = [obj]
+    while stack:
+        o = stack.pop()
+        if torch.is_tensor(o):
+            st = o.untyped_storage()
+            if st.data_ptr() not in seen:
+                seen.add(st.data_ptr())
+                total += st.nbytes()
+        elif isinstance(o, dict):
+            stack.extend(o.values())
+        elif isinstance(o, (list, tuple)):
+            stack.extend(o)
+        elif hasattr(o, '__dict__') or hasattr(o, '__slots__'):
+            for k in list(getattr(o, '__dict__', {}).keys()) + list(getattr(o, '__slots__', ())):
+                if k in ('_sample',):
+                    continue
+                v = getattr(o, k, None)
+                if v is not None and not callable(v):
+                    stack.append(v)
+    return total
+
+
+class ResidentGraphCache:
+    """LRU of the immutable graph part of scenes, resident in HBM: {key: (index tensors on the device, GraphPlan)}."""
+
+    def __init__(self, capacity_bytes):
+        self.capacity = int(capacity_bytes)
+        self.used = 0
+        self.hits = self.misses = 0
+        self._d = collections.OrderedDict()
+
+    def get(self, key):
+        e = self._d.get(key)
+        if e is None:
+            self.misses += 1
+            return None
+        self._d.move_to_end(key)
+        self.hits += 1
+        return e
+
+    def put(self, key, graph_tensors, plan, nbytes):
+        if nbytes > self.capacity:
+            return
+        while self.used + nbytes > self.capacity and self._d:
+            _, (_, _, b) = self._d.popitem(last=False)
+            self.used -= b
+        self._d[key] = (graph_tensors, plan, nbytes)
+        self.used += nbytes
+
+    def __len__(self):
+        return len(self._d)
+
+
+class SceneLoader:
+    """Iterate GPU-resident training batches: ``for sample in loader.epoch(e): loss = step(sample)``."""
+
+    def __init__(self, items, device, batch_size=1, shuffle=True, seed=0, rank=0, world_size=1, prefetch=2,
+                 cache_bytes=32 << 30, end_level=3, cropped=False, model=None):
+        self.items = list(items)
+        self.device = torch.device(device)
+        self.batch_size, self.shuffle, self.seed = int(batch_size), bool(shuffle), int(seed)
+        self.rank, self.world_size, self.prefetch = int(rank), int(world_size), max(1, int(prefetch))
+        self.end_level, self.cropped = end_level, cropped
+        self.model = model                                   # optional: lets the loader build the plan (model.prefetch_plan)
+        self.cache = ResidentGraphCache(cache_bytes) if (cache_bytes and self.batch_size == 1) else None
+        self._copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+
+    # ---- CPU side (background thread) ---------------------------------------------------------------------------
+    def _load(self, i):
+        it = self.items[i]
+        if isinstance(it, HierarchicalBatch):
+            return it
+        if callable(it):
+            return it()
+        return load_scene(it[0], it[1], end_level=self.end_level, cropped=self.cropped)
+
+    def steps_per_epoch(self):
+        n = len(shard_indices(len(self.items), 0, self.seed, False, self.rank, self.world_size))
+        return (n + self.batch_size - 1) // self.batch_size
+
+    def _cpu_batches(self, epoch):
+        idx = shard_indices(len(self.items), epoch, self.seed, self.shuffle, self.rank, self.world_size)
+        for b in range(0, len(idx), self.batch_size):
+            ids = idx[b:b + self.batch_size]
+            samples = [self._load(i) for i in ids]
+            batch = samples[0] if len(samples) == 1 else collate(samples)
+            if self.device.type == 'cuda':
+                key = ids[0] if self.cache is not None else None
+                cached = key is not None and key in self.cache._d       # peek (no LRU update from the worker thread)
+                keys = [k for k in batch.keys() if (k in _FEATURE_KEYS or not cached)]
+                pinned = HierarchicalBatch(**{k: (batch[k].pin_memory() if torch.is_tensor(batch[k]) else batch[k]) for k in keys})
+                yield ids, pinned
+            else:
+                yield ids, batch
+
+    # ---- device side ------------------------------------------------------------------------------------------------
+    def _to_device(self, ids, cpu_batch):
+        if self.device.type != 'cuda':
+            return cpu_batch
+        main = torch.cuda.current_stream(self.device)
+        key = ids[0] if self.cache is not None else None
+        entry = self.cache.get(key) if key is not None else None
+        with torch.cuda.stream(self._copy_stream):
+            dev = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v)
+                   for k, v in ((k, cpu_batch[k]) for k in cpu_batch.keys())}
+        for v in dev.values():
+            if torch.is_tensor(v):
+                v.record_stream(main)
+        main.wait_stream(self._copy_stream)
+        if entry is not None:                                 # resident graph part + its plan: nothing to upload or build
+            graph, plan, _ = entry
+            out = HierarchicalBatch(**graph)
+            for k in _FEATURE_KEYS:
+                if k in dev:
+                    out[k] = dev[k]
+            plan._sample = out
+            out._plan_cache = plan
+            return out
+        if key is not None and any(k not in dev for k in ('edge_index', 'num_vertices')):
+            # the worker skipped the graph tensors expecting a cache hit, but the entry was evicted meanwhile: reload
+            return self._to_device(ids, next(self._reload(ids)))
+        out = HierarchicalBatch(**dev)
+        if self.cache is not None:
+            plan = self.model.prefetch_plan(out) if self.model is not None else _plan.plan_for(out)
+            graph = {k: v for k, v in dev.items() if k not in _FEATURE_KEYS}
+            self._pending = (key, graph, plan)
+        return out
+
+    def _reload(self, ids):
+        s = self._load(ids[0])
+        yield HierarchicalBatch(**{k: (s[k].pin_memory() if torch.is_tensor(s[k]) else s[k]) for k in s.keys()})
+
+    def _commit_pending(self):
+        """Insert the previous step's graph into the cache once its plan is complete (all lazily built pieces exist)."""
+        p = getattr(self, '_pending', None)
+        if p is not None:
+            key, graph, plan = p
+            self.cache.put(key, graph, plan, _tensor_bytes(graph) + _tensor_bytes(plan))
+            self._pending = None
+
+    def epoch(self, epoch=0):
+        q = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+
+        def work():
+            try:
+                for item in self._cpu_batches(epoch):
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                q.put(None)
+            except BaseException as e:  # surface worker errors in the training thread
+                q.put(e)
+
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                if self.cache is not None:
+                    self._commit_pending()
+                yield self._to_device(*item)
+            if self.cache is not None:
+                self._commit_pending()
+        finally:
+            stop.set()
