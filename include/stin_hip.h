@@ -286,7 +286,10 @@ int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int
  * (stin_bf16_t, see the typedef).  What stays fp32: instance-norm statistics (fp64 accumulation), inv_deg / w_src /
  * row_scale, the weight operand W and bias of the GEMMs, the weight gradients dW and every index plan.
  * Vector kernels only: C % 4 == 0, ld % 4 == 0, 8-byte aligned rows, else STIN_E_UNSUPPORTED; the edge stage
- * needs the saved ReLU mask (H in {128, 256, 512, 1024, 2048}) in backward.
+ * needs the saved ReLU mask (H in {128, 256, 512, 1024, 2048}) in backward.  With 16-byte aligned rows (ld % 8 == 0)
+ * the edge stage gives every lane 8 channels (the same 16 bytes per lane and request as the fp32 kernels); the mask
+ * kernels REQUIRE that alignment (STIN_E_ALIGN otherwise) because the lane geometry fixes the bit order inside a mask
+ * slot: a bf16 mask is only meaningful to the bf16 backward kernels, an fp32 mask to the fp32 ones.
  * gemm_nt_bf16: A, row_mask, residual bf16; W, bias fp32 (W is rounded to bf16 while staged); one
  *   v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate, bias/mask/residual added in fp32, one rounding;
  *   C is bf16 (c_is_f32 = 0) or fp32 (c_is_f32 = 1: the network's final [N, 3] output).

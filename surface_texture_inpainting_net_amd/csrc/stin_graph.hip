@@ -4,6 +4,7 @@
 // 64/G rows and every neighbour-row gather is a run of coalesced 16-byte loads.  U neighbour
 // rows are requested before the first is consumed (memory-level parallelism; mean mesh
 // degree is ~6).  Contract: include/stin_hip.h.
+#include <cstdlib>
 #include "stin_common.h"
 
 namespace {
@@ -327,6 +328,255 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask(const T* __restrict
         if (on[k]) st4(dB + L.row * lddb + L.chan(k), acc[k]);
 }
 
+// ===================================================== bf16 rows, 8 channels (16 bytes) per lane
+// The bf16-storage edge stage with the SAME bytes per lane and request as the fp32 kernels: a lane owns 8 channels, so a
+// row of H channels takes H/8 lanes (G = 16 for H = 128 ... 64 for H >= 512) and a wave covers 64/G rows.  Arithmetic
+// per channel is identical to the 4-channel kernels (same fp32 operations, same neighbour order) - only the lane
+// geometry and therefore the bit layout of the saved ReLU mask differ:
+//   slot (H bits) = [k][s][c][min(G, 32) bits]   k = lane chunk, s = 32-lane half of the row (G = 64 only),
+//   c = channel 0..7 of the lane; for G = 16 the 16-bit pieces of channels 2w, 2w+1 share word w.
+// Both backward kernels read exactly this layout; the forward / backward pair always runs on the same geometry because
+// the bf16 mask path REQUIRES 16-byte aligned rows (it never falls back to the 8-byte kernels).
+struct F8 { float v[8]; };
+__device__ __forceinline__ F8 f8zero() { F8 o; 
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = 0.f;
+    return o; }
+__device__ __forceinline__ F8 ld8(const stin_bf16* p) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    F8 o;
+    o.v[0] = __uint_as_float(r.x << 16); o.v[1] = __uint_as_float(r.x & 0xffff0000u);
+    o.v[2] = __uint_as_float(r.y << 16); o.v[3] = __uint_as_float(r.y & 0xffff0000u);
+    o.v[4] = __uint_as_float(r.z << 16); o.v[5] = __uint_as_float(r.z & 0xffff0000u);
+    o.v[6] = __uint_as_float(r.w << 16); o.v[7] = __uint_as_float(r.w & 0xffff0000u);
+    return o;
+}
+__device__ __forceinline__ uint32_t pk2(float lo, float hi) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 h = {(__bf16)lo, (__bf16)hi};
+    return *reinterpret_cast<uint32_t*>(&h);
+}
+__device__ __forceinline__ void st8(stin_bf16* p, const F8& a) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pk2(a.v[0], a.v[1]), pk2(a.v[2], a.v[3]), pk2(a.v[4], a.v[5]), pk2(a.v[6], a.v[7]));
+}
+
+template <int G>
+struct Lane8 {
+    int lg;
+    int64_t row;
+    __device__ __forceinline__ Lane8() {
+        lg = threadIdx.x % G;
+        row = (int64_t)blockIdx.x * (BLOCK / G) + threadIdx.x / G;
+    }
+    __device__ __forceinline__ int chan(int k) const { return (k * G + lg) * 8; }
+};
+
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_fwd8(const stin_bf16* __restrict__ A, int64_t lda,
+                                                     const stin_bf16* __restrict__ B, int64_t ldb,
+                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                     int64_t N, int H, stin_bf16* __restrict__ out, int64_t ldo, int indicator,
+                                                     uint32_t* __restrict__ mask) {
+    constexpr int WK = G / 4;                 // mask words per lane chunk k (8 channels x G lanes / 32)
+    constexpr int LPS = WK / 4;               // lanes that store one neighbour's words of one k (16 bytes each)
+    static_assert(U * LPS <= G, "not enough lanes to store the mask words of U neighbours");
+    Lane8<G> L;
+    if (L.row >= N) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    F8 a[VPL], acc[VPL];
+    bool on[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        on[k] = L.chan(k) < H;
+        a[k] = on[k] ? ld8(A + L.row * lda + L.chan(k)) : f8zero();
+        acc[k] = f8zero();
+    }
+    const int mwords = H >> 5;
+    const int sh = ((threadIdx.x & 63) / G) * G;          // bit position of this row inside the wave ballots
+    const int su = L.lg / LPS, sp = L.lg % LPS;           // neighbour / 16-byte part this lane stores
+    for (int e = beg; e < end; e += U) {
+        F8 b[U][VPL];
+        uint4 mw[VPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = min(e + u, end - 1);
+            const int64_t j = col[ee];
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) b[u][k] = on[k] ? ld8(B + j * ldb + L.chan(k)) : f8zero();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float w = (e + u < end) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                uint32_t wd[WK];
+#pragma unroll
+                for (int q = 0; q < WK; ++q) wd[q] = 0u;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float t = a[k].v[c] + b[u][k].v[c];
+                    acc[k].v[c] += w * fmaxf(t, 0.f);
+                    if (mask != nullptr) {
+                        const unsigned long long bc = __ballot(t > 0.f);
+                        if (G == 16) wd[c >> 1] |= ((uint32_t)(bc >> sh) & 0xffffu) << ((c & 1) * 16);
+                        else if (G == 32) wd[c] = (uint32_t)(bc >> sh);
+                        else { wd[c] = (uint32_t)bc; wd[8 + c] = (uint32_t)(bc >> 32); }
+                    }
+                }
+                if (mask != nullptr && su == u) {
+#pragma unroll
+                    for (int q = 0; q < LPS; ++q)
+                        if (sp == q) mw[k] = make_uint4(wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]);
+                }
+            }
+        }
+        if (mask != nullptr && su < U && e + su < end) {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k)
+                *reinterpret_cast<uint4*>(mask + (int64_t)(e + su) * mwords + k * WK + 4 * sp) = mw[k];
+        }
+    }
+    const int deg = end - beg;
+    const float s = (float)(deg > 0 ? deg : 1);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (on[k]) {
+            F8 o;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o.v[c] = acc[k].v[c] / s;
+            st8(out + L.row * ldo + L.chan(k), o);
+        }
+    if (indicator && L.lg == 0) st4(out + L.row * ldo + H, make_float4(deg > 0 ? 1.f : 0.f, 0.f, 0.f, 0.f));
+}
+
+// this lane's 8 mask words (one per channel) of slot `m` for chunk k, and the bit to test
+template <int G>
+__device__ __forceinline__ void mask_words8(const uint32_t* __restrict__ m, int k, int lg, uint32_t (&w)[8], int& bit) {
+    constexpr int WK = G / 4;
+    if (G == 16) {
+        const uint4 q = *reinterpret_cast<const uint4*>(m + k * WK);
+        w[0] = q.x; w[1] = q.x >> 16; w[2] = q.y; w[3] = q.y >> 16; w[4] = q.z; w[5] = q.z >> 16; w[6] = q.w; w[7] = q.w >> 16;
+        bit = lg;
+    } else {
+        const uint32_t* p = m + k * WK + (G == 64 ? (lg >> 5) * 8 : 0);
+        const uint4 q0 = reinterpret_cast<const uint4*>(p)[0], q1 = reinterpret_cast<const uint4*>(p)[1];
+        w[0] = q0.x; w[1] = q0.y; w[2] = q0.z; w[3] = q0.w; w[4] = q1.x; w[5] = q1.y; w[6] = q1.z; w[7] = q1.w;
+        bit = lg & 31;
+    }
+}
+
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask8(const stin_bf16* __restrict__ Gr, int64_t ldg,
+                                                              const uint32_t* __restrict__ mask,
+                                                              const int32_t* __restrict__ rowptr, int64_t N, int H,
+                                                              stin_bf16* __restrict__ dA, int64_t ldda) {
+    Lane8<G> L;
+    if (L.row >= N) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    const int mwords = H >> 5;
+    int cnt[VPL][8];
+    bool on[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        on[k] = L.chan(k) < H;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cnt[k][c] = 0;
+    }
+    for (int e = beg; e < end; e += U) {
+        uint32_t wv[U][VPL][8];
+        int bit = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = min(e + u, end - 1);
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) mask_words8<G>(mask + (int64_t)ee * mwords, k, L.lg, wv[u][k], bit);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e + u < end) {
+#pragma unroll
+                for (int k = 0; k < VPL; ++k)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) cnt[k][c] += (wv[u][k][c] >> bit) & 1u;
+            }
+        }
+    }
+    const int deg = end - beg;
+    const float s = 1.0f / (float)(deg > 0 ? deg : 1);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (on[k]) {
+            const F8 g = ld8(Gr + L.row * ldg + L.chan(k));
+            F8 o;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o.v[c] = g.v[c] * s * (float)cnt[k][c];
+            st8(dA + L.row * ldda + L.chan(k), o);
+        }
+}
+
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask8(const stin_bf16* __restrict__ Gr, int64_t ldg,
+                                                              const float* __restrict__ w_slot,
+                                                              const uint32_t* __restrict__ mask,
+                                                              const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ col,
+                                                              const int32_t* __restrict__ xslot, int64_t N, int H,
+                                                              stin_bf16* __restrict__ dB, int64_t lddb) {
+    Lane8<G> L;
+    if (L.row >= N) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    const int mwords = H >> 5;
+    F8 acc[VPL];
+    bool on[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        on[k] = L.chan(k) < H;
+        acc[k] = f8zero();
+    }
+    for (int e = beg; e < end; e += U) {
+        F8 g[U][VPL];
+        uint32_t wv[U][VPL][8];
+        float w[U];
+        int bit = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = min(e + u, end - 1);
+            const int64_t i = col[ee];
+            const int64_t xs = xslot[ee];
+            w[u] = (e + u < end) ? w_slot[ee] : 0.f;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                g[u][k] = on[k] ? ld8(Gr + i * ldg + L.chan(k)) : f8zero();
+                mask_words8<G>(mask + xs * mwords, k, L.lg, wv[u][k], bit);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < VPL; ++k)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[k].v[c] += ((wv[u][k][c] >> bit) & 1u) ? w[u] * g[u][k].v[c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (on[k]) st8(dB + L.row * lddb + L.chan(k), acc[k]);
+}
+
+// H in {128, 256, 512, 1024, 2048}: G = H/8 capped at 64, VPL = H / (8 G); U as in STIN_DISPATCH for the same row bytes
+// U (neighbour rows in flight per lane group) tuned on MI355X: with 8 channels per lane the gather kernels want all
+// 8 waves per SIMD resident (<= 64 VGPRs) rather than deep per-wave unrolling - U = 2 (71 vs 98 us at U = 4 for the
+// level-0 forward, 48 vs 104 us at U = 6 for the level-1 backward), U = 1 once a lane holds 2 or 4 chunks; the
+// streaming dA kernel keeps U = 6 / 3 / 3 / 2 / 1.
+#define STIN_L8(KERNEL_, G_, V_, U_, grid_, ...) hipLaunchKernelGGL((KERNEL_<G_, V_, U_>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__)
+#define STIN_DISPATCH8(H_, KERNEL, U16_, U32_, U64_, U64X2_, U64X4_, ...)                                            \
+    do {                                                                                                             \
+        if ((H_) == 128) STIN_L8(KERNEL, 16, 1, U16_, grid_rows(N, 16), __VA_ARGS__);                                \
+        else if ((H_) == 256) STIN_L8(KERNEL, 32, 1, U32_, grid_rows(N, 32), __VA_ARGS__);                           \
+        else if ((H_) == 512) STIN_L8(KERNEL, 64, 1, U64_, grid_rows(N, 64), __VA_ARGS__);                           \
+        else if ((H_) == 1024) STIN_L8(KERNEL, 64, 2, U64X2_, grid_rows(N, 64), __VA_ARGS__);                        \
+        else STIN_L8(KERNEL, 64, 4, U64X4_, grid_rows(N, 64), __VA_ARGS__);                                          \
+    } while (0)
+
 // --------------------------------------------------------------- segment sum / mean
 template <typename T, int G, int VPL, int U>
 __global__ __launch_bounds__(BLOCK) void k_segment_sum(const T* __restrict__ src, int64_t lds_,
@@ -554,6 +804,16 @@ inline bool mask_shape_ok(int H) { return H == 128 || H == 256 || H == 512 || H 
 inline unsigned grid_rows(int64_t N, int G) { return (unsigned)((N + (BLOCK / G) - 1) / (BLOCK / G)); }
 inline unsigned grid_elems(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
+inline bool wide8_ok(int H, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
+    if (!mask_shape_ok(H)) return false;
+    for (const void* p : ptrs)
+        if (p != nullptr && !stin_aligned16(p)) return false;
+    for (int64_t ld : lds)
+        if (ld % 8 != 0) return false;
+    return true;
+}
+
+
 // Dispatch on (G, VPL) for a channel count C (C % 4 == 0, C <= 2048).  U = neighbour rows requested per loop trip,
 // tuned on MI355X at mean degree ~6 (level-0/1/2 edge kernels and the standalone scatter-add, U in {8, 6, 4}):
 // rows of <= 256 B: 4; 512-B rows (G = 32): 6 - one trip for a typical mesh vertex; 1-KB rows (G = 64): 4; then 2, 2, 1
@@ -610,6 +870,16 @@ int edge_fwd_impl(const T* A, int64_t lda, const T* B, int64_t ldb, const int32_
     STIN_REQUIRE(mask == nullptr || (mask_shape_ok(H) && vec), STIN_E_UNSUPPORTED);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(A && B && rowptr && out, STIN_E_NULL);
+    if constexpr (!is_f32((const T*)nullptr)) {
+        // bf16 rows: 16 bytes per lane whenever the rows allow it; with a mask this geometry is mandatory (it fixes the
+        // mask's bit layout for the backward kernels)
+        const bool wide = wide8_ok(H, {A, B, out}, {lda, ldb, ldo});
+        STIN_REQUIRE(mask == nullptr || wide, STIN_E_ALIGN);
+        if (wide) {
+            STIN_DISPATCH8(H, k_edge_fwd8, 2, 2, 2, 1, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+            return stin_launch_status();
+        }
+    }
     if (vec) {
         STIN_DISPATCH(H, k_edge_fwd, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
     } else if constexpr (is_f32((const T*)nullptr)) {
@@ -629,6 +899,11 @@ int edge_bwd_dst_mask_impl(const T* G, int64_t ldg, const uint32_t* mask, const 
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(G && mask && rowptr && dA, STIN_E_NULL);
     STIN_REQUIRE(mask_shape_ok(H) && vec_ok<T>(H, {G, dA}, {ldg, ldda}), STIN_E_UNSUPPORTED);
+    if constexpr (!is_f32((const T*)nullptr)) {
+        STIN_REQUIRE(wide8_ok(H, {G, dA}, {ldg, ldda}), STIN_E_ALIGN);       // the geometry the forward kernel wrote the mask in
+        STIN_DISPATCH8(H, k_edge_bwd_dst_mask8, 6, 3, 3, 2, 1, G, ldg, mask, rowptr, N, H, dA, ldda);
+        return stin_launch_status();
+    }
     STIN_DISPATCH(H, k_edge_bwd_dst_mask, 1, G, ldg, mask, rowptr, N, H, dA, ldda);
     return stin_launch_status();
 }
@@ -641,6 +916,11 @@ int edge_bwd_src_mask_impl(const T* G, int64_t ldg, const float* w_src, const ui
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(G && w_src && mask && rowptr_src && col_src && xslot && dB, STIN_E_NULL);
     STIN_REQUIRE(mask_shape_ok(H) && vec_ok<T>(H, {G, dB}, {ldg, lddb}), STIN_E_UNSUPPORTED);
+    if constexpr (!is_f32((const T*)nullptr)) {
+        STIN_REQUIRE(wide8_ok(H, {G, dB}, {ldg, lddb}), STIN_E_ALIGN);
+        STIN_DISPATCH8(H, k_edge_bwd_src_mask8, 2, 2, 2, 1, 1, G, ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
+        return stin_launch_status();
+    }
     STIN_DISPATCH(H, k_edge_bwd_src_mask, 1, G, ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
     return stin_launch_status();
 }
