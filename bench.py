@@ -58,23 +58,25 @@ def pmc_traffic_bytes(kernel, n, e, h):
         return None
     elem = '__bf16' if kernel.endswith('_bf16') else 'float'
     kernel = kernel.replace('_bf16', '_f32')
-    c4 = h // 4
-    g = 1
-    while g < c4 and g < 64:
-        g *= 2
-    vpl = (c4 + g - 1) // g
-    table = {1: 4, 2: 4, 4: 4, 8: 4, 16: 4, 32: 6}.get(g, {1: 4, 2: 2, 4: 2}.get(vpl, 1))
-    u = max(1, table // (2 if kernel.endswith('bwd_src_f32') else 1))
     short = {'stin_edge_relu_mean_fwd_f32': 'k_edge_fwd', 'stin_edge_relu_mean_bwd_dst_f32': 'k_edge_bwd_dst',
              'stin_edge_relu_mean_bwd_src_f32': 'k_edge_bwd_src',
              'stin_edge_relu_mean_bwd_dst_mask_f32': 'k_edge_bwd_dst_mask',
              'stin_edge_relu_mean_bwd_src_mask_f32': 'k_edge_bwd_src_mask'}[kernel]
-    key = '%s<%s, %d, %d, %d>' % (short, elem, g, vpl, u)
+    if elem == 'float':                                     # Lane<G, VPL>: 4 channels per lane
+        c4 = h // 4
+        g = 1
+        while g < c4 and g < 64:
+            g *= 2
+        prefix = '%s<float, %d, %d,' % (short, g, (c4 + g - 1) // g)
+    else:                                                   # bf16 rows: 8 channels per lane (k_*8 kernels)
+        g = min(64, h // 8)
+        prefix = '%s8<%d, %d,' % (short, g, h // (8 * g))
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
     if not files:
         return None
-    rec = json.load(open(files[-1])).get(key)
-    return None if rec is None else rec['hbm_MB_per_launch'] * 1e6
+    table = json.load(open(files[-1]))
+    hits = [v for k, v in table.items() if k.startswith(prefix)]
+    return hits[0]['hbm_MB_per_launch'] * 1e6 if hits else None
 
 
 def scatter_add_standalone(device, n=200_000, e=1_200_000, c=64, iters=30):

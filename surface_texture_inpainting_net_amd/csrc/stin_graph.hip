@@ -921,7 +921,7 @@ int edge_bwd_src_mask_impl(const T* G, int64_t ldg, const float* w_src, const ui
         STIN_DISPATCH8(H, k_edge_bwd_src_mask8, 2, 2, 2, 1, 1, G, ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
         return stin_launch_status();
     }
-    STIN_DISPATCH(H, k_edge_bwd_src_mask, 1, G, ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
+    STIN_DISPATCH(H, k_edge_bwd_src_mask, 2, G, ldg, w_src, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
     return stin_launch_status();
 }
 
