@@ -156,6 +156,8 @@ def main():
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--time-gemms', action='store_true', help='also bracket every MFMA GEMM launch with HIP events')
     ap.add_argument('--cache-plan', action='store_true', help='reuse the CSR plan across steps (NOT the headline)')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the fwd+loss+bwd-only loop after the timed region (profiling runs: keeps the kernel mix = the step)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="activation storage: f32 = the headline (reference numerics); bf16 = the build's "
                          "mixed-precision mode of BASELINE configs 3/5 (NOT the headline, stated tolerance)")
@@ -226,7 +228,7 @@ def main():
     # all-reduce, no optimizer) - reported beside the headline, never instead of it
     fence()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(0 if args.no_secondary else args.steps):
         step.forward_backward(sample)
     fence()
     dt_fb = time.perf_counter() - t1
@@ -278,8 +280,9 @@ def main():
                        'vertices_per_gpu': n0, 'edges_per_gpu': e0, 'levels': args.levels, 'params': sum(p.numel() for p in net.parameters()),
                        'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan},
             'loss': float(loss),
-            'fwd_loss_bwd_only': {'ms_per_step': dt_fb / args.steps * 1e3, 'vertices_per_s_per_gpu': n0 * args.steps / dt_fb,
-                                  'note': 'same scene, CSR plan reused, no gradient all-reduce, no optimizer step (rank 0)'},
+            'fwd_loss_bwd_only': None if args.no_secondary else {
+                'ms_per_step': dt_fb / args.steps * 1e3, 'vertices_per_s_per_gpu': n0 * args.steps / dt_fb,
+                'note': 'same scene, CSR plan reused, no gradient all-reduce, no optimizer step (rank 0)'},
             'roofline': roofline,
             'edge_stage_ms_per_step': edge_total_ms,
             'edge_kernels': table[:6],
