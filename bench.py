@@ -224,6 +224,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ktimes = SF.KernelTimer.stop()
+    step.finish()                                           # deferred index checks of the timed steps (all clean)
     # secondary figure, BASELINE's literal metric definition (fwd + loss + bwd of one scene; CSR plan reused, no
     # all-reduce, no optimizer) - reported beside the headline, never instead of it
     fence()

@@ -165,7 +165,7 @@ class NormGroups:
 class GraphPlan:
     """All CSR structures of one (possibly batched) hierarchical sample."""
 
-    def __init__(self, sample, linspace_quirk=True, validate=True):
+    def __init__(self, sample, linspace_quirk=True, validate=True, validation=None):
         x = sample.x
         assert x.is_cuda, 'the HIP path needs the sample on the GPU (sample.to("cuda"))'
         self.device = x.device
@@ -192,7 +192,9 @@ class GraphPlan:
         self._norms = {}
         self._batch = {}
         self._validate = validate
+        self._validation = validation or VALIDATION          # 'sync' | 'deferred', see validate()
         self._validated = False
+        self._flag_host = None
 
     def prefetch(self, edge_items=(), pool_levels=(), inputs_ready=False):
         """Build the listed edge sets [(key, level), ...] and pool maps [level, ...] NOW, side by side on a pool of HIP
@@ -278,12 +280,55 @@ class GraphPlan:
         return self._norms[key]
 
     def validate(self):
-        """One host sync per sample: raise like the reference's CPU IndexError when any
-        index was out of range (kernels clamp such indices, so nothing faulted)."""
-        if self._validate and not self._validated:
-            if int(self._bad.item()) != 0:
-                raise IndexError('edge / trace index out of range for the level sizes in sample.num_vertices')
-            self._validated = True
+        """Raise like the reference's CPU IndexError when any index was out of range (the kernels leave such pairs out,
+        so nothing faulted).  validation = 'sync' (default): one host sync per freshly built plan, the error surfaces
+        in the forward call that used the bad sample.  'deferred': the flag is copied to pinned host memory without
+        stalling the host; `check_deferred()` - called at the start of the next forward and by TrainStep after the
+        optimizer step - raises then, i.e. at the latest one step later, and the host keeps running ahead of the GPU."""
+        if not self._validate or self._validated:
+            return
+        if self._validation == 'deferred':
+            if self._flag_host is None:
+                self._flag_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                self._flag_host.copy_(self._bad, non_blocking=True)
+                self._flag_event = torch.cuda.current_stream(self.device).record_event()
+                _PENDING_CHECKS.append(self)
+            return
+        if int(self._bad.item()) != 0:
+            raise IndexError('edge / trace index out of range for the level sizes in sample.num_vertices')
+        self._validated = True
+
+    def _check_now(self, wait):
+        if self._flag_host is None or self._validated:
+            return True
+        if not wait and not self._flag_event.query():
+            return False
+        self._flag_event.synchronize()
+        bad = int(self._flag_host[0])
+        self._flag_host = None
+        if bad != 0:
+            raise IndexError('edge / trace index out of range for the level sizes in sample.num_vertices '
+                             '(reported by the deferred plan validation of an earlier forward call)')
+        self._validated = True
+        return True
+
+
+# 'sync' | 'deferred' (see GraphPlan.validate); STIN_PLAN_VALIDATION overrides the default
+import os as _os
+VALIDATION = _os.environ.get('STIN_PLAN_VALIDATION', 'sync')
+_PENDING_CHECKS = []
+
+
+def check_deferred(wait=False):
+    """Resolve the deferred index checks whose flag copy has completed (all of them with wait=True)."""
+    keep = []
+    try:
+        while _PENDING_CHECKS:
+            p = _PENDING_CHECKS.pop(0)
+            if not p._check_now(wait):
+                keep.append(p)
+    finally:
+        _PENDING_CHECKS[:0] = keep
 
 
 def plan_for(sample, **kw):

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import functional as SF
 from . import modules as M
-from .plan import EdgeSet, NormGroups, plan_for
+from .plan import EdgeSet, NormGroups, check_deferred, plan_for
 
 
 class GraphResnetBlock(nn.Module):
@@ -92,6 +92,9 @@ class SurfaceTextureInpaintingNet(nn.Module):
         # gradients are always fp32): torch.float32 = the reference's numerics (1e-4 bar); torch.bfloat16 = the
         # build's mixed-precision extension for BASELINE configs 3/5 (see set_activation_dtype)
         self.activation_dtype = torch.float32
+        # 'sync': an out-of-range index raises IndexError in the forward call that used it (one host sync per new plan);
+        # 'deferred': it raises at the next forward / TrainStep call instead and the host never stalls (plan.validate)
+        self.plan_validation = 'sync'
         self._filter_type, self._norm_type = filter_type, norm_type
         inplace, use_bias = False, True
         if self._use_embedding:  # created but never used by forward, as in the reference (:277-278, :409-410)
@@ -188,13 +191,15 @@ class SurfaceTextureInpaintingNet(nn.Module):
         over GPU-resident index tensors can call this with inputs_ready=True as soon as the sample exists, so that the
         build overlaps with the step still running (measured on the 200k-vertex step: no net gain while the step is
         launch-bound on the host)."""
-        plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm)
+        plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm, validation=self.plan_validation)
         edges, pools = self._plan_items()
         plan.prefetch(edges, pools, inputs_ready=inputs_ready)
         return plan
 
     def forward(self, sample):
-        plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm)     # pieces not prefetched are built at first use
+        check_deferred()                                                      # deferred index checks of earlier calls
+        plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm,      # pieces not prefetched are built at first use
+                        validation=self.plan_validation)
         num_levels = len(self.decoder_blocks) + 1
         out = sample.x
         if self.activation_dtype != out.dtype:

@@ -132,6 +132,10 @@ class TrainStep:
         self.group = group
         self.use_mask_weighted_loss = use_mask_weighted_loss
         broadcast_parameters(model, 0, group)
+        # a training loop must not stall the host once per step: out-of-range indices of a scene are reported by the
+        # NEXT step (or by finish()) instead of inside the forward call that used them
+        if hasattr(model, 'plan_validation'):
+            model.plan_validation = 'deferred'
         self.bucket = FlatGradBucket(model.parameters())
         self.on_gpu = self.bucket.flat.is_cuda
         if self.on_gpu:
@@ -150,6 +154,12 @@ class TrainStep:
         loss.backward()
         self.bucket.gather_grads()
         return loss.detach()
+
+    def finish(self):
+        """Resolve the deferred index checks of the steps run so far (waits for the GPU)."""
+        if self.on_gpu:
+            from .plan import check_deferred
+            check_deferred(wait=True)
 
     def __call__(self, sample):
         loss = self.forward_backward(sample)

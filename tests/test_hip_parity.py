@@ -636,3 +636,32 @@ def test_plan_prefetch_on_side_streams_equals_lazy_build():
             assert torch.equal(es.by_src.col, ref.by_src.col) and torch.equal(es.xslot, ref.xslot)
         for lvl, pm in plan._pools.items():
             assert torch.equal(pm.trace, lazy._pools[lvl].trace) and torch.equal(pm.children.col, lazy._pools[lvl].children.col)
+
+
+def test_deferred_plan_validation_reports_bad_indices_one_call_later():
+    """plan_validation='deferred' (what TrainStep selects): no host sync in forward; an out-of-range index raises the
+    reference's IndexError at the next forward / check instead of inside the call that used it."""
+    from surface_texture_inpainting_net_amd.plan import check_deferred
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=1, n_levels=1,
+               pooling_type='max', dilations=[1])
+    torch.manual_seed(3)
+    net = S.define_G(**cfg).to(DEV)
+    good = make_synthetic_mesh(3000, 2, seed=1, dilations=()).to(DEV)
+    bad = make_synthetic_mesh(3000, 2, seed=2, dilations=()).to(DEV)
+    bad.edge_index[1, 5] = bad.x.shape[0] + 7
+    with torch.no_grad():
+        with pytest.raises(IndexError):
+            net(bad)                                          # default 'sync': raised by the call itself
+        bad._plan_cache = None
+        net.plan_validation = 'deferred'
+        out = net(bad)                                        # no raise here, nothing faulted (the pair was left out)
+        assert bool(torch.isfinite(out).all())
+        torch.cuda.synchronize()
+        with pytest.raises(IndexError, match='deferred'):
+            net(good)                                         # ... but by the next call
+        assert bool(torch.isfinite(net(good)).all())          # the report is delivered once
+        bad._plan_cache = None
+        net(bad)
+        with pytest.raises(IndexError):
+            check_deferred(wait=True)
+        check_deferred(wait=True)
