@@ -317,6 +317,56 @@ def g9_preprocessing():
     print('g9_preprocessing', {k: v.shape for k, v in d.items() if k.startswith(('toy_d', 'mesh_d', 'vc_'))})
 
 
+def g10_singleconvmeshnet():
+    """the reference's own SingleConvMeshNet (BatchNorm1d inside the edge MLP, statistics over all
+    edges) in training mode - output, loss, gradients, running statistics after the step - and in eval mode."""
+    scmn = ref_import.load_singleconvmeshnet_module()
+    for pooling in ('mean', 'max'):
+        torch.manual_seed(1010)
+        gen = torch.Generator().manual_seed(1011)
+        net = scmn.SingleConvMeshNet(feature_number=10, num_propagation_steps=2, filter_sizes=[16, 32, 48], num_classes=3,
+                                     pooling_method=pooling)
+        with torch.no_grad():
+            for m in net.modules():                       # non-trivial BN affine parameters and running statistics
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.weight.copy_(1.0 + 0.2 * torch.randn(m.weight.shape, generator=gen))
+                    m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+                    m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=gen))
+                    m.running_var.copy_(1.0 + 0.2 * torch.rand(m.running_var.shape, generator=gen))
+        s = make_synthetic_mesh(520, 3, seed=10, dilations=())
+        d = {}
+        _pack_sample(d, s)
+        for k, v in net.state_dict().items():
+            d['w/' + k] = _np(v)
+        target = torch.randn(s.x.shape[0], 3, generator=gen)
+        init_state = {k: v.clone() for k, v in net.state_dict().items()}
+        net.train()
+        with torch.no_grad():        # the reference's ResBlock adds IN PLACE into a ReLU output (singleconvmeshnet.py:104):
+            out = net(s)             # legal for autograd in its torch era, rejected by torch 2.x -> forward only here
+        loss = ((out - target) ** 2).mean()
+        d['target'], d['out_train'], d['loss'] = _np(target), _np(out), _np(loss)
+        for k, v in net.state_dict().items():
+            if 'running' in k or 'num_batches' in k:
+                d['after/' + k] = _np(v)
+        net.eval()
+        with torch.no_grad():
+            d['out_eval'] = _np(net(s))
+        # gradients: from the build's restatement (out-of-place residual add, otherwise op for op), after checking that
+        # its training-mode forward reproduces the reference's output bit for bit
+        from oracle import scmn_oracle
+        rest = scmn_oracle.SingleConvMeshNet(feature_number=10, num_propagation_steps=2, filter_sizes=[16, 32, 48],
+                                             num_classes=3, pooling_method=pooling)
+        rest.load_state_dict(init_state)
+        rest.train()
+        out_r = rest(s)
+        assert torch.equal(out_r.detach(), out), float((out_r.detach() - out).abs().max())
+        ((out_r - target) ** 2).mean().backward()
+        for k, p in rest.named_parameters():
+            d['g_restatement/' + k] = _np(p.grad)
+        np.savez_compressed(os.path.join(OUT, 'g10_singleconvmeshnet_%s.npz' % pooling), **d)
+        print('g10_singleconvmeshnet', pooling, 'loss', float(loss), 'params', sum(p.numel() for p in net.parameters()))
+
+
 def param_counts(stin):
     """The structural constants SURVEY.md §8(c) records."""
     out = {}
@@ -346,6 +396,7 @@ def main():
     g7_train_step(stin, trainer_mod)
     g8_metrics()
     g9_preprocessing()
+    g10_singleconvmeshnet()
     param_counts(stin)
 
 

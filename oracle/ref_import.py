@@ -69,6 +69,16 @@ def load_module(name):
     return importlib.import_module(name)
 
 
+def load_singleconvmeshnet_module():
+    """-> the reference's models.singleconvmeshnet module (its BaseModel comes from the reference's `base` package)."""
+    load_model_module()
+    if 'base' not in sys.modules:
+        m = types.ModuleType('base')
+        m.__path__ = [os.path.join(REFERENCE_ROOT, 'base')]
+        sys.modules['base'] = m
+    return importlib.import_module('models.singleconvmeshnet')
+
+
 def load_preprocessing():
     """-> (preprocessing.graph_dilation, preprocessing.graph_level_generation) with the mesh-IO libraries they import
     but the graph functions do not need (open3d, plyfile) stubbed and tqdm silenced."""

@@ -94,8 +94,12 @@ def get_gcn_filter(input_size, output_size, activation=nn.ReLU, inplace=False, a
     assert input_size >= 0
     assert output_size >= 0
     if with_norm:
-        raise NotImplementedError('with_norm=True (BatchNorm inside the edge MLP) is only used by SingleConvMeshNet, '
-                                  'which is outside the STINet hot path')
+        # BatchNorm1d inside the edge MLP (edge_conv_filter.py:34-44): per-EDGE tensors, see singleconvmeshnet.EdgeConvBN
+        from .singleconvmeshnet import EdgeConvBN
+        assert aggregation == 'mean' and issubclass(activation, torch.nn.ReLU), 'the reference only builds mean / ReLU'
+        if module not in (None, EdgeConv, EdgeConvTransInv):
+            raise NotImplementedError('with_norm filters exist for EdgeConv / EdgeConvTransInv')
+        return EdgeConvBN(input_size, output_size, trans_inv=(module is EdgeConvTransInv))
     if activation is not nn.ReLU:
         raise NotImplementedError('the fused edge stage implements ReLU only')
     cin = 2 * input_size if double_input else input_size

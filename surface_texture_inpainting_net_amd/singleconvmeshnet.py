@@ -1,0 +1,228 @@
+"""SingleConvMeshNet on MI355X: the reference's U-Net over the mesh hierarchy whose EdgeConv filters
+carry BatchNorm1d INSIDE the per-edge MLP (models/singleconvmeshnet.py:10-156,
+models/modules/edge_conv_filter.py:34-44 `with_norm=True`) - same constructor, same `forward(sample)`, same state_dict keys.
+
+The BatchNorm statistics run over all E per-edge activations, so the per-vertex restructure of the inpainting net stops
+half-way: Lin1 has no bias and is linear, hence  Lin1([x_i ; x_j - x_i]) = A_i + B_j  with per-VERTEX GEMMs
+(A = x (Wa - Wb)^T, B = x Wb^T; TransInv: A = -x W1^T, B = x W1^T), but BN1 -> ReLU -> Lin2 -> BN2 need genuine
+per-EDGE tensors: h_e = A_dst + B_src (two row gathers), BN over E rows, one per-EDGE MFMA GEMM, BN over E rows, and a
+CSR segment-mean back to the vertices.  All of it runs on the library's kernels (row gather, segment sum, fp64-accumulated
+column statistics, MFMA GEMMs, pool / unpool); the per-channel affine, ReLU, residual add and concatenation are plain
+elementwise framework ops.  No float atomics: backward of a gather is a segment sum over the opposite CSR.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from . import functional as SF
+from .plan import NormGroups, PoolMap, _ptr, _stream, build_csr
+
+
+class _EdgeIndex:
+    """Both CSRs (with the slot -> edge id permutation) and the int32 endpoints of one edge set."""
+
+    def __init__(self, edge_index, n, bad):
+        lib = _lib.load()
+        src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
+        self.n, self.E = n, int(dst.numel())
+        self.by_dst = build_csr(dst, None, n, max(self.E, 1), bad, want_perm=True)
+        self.by_src = build_csr(src, None, n, max(self.E, 1), bad, want_perm=True)
+        self.src32 = torch.empty(max(self.E, 1), dtype=torch.int32, device=dst.device)[:self.E]
+        self.dst32 = torch.empty(max(self.E, 1), dtype=torch.int32, device=dst.device)[:self.E]
+        for a, b in ((src, self.src32), (dst, self.dst32)):
+            _lib.check(lib.stin_narrow_i64_to_i32(_ptr(a), self.E, n, _ptr(b), _ptr(bad), _stream(a)), 'stin_narrow_i64_to_i32')
+
+
+def _as_edge_index(ei, n):
+    """_EdgeIndex, or a raw [2, E] int64 edge_index as the reference's modules receive it (validated on the spot)."""
+    if isinstance(ei, _EdgeIndex):
+        return ei
+    bad = torch.zeros(1, dtype=torch.int32, device=ei.device)
+    out = _EdgeIndex(ei, n, bad)
+    if int(bad.item()) != 0:
+        raise IndexError('edge index out of range for %d vertices' % n)
+    return out
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """out[e] = x[idx[e]];  backward: segment sum of the edge gradients over the CSR grouped by idx."""
+
+    @staticmethod
+    def forward(ctx, x, idx32, csr):
+        ctx.csr, ctx.n = csr, x.shape[0]
+        return SF.gather_rows(x, idx32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return SF.segment_sum(g, ctx.csr.rowptr, ctx.csr.col, ctx.n, mean=False), None, None
+
+
+class _ScatterMeanFn(torch.autograd.Function):
+    """out[i] = mean of the edge rows whose target is i (0 for vertices without in-edges): scatter_mean."""
+
+    @staticmethod
+    def forward(ctx, m, ei):
+        ctx.ei = ei
+        return SF.segment_sum(m, ei.by_dst.rowptr, ei.by_dst.col, ei.n, mean=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        ei = ctx.ei
+        return SF.gather_rows(g, ei.dst32, ei.by_dst.inv_deg), None
+
+
+class _RowStatsNormFn(torch.autograd.Function):
+    """y = (x - mean) * rstd over ALL rows (biased variance, eps inside the root), plus the batch mean / biased variance
+    as non-differentiable outputs for the running statistics: BatchNorm1d's training-mode normalisation."""
+
+    @staticmethod
+    def forward(ctx, x, groups, eps):
+        x, _ = SF._mat(x)
+        mean, rstd = SF.instance_stats(x, groups) if eps == SF.EPS else SF.colreduce(SF.RED_MOMENTS, x, groups, groups.ptr_sum, eps=eps)
+        y = SF.norm_act_res_fwd(x, mean, rstd, groups, res=None, act=False)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.groups = groups
+        m1, v1 = mean.view(-1), (1.0 / (rstd * rstd) - eps).clamp_(min=0).view(-1)
+        ctx.mark_non_differentiable(m1, v1)
+        return y, m1, v1
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        x, mean, rstd = ctx.saved_tensors
+        return SF.instance_norm_act_bwd(x, g, mean, rstd, ctx.groups, act=False), None, None
+
+
+def batch_norm_rows(x, bn):
+    """nn.BatchNorm1d semantics on [rows, C] (training: batch statistics over all rows + running-stat update with the
+    unbiased variance; eval: running statistics), statistics by the fp64-accumulating column-reduction kernels."""
+    if bn.training or not bn.track_running_stats:
+        n = x.shape[0]
+        y, mean, var = _RowStatsNormFn.apply(x, NormGroups(n, x.device), float(bn.eps))
+        if bn.training and bn.track_running_stats:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+    else:
+        y = (x - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps)
+    if bn.affine:
+        y = y * bn.weight + bn.bias
+    return y
+
+
+class EdgeConvBN(nn.Module):
+    """EdgeConv(aggr='mean') whose MLP is Lin(no bias) - BatchNorm1d - ReLU - Lin(no bias) - BatchNorm1d
+    (edge_conv_filter.py:34-44); `nn` holds the parameters under the reference's names and is never called itself."""
+
+    def __init__(self, cin, cout, trans_inv=False):
+        super().__init__()
+        self.trans_inv = trans_inv
+        self.nn = nn.Sequential(nn.Linear(cin if trans_inv else 2 * cin, 2 * cout, bias=False), nn.BatchNorm1d(2 * cout),
+                                nn.ReLU(), nn.Linear(2 * cout, cout, bias=False), nn.BatchNorm1d(cout))
+
+    def forward(self, x, ei):
+        ei = _as_edge_index(ei, x.shape[0])
+        lin1, bn1, lin2, bn2 = self.nn[0], self.nn[1], self.nn[3], self.nn[4]
+        h2, cin = lin1.weight.shape[0], x.shape[1]
+        if self.trans_inv:
+            wcat = torch.cat([-lin1.weight, lin1.weight], dim=0)
+        else:
+            wa, wb = lin1.weight[:, :cin], lin1.weight[:, cin:]
+            wcat = torch.cat([wa - wb, wb], dim=0)
+        y = SF.linear(x, wcat)                                             # [N, 2 * h2] = [A | B], per-VERTEX GEMM
+        a = _GatherRowsFn.apply(y[:, :h2], ei.dst32, ei.by_dst)
+        b = _GatherRowsFn.apply(y[:, h2:], ei.src32, ei.by_src)
+        h = F.relu(batch_norm_rows(a + b, bn1))                            # [E, 2 cout]
+        m = batch_norm_rows(SF.linear(h, lin2.weight), bn2)                # per-EDGE GEMM, [E, cout]
+        return _ScatterMeanFn.apply(m, ei)
+
+    def __repr__(self):
+        return '{}(nn={}, aggr=mean)'.format('EdgeConvTransInv' if self.trans_inv else 'EdgeConv', self.nn)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, filters):
+        super().__init__()
+        self.filters = nn.ModuleList(filters)
+
+    def forward(self, x, ei):
+        x = F.relu(self.filters[0](x, ei))
+        for f in list(self.filters)[1:]:
+            x = F.relu(x + f(x, ei))
+        return x
+
+
+class SingleConvMeshNet(nn.Module):
+    """Same constructor as the reference (models/singleconvmeshnet.py:13-14); forward(sample) -> [N0, num_classes]."""
+
+    def __init__(self, feature_number, num_propagation_steps, filter_sizes, num_classes=3, pooling_method='mean', aggr='mean'):
+        super().__init__()
+        if aggr != 'mean':
+            raise NotImplementedError('aggr=%r: the reference only ever constructs the mean aggregation' % aggr)
+        self._pooling_method = pooling_method
+        self._graph_levels = len(filter_sizes)
+        left, right = [], []
+        cur = feature_number
+        for level, fs in enumerate(filter_sizes):
+            first = EdgeConvBN(cur, fs, trans_inv=(level == 0 and level < len(filter_sizes) - 1))
+            left.append(ResBlock([first] + [EdgeConvBN(fs, fs) for _ in range(num_propagation_steps - 1)]))
+            if level < len(filter_sizes) - 1:
+                right.append(ResBlock([EdgeConvBN(fs + filter_sizes[level + 1], fs)] +
+                                      [EdgeConvBN(fs, fs) for _ in range(num_propagation_steps - 1)]))
+                cur = fs
+        self.left_geo_cnns = nn.ModuleList(left)
+        self.right_geo_cnns = nn.ModuleList(right)
+        f0 = filter_sizes[0]
+        self.final_convs = nn.ModuleList([nn.Sequential(nn.Linear(f0, f0 // 2), nn.BatchNorm1d(f0 // 2), nn.ReLU(),
+                                                        nn.Linear(f0 // 2, num_classes))])
+
+    # ---- per-sample index structures, cached on the sample ----------------------------------------------------
+    def _indices(self, sample):
+        cache = getattr(sample, '_scmn_cache', None)
+        if cache is None:
+            x = sample.x
+            assert x.is_cuda, 'the HIP path needs the sample on the GPU (sample.to("cuda"))'
+            L = self._graph_levels
+            bad = torch.zeros(1, dtype=torch.int32, device=x.device)
+            sizes = [x.shape[0]]
+            pools = {}
+            for level in range(1, L):
+                trace = sample['hierarchy_trace_index_%d' % level]
+                n_coarse = int(trace.max()) + 1                       # scatter_* without dim_size (:111-113)
+                pools[level] = PoolMap(trace, sizes[-1], n_coarse, bad)
+                sizes.append(n_coarse)
+            edges = {0: _EdgeIndex(sample.edge_index, sizes[0], bad)}
+            for level in range(1, L):
+                edges[level] = _EdgeIndex(sample['hierarchy_edge_index_%d' % level], sizes[level], bad)
+            if int(bad.item()) != 0:
+                raise IndexError('edge / trace index out of range')
+            cache = (edges, pools)
+            try:
+                object.__setattr__(sample, '_scmn_cache', cache)
+            except Exception:
+                pass
+        return cache
+
+    def _pooling(self, x, pool):
+        if self._pooling_method == 'mean':
+            return SF.PoolMeanFn.apply(x, pool)
+        if self._pooling_method == 'max':
+            return SF.PoolMaxFn.apply(x, pool)
+        raise ValueError('Unkown pooling type {}'.format(self._pooling_method))
+
+    def forward(self, sample):
+        edges, pools = self._indices(sample)
+        L = self._graph_levels
+        levels = [self.left_geo_cnns[0](sample.x, edges[0])]
+        for level in range(1, L):
+            levels.append(self.left_geo_cnns[level](self._pooling(levels[-1], pools[level]), edges[level]))
+        current = levels[-1]
+        for level in range(1, L):
+            back = SF.UnpoolFn.apply(current, pools[L - level])
+            fused = torch.cat((levels[-(level + 1)], back), -1)
+            current = self.right_geo_cnns[-level](fused, edges[L - level - 1])
+        lin1, bn, lin2 = self.final_convs[0][0], self.final_convs[0][1], self.final_convs[0][3]
+        out = F.relu(batch_norm_rows(SF.linear(current, lin1.weight, lin1.bias), bn))
+        return SF.linear(out, lin2.weight, lin2.bias)
