@@ -156,6 +156,9 @@ def main():
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--time-gemms', action='store_true', help='also bracket every MFMA GEMM launch with HIP events')
     ap.add_argument('--cache-plan', action='store_true', help='reuse the CSR plan across steps (NOT the headline)')
+    ap.add_argument('--crops', type=int, default=0,
+                    help='BASELINE config 3: a collated batch of this many unequal crops (12-28k vertices each) per step '
+                         'instead of one scene (NOT the headline); combine with --levels 4 --dtype bf16')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the fwd+loss+bwd-only loop after the timed region (profiling runs: keeps the kernel mix = the step)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
@@ -192,7 +195,12 @@ def main():
     if args.dtype == 'bf16':
         net.set_activation_dtype(torch.bfloat16)
     step = TrainStep(net, lr=7e-5, amsgrad=True)
-    sample = make_synthetic_mesh(args.vertices, args.levels, seed=rank).to(device)   # one scene per rank
+    if args.crops > 0:
+        from surface_texture_inpainting_net_amd.data import collate
+        sizes = [12_000 + (16_000 * i) // max(args.crops - 1, 1) for i in range(args.crops)]
+        sample = collate([make_synthetic_mesh(n, args.levels, seed=100 * rank + i) for i, n in enumerate(sizes)]).to(device)
+    else:
+        sample = make_synthetic_mesh(args.vertices, args.levels, seed=rank).to(device)   # one scene per rank
     n0 = sample.x.shape[0]
     e0 = sample.edge_index.shape[1]
 
@@ -279,7 +287,8 @@ def main():
                                    % (n0, e0, args.levels, 'fp32' if args.dtype == 'f32' else 'bf16 activation storage '
                                       '(fp32 accumulate / statistics / weights)'),
                        'vertices_per_gpu': n0, 'edges_per_gpu': e0, 'levels': args.levels, 'params': sum(p.numel() for p in net.parameters()),
-                       'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan},
+                       'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan,
+                       'crops_per_step': args.crops or None},
             'loss': float(loss),
             'fwd_loss_bwd_only': None if args.no_secondary else {
                 'ms_per_step': dt_fb / args.steps * 1e3, 'vertices_per_s_per_gpu': n0 * args.steps / dt_fb,

@@ -22,6 +22,7 @@ class HierarchicalBatch:
     def __init__(self, **tensors):
         object.__setattr__(self, '_store', {})
         object.__setattr__(self, '_plan_cache', None)
+        object.__setattr__(self, '_nv_host', None)          # host copy of num_vertices (level sizes without a device sync)
         for k, v in tensors.items():
             self._store[k] = v
 
@@ -33,7 +34,7 @@ class HierarchicalBatch:
         raise AttributeError(key)
 
     def __setattr__(self, key, value):
-        if key in ('_store', '_plan_cache'):
+        if key in ('_store', '_plan_cache', '_nv_host'):
             object.__setattr__(self, key, value)
         else:
             self._store[key] = value
@@ -59,6 +60,9 @@ class HierarchicalBatch:
         out = HierarchicalBatch()
         for k, v in self._store.items():
             out._store[k] = v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v
+        nv = self._store.get('num_vertices')
+        if torch.is_tensor(nv):                              # the plan needs the level sizes on the host: keep them there
+            out._nv_host = self._nv_host if self._nv_host is not None else (nv if not nv.is_cuda else None)
         return out
 
     def pin_memory(self):

@@ -166,6 +166,8 @@ class SceneLoader:
             # the worker skipped the graph tensors expecting a cache hit, but the entry was evicted meanwhile: reload
             return self._to_device(ids, next(self._reload(ids)))
         out = HierarchicalBatch(**dev)
+        if 'num_vertices' in cpu_batch:
+            out._nv_host = cpu_batch['num_vertices']            # level sizes for the plan without a device sync
         if self.cache is not None:
             plan = self.model.prefetch_plan(out) if self.model is not None else _plan.plan_for(out)
             graph = {k: v for k, v in dev.items() if k not in _FEATURE_KEYS}

@@ -157,8 +157,11 @@ class NormGroups:
         self.quirk = bool((sum_ptr != true_ptr).any())
         self.ptr_true = true_ptr.to(torch.int32).to(device)
         self.ptr_sum = sum_ptr.to(torch.int32).to(device)
-        sid = torch.repeat_interleave(torch.arange(B, dtype=torch.int32), (sum_ptr[1:] - sum_ptr[:-1]))
-        self.sid = sid.to(device) if self.quirk else self.gid
+        if self.quirk:      # slice id per row = number of slice boundaries <= row (on the device: no host-side expansion)
+            rows = torch.arange(n_rows, device=device, dtype=torch.int64)
+            self.sid = torch.searchsorted(self.ptr_sum[1:].to(torch.int64), rows, right=True).to(torch.int32)
+        else:
+            self.sid = self.gid
         self.inv_cnt = (1.0 / counts.to(torch.float32).clamp(min=1)).to(device)
 
 
@@ -170,8 +173,10 @@ class GraphPlan:
         assert x.is_cuda, 'the HIP path needs the sample on the GPU (sample.to("cuda"))'
         self.device = x.device
         self.linspace_quirk = linspace_quirk
-        nv = sample.num_vertices
-        nv = nv.detach().to('cpu', torch.int64)          # [B, L]; one tiny D2H copy per sample
+        nv = getattr(sample, '_nv_host', None)            # host copy kept by HierarchicalBatch.to(): no device sync
+        if nv is None:
+            nv = sample.num_vertices                      # foreign sample types: one tiny D2H copy (a host sync) per plan
+        nv = nv.detach().to('cpu', torch.int64)           # [B, L]
         if nv.dim() == 1:
             nv = nv.view(1, -1)
         self.num_vertices = nv
