@@ -1,5 +1,8 @@
-// Per-vertex dense GEMMs of the STINet hot path on the gfx950 matrix cores, exact fp32
-// (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain, 157 TFLOP/s chip peak).
+// Per-vertex dense GEMMs of the STINet hot path on the gfx950 matrix cores.  Kernel families in this file:
+//   k_gemm_nt / k_gemm_tn              exact fp32 (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain, 157 TFLOP/s peak)
+//   k_gemm_nt_bf16s / k_gemm_tn_bf16s  fp32 storage, operands split on the fly into 16-bit pieces (bf16 x3 / x6, fp16 x3),
+//                                      v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation - what the network runs on
+//   k_gemm_nt_b16 / k_gemm_tn_b16      bf16 storage (the *_bf16 entry points), one MFMA per k-step
 //
 //   stin_gemm_nt_f32 : C[M, Nc] = A[M, K] . W[Nc, K]^T (+ bias)      forward GEMMs and dgrad (with W^T)
 //   stin_gemm_tn_f32 : dW[Nc, K(+1)] = G[M, Nc]^T . [X[M, K] | 1]    weight (+bias) gradients, split over M

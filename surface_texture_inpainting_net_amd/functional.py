@@ -411,7 +411,8 @@ class EdgeConvBlockFn(torch.autograd.Function):
         agg = h W2^T + b2 [deg > 0]                                (per-VERTEX MFMA GEMM, masked bias)
         out = (Y[:, 2H:] or x) + ELU(InstanceNorm(agg))            (HIP epilogue)
 
-    Only per-vertex tensors are saved; ReLU masks are recomputed in backward."""
+    Saved for backward: per-vertex tensors plus the E*H-bit ReLU mask (recompute kernels when the hidden width does not
+    support the mask).  Fast path: one C call per direction (stin_edgeconv_block_fwd / _bwd, same kernels, same order)."""
 
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, Ws, bs, edges, groups, trans_inv):
