@@ -190,6 +190,8 @@ int stin_gather_i64(const int64_t* src, const int32_t* idx, int64_t n_out, int64
 #define STIN_POST_NONE 0            /* out = s                                  */
 #define STIN_POST_SCALE 1           /* out = s * inv_cnt[b]            (mean)    */
 #define STIN_POST_RSTD 2            /* out = 1/sqrt(s * inv_cnt[b] + eps)        */
+#define STIN_POST_NORM_COEF 3       /* DOT_ELU only, ranges == graphs: out0 = -rstd^3 s0 inv_cnt, out1 = -rstd s1 inv_cnt:
+                                       the k / m coefficients of stin_norm_act_bwd_* in the same launch (stin_norm_bwd_coef_f32) */
 size_t stin_colreduce_workspace_bytes(int C, int B);
 int stin_colreduce_f32(int mode, const float* x, int64_t ldx, const float* gout, int64_t ldg, int64_t N,
                        int C, const int32_t* ptr, int B, const int32_t* gid, const int32_t* sid,

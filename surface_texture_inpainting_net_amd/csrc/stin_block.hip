@@ -108,7 +108,7 @@ extern "C" size_t stin_edgeconv_block_bwd_workspace_bytes(int64_t N, int Cp, int
            + up256((size_t)N * H * es)       /* dhE  */
            + up256((size_t)N * Yw * es)      /* dY   */
            + up256((size_t)Cout * (H + 1) * 4) + up256(Yw * (size_t)(Cp + 1) * 4) /* dw2b, dwb */
-           + 4 * up256((size_t)B * Cout * 4) /* T1, S0, k, m */
+           + 2 * up256((size_t)B * Cout * 4) /* k, m */
            + up256(stin_colreduce_workspace_bytes(Cout, B)) + up256(tn) + 256;
 }
 
@@ -141,8 +141,6 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
     void* dY = carve(p, (size_t)N * Yw * es);
     float* dw2b = reinterpret_cast<float*>(carve(p, (size_t)Cout * (H + 1) * 4));
     float* dwb = reinterpret_cast<float*>(carve(p, (size_t)Yw * (Cp + 1) * 4));
-    float* T1 = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
-    float* S0 = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
     float* kk = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
     float* mm = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
     const size_t red_bytes = stin_colreduce_workspace_bytes(Cout, B);
@@ -156,10 +154,10 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         const float* gf = static_cast<const float*>(g);
         const float* hf = static_cast<const float*>(hE);
         float* dYf = static_cast<float*>(dY);
-        // instance norm + ELU backward: two column sums, their coefficients, one elementwise pass
+        // instance norm + ELU backward: two column sums finalised straight into the k / m coefficients, one elementwise pass
         STIN_TRY(stin_colreduce_f32(STIN_RED_DOT_ELU, static_cast<const float*>(agg), Cout, gf, ldg, N, Cout, ptr_true, B, gid,
-                                    nullptr, mean, rstd, nullptr, STIN_POST_NONE, inv_cnt, 0.f, T1, S0, red_ws, red_bytes, stream));
-        STIN_TRY(stin_norm_bwd_coef_f32(T1, S0, rstd, inv_cnt, B, Cout, kk, mm, stream));
+                                    nullptr, mean, rstd, nullptr, STIN_POST_NORM_COEF, inv_cnt, 0.f, kk, mm, red_ws, red_bytes,
+                                    stream));
         STIN_TRY(stin_norm_act_bwd_f32(static_cast<const float*>(agg), Cout, gf, ldg, mean, rstd, rstd, kk, mm, gid, gid, N, Cout,
                                        1, static_cast<float*>(dagg), Cout, stream));
         // second Linear: weight gradient (+ masked bias gradient) and input gradient
@@ -187,9 +185,8 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         const stin_bf16_t* hh = static_cast<const stin_bf16_t*>(hE);
         stin_bf16_t* dYh = static_cast<stin_bf16_t*>(dY);
         STIN_TRY(stin_colreduce_bf16(STIN_RED_DOT_ELU, static_cast<const stin_bf16_t*>(agg), Cout, gh, ldg, N, Cout, ptr_true, B,
-                                     gid, nullptr, mean, rstd, nullptr, STIN_POST_NONE, inv_cnt, 0.f, T1, S0, red_ws, red_bytes,
+                                     gid, nullptr, mean, rstd, nullptr, STIN_POST_NORM_COEF, inv_cnt, 0.f, kk, mm, red_ws, red_bytes,
                                      stream));
-        STIN_TRY(stin_norm_bwd_coef_f32(T1, S0, rstd, inv_cnt, B, Cout, kk, mm, stream));
         STIN_TRY(stin_norm_act_bwd_bf16(static_cast<const stin_bf16_t*>(agg), Cout, gh, ldg, mean, rstd, rstd, kk, mm, gid, gid, N,
                                         Cout, 1, static_cast<stin_bf16_t*>(dagg), Cout, stream));
         STIN_TRY(stin_gemm_tn_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, hh, ldh, N, Cout, H, 1, hh + H, ldh, dw2b, H + 1,

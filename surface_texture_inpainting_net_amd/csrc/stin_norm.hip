@@ -114,7 +114,8 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce(const T* __restrict__ x, in
 constexpr int FIN_COLS = 16, FIN_KL = 16;
 __global__ __launch_bounds__(BLOCK) void k_colreduce_final(const double* __restrict__ partial, int nch, int nout, int C,
                                                            int B, int post, const float* __restrict__ inv_cnt, float eps,
-                                                           float* __restrict__ out0, float* __restrict__ out1) {
+                                                           const float* __restrict__ aux, float* __restrict__ out0,
+                                                           float* __restrict__ out1) {
     __shared__ double sm[FIN_KL][FIN_COLS + 1];
     const int tx = threadIdx.x % FIN_COLS, ty = threadIdx.x / FIN_COLS;
     const int c = blockIdx.x * FIN_COLS + tx, o = blockIdx.y, b = blockIdx.z;
@@ -140,6 +141,10 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce_final(const double* __restr
         float r = (float)s;
         if (post == STIN_POST_SCALE) r = r * inv_cnt[b];
         else if (post == STIN_POST_RSTD) r = 1.0f / sqrtf(r * inv_cnt[b] + eps);
+        else if (post == STIN_POST_NORM_COEF) {          // same float operations as k_norm_coef (stin_pack.hip)
+            const float rs = aux[(int64_t)b * C + c], ic = inv_cnt[b];
+            r = (o == 0) ? -(rs * rs * rs) * r * ic : -(rs * r) * ic;
+        }
         (o == 0 ? out0 : out1)[(int64_t)b * C + c] = r;
     }
 }
@@ -276,7 +281,8 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
     STIN_REQUIRE(N >= 0 && C > 0 && B > 0 && ldx >= C, STIN_E_SIZE);
     STIN_REQUIRE((ptr != nullptr) || B == 1, STIN_E_SIZE);
     STIN_REQUIRE(x && out0 && workspace, STIN_E_NULL);
-    STIN_REQUIRE(post >= STIN_POST_NONE && post <= STIN_POST_RSTD, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(post >= STIN_POST_NONE && post <= STIN_POST_NORM_COEF, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(post != STIN_POST_NORM_COEF || mode == STIN_RED_DOT_ELU, STIN_E_UNSUPPORTED);
     STIN_REQUIRE(post == STIN_POST_NONE || inv_cnt != nullptr, STIN_E_NULL);
     if (mode != STIN_RED_SUM && mode != STIN_RED_MOMENTS) STIN_REQUIRE(mean != nullptr, STIN_E_NULL);
     if (mode == STIN_RED_MOMENTS) STIN_REQUIRE(out1 != nullptr && inv_cnt != nullptr, STIN_E_NULL);
@@ -316,7 +322,7 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
         return stin_launch_status();
     }
     hipLaunchKernelGGL(k_colreduce_final, dim3((unsigned)((C + FIN_COLS - 1) / FIN_COLS), (unsigned)nout, (unsigned)B),
-                       dim3(BLOCK), 0, stream, partial, nch, nout, C, B, post, inv_cnt, eps, out0, out1);
+                       dim3(BLOCK), 0, stream, partial, nch, nout, C, B, post, inv_cnt, eps, rstd, out0, out1);
     return stin_launch_status();
 }
 

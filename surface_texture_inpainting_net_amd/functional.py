@@ -17,7 +17,7 @@ EPS = 1e-5
 # save the edge-stage ReLU decisions as a bit-mask in forward (STIN_EDGE_MASK=0: recompute them in backward)
 USE_EDGE_MASK = os.environ.get('STIN_EDGE_MASK', '1') != '0'
 RED_SUM, RED_CSQ, RED_DOT_ELU, RED_COEF_XC, RED_MOMENTS = 0, 1, 2, 3, 4
-POST_NONE, POST_SCALE, POST_RSTD = 0, 1, 2
+POST_NONE, POST_SCALE, POST_RSTD, POST_NORM_COEF = 0, 1, 2, 3
 
 
 def _mat(t):

@@ -665,3 +665,19 @@ def test_deferred_plan_validation_reports_bad_indices_one_call_later():
         with pytest.raises(IndexError):
             check_deferred(wait=True)
         check_deferred(wait=True)
+
+
+def test_norm_backward_coefficients_fused_into_the_reduction_equal_the_separate_kernel():
+    """STIN_POST_NORM_COEF (what the whole-block backward uses) = DOT_ELU sums followed by stin_norm_bwd_coef_f32, bit for bit."""
+    n, C = 9000, 64
+    batch = torch.cat([torch.zeros(4000), torch.ones(5000)]).long().to(DEV)
+    groups = M._as_groups(batch, n, torch.device(DEV), False)
+    g = torch.Generator().manual_seed(5)
+    x, go = torch.randn(n, C, generator=g).to(DEV), torch.randn(n, C, generator=g).to(DEV)
+    mean, rstd = SF.instance_stats(x, groups)
+    T1, S0 = SF.colreduce(SF.RED_DOT_ELU, x, groups, groups.ptr_true, gout=go, mean=mean, rstd=rstd)
+    k, m = torch.empty_like(rstd), torch.empty_like(rstd)
+    SF._call('stin_norm_bwd_coef_f32', SF._ptr(T1), SF._ptr(S0), SF._ptr(rstd), SF._ptr(groups.inv_cnt), rstd.shape[0], C,
+             SF._ptr(k), SF._ptr(m), SF._stream(x))
+    k2, m2 = SF.colreduce(SF.RED_DOT_ELU, x, groups, groups.ptr_true, gout=go, mean=mean, rstd=rstd, post=SF.POST_NORM_COEF)
+    assert torch.equal(k, k2) and torch.equal(m, m2)
