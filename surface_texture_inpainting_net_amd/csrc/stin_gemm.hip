@@ -1184,13 +1184,14 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     if (M == 0) return STIN_OK;
     STIN_REQUIRE(A && W && C, STIN_E_NULL);
     const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldw % 4 == 0) && stin_aligned16(A) && stin_aligned16(W);
-    // Tile choice, from a per-shape sweep on MI355X (profiles/gemm_tiles.py) and whole-step A/B runs: these skinny GEMMs
-    // are latency-bound, so the 64x64 tile (4x the blocks in flight) wins nearly everywhere.  128x128 is 6-22 % faster
-    // in isolation (operands warm in L2) for Nc % 128 == 0, K >= 256, M >= 6e4, but slower inside the training step,
-    // where A arrives from HBM - so it stays opt-in (STIN_NT_MINBLOCKS / STIN_NT_TILE).
+    // Tile choice, from per-shape sweeps on MI355X (profiles/gemm_tiles.py) and whole-step A/B runs: the skinny GEMMs of the
+    // shipped 3-level network (K <= 256, or K >= 512 with only 256 output columns) are latency-bound, so the 64x64 tile (4x
+    // the blocks in flight) wins there.  Long reductions with enough tiles (the 1024..4096-wide layers of a 5-level network:
+    // K >= 512, >= 500 tiles of 128x128) are 1.15-1.35x faster on 128x128.
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Nc + bn - 1) / bn); };
-    static const int64_t min_blocks = getenv("STIN_NT_MINBLOCKS") ? atoi(getenv("STIN_NT_MINBLOCKS")) : (int64_t)1 << 40;   // tuning aid
+    static const int64_t min_blocks = getenv("STIN_NT_MINBLOCKS") ? atoi(getenv("STIN_NT_MINBLOCKS")) : 500;   // tuning aid
     const int force_tile = stin_nt_force_tile();   // tuning aid: 0 = rule above, 1 = 128x128, 2 = 128x64, 3 = 64x64
+    const bool big_tile = Nc % 128 == 0 && K >= 512 && blocks(128, 128) >= min_blocks;
 #define STIN_NT_ARGS A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc
 #define STIN_NT(KERNEL, BM_, BN_, WM_, WN_, ...)                                                                  \
     do {                                                                                                          \
@@ -1201,18 +1202,26 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
 #define STIN_NT_PICK(KERNEL, ...)                                                              \
     do {                                                                                       \
         if (Nc <= 32) STIN_NT(KERNEL, 128, 32, 4, 1, ##__VA_ARGS__);                           \
-        else if (force_tile == 1 || (force_tile == 0 && Nc % 128 == 0 && K >= 256 && blocks(128, 128) >= min_blocks)) STIN_NT(KERNEL, 128, 128, 2, 2, ##__VA_ARGS__); \
+        else if (force_tile == 1 || (force_tile == 0 && big_tile)) STIN_NT(KERNEL, 128, 128, 2, 2, ##__VA_ARGS__); \
         else if (force_tile == 2) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);  \
         else STIN_NT(KERNEL, 64, 64, 2, 2, ##__VA_ARGS__);                                     \
     } while (0)
     if (wpre) {
         // pre-split W: the 16-byte vector path only (K % 4 == 0, aligned rows) - one tile shape, the data is per-network
         STIN_REQUIRE(vec, STIN_E_ALIGN);
-        dim3 grid(nt_grid(M, Nc, 64, 64));
-        if (precision == STIN_GEMM_BF16X3)
-            hipLaunchKernelGGL((k_gemm_nt_bf16s<64, 64, 2, 2, 2, __bf16, true, true>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS);
-        else
-            hipLaunchKernelGGL((k_gemm_nt_bf16s<64, 64, 2, 2, 2, _Float16, true, true>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS);
+        if (force_tile == 1 || (force_tile == 0 && big_tile)) {
+            dim3 grid(nt_grid(M, Nc, 128, 128));
+            if (precision == STIN_GEMM_BF16X3)
+                hipLaunchKernelGGL((k_gemm_nt_bf16s<128, 128, 2, 2, 2, __bf16, true, true>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS);
+            else
+                hipLaunchKernelGGL((k_gemm_nt_bf16s<128, 128, 2, 2, 2, _Float16, true, true>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS);
+        } else {
+            dim3 grid(nt_grid(M, Nc, 64, 64));
+            if (precision == STIN_GEMM_BF16X3)
+                hipLaunchKernelGGL((k_gemm_nt_bf16s<64, 64, 2, 2, 2, __bf16, true, true>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS);
+            else
+                hipLaunchKernelGGL((k_gemm_nt_bf16s<64, 64, 2, 2, 2, _Float16, true, true>), grid, dim3(BLOCK), 0, stream, STIN_NT_ARGS);
+        }
     } else if (precision == STIN_GEMM_BF16X3) STIN_NT_PICK(k_gemm_nt_bf16s, 2, __bf16);
     else if (precision == STIN_GEMM_BF16X6) STIN_NT_PICK(k_gemm_nt_bf16s, 3, __bf16);
     else if (precision == STIN_GEMM_F16X3) STIN_NT_PICK(k_gemm_nt_bf16s, 2, _Float16);
@@ -1300,7 +1309,10 @@ extern "C" int stin_gemm_nt_bf16(const stin_bf16_t* A_, int64_t lda, const float
     STIN_REQUIRE(A && W && C, STIN_E_NULL);
     const bool vec = (K % 8 == 0) && (lda % 8 == 0) && (ldw % 4 == 0) && stin_aligned16(A) && stin_aligned16(W);
     const int vec_out = (!c_is_f32 && Nc % 8 == 0 && ldc % 8 == 0 && stin_aligned16(C)) ? 1 : 0;
-    const int force_tile = stin_nt_force_tile();   // 64x64 is the best tile for every network shape (profiles/gemm_tiles.py)
+    // 64x64 is the best tile for every shape of the shipped 3-level network; long reductions with enough tiles (the wide
+    // layers of a 5-level network) are 1.1-1.5x faster on 128x64 (profiles/gemm_tiles.py)
+    const int force_tile = stin_nt_force_tile();
+    const bool tall_tile = K >= 512 && ((M + 127) / 128) * ((Nc + 63) / 64) >= 1000;
 #define STIN_NTB(BM_, BN_, WM_, WN_, OUT_)                                                                             \
     do {                                                                                                               \
         dim3 grid(nt_grid(M, Nc, BM_, BN_));                                                                           \
@@ -1311,7 +1323,7 @@ extern "C" int stin_gemm_nt_bf16(const stin_bf16_t* A_, int64_t lda, const float
     do {                                                                                             \
         if (Nc <= 32) STIN_NTB(128, 32, 4, 1, OUT_);                                                 \
         else if (force_tile == 1) STIN_NTB(128, 128, 2, 2, OUT_);                                    \
-        else if (force_tile == 2) STIN_NTB(128, 64, 2, 2, OUT_);                                     \
+        else if (force_tile == 2 || (force_tile == 0 && tall_tile)) STIN_NTB(128, 64, 2, 2, OUT_);   \
         else STIN_NTB(64, 64, 2, 2, OUT_);                                                           \
     } while (0)
     if (c_is_f32) STIN_NTB_PICK(float);
