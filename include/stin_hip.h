@@ -159,6 +159,10 @@ int stin_pool_max_bwd_f32(const float* g, int64_t ldg, const int32_t* arg, const
  * `x[traces]` (models/surfacetextureinpaintingnet.py:390-391) and the mean-pool backward. */
 int stin_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, const float* row_scale,
                          int64_t n_out, int C, float* out, int64_t ldo, stin_stream_t stream);
+/* out[e, :] = a[idx_a[e], :] + b[idx_b[e], :]: the per-edge pre-activation Lin1([x_i ; x_j - x_i]) = A[dst] + B[src]
+ * of the BatchNorm edge MLP (models/modules/edge_conv_filter.py:34-44), one pass instead of two gathers and an add. */
+int stin_gather_add_rows_f32(const float* a, int64_t lda, const int32_t* idx_a, const float* b, int64_t ldb,
+                             const int32_t* idx_b, int64_t n_out, int C, float* out, int64_t ldo, stin_stream_t stream);
 /* Per-level graph-id vector (int64, bit-exact): scatter_max(batch, trace) and
  * batch.index_select(0, trace) (models/surfacetextureinpaintingnet.py:421-422,:446-447). */
 int stin_batch_pool_i64(const int64_t* batch, const int32_t* rowptr, const int32_t* col, int64_t n_coarse,
@@ -187,6 +191,10 @@ int stin_gather_i64(const int64_t* src, const int32_t* idx, int64_t n_out, int64
 #define STIN_RED_DOT_ELU 2
 #define STIN_RED_COEF_XC 3
 #define STIN_RED_MOMENTS 4          /* one pass: out0 = mean, out1 = 1/sqrt(biased var + eps) from fp64 sum x, sum x^2 */
+#define STIN_RED_DOT_BN 5           /* BatchNorm-with-affine backward sums (one range): d = gout (* [gamma n + beta > 0] with
+                                       STIN_RED_DOT_BN_RELU), n = (x - mean) rstd; out0 = sum d n (= dgamma), out1 = sum d
+                                       (= dbeta); coef = [gamma ; beta] as 2 x C floats                          */
+#define STIN_RED_DOT_BN_RELU 6
 #define STIN_POST_NONE 0            /* out = s                                  */
 #define STIN_POST_SCALE 1           /* out = s * inv_cnt[b]            (mean)    */
 #define STIN_POST_RSTD 2            /* out = 1/sqrt(s * inv_cnt[b] + eps)        */
@@ -244,6 +252,19 @@ size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int ones_column);
 int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
                      int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
                      int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream);
+
+/* BatchNorm1d-with-affine over ALL rows, optionally followed by ReLU, for the per-edge MLP of SingleConvMeshNet
+ * (models/modules/edge_conv_filter.py:34-44: Lin - BatchNorm1d - ReLU - Lin - BatchNorm1d over the E edge rows):
+ *   fwd: y = act(gamma * (x - mean) * rstd + beta)            mean / rstd [C] from stin_colreduce_f32(STIN_RED_MOMENTS)
+ *   bwd: dx = rstd * gamma * (d - Q * inv_n - n * P * inv_n)   d = gout * act'(.), n = (x - mean) * rstd,
+ *        P = sum d n (= dgamma), Q = sum d (= dbeta) from stin_colreduce_f32(STIN_RED_DOT_BN[_RELU]).
+ * act: 0 = none, 1 = ReLU.
+ */
+int stin_bn_act_fwd_f32(const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, int64_t N, int C, int act, float* y, int64_t ldy, stin_stream_t stream);
+int stin_bn_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_t ldg, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, const float* P, const float* Q, float inv_n, int64_t N,
+                        int C, int act, float* dx, int64_t lddx, stin_stream_t stream);
 
 /* ------------------------------------------------------- parameter-side helpers --
  * pack: the reference-layout EdgeConv parameters (first_filter.nn.0.{weight,bias} = W1 [H, 2Cin]

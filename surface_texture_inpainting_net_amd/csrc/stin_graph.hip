@@ -711,6 +711,33 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(const T* __restrict__ src
         }
 }
 
+// out[e, :] = a[ia[e], :] + b[ib[e], :]: the per-edge pre-activation A_dst + B_src of SingleConvMeshNet's edge MLP
+template <typename T, int G, int VPL>
+__global__ __launch_bounds__(BLOCK) void k_gather_add_rows(const T* __restrict__ a, int64_t lda, const int32_t* __restrict__ ia,
+                                                           const T* __restrict__ b, int64_t ldb, const int32_t* __restrict__ ib,
+                                                           int64_t N, int C, T* __restrict__ out, int64_t ldo) {
+    Lane<G, VPL> L;
+    if (L.row >= N) return;
+    const int64_t ta = ia[L.row], tb = ib[L.row];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        if (L.chan(k) < C) {
+            const float4 u = ld4(a + ta * lda + L.chan(k));
+            const float4 v = ld4(b + tb * ldb + L.chan(k));
+            st4(out + L.row * ldo + L.chan(k), make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w));
+        }
+}
+
+__global__ void k_gather_add_rows_scalar(const float* __restrict__ a, int64_t lda, const int32_t* __restrict__ ia,
+                                         const float* __restrict__ b, int64_t ldb, const int32_t* __restrict__ ib, int64_t N,
+                                         int C, float* __restrict__ out, int64_t ldo) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * C) return;
+    const int64_t r = t / C;
+    const int c = (int)(t % C);
+    out[r * ldo + c] = a[(int64_t)ia[r] * lda + c] + b[(int64_t)ib[r] * ldb + c];
+}
+
 // ------------------------------------------------- scalar fallbacks (C % 4 != 0 / unaligned)
 enum ScalarOp { OP_EDGE_FWD, OP_EDGE_BWD_DST, OP_EDGE_BWD_SRC, OP_SEG_SUM, OP_POOL_MAX, OP_POOL_MAX_BWD, OP_GATHER };
 
@@ -1116,6 +1143,24 @@ extern "C" int stin_pool_max_bwd_bf16(const stin_bf16_t* g, int64_t ldg, const i
                                       int64_t N, int C, stin_bf16_t* gx, int64_t ldgx, stin_stream_t stream) {
     stin_clear_stale_error();
     return pool_max_bwd_impl<stin_bf16>(b16(g), ldg, arg, trace, N, C, b16(gx), ldgx, (hipStream_t)stream);
+}
+
+extern "C" int stin_gather_add_rows_f32(const float* a, int64_t lda, const int32_t* idx_a, const float* b, int64_t ldb,
+                                        const int32_t* idx_b, int64_t N, int C, float* out, int64_t ldo,
+                                        stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    using T = float;
+    STIN_REQUIRE(N >= 0 && C > 0 && lda >= C && ldb >= C && ldo >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(a && b && idx_a && idx_b && out, STIN_E_NULL);
+    if (vec_ok<T>(C, {a, b, out}, {lda, ldb, ldo})) {
+        STIN_DISPATCH_NOU(C, k_gather_add_rows, a, lda, idx_a, b, ldb, idx_b, N, C, out, ldo);
+    } else {
+        hipLaunchKernelGGL(k_gather_add_rows_scalar, dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, a, lda, idx_a, b, ldb,
+                           idx_b, N, C, out, ldo);
+    }
+    return stin_launch_status();
 }
 
 extern "C" int stin_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, const float* row_scale,

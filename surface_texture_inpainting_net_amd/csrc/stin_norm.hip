@@ -31,7 +31,8 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce(const T* __restrict__ x, in
                                                      const int32_t* __restrict__ sid, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ coef,
                                                      double* __restrict__ partial) {
-    constexpr int NOUT = (MODE == STIN_RED_DOT_ELU || MODE == STIN_RED_MOMENTS) ? 2 : 1;
+    constexpr bool DOT_BN = (MODE == STIN_RED_DOT_BN || MODE == STIN_RED_DOT_BN_RELU);
+    constexpr int NOUT = (MODE == STIN_RED_DOT_ELU || MODE == STIN_RED_MOMENTS || DOT_BN) ? 2 : 1;
     __shared__ double sm[NOUT][BLOCK][VW];
     const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
     const int64_t r0 = ptr != nullptr ? ptr[b] : 0;
@@ -62,7 +63,19 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce(const T* __restrict__ x, in
                 } else {
                     const int g = gid != nullptr ? gid[r] : 0;
                     const V<VW> mu = V<VW>::load(mean + (int64_t)g * C + c);
-                    if (MODE == STIN_RED_CSQ) {
+                    if (DOT_BN) {
+                        const V<VW> rs = V<VW>::load(rstd + c);
+                        const V<VW> go = V<VW>::load(gout + r * ldg + c);
+                        const V<VW> ga = V<VW>::load(coef + c);
+                        const V<VW> be = V<VW>::load(coef + C + c);
+#pragma unroll
+                        for (int i = 0; i < VW; ++i) {
+                            const float n = (xv.v[i] - mu.v[i]) * rs.v[i];
+                            const float d = (MODE == STIN_RED_DOT_BN_RELU && !(ga.v[i] * n + be.v[i] > 0.f)) ? 0.f : go.v[i];
+                            acc0[i] += (double)(d * n);
+                            acc1[i] += (double)d;
+                        }
+                    } else if (MODE == STIN_RED_CSQ) {
 #pragma unroll
                         for (int i = 0; i < VW; ++i) { const float d = xv.v[i] - mu.v[i]; acc0[i] += (double)(d * d); }
                     } else if (MODE == STIN_RED_DOT_ELU) {
@@ -254,6 +267,52 @@ __global__ __launch_bounds__(BLOCK) void k_norm_bwd(const T* __restrict__ x, int
     o.store(dx + r * lddx + c);
 }
 
+// BatchNorm1d-with-affine over all rows (+ ReLU): forward and backward elementwise passes (fp32, SingleConvMeshNet)
+template <int VW>
+__global__ __launch_bounds__(BLOCK) void k_bn_fwd(const float* __restrict__ x, int64_t ldx, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int64_t N, int C, int act,
+                                                  float* __restrict__ y, int64_t ldy) {
+    const int CV = C / VW;
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N * CV) return;
+    const int64_t r = t / CV;
+    const int c = (int)(t % CV) * VW;
+    const V<VW> xv = V<VW>::load(x + r * ldx + c), mu = V<VW>::load(mean + c), rs = V<VW>::load(rstd + c);
+    const V<VW> ga = V<VW>::load(gamma + c), be = V<VW>::load(beta + c);
+    V<VW> o;
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+        const float z = ga.v[i] * ((xv.v[i] - mu.v[i]) * rs.v[i]) + be.v[i];
+        o.v[i] = (act && !(z > 0.f)) ? 0.f : z;
+    }
+    o.store(y + r * ldy + c);
+}
+
+template <int VW>
+__global__ __launch_bounds__(BLOCK) void k_bn_bwd(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gout,
+                                                  int64_t ldg, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const float* __restrict__ P, const float* __restrict__ Q, float inv_n,
+                                                  int64_t N, int C, int act, float* __restrict__ dx, int64_t lddx) {
+    const int CV = C / VW;
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N * CV) return;
+    const int64_t r = t / CV;
+    const int c = (int)(t % CV) * VW;
+    const V<VW> xv = V<VW>::load(x + r * ldx + c), go = V<VW>::load(gout + r * ldg + c);
+    const V<VW> mu = V<VW>::load(mean + c), rs = V<VW>::load(rstd + c), ga = V<VW>::load(gamma + c), be = V<VW>::load(beta + c);
+    const V<VW> pv = V<VW>::load(P + c), qv = V<VW>::load(Q + c);
+    V<VW> o;
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+        const float n = (xv.v[i] - mu.v[i]) * rs.v[i];
+        const float d = (act && !(ga.v[i] * n + be.v[i] > 0.f)) ? 0.f : go.v[i];
+        o.v[i] = rs.v[i] * ga.v[i] * (d - qv.v[i] * inv_n - n * (pv.v[i] * inv_n));
+    }
+    o.store(dx + r * lddx + c);
+}
+
 template <typename T>
 inline bool vec4_ok(int C, std::initializer_list<const void*> data, std::initializer_list<const void*> stats,
                     std::initializer_list<int64_t> lds) {
@@ -277,7 +336,7 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
                    int B, const int32_t* gid, const int32_t* sid, const float* mean, const float* rstd,
                    const float* coef, int post, const float* inv_cnt, float eps, float* out0, float* out1,
                    void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    STIN_REQUIRE(mode >= STIN_RED_SUM && mode <= STIN_RED_MOMENTS, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(mode >= STIN_RED_SUM && mode <= STIN_RED_DOT_BN_RELU, STIN_E_UNSUPPORTED);
     STIN_REQUIRE(N >= 0 && C > 0 && B > 0 && ldx >= C, STIN_E_SIZE);
     STIN_REQUIRE((ptr != nullptr) || B == 1, STIN_E_SIZE);
     STIN_REQUIRE(x && out0 && workspace, STIN_E_NULL);
@@ -288,6 +347,8 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
     if (mode == STIN_RED_MOMENTS) STIN_REQUIRE(out1 != nullptr && inv_cnt != nullptr, STIN_E_NULL);
     if (mode == STIN_RED_DOT_ELU) STIN_REQUIRE(gout && rstd && out1 && ldg >= C, STIN_E_NULL);
     if (mode == STIN_RED_COEF_XC) STIN_REQUIRE(coef != nullptr, STIN_E_NULL);
+    if (mode == STIN_RED_DOT_BN || mode == STIN_RED_DOT_BN_RELU)
+        STIN_REQUIRE(gout && rstd && coef && out1 && ldg >= C && B == 1 && gid == nullptr, STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_colreduce_workspace_bytes(C, B), STIN_E_WORKSPACE);
     double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
 
@@ -301,7 +362,7 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
     int cap = MAX_SLABS / B;
     if (cap < 1) cap = 1;
     int nch = (int)(want < 1 ? 1 : (want > cap ? cap : want));
-    const int nout = (mode == STIN_RED_DOT_ELU || mode == STIN_RED_MOMENTS) ? 2 : 1;
+    const int nout = (mode == STIN_RED_DOT_ELU || mode == STIN_RED_MOMENTS || mode >= STIN_RED_DOT_BN) ? 2 : 1;
     dim3 grid((unsigned)nch, (unsigned)B);
 #define STIN_RED_LAUNCH(M)                                                                                          \
     do {                                                                                                            \
@@ -313,6 +374,8 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
         case STIN_RED_CSQ: STIN_RED_LAUNCH(STIN_RED_CSQ); break;
         case STIN_RED_DOT_ELU: STIN_RED_LAUNCH(STIN_RED_DOT_ELU); break;
         case STIN_RED_MOMENTS: STIN_RED_LAUNCH(STIN_RED_MOMENTS); break;
+        case STIN_RED_DOT_BN: STIN_RED_LAUNCH(STIN_RED_DOT_BN); break;
+        case STIN_RED_DOT_BN_RELU: STIN_RED_LAUNCH(STIN_RED_DOT_BN_RELU); break;
         default: STIN_RED_LAUNCH(STIN_RED_COEF_XC); break;
     }
 #undef STIN_RED_LAUNCH
@@ -421,4 +484,43 @@ extern "C" int stin_norm_act_bwd_bf16(const stin_bf16_t* x, int64_t ldx, const s
     stin_clear_stale_error();
     return norm_bwd_impl<stin_bf16>(b16(x), ldx, b16(gout), ldg, mean, rstd, a, k, m, gid, sid, N, C, act, b16(dx), lddx,
                                     (hipStream_t)stream);
+}
+
+extern "C" int stin_bn_act_fwd_f32(const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, int64_t N, int C, int act, float* y, int64_t ldy, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldy >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(x && mean && rstd && gamma && beta && y, STIN_E_NULL);
+    if (vec4_ok<float>(C, {x, y}, {mean, rstd, gamma, beta}, {ldx, ldy})) {
+        const int64_t n = N * (C / 4);
+        hipLaunchKernelGGL((k_bn_fwd<4>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, mean, rstd, gamma,
+                           beta, N, C, act, y, ldy);
+    } else {
+        const int64_t n = N * C;
+        hipLaunchKernelGGL((k_bn_fwd<1>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, mean, rstd, gamma,
+                           beta, N, C, act, y, ldy);
+    }
+    return stin_launch_status();
+}
+
+extern "C" int stin_bn_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_t ldg, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, const float* P, const float* Q,
+                                   float inv_n, int64_t N, int C, int act, float* dx, int64_t lddx, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldg >= C && lddx >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(x && gout && mean && rstd && gamma && beta && P && Q && dx, STIN_E_NULL);
+    if (vec4_ok<float>(C, {x, gout, dx}, {mean, rstd, gamma, beta, P, Q}, {ldx, ldg, lddx})) {
+        const int64_t n = N * (C / 4);
+        hipLaunchKernelGGL((k_bn_bwd<4>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, gout, ldg, mean,
+                           rstd, gamma, beta, P, Q, inv_n, N, C, act, dx, lddx);
+    } else {
+        const int64_t n = N * C;
+        hipLaunchKernelGGL((k_bn_bwd<1>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, gout, ldg, mean,
+                           rstd, gamma, beta, P, Q, inv_n, N, C, act, dx, lddx);
+    }
+    return stin_launch_status();
 }

@@ -16,7 +16,7 @@ from .plan import _ptr, _stream
 EPS = 1e-5
 # save the edge-stage ReLU decisions as a bit-mask in forward (STIN_EDGE_MASK=0: recompute them in backward)
 USE_EDGE_MASK = os.environ.get('STIN_EDGE_MASK', '1') != '0'
-RED_SUM, RED_CSQ, RED_DOT_ELU, RED_COEF_XC, RED_MOMENTS = 0, 1, 2, 3, 4
+RED_SUM, RED_CSQ, RED_DOT_ELU, RED_COEF_XC, RED_MOMENTS, RED_DOT_BN, RED_DOT_BN_RELU = 0, 1, 2, 3, 4, 5, 6
 POST_NONE, POST_SCALE, POST_RSTD, POST_NORM_COEF = 0, 1, 2, 3
 
 
@@ -169,7 +169,7 @@ def colreduce(mode, x, groups, ptr, *, gout=None, mean=None, rstd=None, coef=Non
     N, C = x.shape
     B = groups.B
     out0 = torch.empty(B, C, dtype=torch.float32, device=x.device)
-    out1 = torch.empty(B, C, dtype=torch.float32, device=x.device) if mode in (RED_DOT_ELU, RED_MOMENTS) else None
+    out1 = torch.empty(B, C, dtype=torch.float32, device=x.device) if mode in (RED_DOT_ELU, RED_MOMENTS, RED_DOT_BN, RED_DOT_BN_RELU) else None
     ldg = 0
     if gout is not None:
         gout, ldg = _mat(gout)

@@ -58,6 +58,32 @@ class _GatherRowsFn(torch.autograd.Function):
         return SF.segment_sum(g, ctx.csr.rowptr, ctx.csr.col, ctx.n, mean=False), None, None
 
 
+class _GatherAddFn(torch.autograd.Function):
+    """h[e] = y[dst[e], :h] + y[src[e], h:] in one pass over y = [A | B]; backward: the two segment sums of the edge
+    gradient over the destination / source CSRs (fixed order, no atomics) written into the halves of dy."""
+
+    @staticmethod
+    def forward(ctx, y, ei):
+        y, ld = SF._mat(y)
+        e, h = ei.dst32.shape[0], y.shape[1] // 2
+        out = torch.empty(e, h, dtype=y.dtype, device=y.device)
+        SF._call('stin_gather_add_rows_f32', SF._ptr(y), ld, SF._ptr(ei.dst32), y.data_ptr() + 4 * h, ld, SF._ptr(ei.src32),
+                 e, h, SF._ptr(out), h, SF._stream(y))
+        ctx.ei, ctx.n = ei, y.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ei, n = ctx.ei, ctx.n
+        g, ldg = SF._mat(g)
+        h = g.shape[1]
+        dy = torch.empty(n, 2 * h, dtype=g.dtype, device=g.device)
+        for off, csr in ((0, ei.by_dst), (h, ei.by_src)):
+            SF._call('stin_segment_sum_f32', SF._ptr(g), ldg, SF._ptr(csr.rowptr), SF._ptr(csr.col), n, h, 0,
+                     dy.data_ptr() + 4 * off, 2 * h, SF._stream(g))
+        return dy, None
+
+
 class _ScatterMeanFn(torch.autograd.Function):
     """out[i] = mean of the edge rows whose target is i (0 for vertices without in-edges): scatter_mean."""
 
@@ -93,23 +119,65 @@ class _RowStatsNormFn(torch.autograd.Function):
         return SF.instance_norm_act_bwd(x, g, mean, rstd, ctx.groups, act=False), None, None
 
 
-def batch_norm_rows(x, bn):
+class _BatchNormActFn(torch.autograd.Function):
+    """y = act(gamma * (x - mean) * rstd + beta) with batch statistics over ALL rows, in three passes over x forward
+    (moments, normalise) and two backward (the dgamma / dbeta column sums, then dx) - the affine map, the ReLU and both
+    of their gradients live inside those kernels instead of separate elementwise / reduce launches."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        x, ldx = SF._mat(x)
+        n, c = x.shape
+        mean, rstd = SF.colreduce(SF.RED_MOMENTS, x, groups, groups.ptr_sum, eps=eps)
+        gamma, beta = gamma.detach().contiguous(), beta.detach().contiguous()
+        y = torch.empty(n, c, dtype=x.dtype, device=x.device)
+        SF._call('stin_bn_act_fwd_f32', SF._ptr(x), ldx, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gamma), SF._ptr(beta), n, c,
+                 int(relu), SF._ptr(y), c, SF._stream(x))
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.groups, ctx.relu = groups, relu
+        m1, v1 = mean.view(-1), (1.0 / (rstd * rstd) - eps).clamp_(min=0).view(-1)
+        ctx.mark_non_differentiable(m1, v1)
+        return y, m1, v1
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        x, ldx = SF._mat(x)
+        g, ldg = SF._mat(g)
+        n, c = x.shape
+        gb = torch.stack([gamma, beta])                                     # coef = [gamma ; beta]
+        P, Q = SF.colreduce(SF.RED_DOT_BN_RELU if ctx.relu else SF.RED_DOT_BN, x, ctx.groups, ctx.groups.ptr_sum, gout=g,
+                            mean=mean, rstd=rstd, coef=gb)
+        dx = torch.empty(n, c, dtype=x.dtype, device=x.device)
+        SF._call('stin_bn_act_bwd_f32', SF._ptr(x), ldx, SF._ptr(g), ldg, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gamma),
+                 SF._ptr(beta), SF._ptr(P), SF._ptr(Q), 1.0 / n, n, c, int(ctx.relu), SF._ptr(dx), c, SF._stream(x))
+        return dx, P.view(-1), Q.view(-1), None, None, None
+
+
+def batch_norm_rows(x, bn, relu=False):
     """nn.BatchNorm1d semantics on [rows, C] (training: batch statistics over all rows + running-stat update with the
-    unbiased variance; eval: running statistics), statistics by the fp64-accumulating column-reduction kernels."""
+    unbiased variance; eval: running statistics), statistics by the fp64-accumulating column-reduction kernels;
+    `relu=True` applies the following ReLU in the same kernels."""
     if bn.training or not bn.track_running_stats:
         n = x.shape[0]
-        y, mean, var = _RowStatsNormFn.apply(x, NormGroups(n, x.device), float(bn.eps))
+        fused = bn.affine and x.dtype == torch.float32 and n > 0
+        if fused:
+            y, mean, var = _BatchNormActFn.apply(x, bn.weight, bn.bias, NormGroups(n, x.device), float(bn.eps), bool(relu))
+        else:
+            y, mean, var = _RowStatsNormFn.apply(x, NormGroups(n, x.device), float(bn.eps))
         if bn.training and bn.track_running_stats:
             with torch.no_grad():
                 bn.num_batches_tracked += 1
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                 bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
                 bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+        if fused:
+            return y
     else:
         y = (x - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps)
     if bn.affine:
         y = y * bn.weight + bn.bias
-    return y
+    return F.relu(y) if relu else y
 
 
 class EdgeConvBN(nn.Module):
@@ -132,9 +200,11 @@ class EdgeConvBN(nn.Module):
             wa, wb = lin1.weight[:, :cin], lin1.weight[:, cin:]
             wcat = torch.cat([wa - wb, wb], dim=0)
         y = SF.linear(x, wcat)                                             # [N, 2 * h2] = [A | B], per-VERTEX GEMM
-        a = _GatherRowsFn.apply(y[:, :h2], ei.dst32, ei.by_dst)
-        b = _GatherRowsFn.apply(y[:, h2:], ei.src32, ei.by_src)
-        h = F.relu(batch_norm_rows(a + b, bn1))                            # [E, 2 cout]
+        if y.dtype == torch.float32:
+            pre = _GatherAddFn.apply(y, ei)               # [E, 2 cout] = A[dst] + B[src]
+        else:
+            pre = _GatherRowsFn.apply(y[:, :h2], ei.dst32, ei.by_dst) + _GatherRowsFn.apply(y[:, h2:], ei.src32, ei.by_src)
+        h = batch_norm_rows(pre, bn1, relu=True)                           # [E, 2 cout]
         m = batch_norm_rows(SF.linear(h, lin2.weight), bn2)                # per-EDGE GEMM, [E, cout]
         return _ScatterMeanFn.apply(m, ei)
 
@@ -224,5 +294,5 @@ class SingleConvMeshNet(nn.Module):
             fused = torch.cat((levels[-(level + 1)], back), -1)
             current = self.right_geo_cnns[-level](fused, edges[L - level - 1])
         lin1, bn, lin2 = self.final_convs[0][0], self.final_convs[0][1], self.final_convs[0][3]
-        out = F.relu(batch_norm_rows(SF.linear(current, lin1.weight, lin1.bias), bn))
+        out = batch_norm_rows(SF.linear(current, lin1.weight, lin1.bias), bn, relu=True)
         return SF.linear(out, lin2.weight, lin2.bias)
