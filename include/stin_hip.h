@@ -43,6 +43,7 @@ extern "C" {
 #define STIN_E_UNSUPPORTED (-5)    /* shape outside what this build supports */
 
 typedef void* stin_stream_t;
+typedef void* stin_event_t;  /* a hipEvent_t owned by the caller (only stin_edgeconv_block_bwd's optional side stream uses events) */
 /* bf16 STORAGE variants (*_bf16): the same operation on row-major bfloat16 matrices (raw 16-bit patterns, the
  * upper half of an fp32).  Every kernel widens to fp32 on load, computes and accumulates in fp32 and rounds to
  * nearest-even on store; statistics, weights, biases, index plans and weight gradients stay fp32.  Halves the HBM
@@ -367,6 +368,12 @@ int stin_gemm_tn_bf16(const stin_bf16_t* G, int64_t ldg, const stin_bf16_t* X, i
  *        agg [N, Cout], mean / rstd [B, Cout] - and out [N, Cout].  Yw = 2 H (+ Cout with a shortcut).
  *   bwd: g = dL/dout; dx [N, Cp] may be NULL; parameter gradients in the reference layout (NULL where the parameter
  *        does not exist).  All temporaries live in the caller's workspace.
+ *        wgrad_stream (optional, NULL = everything on `stream`): the two weight-gradient GEMMs, their slab reductions
+ *        and the unpack are off the dx <- g critical path; given a second stream they are enqueued there, ordered after
+ *        `stream` by ev_dagg / ev_dy (recorded on `stream` when their inputs are complete) and followed by ev_done
+ *        (recorded on wgrad_stream after the unpack).  join != 0 makes `stream` wait for ev_done before returning to the
+ *        caller's next enqueue; with join == 0 the CALLER must order any reader of dW1..dbs after ev_done and keep the
+ *        workspace (and x, hE, g) alive until then.  The three events are caller-owned hipEvent_t.
  */
 size_t stin_edgeconv_block_fwd_workspace_bytes(int Cin, int Cp, int H, int Cout, int has_shortcut, int B);
 int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, int64_t N, int Cin, int Cp, int H, int Cout,
@@ -384,7 +391,8 @@ int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, const void*
                             const int32_t* col_src, const int32_t* xslot, const float* w_src, const int32_t* ptr_true, int B,
                             const int32_t* gid, const float* inv_cnt, int prec_bwd, int bwd_split, void* dx, int64_t lddx,
                             float* dW1, float* db1, float* dW2, float* db2, float* dWs, float* dbs, void* workspace,
-                            size_t workspace_bytes, stin_stream_t stream);
+                            size_t workspace_bytes, stin_stream_t stream, stin_stream_t wgrad_stream, stin_event_t ev_dagg,
+                            stin_event_t ev_dy, stin_event_t ev_done, int join);
 
 /* ------------------------------------------------- offline preprocessing on the GPU --
  * The dilated-edge walk of preprocessing/graph_dilation.py:85-137 (`compute_dilated_edges`), one thread per

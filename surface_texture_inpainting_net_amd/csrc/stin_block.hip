@@ -123,7 +123,8 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
                                        const float* w_src, const int32_t* ptr_true, int B, const int32_t* gid,
                                        const float* inv_cnt, int prec_bwd, int bwd_split, void* dx, int64_t lddx, float* dW1,
                                        float* db1, float* dW2, float* db2, float* dWs, float* dbs, void* workspace,
-                                       size_t workspace_bytes, stin_stream_t stream) {
+                                       size_t workspace_bytes, stin_stream_t stream, stin_stream_t wgrad_stream,
+                                       stin_event_t ev_dagg, stin_event_t ev_dy, stin_event_t ev_done, int join) {
     (void)Y;
     (void)ldy;
     STIN_REQUIRE(storage == 0 || storage == 1, STIN_E_UNSUPPORTED);
@@ -149,6 +150,17 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
     const size_t tn_bytes = workspace_bytes - (size_t)(p - static_cast<char*>(workspace));
     const int pb = bwd_split ? (prec_bwd | STIN_GEMM_W_PRESPLIT) : prec_bwd;
     hipStream_t hs = (hipStream_t)stream;
+    // weight-gradient GEMMs are off the critical path dx <- g: with a wgrad_stream they run beside the edge-stage /
+    // dx kernels of this block (and the head of the next one), ordered by the caller's events
+    const bool side = wgrad_stream != nullptr && wgrad_stream != stream;
+    if (side) STIN_REQUIRE(ev_dagg && ev_dy && ev_done, STIN_E_NULL);
+    stin_stream_t ws_ = side ? wgrad_stream : stream;
+    auto fork = [&](stin_event_t ev) -> int {
+        if (!side) return STIN_OK;
+        hipError_t e = hipEventRecord((hipEvent_t)ev, hs);
+        if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)wgrad_stream, (hipEvent_t)ev, 0);
+        return (int)e;
+    };
 
     if (storage == 0) {
         const float* gf = static_cast<const float*>(g);
@@ -161,8 +173,9 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         STIN_TRY(stin_norm_act_bwd_f32(static_cast<const float*>(agg), Cout, gf, ldg, mean, rstd, rstd, kk, mm, gid, gid, N, Cout,
                                        1, static_cast<float*>(dagg), Cout, stream));
         // second Linear: weight gradient (+ masked bias gradient) and input gradient
+        STIN_TRY(fork(ev_dagg));
         STIN_TRY(stin_gemm_tn_f32(static_cast<const float*>(dagg), Cout, hf, ldh, N, Cout, H, 1, hf + H, ldh, dw2b, H + 1,
-                                  prec_bwd, tn_ws, tn_bytes, stream));
+                                  prec_bwd, tn_ws, tn_bytes, ws_));
         STIN_TRY(stin_gemm_nt_f32(static_cast<const float*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H, Cout,
                                   static_cast<float*>(dhE), H, pb, stream));
         // edge stage backward from the saved ReLU mask -> dY = [dA | dB | g]
@@ -175,8 +188,9 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
             if (e != hipSuccess) return (int)e;
         }
         // first Linear (+ shortcut): packed weight gradient and the block-input gradient (+ identity residual)
+        STIN_TRY(fork(ev_dy));
         STIN_TRY(stin_gemm_tn_f32(dYf, Yw, static_cast<const float*>(x), ldx, N, Yw, Cp, 1, nullptr, 0, dwb, Cp + 1, prec_bwd,
-                                  tn_ws, tn_bytes, stream));
+                                  tn_ws, tn_bytes, ws_));
         if (dx != nullptr)
             STIN_TRY(stin_gemm_nt_f32(dYf, Yw, wcatT, Yw, nullptr, nullptr, 0, has_shortcut ? nullptr : gf, ldg, N, Cp, Yw,
                                       static_cast<float*>(dx), lddx, pb, stream));
@@ -189,8 +203,9 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
                                      stream));
         STIN_TRY(stin_norm_act_bwd_bf16(static_cast<const stin_bf16_t*>(agg), Cout, gh, ldg, mean, rstd, rstd, kk, mm, gid, gid, N,
                                         Cout, 1, static_cast<stin_bf16_t*>(dagg), Cout, stream));
+        STIN_TRY(fork(ev_dagg));
         STIN_TRY(stin_gemm_tn_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, hh, ldh, N, Cout, H, 1, hh + H, ldh, dw2b, H + 1,
-                                   tn_ws, tn_bytes, stream));
+                                   tn_ws, tn_bytes, ws_));
         STIN_TRY(stin_gemm_nt_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H,
                                    Cout, dhE, H, 0, stream));
         STIN_TRY(stin_edge_relu_mean_bwd_dst_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, mask, rowptr_dst, N, H, dYh, Yw,
@@ -202,13 +217,19 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
                                             hipMemcpyDeviceToDevice, hs);
             if (e != hipSuccess) return (int)e;
         }
+        STIN_TRY(fork(ev_dy));
         STIN_TRY(stin_gemm_tn_bf16(dYh, Yw, static_cast<const stin_bf16_t*>(x), ldx, N, Yw, Cp, 1, nullptr, 0, dwb, Cp + 1, tn_ws,
-                                   tn_bytes, stream));
+                                   tn_bytes, ws_));
         if (dx != nullptr)
             STIN_TRY(stin_gemm_nt_bf16(dYh, Yw, wcatT, Yw, nullptr, nullptr, 0, has_shortcut ? nullptr : gh, ldg, N, Cp, Yw, dx,
                                        lddx, 0, stream));
     }
     STIN_TRY(stin_edgeconv_unpack_grads_f32(dwb, dw2b, Cin, Cp, H, Cout, has_shortcut, trans_inv, dW1, db1, dWs, dbs, dW2, db2,
-                                            stream));
+                                            ws_));
+    if (side) {
+        hipError_t e = hipEventRecord((hipEvent_t)ev_done, (hipStream_t)wgrad_stream);
+        if (e == hipSuccess && join) e = hipStreamWaitEvent(hs, (hipEvent_t)ev_done, 0);
+        if (e != hipSuccess) return (int)e;
+    }
     return STIN_OK;
 }

@@ -401,6 +401,74 @@ def linear(x, weight, bias=None, out_fp32=False):
 
 
 # ----------------------------------------------------------------------- autograd ops
+# ---- weight-gradient side stream of the whole-block backward ----------------------------------------------------------
+USE_WGRAD_STREAM = os.environ.get('STIN_WGRAD_STREAM', '1') == '1'
+WGRAD_DEFER_JOIN = os.environ.get('STIN_WGRAD_DEFER', '1') == '1'
+_WGRAD_SIDE = {}
+
+
+class _WgradSide:
+    """Per device: the HIP stream the weight-gradient GEMMs of stin_edgeconv_block_bwd run on and a ring of event
+    triples that order it against the compute stream (a fresh triple per block call, so no event is re-recorded while
+    a wait on its previous record may still be queued)."""
+    RING = 64
+
+    def __init__(self, dev):
+        self.stream = torch.cuda.Stream(device=dev)
+        self.ring = [[torch.cuda.Event() for _ in range(3)] for _ in range(self.RING)]
+        for tri in self.ring:
+            for e in tri:
+                e.record(self.stream)               # forces creation of the hipEvent_t handles
+        self.at = 0
+        self.last_done = self.ring[0][2]
+
+    def next_events(self):
+        self.at = (self.at + 1) % self.RING
+        tri = self.ring[self.at]
+        self.last_done = tri[2]
+        return tri
+
+
+def _wgrad_side(dev):
+    side = _WGRAD_SIDE.get(dev.index)
+    if side is None:
+        side = _WGRAD_SIDE[dev.index] = _WgradSide(dev)
+    return side
+
+
+def _wgrad_side_args(dev, keep_alive, params):
+    """-> (wgrad_stream, ev_dagg, ev_dy, ev_done, join) for stin_edgeconv_block_bwd.  The join with the compute stream is
+    deferred to the end of the backward pass when nothing can read the gradients earlier (every parameter is a leaf whose
+    .grad is None - autograd then adopts the returned tensor without a kernel - and has no hooks); otherwise in-call."""
+    if not USE_WGRAD_STREAM:
+        return 0, 0, 0, 0, 0
+    side = _wgrad_side(dev)
+    for t in keep_alive:
+        t.record_stream(side.stream)
+    deferred = WGRAD_DEFER_JOIN and all(p is None or (p.is_leaf and p.grad is None and not p._backward_hooks and
+                                 not getattr(p, '_post_accumulate_grad_hooks', None)) for p in params)
+    ev = side.next_events()
+    return side.stream.cuda_stream, ev[0].cuda_event, ev[1].cuda_event, ev[2].cuda_event, int(not deferred)
+
+
+def _wgrad_deferred_join(dev, params, grads):
+    """Queue the end-of-backward join for one block whose weight gradients were left on the side stream: the compute
+    stream waits for ev_done (recorded after every side-stream kernel enqueued so far), and the gradient tensors must
+    have been adopted by autograd as they are - a copy would have read them before this join.  One callback per block
+    call and no state between passes, so an aborted backward cannot leave a join behind."""
+    side = _wgrad_side(dev)
+    adopted = [(p, t.data_ptr()) for p, t in zip(params, grads) if p is not None and t is not None]
+
+    def join():
+        torch.cuda.current_stream(dev).wait_event(side.last_done)    # the newest ev_done: after all side work so far
+        for p, ptr in adopted:
+            if p.grad is not None and p.grad.data_ptr() != ptr:
+                raise RuntimeError('weight-gradient stream: autograd copied a gradient before the end-of-backward join; '
+                                   'set STIN_WGRAD_STREAM=0 for this autograd configuration')
+
+    torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
 class EdgeConvBlockFn(torch.autograd.Function):
     """One GraphResnetBlock with an EdgeConv(mean) filter and instance norm, fused at the
     autograd level (reference models/surfacetextureinpaintingnet.py:507-521), taking the
@@ -465,6 +533,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
             ctx.has_b1, ctx.has_b2, ctx.has_bs = b1 is not None, b2 is not None, bs is not None
             ctx.w1_shape = tuple(W1.shape)
             ctx.bsp = bsp
+            ctx.params = (W1, b1, W2, b2, Ws, bs)
             return out
         pack = torch.empty(Yw * Cp * 2 + 2 * H * Cout + Yw, dtype=torch.float32, device=dev)
         wcat = pack[:Yw * Cp].view(Yw, Cp)
@@ -520,13 +589,16 @@ class EdgeConvBlockFn(torch.autograd.Function):
             ws_bytes = lib.stin_edgeconv_block_bwd_workspace_bytes(N, Cp, H, Cout, int(ctx.has_shortcut), groups.B, int(b16))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             cs = edges.by_src
+            side = _wgrad_side_args(dev, (ws, x, hE, g), ctx.params)
             _call('stin_edgeconv_block_bwd', int(b16), _ptr(g), ldg, _ptr(x), x.stride(0), N, Cin, Cp, H, Cout,
                   int(ctx.has_shortcut), int(ctx.trans_inv), _ptr(Y), Y.stride(0), _ptr(hE), hE.stride(0), _ptr(ctx.mask),
                   _ptr(agg), _ptr(mean), _ptr(rstd), _ptr(wcatT), _ptr(w2T), _ptr(edges.by_dst.rowptr), _ptr(cs.rowptr),
                   _ptr(cs.col), _ptr(edges.xslot), _ptr(edges.w_src), _ptr(groups.ptr_true), groups.B, _ptr(groups.gid),
                   _ptr(groups.inv_cnt), int(PREC_BWD), ctx.bsp, _ptr(dx), Cp, _ptr(dW1), _ptr(db1), _ptr(dW2), _ptr(db2),
-                  _ptr(dWs), _ptr(dbs), _ptr(ws), ws_bytes, _stream(x))
+                  _ptr(dWs), _ptr(dbs), _ptr(ws), ws_bytes, _stream(x), *side)
             ctx.mask = None
+            if side[0] and not side[4]:
+                _wgrad_deferred_join(dev, ctx.params, (dW1, db1, dW2, db2, dWs, dbs))
             if dx is not None and Cp != Cin:
                 dx = dx[:, :Cin]
             return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None

@@ -681,3 +681,37 @@ def test_norm_backward_coefficients_fused_into_the_reduction_equal_the_separate_
              SF._ptr(k), SF._ptr(m), SF._stream(x))
     k2, m2 = SF.colreduce(SF.RED_DOT_ELU, x, groups, groups.ptr_true, gout=go, mean=mean, rstd=rstd, post=SF.POST_NORM_COEF)
     assert torch.equal(k, k2) and torch.equal(m, m2)
+
+
+def test_weight_gradient_side_stream_is_bit_identical_in_every_autograd_mode():
+    """stin_edgeconv_block_bwd with a wgrad_stream (the default): same bits as the single-stream order for (a) a plain
+    backward into empty .grad (join deferred to the end of the pass), (b) accumulation into existing .grad (joined inside
+    the call), (c) torch.autograd.grad, repeated so that freed workspaces get recycled while side work is queued."""
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 4])
+    torch.manual_seed(7)
+    net = S.define_G(**cfg).to(DEV)
+    s = make_synthetic_mesh(40_000, 3, seed=12, dilations=(2, 4)).to(DEV)
+    params = list(net.parameters())
+
+    def grads(mode):
+        net.zero_grad(set_to_none=True)
+        loss = net(s).square().mean()
+        if mode == 'grad':
+            return [g.clone() for g in torch.autograd.grad(loss, params)]
+        loss.backward()
+        if mode == 'accumulate':
+            net(s).square().mean().backward()
+        return [p.grad.clone() for p in params]
+
+    old = SF.USE_WGRAD_STREAM
+    try:
+        for mode in ('backward', 'accumulate', 'grad'):
+            SF.USE_WGRAD_STREAM = False
+            want = grads(mode)
+            SF.USE_WGRAD_STREAM = True
+            for _ in range(3):
+                got = grads(mode)
+                assert all(torch.equal(a, b) for a, b in zip(got, want)), mode
+    finally:
+        SF.USE_WGRAD_STREAM = old
