@@ -229,6 +229,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
+    dt_enqueue = time.perf_counter() - t0                   # host side done (everything enqueued); the GPU may still be running
     fence()
     dt = time.perf_counter() - t0
     ktimes = SF.KernelTimer.stop()
@@ -290,6 +291,7 @@ def main():
                        'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan,
                        'crops_per_step': args.crops or None},
             'loss': float(loss),
+            'host_enqueue_ms_per_step': dt_enqueue / args.steps * 1e3,   # < ms_per_step: the GPU, not the host, bounds the step
             'fwd_loss_bwd_only': None if args.no_secondary else {
                 'ms_per_step': dt_fb / args.steps * 1e3, 'vertices_per_s_per_gpu': n0 * args.steps / dt_fb,
                 'note': 'same scene, CSR plan reused, no gradient all-reduce, no optimizer step (rank 0)'},
