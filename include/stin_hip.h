@@ -289,6 +289,10 @@ int stin_edgeconv_unpack_grads_f32(const float* dwb, const float* dw2b, int Cin,
                                    float* dW2, float* db2, stin_stream_t stream);
 int stin_norm_bwd_coef_f32(const float* T1, const float* S0, const float* rstd, const float* inv_cnt, int B, int C,
                            float* k, float* m, stin_stream_t stream);
+/* linspace-slice quirk of FastInstanceNorm (fastinstancenorm.py:53-82): m = -(rstd S0 + U) inv_cnt, where
+ * U = stin_colreduce(STIN_RED_COEF_XC, coef = k) - the second coefficient of stin_norm_act_bwd_* when slices != graphs. */
+int stin_norm_bwd_coef_m_quirk_f32(const float* S0, const float* U, const float* rstd, const float* inv_cnt, int B, int C,
+                                   float* m, stin_stream_t stream);
 
 /* ----------------------------------------------------------- train-step epilogues --
  * masked_l1_loss: the trainer's loss and its gradient in one pass
@@ -360,8 +364,10 @@ int stin_gemm_tn_bf16(const stin_bf16_t* G, int64_t ldg, const stin_bf16_t* X, i
  * order of the fused block (pack -> Y GEMM -> edge stage -> agg GEMM -> moments -> norm/ELU/residual; and its
  * backward), so the arithmetic is identical to calling them one by one - what they remove is ~9 / ~16 host-side
  * foreign calls per block and direction.  storage: 0 = fp32 rows, 1 = bf16 rows (x, Y, hE, agg, out, g, dx).
- * Fast-path preconditions (callers fall back to the individual entry points otherwise): H supports the saved ReLU mask,
- * norm statistics over the true per-graph row ranges (no linspace-slice quirk).
+ * Fast-path precondition (callers fall back to the individual entry points otherwise): H supports the saved ReLU mask.
+ * slice_quirk != 0 (fwd) / sid != NULL (bwd): the reference's linspace-slice statistics for batches of unequal graphs
+ * (fastinstancenorm.py:53-82) - sums over the `ptr_sum` slices, centring through gid: two-pass statistics forward, the
+ * extra COEF_XC reduction backward; ptr_true are the true per-graph row ranges.
  *   fwd: x [N, Cp] (input zero-padded to Cp columns), reference-layout parameters, destination CSR, norm groups
  *        (ptr_sum/gid may be NULL for one graph; inv_cnt [B]); writes what backward needs - wcatT [Cp, Yw], w2T [H, Cout]
  *        (fp32 or pre-split per bwd_split), Y [N, Yw], hE [N, H + pad] (column H = [deg > 0]), mask [E * H / 32],
@@ -380,7 +386,7 @@ int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, int64_t N, 
                             int has_shortcut, int trans_inv, const float* W1, const float* b1, const float* W2,
                             const float* b2, const float* Ws, const float* bs, const int32_t* rowptr_dst,
                             const int32_t* col_dst, const int32_t* ptr_sum, int B, const int32_t* gid, const float* inv_cnt,
-                            float eps, int prec_fwd, int fwd_split, int bwd_split, float* wcatT, float* w2T, void* Y,
+                            int slice_quirk, float eps, int prec_fwd, int fwd_split, int bwd_split, float* wcatT, float* w2T, void* Y,
                             int64_t ldy, void* hE, int64_t ldh, uint32_t* mask, void* agg, float* mean, float* rstd, void* out,
                             int64_t ldo, void* workspace, size_t workspace_bytes, stin_stream_t stream);
 size_t stin_edgeconv_block_bwd_workspace_bytes(int64_t N, int Cp, int H, int Cout, int has_shortcut, int B, int storage);
@@ -389,7 +395,8 @@ int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, const void*
                             int64_t ldh, const uint32_t* mask, const void* agg, const float* mean, const float* rstd,
                             const float* wcatT, const float* w2T, const int32_t* rowptr_dst, const int32_t* rowptr_src,
                             const int32_t* col_src, const int32_t* xslot, const float* w_src, const int32_t* ptr_true, int B,
-                            const int32_t* gid, const float* inv_cnt, int prec_bwd, int bwd_split, void* dx, int64_t lddx,
+                            const int32_t* gid, const int32_t* sid, const float* inv_cnt, int prec_bwd, int bwd_split, void* dx,
+                            int64_t lddx,
                             float* dW1, float* db1, float* dW2, float* db2, float* dWs, float* dbs, void* workspace,
                             size_t workspace_bytes, stin_stream_t stream, stin_stream_t wgrad_stream, stin_event_t ev_dagg,
                             stin_event_t ev_dy, stin_event_t ev_done, int join);

@@ -89,12 +89,13 @@ for _n in ('stin_dilated_walk_f32', 'stin_dilated_walk_f64'):
     SIGNATURES[_n] = (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, ctypes.POINTER(c_i32), c_int, c_ptr, c_ptr])
 SIGNATURES['stin_edgeconv_block_fwd_workspace_bytes'] = (c_size, [c_int] * 6)
 SIGNATURES['stin_edgeconv_block_fwd'] = (c_int, [c_int, c_ptr, c_i64, c_i64] + [c_int] * 6 + [c_ptr] * 6 + [c_ptr] * 3 + [c_int, c_ptr, c_ptr,
-                                                 c_f32, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr,
+                                                 c_int, c_f32, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr,
                                                  c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_size, c_ptr])
 SIGNATURES['stin_edgeconv_block_bwd_workspace_bytes'] = (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int, c_int])
 SIGNATURES['stin_edgeconv_block_bwd'] = (c_int, [c_int, c_ptr, c_i64, c_ptr, c_i64, c_i64] + [c_int] * 6 + [c_ptr, c_i64, c_ptr, c_i64,
-                                                 c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr] + [c_ptr] * 6 + [c_int, c_ptr, c_ptr, c_int,
+                                                 c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr] + [c_ptr] * 6 + [c_int, c_ptr, c_ptr, c_ptr, c_int,
                                                  c_int, c_ptr, c_i64] + [c_ptr] * 6 + [c_ptr, c_size, c_ptr] + [c_ptr] * 4 + [c_int])
+SIGNATURES['stin_norm_bwd_coef_m_quirk_f32'] = (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr])
 SIGNATURES['stin_gather_add_rows_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_bn_act_fwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_bn_act_bwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int,

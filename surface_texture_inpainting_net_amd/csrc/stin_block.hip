@@ -43,7 +43,7 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
                                        int has_shortcut, int trans_inv, const float* W1, const float* b1, const float* W2,
                                        const float* b2, const float* Ws, const float* bs, const int32_t* rowptr_dst,
                                        const int32_t* col_dst, const int32_t* ptr_sum, int B, const int32_t* gid,
-                                       const float* inv_cnt, float eps, int prec_fwd, int fwd_split, int bwd_split,
+                                       const float* inv_cnt, int slice_quirk, float eps, int prec_fwd, int fwd_split, int bwd_split,
                                        float* wcatT, float* w2T, void* Y, int64_t ldy, void* hE, int64_t ldh, uint32_t* mask,
                                        void* agg, float* mean, float* rstd, void* out, int64_t ldo, void* workspace,
                                        size_t workspace_bytes, stin_stream_t stream) {
@@ -74,9 +74,18 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
         STIN_TRY(stin_edge_relu_mean_fwd_f32(Yf, ldy, Yf + H, ldy, rowptr_dst, col_dst, N, H, hf, ldh, 1, mask, stream));
         STIN_TRY(stin_gemm_nt_f32(hf, ldh, w2_op, H, b2, hf + H, ldh, nullptr, 0, N, Cout, H, static_cast<float*>(agg), Cout,
                                   pf, stream));
-        STIN_TRY(stin_colreduce_f32(STIN_RED_MOMENTS, static_cast<const float*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum, B, gid,
-                                    nullptr, nullptr, nullptr, nullptr, STIN_POST_NONE, inv_cnt, eps, mean, rstd, red_ws,
-                                    red_bytes, stream));
+        if (!slice_quirk) {
+            STIN_TRY(stin_colreduce_f32(STIN_RED_MOMENTS, static_cast<const float*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum, B,
+                                        gid, nullptr, nullptr, nullptr, nullptr, STIN_POST_NONE, inv_cnt, eps, mean, rstd, red_ws,
+                                        red_bytes, stream));
+        } else {  // sums over the linspace slices, centring through the graph id: two passes as the reference does
+            STIN_TRY(stin_colreduce_f32(STIN_RED_SUM, static_cast<const float*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum, B, gid,
+                                        nullptr, nullptr, nullptr, nullptr, STIN_POST_SCALE, inv_cnt, eps, mean, nullptr, red_ws,
+                                        red_bytes, stream));
+            STIN_TRY(stin_colreduce_f32(STIN_RED_CSQ, static_cast<const float*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum, B, gid,
+                                        nullptr, mean, nullptr, nullptr, STIN_POST_RSTD, inv_cnt, eps, rstd, nullptr, red_ws,
+                                        red_bytes, stream));
+        }
         STIN_TRY(stin_norm_act_res_fwd_f32(static_cast<const float*>(agg), Cout, mean, rstd, gid, static_cast<const float*>(res),
                                            ld_res, N, Cout, 1, static_cast<float*>(out), ldo, stream));
     } else {
@@ -86,9 +95,18 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
                                    ldy, 0, stream));
         STIN_TRY(stin_edge_relu_mean_fwd_bf16(Yh, ldy, Yh + H, ldy, rowptr_dst, col_dst, N, H, hh, ldh, 1, mask, stream));
         STIN_TRY(stin_gemm_nt_bf16(hh, ldh, w2_op, H, b2, hh + H, ldh, nullptr, 0, N, Cout, H, agg, Cout, 0, stream));
-        STIN_TRY(stin_colreduce_bf16(STIN_RED_MOMENTS, static_cast<const stin_bf16_t*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum, B,
-                                     gid, nullptr, nullptr, nullptr, nullptr, STIN_POST_NONE, inv_cnt, eps, mean, rstd, red_ws,
-                                     red_bytes, stream));
+        if (!slice_quirk) {
+            STIN_TRY(stin_colreduce_bf16(STIN_RED_MOMENTS, static_cast<const stin_bf16_t*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum,
+                                         B, gid, nullptr, nullptr, nullptr, nullptr, STIN_POST_NONE, inv_cnt, eps, mean, rstd,
+                                         red_ws, red_bytes, stream));
+        } else {
+            STIN_TRY(stin_colreduce_bf16(STIN_RED_SUM, static_cast<const stin_bf16_t*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum, B,
+                                         gid, nullptr, nullptr, nullptr, nullptr, STIN_POST_SCALE, inv_cnt, eps, mean, nullptr,
+                                         red_ws, red_bytes, stream));
+            STIN_TRY(stin_colreduce_bf16(STIN_RED_CSQ, static_cast<const stin_bf16_t*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum, B,
+                                         gid, nullptr, mean, nullptr, nullptr, STIN_POST_RSTD, inv_cnt, eps, rstd, nullptr, red_ws,
+                                         red_bytes, stream));
+        }
         STIN_TRY(stin_norm_act_res_fwd_bf16(static_cast<const stin_bf16_t*>(agg), Cout, mean, rstd, gid,
                                             static_cast<const stin_bf16_t*>(res), ld_res, N, Cout, 1,
                                             static_cast<stin_bf16_t*>(out), ldo, stream));
@@ -108,7 +126,7 @@ extern "C" size_t stin_edgeconv_block_bwd_workspace_bytes(int64_t N, int Cp, int
            + up256((size_t)N * H * es)       /* dhE  */
            + up256((size_t)N * Yw * es)      /* dY   */
            + up256((size_t)Cout * (H + 1) * 4) + up256(Yw * (size_t)(Cp + 1) * 4) /* dw2b, dwb */
-           + 2 * up256((size_t)B * Cout * 4) /* k, m */
+           + 5 * up256((size_t)B * Cout * 4) /* k, m (+ T1, S0, U with the linspace-slice quirk) */
            + up256(stin_colreduce_workspace_bytes(Cout, B)) + up256(tn) + 256;
 }
 
@@ -121,7 +139,7 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
                                        const float* rstd, const float* wcatT, const float* w2T, const int32_t* rowptr_dst,
                                        const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot,
                                        const float* w_src, const int32_t* ptr_true, int B, const int32_t* gid,
-                                       const float* inv_cnt, int prec_bwd, int bwd_split, void* dx, int64_t lddx, float* dW1,
+                                       const int32_t* sid, const float* inv_cnt, int prec_bwd, int bwd_split, void* dx, int64_t lddx, float* dW1,
                                        float* db1, float* dW2, float* db2, float* dWs, float* dbs, void* workspace,
                                        size_t workspace_bytes, stin_stream_t stream, stin_stream_t wgrad_stream,
                                        stin_event_t ev_dagg, stin_event_t ev_dy, stin_event_t ev_done, int join) {
@@ -144,6 +162,10 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
     float* dwb = reinterpret_cast<float*>(carve(p, (size_t)Yw * (Cp + 1) * 4));
     float* kk = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
     float* mm = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
+    float* t1 = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
+    float* s0 = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
+    float* uu = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
+    const int32_t* sid_n = sid ? sid : gid;     // slice id of the norm backward (== graph id without the quirk)
     const size_t red_bytes = stin_colreduce_workspace_bytes(Cout, B);
     void* red_ws = carve(p, red_bytes);
     void* tn_ws = p;
@@ -167,11 +189,22 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         const float* hf = static_cast<const float*>(hE);
         float* dYf = static_cast<float*>(dY);
         // instance norm + ELU backward: two column sums finalised straight into the k / m coefficients, one elementwise pass
-        STIN_TRY(stin_colreduce_f32(STIN_RED_DOT_ELU, static_cast<const float*>(agg), Cout, gf, ldg, N, Cout, ptr_true, B, gid,
-                                    nullptr, mean, rstd, nullptr, STIN_POST_NORM_COEF, inv_cnt, 0.f, kk, mm, red_ws, red_bytes,
-                                    stream));
-        STIN_TRY(stin_norm_act_bwd_f32(static_cast<const float*>(agg), Cout, gf, ldg, mean, rstd, rstd, kk, mm, gid, gid, N, Cout,
-                                       1, static_cast<float*>(dagg), Cout, stream));
+        if (!sid) {
+            STIN_TRY(stin_colreduce_f32(STIN_RED_DOT_ELU, static_cast<const float*>(agg), Cout, gf, ldg, N, Cout, ptr_true, B, gid,
+                                        nullptr, mean, rstd, nullptr, STIN_POST_NORM_COEF, inv_cnt, 0.f, kk, mm, red_ws, red_bytes,
+                                        stream));
+        } else {  // linspace-slice quirk: k from the per-graph sums, then U = sum over the slice of k xc, then m
+            STIN_TRY(stin_colreduce_f32(STIN_RED_DOT_ELU, static_cast<const float*>(agg), Cout, gf, ldg, N, Cout, ptr_true, B, gid,
+                                        nullptr, mean, rstd, nullptr, STIN_POST_NONE, inv_cnt, 0.f, t1, s0, red_ws, red_bytes,
+                                        stream));
+            STIN_TRY(stin_norm_bwd_coef_f32(t1, s0, rstd, inv_cnt, B, Cout, kk, mm, stream));
+            STIN_TRY(stin_colreduce_f32(STIN_RED_COEF_XC, static_cast<const float*>(agg), Cout, nullptr, 0, N, Cout, ptr_true, B,
+                                        gid, sid, mean, nullptr, kk, STIN_POST_NONE, inv_cnt, 0.f, uu, nullptr, red_ws, red_bytes,
+                                        stream));
+            STIN_TRY(stin_norm_bwd_coef_m_quirk_f32(s0, uu, rstd, inv_cnt, B, Cout, mm, stream));
+        }
+        STIN_TRY(stin_norm_act_bwd_f32(static_cast<const float*>(agg), Cout, gf, ldg, mean, rstd, rstd, kk, mm, gid, sid_n, N,
+                                       Cout, 1, static_cast<float*>(dagg), Cout, stream));
         // second Linear: weight gradient (+ masked bias gradient) and input gradient
         STIN_TRY(fork(ev_dagg));
         STIN_TRY(stin_gemm_tn_f32(static_cast<const float*>(dagg), Cout, hf, ldh, N, Cout, H, 1, hf + H, ldh, dw2b, H + 1,
@@ -198,10 +231,21 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         const stin_bf16_t* gh = static_cast<const stin_bf16_t*>(g);
         const stin_bf16_t* hh = static_cast<const stin_bf16_t*>(hE);
         stin_bf16_t* dYh = static_cast<stin_bf16_t*>(dY);
-        STIN_TRY(stin_colreduce_bf16(STIN_RED_DOT_ELU, static_cast<const stin_bf16_t*>(agg), Cout, gh, ldg, N, Cout, ptr_true, B,
-                                     gid, nullptr, mean, rstd, nullptr, STIN_POST_NORM_COEF, inv_cnt, 0.f, kk, mm, red_ws, red_bytes,
-                                     stream));
-        STIN_TRY(stin_norm_act_bwd_bf16(static_cast<const stin_bf16_t*>(agg), Cout, gh, ldg, mean, rstd, rstd, kk, mm, gid, gid, N,
+        if (!sid) {
+            STIN_TRY(stin_colreduce_bf16(STIN_RED_DOT_ELU, static_cast<const stin_bf16_t*>(agg), Cout, gh, ldg, N, Cout, ptr_true, B,
+                                         gid, nullptr, mean, rstd, nullptr, STIN_POST_NORM_COEF, inv_cnt, 0.f, kk, mm, red_ws,
+                                         red_bytes, stream));
+        } else {
+            STIN_TRY(stin_colreduce_bf16(STIN_RED_DOT_ELU, static_cast<const stin_bf16_t*>(agg), Cout, gh, ldg, N, Cout, ptr_true, B,
+                                         gid, nullptr, mean, rstd, nullptr, STIN_POST_NONE, inv_cnt, 0.f, t1, s0, red_ws, red_bytes,
+                                         stream));
+            STIN_TRY(stin_norm_bwd_coef_f32(t1, s0, rstd, inv_cnt, B, Cout, kk, mm, stream));
+            STIN_TRY(stin_colreduce_bf16(STIN_RED_COEF_XC, static_cast<const stin_bf16_t*>(agg), Cout, nullptr, 0, N, Cout, ptr_true,
+                                         B, gid, sid, mean, nullptr, kk, STIN_POST_NONE, inv_cnt, 0.f, uu, nullptr, red_ws,
+                                         red_bytes, stream));
+            STIN_TRY(stin_norm_bwd_coef_m_quirk_f32(s0, uu, rstd, inv_cnt, B, Cout, mm, stream));
+        }
+        STIN_TRY(stin_norm_act_bwd_bf16(static_cast<const stin_bf16_t*>(agg), Cout, gh, ldg, mean, rstd, rstd, kk, mm, gid, sid_n, N,
                                         Cout, 1, static_cast<stin_bf16_t*>(dagg), Cout, stream));
         STIN_TRY(fork(ev_dagg));
         STIN_TRY(stin_gemm_tn_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, hh, ldh, N, Cout, H, 1, hh + H, ldh, dw2b, H + 1,

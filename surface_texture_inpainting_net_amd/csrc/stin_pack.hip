@@ -115,6 +115,14 @@ __global__ void k_norm_coef(const float* __restrict__ T1, const float* __restric
     kk[t] = -(r * r * r) * T1[t] * ic;
     mm[t] = -(r * S0[t]) * ic;
 }
+
+// linspace-slice quirk: m = -(rstd S0 + U) inv_cnt with U = sum over the slice of k xc (separately rounded mul / add)
+__global__ void k_norm_coef_m_quirk(const float* __restrict__ S0, const float* __restrict__ U, const float* __restrict__ rstd,
+                                    const float* __restrict__ inv_cnt, int B, int C, float* __restrict__ mm) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C) return;
+    mm[t] = __fmul_rn(-__fadd_rn(__fmul_rn(rstd[t], S0[t]), U[t]), inv_cnt[t / C]);
+}
 }  // namespace
 
 static inline bool split_mode_ok(int m) { return m == 0 || m == STIN_GEMM_BF16X3 || m == STIN_GEMM_F16X3; }
@@ -169,6 +177,16 @@ extern "C" int stin_norm_bwd_coef_f32(const float* T1, const float* S0, const fl
     STIN_REQUIRE(T1 && S0 && rstd && inv_cnt && k && m, STIN_E_NULL);
     hipLaunchKernelGGL(k_norm_coef, dim3((unsigned)((B * C + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream_, T1,
                        S0, rstd, inv_cnt, B, C, k, m);
+    return stin_launch_status();
+}
+
+extern "C" int stin_norm_bwd_coef_m_quirk_f32(const float* S0, const float* U, const float* rstd, const float* inv_cnt, int B,
+                                              int C, float* m, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(B > 0 && C > 0, STIN_E_SIZE);
+    STIN_REQUIRE(S0 && U && rstd && inv_cnt && m, STIN_E_NULL);
+    hipLaunchKernelGGL(k_norm_coef_m_quirk, dim3((unsigned)((B * C + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream_,
+                       S0, U, rstd, inv_cnt, B, C, m);
     return stin_launch_status();
 }
 

@@ -238,7 +238,9 @@ def instance_norm_act_bwd(x, gout, mean, rstd, groups, act=True, out=None):
     else:
         k = -(rstd * rstd * rstd) * T1 * inv_cnt                   # indexed by the SUM slice (sid)
         U = colreduce(RED_COEF_XC, x, groups, groups.ptr_true, mean=mean, coef=k, use_sid=True)
-        m = -(rstd * S0 + U) * inv_cnt
+        m = torch.empty_like(rstd)
+        _call('stin_norm_bwd_coef_m_quirk_f32', _ptr(S0), _ptr(U), _ptr(rstd), _ptr(groups.inv_cnt), rstd.shape[0], C, _ptr(m),
+              _stream(x))
     dx = out if out is not None else torch.empty(N, C, dtype=x.dtype, device=x.device)
     _call('stin_norm_act_bwd' + _sfx(x), _ptr(x), ldx, _ptr(gout), ldg, _ptr(mean), _ptr(rstd), _ptr(rstd), _ptr(k.contiguous()),
           _ptr(m.contiguous()), _ptr(groups.gid), _ptr(groups.sid), N, C, int(act), _ptr(dx), dx.stride(0), _stream(x))
@@ -436,7 +438,35 @@ def _wgrad_side(dev):
     return side
 
 
-def _wgrad_side_args(dev, keep_alive, params):
+USE_DIRECT_GRADS = os.environ.get('STIN_DIRECT_GRADS', '1') == '1'
+
+
+def _direct_grad_views(params):
+    """(dW1, db1, dW2, db2, dWs, dbs) as the parameters' views in an accepting train_step.FlatGradBucket, or None.
+    The backward then OVERWRITES those views (one backward per step, every weight used by one block) and returns no
+    gradient to autograd for them: no per-parameter accumulate node, no copy into the bucket afterwards, and nothing of
+    autograd can read a gradient before the end-of-backward join of the weight-gradient stream."""
+    if not USE_DIRECT_GRADS:
+        return None
+    bucket, out = None, []
+    for p in params:
+        if p is None:
+            out.append(None)
+            continue
+        slot = getattr(p, '_stin_slot', None)
+        if slot is None or not slot[0].accepting or (bucket is not None and slot[0] is not bucket) or slot[0].written[slot[1]]:
+            return None
+        bucket = slot[0]
+        out.append(bucket.views[slot[1]])
+    if bucket is None:
+        return None
+    for p in params:
+        if p is not None:
+            bucket.written[p._stin_slot[1]] = True
+    return out
+
+
+def _wgrad_side_args(dev, keep_alive, params, direct=False):
     """-> (wgrad_stream, ev_dagg, ev_dy, ev_done, join) for stin_edgeconv_block_bwd.  The join with the compute stream is
     deferred to the end of the backward pass when nothing can read the gradients earlier (every parameter is a leaf whose
     .grad is None - autograd then adopts the returned tensor without a kernel - and has no hooks); otherwise in-call."""
@@ -445,8 +475,8 @@ def _wgrad_side_args(dev, keep_alive, params):
     side = _wgrad_side(dev)
     for t in keep_alive:
         t.record_stream(side.stream)
-    deferred = WGRAD_DEFER_JOIN and all(p is None or (p.is_leaf and p.grad is None and not p._backward_hooks and
-                                 not getattr(p, '_post_accumulate_grad_hooks', None)) for p in params)
+    deferred = WGRAD_DEFER_JOIN and (direct or all(p is None or (p.is_leaf and p.grad is None and not p._backward_hooks and
+                                 not getattr(p, '_post_accumulate_grad_hooks', None)) for p in params))
     ev = side.next_events()
     return side.stream.cuda_stream, ev[0].cuda_event, ev[1].cuda_event, ev[2].cuda_event, int(not deferred)
 
@@ -502,7 +532,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         # (instead of once per GEMM block); plain fp32 for the other precisions and for bf16-storage activations
         fsp = PREC_FWD if (not b16 and PREC_FWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT) else 0
         bsp = PREC_BWD if (not b16 and PREC_BWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT and Cout % 4 == 0) else 0
-        fast = (USE_BLOCK_CALL and USE_EDGE_MASK and edge_mask_supported(H) and not groups.quirk and N > 1
+        fast = (USE_BLOCK_CALL and USE_EDGE_MASK and edge_mask_supported(H) and N > 1
                 and not KernelTimer.enabled)          # (the bench's per-kernel HIP-event brackets need the per-kernel path)
         ctx.fast = fast
         if fast:
@@ -523,7 +553,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
             cd = edges.by_dst
             _call('stin_edgeconv_block_fwd', int(b16), _ptr(xp), xp.stride(0), N, Cin, Cp, H, Cout, int(has_shortcut),
                   int(trans_inv), _ptr(W1c), _ptr(b1), _ptr(W2c), _ptr(b2), _ptr(Ws), _ptr(bs), _ptr(cd.rowptr), _ptr(cd.col),
-                  _ptr(groups.ptr_sum), B, _ptr(groups.gid), _ptr(groups.inv_cnt), float(EPS), int(PREC_FWD), fsp, bsp,
+                  _ptr(groups.ptr_sum), B, _ptr(groups.gid), _ptr(groups.inv_cnt), int(groups.quirk), float(EPS), int(PREC_FWD), fsp, bsp,
                   _ptr(wcatT), _ptr(w2T), _ptr(Y), Yw, _ptr(hE), H + pad, _ptr(mask), _ptr(agg), _ptr(mean), _ptr(rstd),
                   _ptr(out), Cout, _ptr(ws), ws_bytes, _stream(x))
             ctx.save_for_backward(xp, Y, hE, agg, mean, rstd, wcatT, w2T)
@@ -580,25 +610,33 @@ class EdgeConvBlockFn(torch.autograd.Function):
             dev, N, b16 = x.device, x.shape[0], x.dtype == torch.bfloat16
             _same(x, g)
             dx = torch.empty(N, Cp, dtype=x.dtype, device=dev) if ctx.needs_input_grad[0] else None
-            dW1 = torch.empty(ctx.w1_shape, dtype=torch.float32, device=dev)
-            db1 = torch.empty(H, dtype=torch.float32, device=dev) if ctx.has_b1 else None
-            dWs = torch.empty(Cout, Cin, dtype=torch.float32, device=dev) if ctx.has_shortcut else None
-            dbs = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bs else None
-            dW2 = torch.empty(Cout, H, dtype=torch.float32, device=dev)
-            db2 = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b2 else None
+            direct = _direct_grad_views(ctx.params)
+            if direct is not None:            # a TrainStep bucket is accepting: write the gradients where the optimizer reads them
+                dW1, db1, dW2, db2, dWs, dbs = direct
+            else:
+                dW1 = torch.empty(ctx.w1_shape, dtype=torch.float32, device=dev)
+                db1 = torch.empty(H, dtype=torch.float32, device=dev) if ctx.has_b1 else None
+                dWs = torch.empty(Cout, Cin, dtype=torch.float32, device=dev) if ctx.has_shortcut else None
+                dbs = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bs else None
+                dW2 = torch.empty(Cout, H, dtype=torch.float32, device=dev)
+                db2 = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b2 else None
             ws_bytes = lib.stin_edgeconv_block_bwd_workspace_bytes(N, Cp, H, Cout, int(ctx.has_shortcut), groups.B, int(b16))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             cs = edges.by_src
-            side = _wgrad_side_args(dev, (ws, x, hE, g), ctx.params)
+            side = _wgrad_side_args(dev, (ws, x, hE, g), ctx.params, direct is not None)
             _call('stin_edgeconv_block_bwd', int(b16), _ptr(g), ldg, _ptr(x), x.stride(0), N, Cin, Cp, H, Cout,
                   int(ctx.has_shortcut), int(ctx.trans_inv), _ptr(Y), Y.stride(0), _ptr(hE), hE.stride(0), _ptr(ctx.mask),
                   _ptr(agg), _ptr(mean), _ptr(rstd), _ptr(wcatT), _ptr(w2T), _ptr(edges.by_dst.rowptr), _ptr(cs.rowptr),
                   _ptr(cs.col), _ptr(edges.xslot), _ptr(edges.w_src), _ptr(groups.ptr_true), groups.B, _ptr(groups.gid),
-                  _ptr(groups.inv_cnt), int(PREC_BWD), ctx.bsp, _ptr(dx), Cp, _ptr(dW1), _ptr(db1), _ptr(dW2), _ptr(db2),
+                  _ptr(groups.sid if groups.quirk else None), _ptr(groups.inv_cnt), int(PREC_BWD), ctx.bsp, _ptr(dx), Cp, _ptr(dW1), _ptr(db1), _ptr(dW2), _ptr(db2),
                   _ptr(dWs), _ptr(dbs), _ptr(ws), ws_bytes, _stream(x), *side)
             ctx.mask = None
             if side[0] and not side[4]:
-                _wgrad_deferred_join(dev, ctx.params, (dW1, db1, dW2, db2, dWs, dbs))
+                _wgrad_deferred_join(dev, ctx.params, () if direct is not None else (dW1, db1, dW2, db2, dWs, dbs))
+            if direct is not None:
+                if dx is not None and Cp != Cin:
+                    dx = dx[:, :Cin]
+                return dx, None, None, None, None, None, None, None, None, None
             if dx is not None and Cp != Cin:
                 dx = dx[:, :Cin]
             return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None

@@ -29,6 +29,16 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _upload(host_tensor, device):
+    """Small host tensor -> device without stalling the host: pinned staging buffer + non-blocking copy (the caching
+    host allocator keeps the staging block alive until the copy has run)."""
+    if torch.device(device).type != 'cuda':
+        return host_tensor.to(device)
+    pinned = torch.empty(host_tensor.shape, dtype=host_tensor.dtype, pin_memory=True)
+    pinned.copy_(host_tensor)
+    return pinned.to(device, non_blocking=True)
+
+
 _SIDE_STREAMS = {}
 
 
@@ -155,14 +165,16 @@ class NormGroups:
         else:
             sum_ptr = true_ptr
         self.quirk = bool((sum_ptr != true_ptr).any())
-        self.ptr_true = true_ptr.to(torch.int32).to(device)
-        self.ptr_sum = sum_ptr.to(torch.int32).to(device)
+        # one pinned, non-blocking upload for both pointer arrays (a pageable .to(device) would stall the host until the
+        # GPU has drained everything queued before it - once per level and step)
+        ptrs = _upload(torch.stack([true_ptr, sum_ptr]).to(torch.int32), device)
+        self.ptr_true, self.ptr_sum = ptrs[0], ptrs[1]
         if self.quirk:      # slice id per row = number of slice boundaries <= row (on the device: no host-side expansion)
             rows = torch.arange(n_rows, device=device, dtype=torch.int64)
             self.sid = torch.searchsorted(self.ptr_sum[1:].to(torch.int64), rows, right=True).to(torch.int32)
         else:
             self.sid = self.gid
-        self.inv_cnt = (1.0 / counts.to(torch.float32).clamp(min=1)).to(device)
+        self.inv_cnt = _upload(1.0 / counts.to(torch.float32).clamp(min=1), device)
 
 
 class GraphPlan:

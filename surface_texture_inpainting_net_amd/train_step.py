@@ -36,37 +36,48 @@ class FlatGradBucket:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views = []
         off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+        for i, p in enumerate(self.params):
+            v = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(v)
+            p.grad = v
             off += p.numel()
+            if dev.type == 'cuda':
+                # the whole-block backward (functional.EdgeConvBlockFn) writes this parameter's gradient straight
+                # into its bucket view while the bucket is `accepting`, instead of handing a fresh tensor to autograd
+                p._stin_slot = (self, i)
+        self.accepting = False
+        self.written = [False] * len(self.params)
 
     def zero(self):
         self.flat.zero_()
-        off = 0
-        for p in self.params:                      # re-attach (zero_grad(set_to_none=True) safe)
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        for p, v in zip(self.params, self.views):  # re-attach (zero_grad(set_to_none=True) safe)
+            p.grad = v
 
     def detach_grads(self):
         """Before backward: leave .grad unset so autograd STORES each gradient instead of launching one
         accumulate-add per parameter (74 tiny kernels per step)."""
         for p in self.params:
             p.grad = None
+        self.written = [False] * len(self.params)
+        self.accepting = True
 
     def gather_grads(self):
         """After backward: copy all gradients into the flat bucket with one multi-tensor copy and point
         .grad back at the bucket views (parameters without a gradient get zeros)."""
+        self.accepting = False
         views, grads = [], []
-        off = 0
-        for p in self.params:
-            v = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-            if p.grad is None:
-                v.zero_()
-            else:
+        for i, p in enumerate(self.params):
+            v = self.views[i]
+            if p.grad is not None:
+                if self.written[i]:
+                    raise RuntimeError('a parameter received a gradient both directly in its bucket view and through autograd '
+                                       '(a weight used by two blocks?): unsupported by the direct-write path')
                 views.append(v)
                 grads.append(p.grad)
+            elif not self.written[i]:
+                v.zero_()
             p.grad = v
         if views:
             torch._foreach_copy_(views, grads)
@@ -145,13 +156,16 @@ class TrainStep:
 
     def forward_backward(self, sample):
         self.bucket.detach_grads()
-        if self.on_gpu:
-            from . import functional as SF
-            loss = SF.masked_l1_loss(self.model(sample), sample.color, sample.mask, self.use_mask_weighted_loss)
-        else:
-            pred = graph_forward(self.model, sample)
-            loss = compute_loss(pred, sample.color, sample.mask if self.use_mask_weighted_loss else None)
-        loss.backward()
+        try:
+            if self.on_gpu:
+                from . import functional as SF
+                loss = SF.masked_l1_loss(self.model(sample), sample.color, sample.mask, self.use_mask_weighted_loss)
+            else:
+                pred = graph_forward(self.model, sample)
+                loss = compute_loss(pred, sample.color, sample.mask if self.use_mask_weighted_loss else None)
+            loss.backward()
+        finally:
+            self.bucket.accepting = False           # also when forward / backward raised: no stray direct writes later
         self.bucket.gather_grads()
         return loss.detach()
 

@@ -715,3 +715,97 @@ def test_weight_gradient_side_stream_is_bit_identical_in_every_autograd_mode():
                 assert all(torch.equal(a, b) for a, b in zip(got, want)), mode
     finally:
         SF.USE_WGRAD_STREAM = old
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('batched', [False, True])
+def test_block_call_equals_per_kernel_path_bitwise(batched, dtype):
+    """stin_edgeconv_block_fwd/bwd only enqueue the individual entry points: outputs and gradients must equal the
+    per-kernel host path bit for bit - single graph, and a batch of unequal crops (the reference's linspace-slice
+    statistics, fastinstancenorm.py:53-82, inside the block call)."""
+    from surface_texture_inpainting_net_amd.data import collate
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 1])
+    torch.manual_seed(9)
+    net = S.define_G(**cfg).to(DEV)
+    if dtype == 'bf16':
+        net.set_activation_dtype(torch.bfloat16)
+    if batched:
+        s = collate([make_synthetic_mesh(n, 3, seed=60 + i, dilations=(2,)) for i, n in enumerate((900, 1500, 700, 1210))]).to(DEV)
+    else:
+        s = make_synthetic_mesh(5000, 3, seed=60, dilations=(2,)).to(DEV)
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        out = net(s)
+        out.float().square().mean().backward()
+        return [out.detach().clone()] + [p.grad.clone() for p in net.parameters()]
+
+    old = SF.USE_BLOCK_CALL
+    try:
+        SF.USE_BLOCK_CALL = False
+        want = run()
+        SF.USE_BLOCK_CALL = True
+        got = run()
+    finally:
+        SF.USE_BLOCK_CALL = old
+    if batched:
+        assert any(g.quirk for g in s._plan_cache._norms.values()), 'the batch must exercise the linspace-slice path'
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+def test_batch_of_unequal_crops_full_width_vs_oracle():
+    """The linspace-slice quirk through the whole-block calls (ngf = 64: saved-mask widths) against the CPU oracle."""
+    from surface_texture_inpainting_net_amd.data import collate
+    batch = collate([make_synthetic_mesh(n, 3, seed=70 + i, dilations=(2,)) for i, n in enumerate((800, 1300, 600))])
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=2, n_levels=2,
+               pooling_type='max', dilations=[1, 2])
+    torch.manual_seed(22)
+    ref = stin_oracle.define_G(**cfg)
+    net = S.define_G(**cfg)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(DEV)
+    want = ref(batch)
+    stin_oracle.compute_loss(stin_oracle.graph_forward(ref, batch), batch.color, batch.mask).backward()
+    bd = batch.to(DEV)
+    got = net(bd)
+    stin_oracle.compute_loss(torch.where((bd.mask > 0).expand_as(bd.color), got, bd.color), bd.color, bd.mask).backward()
+    assert float((got.detach().cpu() - want.detach()).abs().max()) <= FWD_TOL
+    scale = max(float(p.grad.abs().max()) for p in ref.parameters())
+    num = den = 0.0
+    for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+        d = p.grad.cpu() - q.grad
+        assert float(d.abs().max()) <= 1e-2 * scale, k
+        num += float(d.double().pow(2).sum())
+        den += float(q.grad.double().pow(2).sum())
+    assert (num / den) ** 0.5 <= 3e-3
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_train_step_direct_bucket_gradients_equal_autograd_gradients(dtype):
+    """TrainStep lets the whole-block backward write weight gradients straight into the flat all-reduce bucket (no
+    per-parameter accumulate node, no copy): the bucket must hold exactly the gradients autograd would have produced,
+    step after step."""
+    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 4])
+    torch.manual_seed(13)
+    net = S.define_G(**cfg).to(DEV)
+    if dtype == 'bf16':
+        net.set_activation_dtype(torch.bfloat16)
+    s = make_synthetic_mesh(20_000, 3, seed=14, dilations=(2, 4)).to(DEV)
+    step = TrainStep(net, lr=0.0)                       # lr 0: parameters stay put, every step must give the same gradients
+    names = [k for k, p in net.named_parameters() if p.requires_grad]
+    for _ in range(3):
+        step(s)
+        direct = step.bucket.flat.clone()
+        assert sum(step.bucket.written) >= 4 * 7, 'the block weights took the direct path'
+    for p in net.parameters():
+        p.grad = None
+    loss = SF.masked_l1_loss(net(s), s.color, s.mask, True)
+    loss.backward()
+    off = 0
+    for k, p in zip(names, step.bucket.params):
+        want = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.equal(direct[off:off + p.numel()].view_as(p), want), k
+        off += p.numel()
