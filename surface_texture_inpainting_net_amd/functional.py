@@ -406,6 +406,10 @@ def linear(x, weight, bias=None, out_fp32=False):
 # ---- weight-gradient side stream of the whole-block backward ----------------------------------------------------------
 USE_WGRAD_STREAM = os.environ.get('STIN_WGRAD_STREAM', '1') == '1'
 WGRAD_DEFER_JOIN = os.environ.get('STIN_WGRAD_DEFER', '1') == '1'
+# the overlap pays where kernels are too short to fill the GPU; a weight-gradient GEMM of N * Yw * Cp above this keeps the
+# whole chip busy for hundreds of microseconds and only slows the critical-path kernels it runs beside (measured: 500 k
+# vertices / 4 levels +4.7 %, every block <= 1.5e10; 1 M vertices / 3 levels -13 %, every block >= 2e10)
+WGRAD_MAX_WORK = float(os.environ.get('STIN_WGRAD_MAX_WORK', 1.6e10))
 _WGRAD_SIDE = {}
 
 
@@ -466,11 +470,11 @@ def _direct_grad_views(params):
     return out
 
 
-def _wgrad_side_args(dev, keep_alive, params, direct=False):
+def _wgrad_side_args(dev, keep_alive, params, direct=False, work=0):
     """-> (wgrad_stream, ev_dagg, ev_dy, ev_done, join) for stin_edgeconv_block_bwd.  The join with the compute stream is
     deferred to the end of the backward pass when nothing can read the gradients earlier (every parameter is a leaf whose
     .grad is None - autograd then adopts the returned tensor without a kernel - and has no hooks); otherwise in-call."""
-    if not USE_WGRAD_STREAM:
+    if not USE_WGRAD_STREAM or work > WGRAD_MAX_WORK:
         return 0, 0, 0, 0, 0
     side = _wgrad_side(dev)
     for t in keep_alive:
@@ -623,7 +627,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
             ws_bytes = lib.stin_edgeconv_block_bwd_workspace_bytes(N, Cp, H, Cout, int(ctx.has_shortcut), groups.B, int(b16))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             cs = edges.by_src
-            side = _wgrad_side_args(dev, (ws, x, hE, g), ctx.params, direct is not None)
+            side = _wgrad_side_args(dev, (ws, x, hE, g), ctx.params, direct is not None, work=float(N) * Y.shape[1] * Cp)
             _call('stin_edgeconv_block_bwd', int(b16), _ptr(g), ldg, _ptr(x), x.stride(0), N, Cin, Cp, H, Cout,
                   int(ctx.has_shortcut), int(ctx.trans_inv), _ptr(Y), Y.stride(0), _ptr(hE), hE.stride(0), _ptr(ctx.mask),
                   _ptr(agg), _ptr(mean), _ptr(rstd), _ptr(wcatT), _ptr(w2T), _ptr(edges.by_dst.rowptr), _ptr(cs.rowptr),
