@@ -408,9 +408,11 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, 
     const int wi = wave >> 1, wj = wave & 1;
     const int tiles = tiles_i * tiles_j;
     const int64_t b = blockIdx.x;
+    // chunks >= 8: XCD x (blocks b = x mod 8) owns the row chunks x, x+8, ... - its tiles re-read the same rows from its own L2.
+    // Fewer chunks than XCDs (the wide layers: >= 64 output tiles): plain order, so that every XCD gets tiles of every chunk.
     const int64_t xcd = b % 8, q = b / 8;
-    const int64_t chunk = (q / tiles) * 8 + xcd;
-    const int tile = (int)(q % tiles);
+    const int64_t chunk = chunks >= 8 ? (q / tiles) * 8 + xcd : b / tiles;
+    const int tile = (int)(chunks >= 8 ? q % tiles : b % tiles);
     if (chunk >= chunks) return;                                  // block-uniform
     const int tj = tile % tiles_j, ti = tile / tiles_j;
     const int i0 = ti * TI, j0 = tj * TJ;
@@ -565,9 +567,11 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
     const int wi = wave >> 1, wj = wave & 1;
     const int tiles = tiles_i * tiles_j;
     const int64_t b = blockIdx.x;
+    // chunks >= 8: XCD x (blocks b = x mod 8) owns the row chunks x, x+8, ... - its tiles re-read the same rows from its own L2.
+    // Fewer chunks than XCDs (the wide layers: >= 64 output tiles): plain order, so that every XCD gets tiles of every chunk.
     const int64_t xcd = b % 8, q = b / 8;
-    const int64_t chunk = (q / tiles) * 8 + xcd;
-    const int tile = (int)(q % tiles);
+    const int64_t chunk = chunks >= 8 ? (q / tiles) * 8 + xcd : b / tiles;
+    const int tile = (int)(chunks >= 8 ? q % tiles : b % tiles);
     if (chunk >= chunks) return;
     const int tj = tile % tiles_j, ti = tile / tiles_j;
     const int i0 = ti * TI, j0 = tj * TJ;
@@ -949,9 +953,11 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restri
     const int wi = wave >> 1, wj = wave & 1;
     const int tiles = tiles_i * tiles_j;
     const int64_t b = blockIdx.x;
+    // chunks >= 8: XCD x (blocks b = x mod 8) owns the row chunks x, x+8, ... - its tiles re-read the same rows from its own L2.
+    // Fewer chunks than XCDs (the wide layers: >= 64 output tiles): plain order, so that every XCD gets tiles of every chunk.
     const int64_t xcd = b % 8, q = b / 8;
-    const int64_t chunk = (q / tiles) * 8 + xcd;
-    const int tile = (int)(q % tiles);
+    const int64_t chunk = chunks >= 8 ? (q / tiles) * 8 + xcd : b / tiles;
+    const int tile = (int)(chunks >= 8 ? q % tiles : b % tiles);
     if (chunk >= chunks) return;
     const int tj = tile % tiles_j, ti = tile / tiles_j;
     const int i0 = ti * TI, j0 = tj * TJ;
@@ -1159,6 +1165,7 @@ inline int tn_rows_per_chunk(int64_t M, int tiles) {
     // ~512 blocks (2 resident per CU, one round; measured best of 256..1536), chunks a multiple of the LDS slab
     static const int target = getenv("STIN_TN_BLOCKS") ? atoi(getenv("STIN_TN_BLOCKS")) : 512;   // tuning aid
     int64_t chunks = (target + tiles - 1) / tiles;
+    if (chunks > 8) chunks = (chunks + 7) / 8 * 8;          // whole rounds of 8 chunks (one per XCD, see the kernels' block map)
     int64_t rows = (M + chunks - 1) / chunks;
     if (rows < 4 * TN_R) rows = 4 * TN_R;
     if (rows > 128 * TN_R) rows = 128 * TN_R;
@@ -1263,7 +1270,7 @@ extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int
     if (chunks > 0) {
         const bool vec = (Nc % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldx % 4 == 0) && stin_aligned16(G) &&
                          stin_aligned16(X);
-        const int64_t blocks = ((chunks + 7) / 8) * 8 * (int64_t)tiles_i * tiles_j;   // 8 chunks (one per XCD) per round
+        const int64_t blocks = (chunks >= 8 ? ((chunks + 7) / 8) * 8 : chunks) * (int64_t)tiles_i * tiles_j;   // 8 chunks (one per XCD) per round
 #define STIN_TN(TI_, TJ_)                                                                                            \
     do {                                                                                                             \
         if (vec) hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
@@ -1355,7 +1362,7 @@ extern "C" int stin_gemm_tn_bf16(const stin_bf16_t* G_, int64_t ldg, const stin_
     if (chunks > 0) {
         const bool vec = (Nc % 8 == 0) && (K % 8 == 0) && (ldg % 8 == 0) && (ldx % 8 == 0) && stin_aligned16(G) &&
                          stin_aligned16(X);
-        const int64_t blocks = ((chunks + 7) / 8) * 8 * (int64_t)tiles_i * tiles_j;
+        const int64_t blocks = (chunks >= 8 ? ((chunks + 7) / 8) * 8 : chunks) * (int64_t)tiles_i * tiles_j;
 #define STIN_TNK(TI_, TJ_)                                                                                            \
     do {                                                                                                              \
         if (vec) hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
