@@ -27,8 +27,13 @@ constexpr int BK = 32;
 // x-fastest: the column blocks of one row tile would start thousands of workgroups apart, on different XCDs).
 __device__ __forceinline__ bool nt_block_tile(int64_t M, int Nc, int BM, int BN, int64_t& m0, int& n0) {
     const int64_t L = blockIdx.x;
-    const int64_t j = L >> 3;
     const int ncol = (Nc + BN - 1) / BN;
+    if ((M + BM - 1) / BM < 16) {        // too few row tiles to give every XCD its own (coarsest levels): plain order
+        m0 = (L / ncol) * BM;
+        n0 = (int)(L % ncol) * BN;
+        return true;
+    }
+    const int64_t j = L >> 3;
     const int64_t rt = (j / ncol) * 8 + (L & 7);
     if (rt * BM >= M) return false;
     m0 = rt * BM;
@@ -37,7 +42,7 @@ __device__ __forceinline__ bool nt_block_tile(int64_t M, int Nc, int BM, int BN,
 }
 inline unsigned nt_grid(int64_t M, int Nc, int BM, int BN) {
     const int64_t nrow = (M + BM - 1) / BM, ncol = (Nc + BN - 1) / BN;
-    return (unsigned)(((nrow + 7) / 8) * 8 * ncol);
+    return (unsigned)((nrow < 16 ? nrow : ((nrow + 7) / 8) * 8) * ncol);
 }
 
 // ----------------------------------------------------------------------------- NT
