@@ -427,6 +427,7 @@ class _WgradSide:
                 e.record(self.stream)               # forces creation of the hipEvent_t handles
         self.at = 0
         self.last_done = self.ring[0][2]
+        self.hold = []                              # tensors the side stream may still be reading (dropped at the join)
 
     def next_events(self):
         self.at = (self.at + 1) % self.RING
@@ -477,10 +478,13 @@ def _wgrad_side_args(dev, keep_alive, params, direct=False, work=0):
     if not USE_WGRAD_STREAM or work > WGRAD_MAX_WORK:
         return 0, 0, 0, 0, 0
     side = _wgrad_side(dev)
-    for t in keep_alive:
-        t.record_stream(side.stream)
     deferred = WGRAD_DEFER_JOIN and (direct or all(p is None or (p.is_leaf and p.grad is None and not p._backward_hooks and
                                  not getattr(p, '_post_accumulate_grad_hooks', None)) for p in params))
+    if deferred:
+        # the side stream reads these after this call has returned: keep them referenced until the end-of-backward join
+        # (then they are freed in compute-stream order AFTER the join - no record_stream: its deferred frees made the
+        # caching allocator's pool grow by ~80 MB per step over hundreds of steps with changing scene sizes)
+        side.hold.append(keep_alive)
     ev = side.next_events()
     return side.stream.cuda_stream, ev[0].cuda_event, ev[1].cuda_event, ev[2].cuda_event, int(not deferred)
 
@@ -495,6 +499,7 @@ def _wgrad_deferred_join(dev, params, grads):
 
     def join():
         torch.cuda.current_stream(dev).wait_event(side.last_done)    # the newest ev_done: after all side work so far
+        side.hold.clear()                                             # freed from here on = ordered after the join
         for p, ptr in adopted:
             if p.grad is not None and p.grad.data_ptr() != ptr:
                 raise RuntimeError('weight-gradient stream: autograd copied a gradient before the end-of-backward join; '
