@@ -240,6 +240,8 @@ int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_
                                 |a| >= 2^-6, |w| >= 2^-9 (absolute 2^-28 / 2^-31 below: made for normalised
                                 activations); A, W pre-scaled by 2^3, 2^6 internally (exact); needs
                                 |A| < 8188, |W| < 1023 (outside: inf/NaN, never a silently wrong value)   */
+#define STIN_GEMM_W_BF16 0x200     /* stin_gemm_nt_bf16 flag / stin_edgeconv_pack_f32 mode: the weight operand holds bf16 [Nc][K]
+                                       (ldw in bf16 elements, K % 8 == 0, 16-byte aligned rows) instead of fp32 */
 #define STIN_GEMM_W_PRESPLIT 0x100 /* nt, OR-ed into BF16X3 / F16X3: W already holds its two 16-bit pieces, per 4-wide
                                       k-group [hi x 4 | lo x 4] in the 16 bytes of the fp32 values it replaces (same
                                       shape / ld / footprint; made by stin_gemm_split_weights_f32 or the pack kernel) -
@@ -320,7 +322,8 @@ int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int
  * slot: a bf16 mask is only meaningful to the bf16 backward kernels, an fp32 mask to the fp32 ones.
  * gemm_nt_bf16: A, row_mask, residual bf16; W, bias fp32 (W is rounded to bf16 while staged); one
  *   v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate, bias/mask/residual added in fp32, one rounding;
- *   C is bf16 (c_is_f32 = 0) or fp32 (c_is_f32 = 1: the network's final [N, 3] output).
+ *   C is bf16 (c_is_f32 = 0) or fp32 (c_is_f32 = 1: the network's final [N, 3] output); OR-ing STIN_GEMM_W_BF16 into
+ *   c_is_f32 declares W as a bf16 [Nc][K] operand (written by stin_edgeconv_pack_f32 in that mode).
  * gemm_tn_bf16: G, X, row_weight bf16 -> fp32 dW; workspace = stin_gemm_tn_workspace_bytes.
  */
 int stin_segment_sum_bf16(const stin_bf16_t* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col,

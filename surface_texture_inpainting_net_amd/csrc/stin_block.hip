@@ -60,9 +60,13 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
     void* red_ws = p;
     const size_t red_bytes = stin_colreduce_workspace_bytes(Cout, B);
 
+    // bf16 rows: the GEMM weight operands are written as bf16 once here (half the bytes every tile load, no conversion)
+    // when every reduction length is a multiple of 8; fwd_split / bwd_split then carry STIN_GEMM_W_BF16
+    if (storage == 1) fwd_split = bwd_split = (Cp % 8 == 0 && Cout % 8 == 0) ? STIN_GEMM_W_BF16 : 0;
     STIN_TRY(stin_edgeconv_pack_f32(W1, b1, Ws, bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T,
                                     fwd_split ? w2s : nullptr, fwd_split, bwd_split, stream));
     const float* w2_op = fwd_split ? w2s : W2;
+    const int wbf = (storage == 1 && fwd_split) ? STIN_GEMM_W_BF16 : 0;
     const int pf = fwd_split ? (prec_fwd | STIN_GEMM_W_PRESPLIT) : prec_fwd;
     const void* res = has_shortcut ? col_off(static_cast<const void*>(Y), 2 * (int64_t)H, storage) : x;
     const int64_t ld_res = has_shortcut ? ldy : ldx;
@@ -92,9 +96,9 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
         stin_bf16_t* Yh = static_cast<stin_bf16_t*>(Y);
         stin_bf16_t* hh = static_cast<stin_bf16_t*>(hE);
         STIN_TRY(stin_gemm_nt_bf16(static_cast<const stin_bf16_t*>(x), ldx, wcat, Cp, bcat, nullptr, 0, nullptr, 0, N, Yw, Cp, Yh,
-                                   ldy, 0, stream));
+                                   ldy, wbf, stream));
         STIN_TRY(stin_edge_relu_mean_fwd_bf16(Yh, ldy, Yh + H, ldy, rowptr_dst, col_dst, N, H, hh, ldh, 1, mask, stream));
-        STIN_TRY(stin_gemm_nt_bf16(hh, ldh, w2_op, H, b2, hh + H, ldh, nullptr, 0, N, Cout, H, agg, Cout, 0, stream));
+        STIN_TRY(stin_gemm_nt_bf16(hh, ldh, w2_op, H, b2, hh + H, ldh, nullptr, 0, N, Cout, H, agg, Cout, wbf, stream));
         if (!slice_quirk) {
             STIN_TRY(stin_colreduce_bf16(STIN_RED_MOMENTS, static_cast<const stin_bf16_t*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum,
                                          B, gid, nullptr, nullptr, nullptr, nullptr, STIN_POST_NONE, inv_cnt, eps, mean, rstd,
@@ -250,8 +254,9 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         STIN_TRY(fork(ev_dagg));
         STIN_TRY(stin_gemm_tn_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, hh, ldh, N, Cout, H, 1, hh + H, ldh, dw2b, H + 1,
                                    tn_ws, tn_bytes, ws_));
+        const int wbb = (Cp % 8 == 0 && Cout % 8 == 0) ? STIN_GEMM_W_BF16 : 0;   // as written by the forward call's pack
         STIN_TRY(stin_gemm_nt_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H,
-                                   Cout, dhE, H, 0, stream));
+                                   Cout, dhE, H, wbb, stream));
         STIN_TRY(stin_edge_relu_mean_bwd_dst_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, mask, rowptr_dst, N, H, dYh, Yw,
                                                        stream));
         STIN_TRY(stin_edge_relu_mean_bwd_src_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, w_src, mask, rowptr_src, col_src,
@@ -266,7 +271,7 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
                                    tn_bytes, ws_));
         if (dx != nullptr)
             STIN_TRY(stin_gemm_nt_bf16(dYh, Yw, wcatT, Yw, nullptr, nullptr, 0, has_shortcut ? nullptr : gh, ldg, N, Cp, Yw, dx,
-                                       lddx, 0, stream));
+                                       lddx, wbb, stream));
     }
     STIN_TRY(stin_edgeconv_unpack_grads_f32(dwb, dw2b, Cin, Cp, H, Cout, has_shortcut, trans_inv, dW1, db1, dWs, dbs, dW2, db2,
                                             ws_));

@@ -757,7 +757,7 @@ __device__ __forceinline__ uint4 f8_to_bf16x8(float4 a, float4 b) {
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-template <int BM, int BN, int WM, int WN, typename OUT, bool VEC>
+template <int BM, int BN, int WM, int WN, typename OUT, bool VEC, bool WB = false>   // WB: W already holds bf16 (ldw in bf16 elements)
 __global__ __launch_bounds__(BLOCK) void k_gemm_nt_b16(const stin_bf16* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ W, int64_t ldw,
                                                        const float* __restrict__ bias,
@@ -812,6 +812,12 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_b16(const stin_bf16* __restri
 #pragma unroll
         for (int s = 0; s < W_CH; ++s) {
             const int row = n0 + r0 + s * 32;
+            if constexpr (WB) {                                   // pre-converted weights: 16 bytes = 8 k-values, no conversion
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (row < Nc && k < K) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const stin_bf16*>(W) + (int64_t)row * ldw + k);
+                rw[s] = v;
+                continue;
+            }
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
             if (row < Nc) {
                 const float* p = W + (int64_t)row * ldw + k;
@@ -1319,7 +1325,10 @@ extern "C" int stin_gemm_nt_bf16(const stin_bf16_t* A_, int64_t lda, const float
     STIN_REQUIRE(residual == nullptr || ld_res >= Nc, STIN_E_SIZE);
     if (M == 0) return STIN_OK;
     STIN_REQUIRE(A && W && C, STIN_E_NULL);
-    const bool vec = (K % 8 == 0) && (lda % 8 == 0) && (ldw % 4 == 0) && stin_aligned16(A) && stin_aligned16(W);
+    const bool wb = (c_is_f32 & STIN_GEMM_W_BF16) != 0;          // flags: bit 0 = fp32 output, STIN_GEMM_W_BF16 = bf16 weight operand
+    c_is_f32 &= 1;
+    const bool vec = (K % 8 == 0) && (lda % 8 == 0) && (ldw % (wb ? 8 : 4) == 0) && stin_aligned16(A) && stin_aligned16(W);
+    STIN_REQUIRE(!wb || vec, STIN_E_ALIGN);
     const int vec_out = (!c_is_f32 && Nc % 8 == 0 && ldc % 8 == 0 && stin_aligned16(C)) ? 1 : 0;
     // 64x64 is the best tile for every shape of the shipped 3-level network; long reductions with enough tiles (the wide
     // layers of a 5-level network) are 1.1-1.5x faster on 128x64 (profiles/gemm_tiles.py)
@@ -1328,7 +1337,8 @@ extern "C" int stin_gemm_nt_bf16(const stin_bf16_t* A_, int64_t lda, const float
 #define STIN_NTB(BM_, BN_, WM_, WN_, OUT_)                                                                             \
     do {                                                                                                               \
         dim3 grid(nt_grid(M, Nc, BM_, BN_));                                                                           \
-        if (vec) hipLaunchKernelGGL((k_gemm_nt_b16<BM_, BN_, WM_, WN_, OUT_, true>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (OUT_*)C, ldc, vec_out); \
+        if (wb) hipLaunchKernelGGL((k_gemm_nt_b16<BM_, BN_, WM_, WN_, OUT_, true, true>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (OUT_*)C, ldc, vec_out); \
+        else if (vec) hipLaunchKernelGGL((k_gemm_nt_b16<BM_, BN_, WM_, WN_, OUT_, true>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (OUT_*)C, ldc, vec_out); \
         else hipLaunchKernelGGL((k_gemm_nt_b16<BM_, BN_, WM_, WN_, OUT_, false>), grid, dim3(BLOCK), 0, stream, A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (OUT_*)C, ldc, vec_out);    \
     } while (0)
 #define STIN_NTB_PICK(OUT_)                                                                          \

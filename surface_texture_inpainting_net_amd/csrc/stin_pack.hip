@@ -9,10 +9,14 @@ constexpr int BLOCK = 256;
 // Weight operand of stin_gemm_nt_f32 in PRE-SPLIT form (precision | STIN_GEMM_W_PRESPLIT): the two 16-bit pieces the
 // kernel would otherwise compute for every block that stages the tile.  Same footprint as fp32: the 16 bytes of the
 // k-group 4g..4g+3 of a row hold [hi x 4 | lo x 4]; piece type / pre-scale as in stin_gemm.hip (fp16: x 64, bf16: x 1).
-// mode 0 = plain fp32.
+// mode 0 = plain fp32; STIN_GEMM_W_BF16 = plain bf16 (the weight operand of the bf16-storage GEMMs).
 __device__ __forceinline__ void put_weight(float* __restrict__ base, int64_t row_off, int c, float v, int mode) {
     if (mode == 0) {
         base[row_off + c] = v;
+        return;
+    }
+    if (mode == STIN_GEMM_W_BF16) {                      // plain bf16 row-major in the same buffer (bf16 element indices)
+        reinterpret_cast<__bf16*>(base)[row_off + c] = (__bf16)v;
         return;
     }
     uint16_t* h = reinterpret_cast<uint16_t*>(base + row_off + (c & ~3)) + (c & 3);
@@ -147,7 +151,8 @@ extern "C" int stin_edgeconv_pack_f32(const float* W1, const float* b1, const fl
     stin_clear_stale_error();
     STIN_REQUIRE(Cin > 0 && Cp >= Cin && H > 0 && Cout > 0, STIN_E_SIZE);
     STIN_REQUIRE(W1 && W2 && wcat && bcat && wcatT && w2T && (!has_shortcut || Ws), STIN_E_NULL);
-    STIN_REQUIRE(split_mode_ok(fwd_split) && split_mode_ok(bwd_split), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE((split_mode_ok(fwd_split) || fwd_split == STIN_GEMM_W_BF16) && (split_mode_ok(bwd_split) || bwd_split == STIN_GEMM_W_BF16),
+                 STIN_E_UNSUPPORTED);
     STIN_REQUIRE(fwd_split == 0 || (w2s != nullptr && Cp % 4 == 0 && H % 4 == 0), STIN_E_ALIGN);
     STIN_REQUIRE(bwd_split == 0 || (Cout % 4 == 0 && H % 2 == 0), STIN_E_ALIGN);     // Yw = 2H (+ Cout) must be a multiple of 4
     const int Yw = 2 * H + (has_shortcut ? Cout : 0);
