@@ -26,7 +26,12 @@ def _stream(t):
 
 
 def _ptr(t):
-    return 0 if t is None else t.data_ptr()
+    if t is None:
+        return 0
+    p = t.data_ptr()
+    if p == 0 and t.untyped_storage().nbytes() > 0:       # zero-element view (an empty edge set): still a valid address
+        p = t.untyped_storage().data_ptr() + t.storage_offset() * t.element_size()
+    return p
 
 
 def _upload(host_tensor, device):
