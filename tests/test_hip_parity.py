@@ -883,3 +883,45 @@ def test_graph_resnet_block_on_degenerate_graphs_vs_oracle(case):
         scale = max(1e-6, max(float(p.grad.abs().max()) for p in ref.parameters()))
         for (k, p), q in zip(blk.named_parameters(), ref.parameters()):
             assert float((p.grad.cpu() - q.grad).abs().max()) <= (5e-2 if case == 'two_vertices' else 2e-3) * scale, (case, cin, k)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_model_with_an_empty_dilated_edge_set(dtype):
+    """A dilation whose walk found no edge at all (graph_dilation.py may return an empty list for a level): the
+    bottleneck block on that set sees only isolated vertices.  fp32: against the oracle; bf16: runs, finite, and the
+    block call equals the per-kernel path."""
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 4])
+    torch.manual_seed(17)
+    ref = stin_oracle.define_G(**cfg)
+    net = S.define_G(**cfg)
+    net.load_state_dict(ref.state_dict())
+    net = net.to(DEV)
+    s = make_synthetic_mesh(3000, 3, seed=33, dilations=(2, 4))
+    key = [k for k in s.keys() if k.startswith('hierarchy_dil_4_edge_index')][0]
+    s[key] = torch.zeros(2, 0, dtype=torch.int64)
+    sd = s.to(DEV)
+    if dtype == 'f32':
+        want = ref(s)
+        want.square().mean().backward()
+        got = net(sd)
+        got.square().mean().backward()
+        assert float((got.detach().cpu() - want.detach()).abs().max()) <= FWD_TOL
+        scale = max(float(p.grad.abs().max()) for p in ref.parameters())
+        for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+            assert float((p.grad.cpu() - q.grad).abs().max()) <= 1e-2 * scale, k
+    else:
+        net.set_activation_dtype(torch.bfloat16)
+        outs = []
+        for blockcall in (True, False):
+            old = SF.USE_BLOCK_CALL
+            SF.USE_BLOCK_CALL = blockcall
+            try:
+                net.zero_grad(set_to_none=True)
+                out = net(sd)
+                out.float().square().mean().backward()
+                outs.append([out.detach().clone()] + [p.grad.clone() for p in net.parameters()])
+            finally:
+                SF.USE_BLOCK_CALL = old
+        assert all(torch.isfinite(t).all() for t in outs[0])
+        assert all(torch.equal(a, b) for a, b in zip(*outs))
