@@ -17,12 +17,13 @@ def test_oracle_model_matches_reference_fixture(name):
     s = fx.sample()
     s.x = s.x.clone().requires_grad_(True)
     out = net(s)
-    # same ops in the same order on the same CPU build: forward is expected bit-exact
-    assert torch.equal(out, fx.out), float((out - fx.out).abs().max())
+    # same ops in the same order: bit-exact on the host that generated the fixture; another CPU's BLAS kernels may sum in a
+    # different order (measured 1.2e-6 on the GPU boxes' EPYC hosts), hence a bound instead of torch.equal
+    assert float((out - fx.out).abs().max()) <= 2e-5
     pred = stin_oracle.graph_forward(net, s)
     loss = stin_oracle.compute_loss(pred, s.color, weights=s.mask)
-    assert torch.equal(pred, fx.pred)
-    assert abs(float(loss.detach()) - float(fx.loss)) <= 1e-7
+    assert float((pred - fx.pred).abs().max()) <= 2e-5
+    assert abs(float(loss.detach()) - float(fx.loss)) <= 1e-6
     loss.backward()
     assert rel_err(s.x.grad, fx.gx) < 1e-5
     # some grads are analytically zero (a bias in front of an instance norm): compare against the
