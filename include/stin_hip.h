@@ -269,6 +269,16 @@ int stin_bn_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_t 
                         const float* gamma, const float* beta, const float* P, const float* Q, float inv_n, int64_t N,
                         int C, int act, float* dx, int64_t lddx, stin_stream_t stream);
 
+/* BatchNorm1d over the E edge rows followed by aggr='mean' (the second norm of that edge MLP): the affine map commutes with
+ * the mean, so the forward normalises the N aggregated rows (stin_segment_sum_f32(mean) then stin_bn_act_fwd_f32, rows
+ * without in-edges zeroed); this is the joint backward - the gradient of the raw edge rows m [E, C] from the VERTEX
+ * gradient g [N, C] (zero on rows without in-edges):
+ *   dm[e] = gamma rstd (g[dst e] * inv_deg[dst e] - Q inv_e - nhat_e P inv_e),  nhat_e = (m[e] - mean) rstd,
+ * with P = sum_i g_i nhat(agg_i), Q = sum_i g_i from stin_colreduce_f32(STIN_RED_DOT_BN) over the N aggregated rows. */
+int stin_bn_mean_bwd_f32(const float* m, int64_t ldm, const float* g, int64_t ldg, const int32_t* dst, const float* inv_deg,
+                         const float* mean, const float* rstd, const float* gamma, const float* P, const float* Q,
+                         float inv_e, int64_t E, int C, float* dm, int64_t lddm, stin_stream_t stream);
+
 /* ------------------------------------------------------- parameter-side helpers --
  * pack: the reference-layout EdgeConv parameters (first_filter.nn.0.{weight,bias} = W1 [H, 2Cin]
  * (or [H, Cin] for EdgeConvTransInv), first_filter.nn.2.weight = W2 [Cout, H], shortcut.{weight,bias})

@@ -313,6 +313,37 @@ __global__ __launch_bounds__(BLOCK) void k_bn_bwd(const float* __restrict__ x, i
     o.store(dx + r * lddx + c);
 }
 
+// BatchNorm1d over the E edge rows FOLLOWED by the mean over each target's in-edges (SingleConvMeshNet's second edge norm,
+// edge_conv_filter.py:34-44 + aggr='mean'): the affine map commutes with the mean, so forward normalises the N aggregated
+// rows; this is the backward of both at once - the gradient of the raw edge rows m from the VERTEX gradient g:
+//   dm[e] = gamma rstd ( g[dst e] / deg(dst e) - Q / E - nhat_e P / E ),   nhat_e = (m[e] - mean) rstd,
+// P = sum_i g_i nhat(agg_i), Q = sum_i g_i over the vertices with in-edges (column sums over N rows, not E).
+template <int VW>
+__global__ __launch_bounds__(BLOCK) void k_bn_mean_bwd(const float* __restrict__ m, int64_t ldm, const float* __restrict__ g,
+                                                       int64_t ldg, const int32_t* __restrict__ dst,
+                                                       const float* __restrict__ inv_deg, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ P, const float* __restrict__ Q, float inv_e,
+                                                       int64_t E, int C, float* __restrict__ dm, int64_t lddm) {
+    const int CV = C / VW;
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= E * CV) return;
+    const int64_t e = t / CV;
+    const int c = (int)(t % CV) * VW;
+    const int64_t i = dst[e];
+    const float w = inv_deg[i];
+    const V<VW> mv = V<VW>::load(m + e * ldm + c), gv = V<VW>::load(g + i * ldg + c);
+    const V<VW> mu = V<VW>::load(mean + c), rs = V<VW>::load(rstd + c), ga = V<VW>::load(gamma + c);
+    const V<VW> pv = V<VW>::load(P + c), qv = V<VW>::load(Q + c);
+    V<VW> o;
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+        const float n = (mv.v[k] - mu.v[k]) * rs.v[k];
+        o.v[k] = rs.v[k] * ga.v[k] * (gv.v[k] * w - qv.v[k] * inv_e - n * (pv.v[k] * inv_e));
+    }
+    o.store(dm + e * lddm + c);
+}
+
 template <typename T>
 inline bool vec4_ok(int C, std::initializer_list<const void*> data, std::initializer_list<const void*> stats,
                     std::initializer_list<int64_t> lds) {
@@ -521,6 +552,27 @@ extern "C" int stin_bn_act_bwd_f32(const float* x, int64_t ldx, const float* gou
         const int64_t n = N * C;
         hipLaunchKernelGGL((k_bn_bwd<1>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx, gout, ldg, mean,
                            rstd, gamma, beta, P, Q, inv_n, N, C, act, dx, lddx);
+    }
+    return stin_launch_status();
+}
+
+extern "C" int stin_bn_mean_bwd_f32(const float* m, int64_t ldm, const float* g, int64_t ldg, const int32_t* dst,
+                                    const float* inv_deg, const float* mean, const float* rstd, const float* gamma,
+                                    const float* P, const float* Q, float inv_e, int64_t E, int C, float* dm, int64_t lddm,
+                                    stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    STIN_REQUIRE(E >= 0 && C > 0 && ldm >= C && ldg >= C && lddm >= C, STIN_E_SIZE);
+    if (E == 0) return STIN_OK;
+    STIN_REQUIRE(m && g && dst && inv_deg && mean && rstd && gamma && P && Q && dm, STIN_E_NULL);
+    if (vec4_ok<float>(C, {m, g, dm}, {mean, rstd, gamma, P, Q}, {ldm, ldg, lddm})) {
+        const int64_t n = E * (C / 4);
+        hipLaunchKernelGGL((k_bn_mean_bwd<4>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, m, ldm, g, ldg, dst,
+                           inv_deg, mean, rstd, gamma, P, Q, inv_e, E, C, dm, lddm);
+    } else {
+        const int64_t n = E * C;
+        hipLaunchKernelGGL((k_bn_mean_bwd<1>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, m, ldm, g, ldg, dst,
+                           inv_deg, mean, rstd, gamma, P, Q, inv_e, E, C, dm, lddm);
     }
     return stin_launch_status();
 }

@@ -32,6 +32,15 @@ class _EdgeIndex:
         self.dst32 = torch.empty(max(self.E, 1), dtype=torch.int32, device=dst.device)[:self.E]
         for a, b in ((src, self.src32), (dst, self.dst32)):
             _lib.check(lib.stin_narrow_i64_to_i32(_ptr(a), self.E, n, _ptr(b), _ptr(bad), _stream(a)), 'stin_narrow_i64_to_i32')
+        self._has_in = None
+
+    @property
+    def has_in(self):
+        """[N, 1] float: 1 where the vertex has at least one in-edge."""
+        if self._has_in is None:
+            rp = self.by_dst.rowptr
+            self._has_in = (rp[1:] > rp[:-1]).to(torch.float32).view(-1, 1)
+        return self._has_in
 
 
 def _as_edge_index(ei, n):
@@ -154,6 +163,62 @@ class _BatchNormActFn(torch.autograd.Function):
         return dx, P.view(-1), Q.view(-1), None, None, None
 
 
+class _BatchNormMeanFn(torch.autograd.Function):
+    """scatter_mean(BatchNorm1d(m)) over the in-edges of every vertex with the batch statistics of the E edge rows: the
+    affine map commutes with the mean, so forward = statistics over m, segment mean of the RAW rows, then one affine
+    pass over N rows (vertices without in-edges stay 0); backward = column sums over N rows + one pass that turns the
+    vertex gradient into the edge-row gradient (stin_bn_mean_bwd_f32) - instead of a normalise pass, a gather and three
+    more passes over [E, C]."""
+
+    @staticmethod
+    def forward(ctx, m, gamma, beta, ei, groups_e, groups_n, eps):
+        m, ldm = SF._mat(m)
+        e, c = m.shape
+        mean, rstd = SF.colreduce(SF.RED_MOMENTS, m, groups_e, groups_e.ptr_sum, eps=eps)
+        gamma, beta = gamma.detach().contiguous(), beta.detach().contiguous()
+        agg = SF.segment_sum(m, ei.by_dst.rowptr, ei.by_dst.col, ei.n, mean=True)
+        out = torch.empty(ei.n, c, dtype=m.dtype, device=m.device)
+        SF._call('stin_bn_act_fwd_f32', SF._ptr(agg), c, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gamma), SF._ptr(beta), ei.n, c, 0,
+                 SF._ptr(out), c, SF._stream(m))
+        out.mul_(ei.has_in)
+        ctx.save_for_backward(m, agg, mean, rstd, gamma, beta)
+        ctx.ei, ctx.groups_n = ei, groups_n
+        m1, v1 = mean.view(-1), (1.0 / (rstd * rstd) - eps).clamp_(min=0).view(-1)
+        ctx.mark_non_differentiable(m1, v1)
+        return out, m1, v1
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        m, agg, mean, rstd, gamma, beta = ctx.saved_tensors
+        ei = ctx.ei
+        m, ldm = SF._mat(m)
+        e, c = m.shape
+        g = g * ei.has_in                                                 # rows without in-edges produced a constant 0
+        P, Q = SF.colreduce(SF.RED_DOT_BN, agg, ctx.groups_n, ctx.groups_n.ptr_sum, gout=g, mean=mean, rstd=rstd,
+                            coef=torch.stack([gamma, beta]))
+        dm = torch.empty(e, c, dtype=m.dtype, device=m.device)
+        SF._call('stin_bn_mean_bwd_f32', SF._ptr(m), ldm, SF._ptr(g), c, SF._ptr(ei.dst32), SF._ptr(ei.by_dst.inv_deg), SF._ptr(mean),
+                 SF._ptr(rstd), SF._ptr(gamma), SF._ptr(P), SF._ptr(Q), 1.0 / max(e, 1), e, c, SF._ptr(dm), c, SF._stream(m))
+        return dm, P.view(-1), Q.view(-1), None, None, None, None
+
+
+def batch_norm_mean(m, bn, ei):
+    """scatter_mean(bn(m), edge_index[1]) for an affine BatchNorm1d in training mode (running statistics updated as
+    nn.BatchNorm1d does), fused; None when this fast path does not apply."""
+    e = m.shape[0]
+    if not (bn.training and bn.affine and m.dtype == torch.float32 and e > 1):
+        return None
+    out, mean, var = _BatchNormMeanFn.apply(m, bn.weight, bn.bias, ei, NormGroups(e, m.device), NormGroups(ei.n, m.device),
+                                            float(bn.eps))
+    if bn.track_running_stats:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var * (e / max(e - 1, 1)), alpha=mom)
+    return out
+
+
 def batch_norm_rows(x, bn, relu=False):
     """nn.BatchNorm1d semantics on [rows, C] (training: batch statistics over all rows + running-stat update with the
     unbiased variance; eval: running statistics), statistics by the fp64-accumulating column-reduction kernels;
@@ -205,8 +270,11 @@ class EdgeConvBN(nn.Module):
         else:
             pre = _GatherRowsFn.apply(y[:, :h2], ei.dst32, ei.by_dst) + _GatherRowsFn.apply(y[:, h2:], ei.src32, ei.by_src)
         h = batch_norm_rows(pre, bn1, relu=True)                           # [E, 2 cout]
-        m = batch_norm_rows(SF.linear(h, lin2.weight), bn2)                # per-EDGE GEMM, [E, cout]
-        return _ScatterMeanFn.apply(m, ei)
+        m = SF.linear(h, lin2.weight)                                      # per-EDGE GEMM, [E, cout]
+        out = batch_norm_mean(m, bn2, ei)                                  # BN2 + mean over the in-edges, fused
+        if out is None:
+            out = _ScatterMeanFn.apply(batch_norm_rows(m, bn2), ei)
+        return out
 
     def __repr__(self):
         return '{}(nn={}, aggr=mean)'.format('EdgeConvTransInv' if self.trans_inv else 'EdgeConv', self.nn)

@@ -145,3 +145,38 @@ def test_hip_gather_add_rows_bit_exact(H):
     ref[:, :H].index_add_(0, ei[1].cpu(), g.cpu().double())
     ref[:, H:].index_add_(0, ei[0].cpu(), g.cpu().double())
     assert float((y.grad.cpu().double() - ref).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('C', [64, 6])
+def test_hip_fused_batchnorm_then_mean_matches_fp64_autograd(C):
+    """batch_norm_mean = scatter_mean(BatchNorm1d(m), dst) with statistics over the E edge rows, vertices without
+    in-edges exactly 0 - forward, all three gradients and the running statistics against fp64 torch."""
+    from surface_texture_inpainting_net_amd.singleconvmeshnet import _as_edge_index, batch_norm_mean
+    torch.manual_seed(8)
+    n, e = 900, 5000
+    ei = torch.stack([torch.randint(0, n, (e,)), torch.randint(7, n, (e,))])      # vertices 0..6: no in-edge
+    m = (torch.randn(e, C) * 1.5 + 0.3).to('cuda:0').requires_grad_()
+    bn = torch.nn.BatchNorm1d(C).to('cuda:0')
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    w = torch.randn(n, C, device='cuda:0')
+    out = batch_norm_mean(m, bn, _as_edge_index(ei.to('cuda:0'), n))
+    assert out is not None and float(out[:7].abs().max()) == 0.0
+    (out * w).sum().backward()
+    ref = torch.nn.BatchNorm1d(C).double()
+    with torch.no_grad():
+        ref.weight.copy_(bn.weight.detach().cpu().double())
+        ref.bias.copy_(bn.bias.detach().cpu().double())
+    mr = m.detach().cpu().double().requires_grad_()
+    y = ref(mr)
+    cnt = torch.zeros(n, dtype=torch.float64).index_add_(0, ei[1], torch.ones(e, dtype=torch.float64)).clamp(min=1)
+    outr = torch.zeros(n, C, dtype=torch.float64).index_add_(0, ei[1], y) / cnt[:, None]
+    (outr * w.cpu().double()).sum().backward()
+    assert float((out.detach().cpu().double() - outr.detach()).abs().max()) <= 1e-5
+    assert float((m.grad.cpu().double() - mr.grad).abs().max()) <= 1e-4 * float(mr.grad.abs().max())
+    for p, q in ((bn.weight, ref.weight), (bn.bias, ref.bias)):
+        assert float((p.grad.cpu().double() - q.grad).abs().max()) <= 1e-4 * float(q.grad.abs().max())
+    assert torch.allclose(bn.running_mean.cpu().double(), ref.running_mean, atol=1e-6)
+    assert torch.allclose(bn.running_var.cpu().double(), ref.running_var, atol=1e-5)
