@@ -38,7 +38,8 @@ extern "C" size_t stin_edgeconv_block_fwd_workspace_bytes(int Cin, int Cp, int H
 
 // Forward.  storage: 0 = fp32 rows, 1 = bf16 rows (x, Y, hE, agg, out).  Saved for backward by the caller: x, Y, hE,
 // mask, agg, mean, rstd, wcatT, w2T.  Requirements of this fast path (the caller falls back to the individual entry
-// points otherwise): saved ReLU mask supported for H, statistics over true per-graph ranges (no linspace-slice quirk).
+// points otherwise): saved ReLU mask supported for H.  slice_quirk: statistics over the reference's linspace slices
+// (fastinstancenorm.py:53-82) instead of the true per-graph ranges - two passes, as the reference computes them.
 extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, int64_t N, int Cin, int Cp, int H, int Cout,
                                        int has_shortcut, int trans_inv, const float* W1, const float* b1, const float* W2,
                                        const float* b2, const float* Ws, const float* bs, const int32_t* rowptr_dst,
