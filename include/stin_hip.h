@@ -279,6 +279,12 @@ int stin_bn_mean_bwd_f32(const float* m, int64_t ldm, const float* g, int64_t ld
                          const float* mean, const float* rstd, const float* gamma, const float* P, const float* Q,
                          float inv_e, int64_t E, int C, float* dm, int64_t lddm, stin_stream_t stream);
 
+/* nn.BatchNorm1d's running-statistics update from the batch statistics (mean, rstd = 1/sqrt(biased var + eps)) in one
+ * launch: running_mean <- (1 - m) running_mean + m mean; running_var <- (1 - m) running_var + m * unbias * max(1/rstd^2 -
+ * eps, 0), unbias = n / (n - 1). */
+int stin_bn_running_stats_f32(const float* mean, const float* rstd, int C, float eps, float unbias, float momentum,
+                              float* running_mean, float* running_var, stin_stream_t stream);
+
 /* ------------------------------------------------------- parameter-side helpers --
  * pack: the reference-layout EdgeConv parameters (first_filter.nn.0.{weight,bias} = W1 [H, 2Cin]
  * (or [H, Cin] for EdgeConvTransInv), first_filter.nn.2.weight = W2 [Cout, H], shortcut.{weight,bias})

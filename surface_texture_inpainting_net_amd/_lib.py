@@ -98,6 +98,7 @@ SIGNATURES['stin_edgeconv_block_bwd'] = (c_int, [c_int, c_ptr, c_i64, c_ptr, c_i
 SIGNATURES['stin_norm_bwd_coef_m_quirk_f32'] = (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr])
 SIGNATURES['stin_gather_add_rows_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_bn_mean_bwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64] + [c_ptr] * 7 + [c_f32, c_i64, c_int, c_ptr, c_i64, c_ptr])
+SIGNATURES['stin_bn_running_stats_f32'] = (c_int, [c_ptr, c_ptr, c_int, c_f32, c_f32, c_f32, c_ptr, c_ptr, c_ptr])
 SIGNATURES['stin_bn_act_fwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_bn_act_bwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int,
                                              c_int, c_ptr, c_i64, c_ptr])

@@ -344,6 +344,18 @@ __global__ __launch_bounds__(BLOCK) void k_bn_mean_bwd(const float* __restrict__
     o.store(dm + e * lddm + c);
 }
 
+// nn.BatchNorm1d's running-statistics update from the batch (mean, rstd) of the kernels above, one launch:
+//   running_mean <- (1 - m) running_mean + m mean ;  running_var <- (1 - m) running_var + m unbias max(1/rstd^2 - eps, 0)
+__global__ void k_bn_running(const float* __restrict__ mean, const float* __restrict__ rstd, int C, float eps, float unbias,
+                             float momentum, float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float r = rstd[c];
+    const float var = fmaxf(1.0f / (r * r) - eps, 0.f);
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (var * unbias);
+}
+
 template <typename T>
 inline bool vec4_ok(int C, std::initializer_list<const void*> data, std::initializer_list<const void*> stats,
                     std::initializer_list<int64_t> lds) {
@@ -574,5 +586,15 @@ extern "C" int stin_bn_mean_bwd_f32(const float* m, int64_t ldm, const float* g,
         hipLaunchKernelGGL((k_bn_mean_bwd<1>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, m, ldm, g, ldg, dst,
                            inv_deg, mean, rstd, gamma, P, Q, inv_e, E, C, dm, lddm);
     }
+    return stin_launch_status();
+}
+
+extern "C" int stin_bn_running_stats_f32(const float* mean, const float* rstd, int C, float eps, float unbias, float momentum,
+                                         float* running_mean, float* running_var, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(C > 0, STIN_E_SIZE);
+    STIN_REQUIRE(mean && rstd && running_mean && running_var, STIN_E_NULL);
+    hipLaunchKernelGGL(k_bn_running, dim3((unsigned)((C + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream_, mean, rstd, C,
+                       eps, unbias, momentum, running_mean, running_var);
     return stin_launch_status();
 }

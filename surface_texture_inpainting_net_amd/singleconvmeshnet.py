@@ -118,9 +118,9 @@ class _RowStatsNormFn(torch.autograd.Function):
         y = SF.norm_act_res_fwd(x, mean, rstd, groups, res=None, act=False)
         ctx.save_for_backward(x, mean, rstd)
         ctx.groups = groups
-        m1, v1 = mean.view(-1), (1.0 / (rstd * rstd) - eps).clamp_(min=0).view(-1)
-        ctx.mark_non_differentiable(m1, v1)
-        return y, m1, v1
+        m1, r1 = mean.view(-1), rstd.view(-1)
+        ctx.mark_non_differentiable(m1, r1)
+        return y, m1, r1
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
@@ -144,9 +144,9 @@ class _BatchNormActFn(torch.autograd.Function):
                  int(relu), SF._ptr(y), c, SF._stream(x))
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.groups, ctx.relu = groups, relu
-        m1, v1 = mean.view(-1), (1.0 / (rstd * rstd) - eps).clamp_(min=0).view(-1)
-        ctx.mark_non_differentiable(m1, v1)
-        return y, m1, v1
+        m1, r1 = mean.view(-1), rstd.view(-1)
+        ctx.mark_non_differentiable(m1, r1)
+        return y, m1, r1
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
@@ -183,9 +183,9 @@ class _BatchNormMeanFn(torch.autograd.Function):
         out.mul_(ei.has_in)
         ctx.save_for_backward(m, agg, mean, rstd, gamma, beta)
         ctx.ei, ctx.groups_n = ei, groups_n
-        m1, v1 = mean.view(-1), (1.0 / (rstd * rstd) - eps).clamp_(min=0).view(-1)
-        ctx.mark_non_differentiable(m1, v1)
-        return out, m1, v1
+        m1, r1 = mean.view(-1), rstd.view(-1)
+        ctx.mark_non_differentiable(m1, r1)
+        return out, m1, r1
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
@@ -202,20 +202,44 @@ class _BatchNormMeanFn(torch.autograd.Function):
         return dm, P.view(-1), Q.view(-1), None, None, None, None
 
 
+_SINGLE_GROUPS = {}
+
+
+def _all_rows(n, device):
+    """The one-range NormGroups of an [n, C] matrix (cached: it is immutable and costs a fill launch to build)."""
+    key = (int(n), str(device))
+    g = _SINGLE_GROUPS.get(key)
+    if g is None:
+        if len(_SINGLE_GROUPS) > 256:
+            _SINGLE_GROUPS.clear()
+        g = _SINGLE_GROUPS[key] = NormGroups(n, device)
+    return g
+
+
+_NBT_BUMPED = [False]        # SingleConvMeshNet.forward bumps every num_batches_tracked in one multi-tensor launch
+
+
+def _update_running(bn, mean, rstd, n):
+    """nn.BatchNorm1d's running statistics from the batch (mean, rstd) of n rows: one HIP launch (+ the batch counter)."""
+    if not (bn.training and bn.track_running_stats):
+        return
+    with torch.no_grad():
+        if not _NBT_BUMPED[0]:
+            bn.num_batches_tracked += 1
+        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        SF._call('stin_bn_running_stats_f32', SF._ptr(mean), SF._ptr(rstd), mean.numel(), float(bn.eps), n / max(n - 1, 1),
+                 float(mom), SF._ptr(bn.running_mean), SF._ptr(bn.running_var), SF._stream(mean))
+
+
 def batch_norm_mean(m, bn, ei):
     """scatter_mean(bn(m), edge_index[1]) for an affine BatchNorm1d in training mode (running statistics updated as
     nn.BatchNorm1d does), fused; None when this fast path does not apply."""
     e = m.shape[0]
     if not (bn.training and bn.affine and m.dtype == torch.float32 and e > 1):
         return None
-    out, mean, var = _BatchNormMeanFn.apply(m, bn.weight, bn.bias, ei, NormGroups(e, m.device), NormGroups(ei.n, m.device),
-                                            float(bn.eps))
-    if bn.track_running_stats:
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1 - mom).add_(var * (e / max(e - 1, 1)), alpha=mom)
+    out, mean, rstd = _BatchNormMeanFn.apply(m, bn.weight, bn.bias, ei, _all_rows(e, m.device), _all_rows(ei.n, m.device),
+                                             float(bn.eps))
+    _update_running(bn, mean, rstd, e)
     return out
 
 
@@ -227,15 +251,10 @@ def batch_norm_rows(x, bn, relu=False):
         n = x.shape[0]
         fused = bn.affine and x.dtype == torch.float32 and n > 0
         if fused:
-            y, mean, var = _BatchNormActFn.apply(x, bn.weight, bn.bias, NormGroups(n, x.device), float(bn.eps), bool(relu))
+            y, mean, rstd = _BatchNormActFn.apply(x, bn.weight, bn.bias, _all_rows(n, x.device), float(bn.eps), bool(relu))
         else:
-            y, mean, var = _RowStatsNormFn.apply(x, NormGroups(n, x.device), float(bn.eps))
-        if bn.training and bn.track_running_stats:
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
-                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(var * (n / max(n - 1, 1)), alpha=mom)
+            y, mean, rstd = _RowStatsNormFn.apply(x, _all_rows(n, x.device), float(bn.eps))
+        _update_running(bn, mean, rstd, n)
         if fused:
             return y
     else:
@@ -351,6 +370,21 @@ class SingleConvMeshNet(nn.Module):
         raise ValueError('Unkown pooling type {}'.format(self._pooling_method))
 
     def forward(self, sample):
+        bumped = False
+        if self.training:                                    # every BatchNorm's batch counter in ONE multi-tensor launch
+            nbt = [m.num_batches_tracked for m in self.modules()
+                   if isinstance(m, nn.BatchNorm1d) and m.track_running_stats and m.training]
+            if nbt:
+                with torch.no_grad():
+                    torch._foreach_add_(nbt, 1)
+                bumped = True
+        _NBT_BUMPED[0] = bumped
+        try:
+            return self._forward(sample)
+        finally:
+            _NBT_BUMPED[0] = False
+
+    def _forward(self, sample):
         edges, pools = self._indices(sample)
         L = self._graph_levels
         levels = [self.left_geo_cnns[0](sample.x, edges[0])]
