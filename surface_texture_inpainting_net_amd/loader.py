@@ -16,6 +16,7 @@ Items are ``(graph_path, mask_path)`` pairs in the reference's on-disk schema (s
 ``HierarchicalBatch`` objects, or zero-argument callables returning one.
 """
 import collections
+import ctypes
 import queue
 import threading
 
@@ -97,6 +98,30 @@ class ResidentGraphCache:
         return len(self._d)
 
 
+class _StagingSlot:
+    """One pinned staging area of the upload ring: a persistent pinned byte buffer per key (grown on demand) and the
+    event after which the H2D copies issued from it have completed - the worker waits for it before overwriting the slot.
+    Staging through persistent buffers keeps the worker thread's work at one GIL-releasing memcpy per tensor."""
+
+    def __init__(self):
+        self.bufs = {}
+        self.done = None
+
+    def stage(self, key, t):
+        t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = self.bufs[key] = torch.empty(max(int(nbytes * 1.25), 64), dtype=torch.uint8, pin_memory=True)
+        view = buf[:nbytes].view(t.dtype).view(t.shape)
+        # a plain single-threaded memcpy with the GIL released (ctypes): torch's CPU copy_ fans out over the intra-op
+        # thread pool, and waking ~256 sleeping OpenMP threads for a few megabytes cost 7 ms per tensor AND slowed the
+        # training thread (step enqueue 5 -> 11-16 ms) while they spun
+        if nbytes:
+            ctypes.memmove(view.data_ptr(), t.data_ptr(), nbytes)
+        return view
+
+
 class SceneLoader:
     """Iterate GPU-resident training batches: ``for sample in loader.epoch(e): loss = step(sample)``."""
 
@@ -110,6 +135,7 @@ class SceneLoader:
         self.model = model                                   # optional: lets the loader build the plan (model.prefetch_plan)
         self.cache = ResidentGraphCache(cache_bytes) if (cache_bytes and self.batch_size == 1) else None
         self._copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        self._ring = [_StagingSlot() for _ in range(self.prefetch + 2)] if self.device.type == 'cuda' else []
 
     # ---- CPU side (background thread) ---------------------------------------------------------------------------
     def _load(self, i):
@@ -126,6 +152,7 @@ class SceneLoader:
 
     def _cpu_batches(self, epoch):
         idx = shard_indices(len(self.items), epoch, self.seed, self.shuffle, self.rank, self.world_size)
+        turn = 0
         for b in range(0, len(idx), self.batch_size):
             ids = idx[b:b + self.batch_size]
             samples = [self._load(i) for i in ids]
@@ -134,7 +161,13 @@ class SceneLoader:
                 key = ids[0] if self.cache is not None else None
                 cached = key is not None and key in self.cache._d       # peek (no LRU update from the worker thread)
                 keys = [k for k in batch.keys() if (k in _FEATURE_KEYS or not cached)]
-                pinned = HierarchicalBatch(**{k: (batch[k].pin_memory() if torch.is_tensor(batch[k]) else batch[k]) for k in keys})
+                slot = self._ring[turn % len(self._ring)]
+                turn += 1
+                if slot.done is not None:
+                    slot.done.synchronize()                     # the uploads issued from this slot have left it
+                    slot.done = None
+                pinned = HierarchicalBatch(**{k: (slot.stage(k, batch[k]) if torch.is_tensor(batch[k]) else batch[k]) for k in keys})
+                pinned._slot = slot
                 yield ids, pinned
             else:
                 yield ids, batch
@@ -152,6 +185,9 @@ class SceneLoader:
         for v in dev.values():
             if torch.is_tensor(v):
                 v.record_stream(main)
+        slot = getattr(cpu_batch, '_slot', None)
+        if slot is not None:
+            slot.done = self._copy_stream.record_event()        # the worker may overwrite the slot after this
         main.wait_stream(self._copy_stream)
         if entry is not None:                                 # resident graph part + its plan: nothing to upload or build
             graph, plan, _ = entry
@@ -167,7 +203,8 @@ class SceneLoader:
             return self._to_device(ids, next(self._reload(ids)))
         out = HierarchicalBatch(**dev)
         if 'num_vertices' in cpu_batch:
-            out._nv_host = cpu_batch['num_vertices']            # level sizes for the plan without a device sync
+            out._nv_host = cpu_batch['num_vertices'].clone()    # level sizes for the plan without a device sync (a copy:
+                                                                # the staging slot is overwritten by a later batch)
         if self.cache is not None:
             plan = self.model.prefetch_plan(out) if self.model is not None else _plan.plan_for(out)
             graph = {k: v for k, v in dev.items() if k not in _FEATURE_KEYS}
