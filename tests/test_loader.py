@@ -66,3 +66,28 @@ def test_resident_graph_cache_reuses_plans_and_gives_identical_results():
             for i, b in enumerate(tiny.epoch(epoch)):
                 assert i == 1 or torch.equal(net(b), want[i])
         assert len(tiny.cache) == 0
+
+
+def test_loader_keeps_parsed_scene_files_in_host_memory(tmp_path, monkeypatch):
+    """File items (the reference's graph .pt + mask .npz): parsed once, revisits served from the host LRU; a cache too
+    small for a scene behaves like none."""
+    from surface_texture_inpainting_net_amd import loader as L
+    from surface_texture_inpainting_net_amd import scene_io
+    items = []
+    for i in range(3):
+        s = make_synthetic_mesh(300 + 50 * i, 3, seed=i, dilations=(2,))
+        gp, mp = str(tmp_path / ('g%d.pt' % i)), str(tmp_path / ('m%d.npz' % i))
+        scene_io.save_scene_like_reference(s, gp, mp, dilation_dists=(2,))
+        items.append((gp, mp))
+    calls = []
+    real = L.load_scene
+    monkeypatch.setattr(L, 'load_scene', lambda *a, **k: (calls.append(a[0]), real(*a, **k))[1])
+    ld = SceneLoader(items, 'cpu', shuffle=False)
+    first = [b.x.clone() for b in ld.epoch(0)]
+    again = [b.x.clone() for b in ld.epoch(1)]
+    assert len(calls) == 3 and all(torch.equal(a, b) for a, b in zip(first, again))
+    calls.clear()
+    tiny = SceneLoader(items, 'cpu', shuffle=False, host_cache_bytes=1024)
+    for e in range(2):
+        list(tiny.epoch(e))
+    assert len(calls) == 6
