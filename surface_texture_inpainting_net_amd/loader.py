@@ -16,6 +16,7 @@ Items are ``(graph_path, mask_path)`` pairs in the reference's on-disk schema (s
 ``HierarchicalBatch`` objects, or zero-argument callables returning one.
 """
 import collections
+import concurrent.futures
 import ctypes
 import queue
 import threading
@@ -126,20 +127,23 @@ class SceneLoader:
     """Iterate GPU-resident training batches: ``for sample in loader.epoch(e): loss = step(sample)``."""
 
     def __init__(self, items, device, batch_size=1, shuffle=True, seed=0, rank=0, world_size=1, prefetch=2,
-                 cache_bytes=32 << 30, end_level=3, cropped=False, model=None, host_cache_bytes=64 << 30):
+                 cache_bytes=32 << 30, end_level=3, cropped=False, model=None, host_cache_bytes=64 << 30, worker_threads=4, workers=2):
         self.items = list(items)
         self.device = torch.device(device)
         self.batch_size, self.shuffle, self.seed = int(batch_size), bool(shuffle), int(seed)
         self.rank, self.world_size, self.prefetch = int(rank), int(world_size), max(1, int(prefetch))
         self.end_level, self.cropped = end_level, cropped
         self.model = model                                   # optional: lets the loader build the plan (model.prefetch_plan)
+        self.worker_threads = max(1, int(worker_threads))    # intra-op threads of each WORKER thread's torch ops (collate ...)
+        self.workers = max(1, int(workers))                  # worker threads preparing batches side by side (order is kept)
+        self._host_lock = threading.Lock()
         self.cache = ResidentGraphCache(cache_bytes) if (cache_bytes and self.batch_size == 1) else None
         self._copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
         # parsed scenes (file items) kept in host RAM, LRU in bytes: a revisit costs a dict lookup instead of ~30 ms of
         # torch.load + layout conversion in the worker thread (ScanNet: ~1200 scenes x ~48 MB = 58 GB for one rank)
         self._host_cache = collections.OrderedDict()
         self._host_cache_cap, self._host_cache_used = int(host_cache_bytes or 0), 0
-        self._ring = [_StagingSlot() for _ in range(self.prefetch + 2)] if self.device.type == 'cuda' else []
+        self._ring = [_StagingSlot() for _ in range(self.prefetch + self.workers + 2)] if self.device.type == 'cuda' else []
 
     # ---- CPU side (background thread) ---------------------------------------------------------------------------
     def _load(self, i):
@@ -148,46 +152,52 @@ class SceneLoader:
             return it
         if callable(it):
             return it()
-        hit = self._host_cache.get(i)
-        if hit is not None:
-            self._host_cache.move_to_end(i)
-            return hit[0]
+        with self._host_lock:
+            hit = self._host_cache.get(i)
+            if hit is not None:
+                self._host_cache.move_to_end(i)
+                return hit[0]
         scene = load_scene(it[0], it[1], end_level=self.end_level, cropped=self.cropped)
         if self._host_cache_cap:
             nb = _tensor_bytes({k: scene[k] for k in scene.keys()})
             if nb <= self._host_cache_cap:
-                while self._host_cache_used + nb > self._host_cache_cap and self._host_cache:
-                    _, (_, b) = self._host_cache.popitem(last=False)
-                    self._host_cache_used -= b
-                self._host_cache[i] = (scene, nb)
-                self._host_cache_used += nb
+                with self._host_lock:
+                    while self._host_cache_used + nb > self._host_cache_cap and self._host_cache:
+                        _, (_, b) = self._host_cache.popitem(last=False)
+                        self._host_cache_used -= b
+                    if i not in self._host_cache:
+                        self._host_cache[i] = (scene, nb)
+                        self._host_cache_used += nb
         return scene
 
     def steps_per_epoch(self):
         n = len(shard_indices(len(self.items), 0, self.seed, False, self.rank, self.world_size))
         return (n + self.batch_size - 1) // self.batch_size
 
-    def _cpu_batches(self, epoch):
+    def _batch_ids(self, epoch):
         idx = shard_indices(len(self.items), epoch, self.seed, self.shuffle, self.rank, self.world_size)
-        turn = 0
-        for b in range(0, len(idx), self.batch_size):
-            ids = idx[b:b + self.batch_size]
-            samples = [self._load(i) for i in ids]
-            batch = samples[0] if len(samples) == 1 else collate(samples)
-            if self.device.type == 'cuda':
-                key = ids[0] if self.cache is not None else None
-                cached = key is not None and key in self.cache._d       # peek (no LRU update from the worker thread)
-                keys = [k for k in batch.keys() if (k in _FEATURE_KEYS or not cached)]
-                slot = self._ring[turn % len(self._ring)]
-                turn += 1
-                if slot.done is not None:
-                    slot.done.synchronize()                     # the uploads issued from this slot have left it
-                    slot.done = None
-                pinned = HierarchicalBatch(**{k: (slot.stage(k, batch[k]) if torch.is_tensor(batch[k]) else batch[k]) for k in keys})
-                pinned._slot = slot
-                yield ids, pinned
-            else:
-                yield ids, batch
+        return [idx[b:b + self.batch_size] for b in range(0, len(idx), self.batch_size)]
+
+    def _prepare(self, turn, ids):
+        """CPU side of batch number `turn` (a worker thread): load, collate, stage into the turn's pinned slot."""
+        samples = [self._load(i) for i in ids]
+        batch = samples[0] if len(samples) == 1 else collate(samples)
+        if self.device.type != 'cuda':
+            return ids, batch
+        key = ids[0] if self.cache is not None else None
+        cached = key is not None and key in self.cache._d       # peek (no LRU update from a worker thread)
+        keys = [k for k in batch.keys() if (k in _FEATURE_KEYS or not cached)]
+        slot = self._ring[turn % len(self._ring)]
+        if slot.done is not None:
+            slot.done.synchronize()                             # the uploads issued from this slot have left it
+            slot.done = None
+        pinned = HierarchicalBatch(**{k: (slot.stage(k, batch[k]) if torch.is_tensor(batch[k]) else batch[k]) for k in keys})
+        pinned._slot = slot
+        return ids, pinned
+
+    def _cpu_batches(self, epoch):
+        for turn, ids in enumerate(self._batch_ids(epoch)):
+            yield self._prepare(turn, ids)
 
     # ---- device side ------------------------------------------------------------------------------------------------
     def _to_device(self, ids, cpu_batch):
@@ -241,37 +251,32 @@ class SceneLoader:
             self._pending = None
 
     def epoch(self, epoch=0):
-        q = queue.Queue(maxsize=self.prefetch)
-        stop = threading.Event()
+        """Batches of one epoch in order.  `workers` threads prepare the next `prefetch` batches side by side (their torch
+        CPU ops limited to `worker_threads` intra-op threads each, thread-locally: waking the process-wide pool of
+        hundreds of threads costs milliseconds per op and slows the training thread); slot `turn % ring` of the pinned
+        staging ring belongs to batch `turn`, and a batch is only submitted after batch `turn - prefetch - 1` was handed
+        to the GPU, so a slot is never overwritten before its uploads were issued (and `slot.done` covers their
+        completion)."""
+        tasks = self._batch_ids(epoch)
 
-        def work():
-            try:
-                for item in self._cpu_batches(epoch):
-                    while not stop.is_set():
-                        try:
-                            q.put(item, timeout=0.1)
-                            break
-                        except queue.Full:
-                            continue
-                    if stop.is_set():
-                        return
-                q.put(None)
-            except BaseException as e:  # surface worker errors in the training thread
-                q.put(e)
+        def init():
+            torch.set_num_threads(self.worker_threads)
 
-        t = threading.Thread(target=work, daemon=True)
-        t.start()
+        ex = concurrent.futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix='stin-loader', initializer=init)
+        window = collections.deque()
         try:
-            while True:
-                item = q.get()
-                if item is None:
-                    break
-                if isinstance(item, BaseException):
-                    raise item
+            nxt = 0
+            while nxt < len(tasks) or window:
+                while nxt < len(tasks) and len(window) <= self.prefetch:
+                    window.append(ex.submit(self._prepare, nxt, tasks[nxt]))
+                    nxt += 1
+                item = window.popleft().result()                 # re-raises a worker's exception here
                 if self.cache is not None:
                     self._commit_pending()
                 yield self._to_device(*item)
             if self.cache is not None:
                 self._commit_pending()
         finally:
-            stop.set()
+            for f in window:
+                f.cancel()
+            ex.shutdown(wait=True)
