@@ -724,6 +724,8 @@ def test_block_call_equals_per_kernel_path_bitwise(batched, dtype):
     per-kernel host path bit for bit - single graph, and a batch of unequal crops (the reference's linspace-slice
     statistics, fastinstancenorm.py:53-82, inside the block call)."""
     from surface_texture_inpainting_net_amd.data import collate
+    if dtype == 'bf16' and not SF.USE_EDGE_MASK:
+        pytest.skip('bf16 storage needs the saved ReLU mask (STIN_EDGE_MASK=0 set)')
     cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
                pooling_type='max', dilations=[1, 2, 1])
     torch.manual_seed(9)
@@ -787,6 +789,8 @@ def test_train_step_direct_bucket_gradients_equal_autograd_gradients(dtype):
     per-parameter accumulate node, no copy): the bucket must hold exactly the gradients autograd would have produced,
     step after step."""
     from surface_texture_inpainting_net_amd.train_step import TrainStep
+    if dtype == 'bf16' and not SF.USE_EDGE_MASK:
+        pytest.skip('bf16 storage needs the saved ReLU mask (STIN_EDGE_MASK=0 set)')
     cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
                pooling_type='max', dilations=[1, 2, 4])
     torch.manual_seed(13)
@@ -799,7 +803,8 @@ def test_train_step_direct_bucket_gradients_equal_autograd_gradients(dtype):
     for _ in range(3):
         step(s)
         direct = step.bucket.flat.clone()
-        assert sum(step.bucket.written) >= 4 * 7, 'the block weights took the direct path'
+        if SF.USE_DIRECT_GRADS and SF.USE_BLOCK_CALL and SF.USE_EDGE_MASK:          # (environment toggles)
+            assert sum(step.bucket.written) >= 4 * 7, 'the block weights took the direct path'
     for p in net.parameters():
         p.grad = None
     loss = SF.masked_l1_loss(net(s), s.color, s.mask, True)
@@ -890,6 +895,8 @@ def test_model_with_an_empty_dilated_edge_set(dtype):
     """A dilation whose walk found no edge at all (graph_dilation.py may return an empty list for a level): the
     bottleneck block on that set sees only isolated vertices.  fp32: against the oracle; bf16: runs, finite, and the
     block call equals the per-kernel path."""
+    if dtype == 'bf16' and not SF.USE_EDGE_MASK:
+        pytest.skip('bf16 storage needs the saved ReLU mask (STIN_EDGE_MASK=0 set)')
     cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
                pooling_type='max', dilations=[1, 2, 4])
     torch.manual_seed(17)
