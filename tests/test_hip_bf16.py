@@ -21,7 +21,8 @@ from surface_texture_inpainting_net_amd.modules import _as_groups
 from surface_texture_inpainting_net_amd.plan import EdgeSet, PoolMap
 from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not SF.USE_EDGE_MASK, reason='bf16 storage needs the saved ReLU mask (STIN_EDGE_MASK=0 set)')]
 DEV = 'cuda:0'
 BF = torch.bfloat16
 
