@@ -4,6 +4,8 @@ synthetic ScanNet-sized mesh (BASELINE.json: 200k vertices / 1.2M directed edges
 the shipped 3-D config), one scene per GPU, pure data parallel with one RCCL gradient all-reduce.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...          # N > 1 without a launcher: starts N ranks itself (torch.distributed.run child,
+                                          # before this process has touched the GPU) and exits with their status
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
@@ -14,6 +16,8 @@ Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for the roofline / cpu_
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +29,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_16BIT_PEAK_TF = 2500.0    # dense bf16 / f16 MFMA peak (same guide); the fp32-storage GEMMs issue 3 such MFMAs per product
+MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 peak = the rate an exact-fp32 GEMM could reach
+HBM_COPY_GBS = 6290.0          # achievable HBM copy rate measured in the guide (used for the GEMMs' byte-side lower bound)
 
 CONFIG_3D = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=9,
                  n_levels=2, pooling_type='max', dilations=[1, 1, 1, 2, 4, 8, 16, 1, 1], checkpoint_bottleneck=True,
@@ -139,9 +146,87 @@ def cpu_baseline(n0_target, levels, seed):
         t = run(sample)
     nv = sample.x.shape[0]
     return {'value': nv / t, 'unit': 'vertices/s', 'cores': best_threads, 'kind': 'port',
+            'cpu_model': _cpu_model(),
             'sample': 'one fwd+loss+bwd of the CPU oracle (unfused PyG-form restatement, torch %s CPU, fp32, %d of %d '
-                      'host threads) on a synthetic %d-vertex %d-level mesh, %.1f s'
-                      % (torch.__version__, best_threads, ncpu, nv, levels, t)}
+                      'host threads of %s) on a synthetic %d-vertex %d-level mesh, %.1f s'
+                      % (torch.__version__, best_threads, ncpu, _cpu_model(), nv, levels, t)}
+
+
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown CPU'
+
+
+def hbm_honest_edge_kernel(device, n=1_000_000, e=6_000_000, h=128, iters=10):
+    """The level-0 forward edge kernel at the 1 M-vertex / 6 M-edge size of BASELINE config 5: its gathered operand B is
+    n*h*4 = 512 MB, twice the 256 MB Infinity Cache, so this figure is an HBM figure (at 200 k vertices B is 102 MB and
+    lives in the Infinity Cache - the headline `roofline` is the algorithmic-byte convention of SURVEY §8d)."""
+    from surface_texture_inpainting_net_amd import functional as SF
+    from surface_texture_inpainting_net_amd.plan import EdgeSet
+    g = torch.Generator().manual_seed(1)
+    ei = torch.randint(0, n, (2, e), generator=g).to(device)
+    bad = torch.zeros(1, dtype=torch.int32, device=device)
+    edges = EdgeSet(ei, n, bad)
+    Y = torch.randn(n, 2 * h, device=device)
+    out = torch.empty(n, h + 4, device=device)
+    mask = torch.empty(e * (h // 32), dtype=torch.int32, device=device)
+    for _ in range(2):
+        SF.edge_relu_mean_fwd(Y[:, :h], Y[:, h:], edges.by_dst, out, indicator=True, mask=mask)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        SF.edge_relu_mean_fwd(Y[:, :h], Y[:, h:], edges.by_dst, out, indicator=True, mask=mask)
+    b.record()
+    torch.cuda.synchronize()
+    dt = a.elapsed_time(b) * 1e-3 / iters
+    nbytes = edge_bytes('stin_edge_relu_mean_fwd_f32', n, e, h)
+    return {'kernel': 'stin_edge_relu_mean_fwd_f32[N=%d,E=%d,H=%d]' % (n, e, h), 'us': dt * 1e6, 'algorithmic_MB': nbytes / 1e6,
+            'GBps': nbytes / dt / 1e9, 'frac_of_hbm_peak': nbytes / dt / 1e9 / HBM_PEAK_GBS,
+            'note': 'gathered operand 512 MB > 256 MB Infinity Cache: served by HBM (random graph, fp32 rows)'}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as children of a
+    torch.distributed.run process.  This parent has not touched the GPU (counting devices does not initialise HIP) and
+    never execs: it waits for the launcher and exits with its status, so one failed rank fails the run."""
+    ndev = torch.cuda.device_count()
+    if args.backend == 'nccl' and ndev < args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) visible; RCCL needs one device per rank '
+                         '(use --backend gloo to smoke-test the multi-rank path on fewer GPUs)\n' % (args.gpus, ndev))
+        sys.exit(2)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """One contiguous share of the host's cores per rank (8 ranks enqueue ~4-5 ms of launches per step each; left
+    floating they migrate across sockets and fight over cores).  -> the cores this rank may run on."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        share = max(1, len(cores) // local_world)
+        mine = cores[local_rank * share:(local_rank + 1) * share] or cores
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), 16)))
+        return len(mine)
+    except (AttributeError, OSError):
+        return None
 
 
 def main():
@@ -154,22 +239,31 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to smoke-test "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
-    ap.add_argument('--time-gemms', action='store_true', help='also bracket every MFMA GEMM launch with HIP events')
+    ap.add_argument('--time-gemms', action='store_true', help='bracket every MFMA GEMM launch INSIDE the timed region too '
+                    '(the default line times the GEMMs in a separate pass after it)')
     ap.add_argument('--cache-plan', action='store_true', help='reuse the CSR plan across steps (NOT the headline)')
     ap.add_argument('--crops', type=int, default=0,
                     help='BASELINE config 3: a collated batch of this many unequal crops (12-28k vertices each) per step '
                          'instead of one scene (NOT the headline); combine with --levels 4 --dtype bf16')
     ap.add_argument('--no-secondary', action='store_true',
-                    help='skip the fwd+loss+bwd-only loop after the timed region (profiling runs: keeps the kernel mix = the step)')
+                    help='skip the passes after the timed region (fwd+loss+bwd-only loop, GEMM table, standalone kernels, CPU '
+                         'baseline) - profiling runs: keeps the kernel mix = the step')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="activation storage: f32 = the headline (reference numerics); bf16 = the build's "
                          "mixed-precision mode of BASELINE configs 3/5 (NOT the headline, stated tolerance)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)                                     # does not return
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: WORLD_SIZE=%d but --gpus %d - launch with --nproc-per-node == --gpus\n' % (world, args.gpus))
+        sys.exit(2)
+    cores_per_rank = pin_rank_to_cores(local_rank, local_world) if world > 1 else None
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
@@ -184,7 +278,7 @@ def main():
     from surface_texture_inpainting_net_amd import functional as SF
     from surface_texture_inpainting_net_amd import surfacetextureinpaintingnet as S
     from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
-    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    from surface_texture_inpainting_net_amd.train_step import TrainStep, replicas_identical
     _lib.load()
 
     torch.manual_seed(49)                                   # reference config seed; identical replicas
@@ -194,7 +288,7 @@ def main():
     net = S.define_G(**cfg).to(device)
     if args.dtype == 'bf16':
         net.set_activation_dtype(torch.bfloat16)
-    step = TrainStep(net, lr=7e-5, amsgrad=True)
+    step = TrainStep(net, lr=7e-5, amsgrad=True, time_allreduce=world > 1)
     if args.crops > 0:
         from surface_texture_inpainting_net_amd.data import collate
         sizes = [12_000 + (16_000 * i) // max(args.crops - 1, 1) for i in range(args.crops)]
@@ -222,9 +316,10 @@ def main():
     gc.disable()            # no cyclic-GC pause inside the timed region (collected again right after it)
     fence()
     sfx = '_' + args.dtype
-    timed = ['stin_edge_relu_mean_fwd' + sfx, 'stin_edge_relu_mean_bwd_dst_f32', 'stin_edge_relu_mean_bwd_src_f32',
-             'stin_edge_relu_mean_bwd_dst_mask' + sfx, 'stin_edge_relu_mean_bwd_src_mask' + sfx] + \
-            (['stin_gemm_nt' + sfx, 'stin_gemm_tn' + sfx] if args.time_gemms else [])
+    edge_names = ['stin_edge_relu_mean_fwd' + sfx, 'stin_edge_relu_mean_bwd_dst_f32', 'stin_edge_relu_mean_bwd_src_f32',
+                  'stin_edge_relu_mean_bwd_dst_mask' + sfx, 'stin_edge_relu_mean_bwd_src_mask' + sfx]
+    gemm_names = ['stin_gemm_nt' + sfx, 'stin_gemm_tn' + sfx]
+    timed = edge_names + (gemm_names if args.time_gemms else [])
     # HIP-event brackets need the per-kernel host path (the whole-block C calls enqueue their kernels natively) and event
     # pairs are not free: bracket the edge launches of about one timed step in ten, the rest runs un-instrumented.
     SF.KernelTimer.start(timed, max_records=1_000_000)
@@ -232,6 +327,7 @@ def main():
     per_step = max(1, len(SF.KernelTimer.records))
     SF.KernelTimer.stop()
     fence()
+    step.bucket.allreduce_log = []
     SF.KernelTimer.start(timed, max_records=1_000_000 if args.time_gemms else per_step * max(1, args.steps // 10))
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -241,6 +337,13 @@ def main():
     dt = time.perf_counter() - t0
     ktimes = SF.KernelTimer.stop()
     step.finish()                                           # deferred index checks of the timed steps (all clean)
+    allreduce_us = None
+    if world > 1 and step.bucket.allreduce_log:
+        ts = [a.elapsed_time(b) * 1e3 for a, b in step.bucket.allreduce_log]
+        allreduce_us = {'mean': sum(ts) / len(ts), 'min': min(ts), 'max': max(ts), 'bytes': step.bucket.flat.numel() * 4,
+                        'overlapped_segments': len(step.bucket.segments or []),
+                        'note': 'HIP events around the end-of-backward all-reduce of the flat fp32 gradient bucket (rank 0); '
+                                'segments reduced during the backward pass are not inside the bracket'}
     # secondary figure, BASELINE's literal metric definition (fwd + loss + bwd of one scene; CSR plan reused, no
     # all-reduce, no optimizer) - reported beside the headline, never instead of it
     fence()
@@ -249,43 +352,72 @@ def main():
         step.forward_backward(sample)
     fence()
     dt_fb = time.perf_counter() - t1
+    # GEMM pass (after the timed region): every MFMA GEMM launch of two more steps bracketed with HIP events; the
+    # per-kernel path runs the weight-gradient GEMMs on the compute stream, so these are stand-alone durations
+    gtimes = {}
+    if args.time_gemms:
+        gtimes = {k: v for k, v in ktimes.items() if k[0] in gemm_names}
+        gemm_steps = float(args.steps)
+    elif not args.no_secondary:
+        gemm_steps = 2.0
+        SF.KernelTimer.start(gemm_names, max_records=1_000_000)
+        for _ in range(int(gemm_steps)):
+            one_step()
+        gtimes = SF.KernelTimer.stop()
     gc.enable()
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        nv = torch.tensor([n0], dtype=torch.float64, device=device)
+        per_rank = torch.zeros(world, dtype=torch.float64, device=device)
+        per_rank[rank] = dt
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+        rank_ms = [float(v) / args.steps * 1e3 for v in per_rank.tolist()]
+        dt = max(float(v) for v in per_rank.tolist())       # MAX over ranks
+        nv = torch.tensor([float(n0), 1.0], dtype=torch.float64, device=device)
         dist.all_reduce(nv, op=dist.ReduceOp.SUM)
-        total_vertices = float(nv.item())
+        total_vertices, ranks_counted = float(nv[0].item()), int(round(float(nv[1].item())))
+        identical = replicas_identical(net)                 # parameters bit-identical across ranks after the run
+        if not identical:
+            sys.stderr.write('bench.py: replicas diverged (parameters differ across ranks after %d steps)\n' % args.steps)
     else:
-        total_vertices = float(n0)
+        total_vertices, ranks_counted, identical = float(n0), 1, True
 
     if rank == 0:
         table, gemms = [], []
         for (name, tag), ts in ktimes.items():
             if 'gemm' in name:
-                m, nc, k = tag
-                avg = sum(ts) / len(ts)
-                gemms.append({'kernel': name, 'M': m, 'Nc': nc, 'K': k, 'launches': len(ts), 'avg_us': avg * 1e6,
-                              'total_ms': sum(ts) * 1e3, 'TFLOPs': 2.0 * m * nc * k / avg / 1e12,
-                              'GBps_min_traffic': (2.0 if args.dtype == 'bf16' else 4.0) * (m * nc + m * k + nc * k) / avg / 1e9})
                 continue
             n, e, h = tag
             nbytes = edge_bytes(name, n, e, h)
             avg = sum(ts) / len(ts)
             table.append({'kernel': name, 'N': n, 'E': e, 'H': h, 'launches': len(ts), 'avg_us': avg * 1e6,
                           'total_ms': sum(ts) * 1e3, 'algorithmic_MB': nbytes / 1e6, 'GBps': nbytes / avg / 1e9})
+        esz = 2.0 if args.dtype == 'bf16' else 4.0
+        for (name, tag), ts in gtimes.items():
+            m, nc, k = tag
+            avg = sum(ts) / len(ts)
+            min_bytes = esz * (m * nc + m * k) + 4.0 * nc * k
+            mfma_flops = 2.0 * m * nc * k * (1 if args.dtype == 'bf16' else 3)     # executed on the 16-bit matrix cores
+            bound_us = max(min_bytes / (HBM_COPY_GBS * 1e9), mfma_flops / (MFMA_16BIT_PEAK_TF * 1e12)) * 1e6
+            gemms.append({'kernel': name, 'M': m, 'Nc': nc, 'K': k, 'launches': len(ts), 'avg_us': avg * 1e6,
+                          'total_ms': sum(ts) * 1e3, 'TFLOPs': 2.0 * m * nc * k / avg / 1e12,
+                          'mfma_TFLOPs_executed': mfma_flops / avg / 1e12, 'GBps_min_traffic': min_bytes / avg / 1e9,
+                          'roofline_bound_us': bound_us, 'frac_of_roofline': bound_us / (avg * 1e6)})
         table.sort(key=lambda r: -r['total_ms'])
         dom = table[0]
+        edge_total_ms = sum(r['total_ms'] for r in table) / (sum(r['launches'] for r in table) / per_step)
         roofline = {'bound': 'hbm', 'kernel': '%s[N=%d,E=%d,H=%d]' % (dom['kernel'], dom['N'], dom['E'], dom['H']),
                     'achieved': dom['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom['GBps'] / HBM_PEAK_GBS,
                     'traffic': pmc_traffic_bytes(dom['kernel'], dom['N'], dom['E'], dom['H']),
-                    'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC: (2*FETCH_SIZE + WRITE_SIZE) KiB, profiles/)',
-                    'avg_us': dom['avg_us'], 'algorithmic_bytes': dom['algorithmic_MB'] * 1e6}
-        edge_total_ms = sum(r['total_ms'] for r in table) / args.steps
+                    'traffic_unit': 'FABRIC bytes per launch incl. Infinity-Cache hits ((2*FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 '
+                                    'PMC), REPLAYED from the committed profiles/r*_pmc_traffic.json - not measured in this run',
+                    'avg_us': dom['avg_us'], 'algorithmic_bytes': dom['algorithmic_MB'] * 1e6,
+                    'convention': 'algorithmic bytes (SURVEY 8d): every gathered row charged once per edge; at 200k vertices the '
+                                  'gathered operand (102 MB) is Infinity-Cache resident - see hbm_honest for the HBM-served size',
+                    'selection': 'the edge-stage (HBM-bound) kernel/shape with the largest total time; the GEMMs (MFMA side, a '
+                                 'larger share of the step) are in roofline_gemm'}
         out = {
             'metric': 'vertices/sec forward+backward on 200k-vert ScanNet mesh; scatter-add GB/s vs HBM roofline',
-            'value': total_vertices * args.steps / dt, 'unit': 'vertices/s', 'n_gpus': world, 'steps': args.steps,
+            'value': total_vertices * args.steps / dt, 'unit': 'vertices/s', 'n_gpus': ranks_counted, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'SurfaceTextureInpaintingNet 3-D config (ngf 64, n_levels %d, n_blocks 9, ' % cfg['n_levels'] +
@@ -297,6 +429,13 @@ def main():
                        'vertices_per_gpu': n0, 'edges_per_gpu': e0, 'levels': args.levels, 'params': sum(p.numel() for p in net.parameters()),
                        'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan,
                        'crops_per_step': args.crops or None},
+            'gemm_precision': ({'fwd': SF.PREC_NAMES[SF.PREC_FWD], 'bwd': SF.PREC_NAMES[SF.PREC_BWD],
+                                'note': 'fp32 storage, operands split into 16-bit pieces on the MFMA path (fp16x3: 22-bit '
+                                        'products; bf16x3: 16-bit products), fp32 accumulate'} if args.dtype == 'f32' else
+                               {'fwd': 'bf16', 'bwd': 'bf16', 'note': 'bf16 storage, one bf16 MFMA per k-step, fp32 accumulate'}),
+            'distributed': {'world_size': world, 'backend': (dist.get_backend() if world > 1 else None),
+                            'ranks_counted_by_allreduce': ranks_counted, 'ms_per_step_per_rank': rank_ms,
+                            'allreduce_us': allreduce_us, 'replicas_bit_identical': identical, 'cores_per_rank': cores_per_rank},
             'loss': float(loss),
             'host_enqueue_ms_per_step': dt_enqueue / args.steps * 1e3,   # < ms_per_step: the GPU, not the host, bounds the step
             'fwd_loss_bwd_only': None if args.no_secondary else {
@@ -310,17 +449,35 @@ def main():
             gemms.sort(key=lambda r: -r['total_ms'])
             flops = sum(2.0 * r['M'] * r['Nc'] * r['K'] * r['launches'] for r in gemms)
             tsum = sum(r['total_ms'] for r in gemms) * 1e-3
-            out['gemm'] = {'ms_per_step': tsum / args.steps * 1e3, 'GFLOP_per_step': flops / args.steps / 1e9,
-                           'TFLOPs': flops / tsum / 1e12, 'mfma_f32_peak_TFLOPs': 157.3,
-                           'mfma_utilisation': flops / tsum / 1e12 / 157.3, 'kernels': gemms[:24]}
-        if world == 1:
+            mult = 1 if args.dtype == 'bf16' else 3
+            g0 = gemms[0]
+            out['roofline_gemm'] = {
+                'bound': 'mfma', 'kernel': '%s[M=%d,Nc=%d,K=%d]' % (g0['kernel'], g0['M'], g0['Nc'], g0['K']),
+                'achieved': g0['mfma_TFLOPs_executed'], 'peak': MFMA_16BIT_PEAK_TF, 'unit': 'TFLOP/s',
+                'frac': g0['mfma_TFLOPs_executed'] / MFMA_16BIT_PEAK_TF, 'avg_us': g0['avg_us'],
+                'roofline_bound_us': g0['roofline_bound_us'], 'frac_of_roofline': g0['frac_of_roofline'],
+                'note': 'the GEMM shape with the largest total time; achieved = executed 16-bit MFMA flops (%d per fp32 product) '
+                        '/ stand-alone duration; roofline_bound_us = max(min HBM bytes / %.2f TB/s copy rate, executed flops / '
+                        '2.5 PF) - these tall-skinny shapes are bounded by their output bytes' % (mult, HBM_COPY_GBS / 1e3),
+                'mfma_busy_replayed': 'SQ-counter MFMA-busy per kernel: profiles/ (rocprofv3 --pmc pass, not measured in this run)'}
+            out['gemm'] = {'ms_per_step': tsum / gemm_steps * 1e3, 'GFLOP_per_step': flops / gemm_steps / 1e9,
+                           'TFLOPs_fp32_equivalent': flops / tsum / 1e12, 'mfma_TFLOPs_executed': mult * flops / tsum / 1e12,
+                           'frac_of_16bit_mfma_peak': mult * flops / tsum / 1e12 / MFMA_16BIT_PEAK_TF,
+                           'frac_of_f32_mfma_peak': flops / tsum / 1e12 / MFMA_F32_PEAK_TF,
+                           'time_weighted_frac_of_roofline': sum(r['roofline_bound_us'] * r['launches'] for r in gemms) /
+                                                             sum(r['avg_us'] * r['launches'] for r in gemms),
+                           'kernels': gemms[:24]}
+        if world == 1 and not args.no_secondary:
             out['scatter_add'] = scatter_add_standalone(device)
+            out['hbm_honest'] = hbm_honest_edge_kernel(device)
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(args.vertices, args.levels, seed=0)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        if not identical:
+            sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -318,14 +318,15 @@ int stin_norm_bwd_coef_m_quirk_f32(const float* S0, const float* U, const float*
  * loss = mean |pred - color| * 0.99^mask (use_weight = trainer.use_mask_weighted_loss),
  * grad = dloss/dout.  fp64 block partials summed in a fixed order.  mask: int64 [N].
  * adam: torch.optim.Adam(amsgrad) on ONE flat parameter/gradient/state buffer (the reference's
- * optimizer, experiments/3d_inpainting/config/...json:95-102), step = 1-based update count.
+ * optimizer, experiments/3d_inpainting/config/...json:95-102), step = 1-based update count; the hyper-parameters are
+ * doubles (python floats in torch) and the bias corrections 1 - beta^step are formed in double on the host, as torch does.
  */
 size_t stin_masked_l1_workspace_bytes(int64_t N, int C);
 int stin_masked_l1_loss_f32(const float* out, const float* color, const int64_t* mask, int64_t N, int C,
                             int use_weight, float* loss, float* grad, void* workspace, size_t workspace_bytes,
                             stin_stream_t stream);
-int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int step, int amsgrad, stin_stream_t stream);
+int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int step, int amsgrad, stin_stream_t stream);
 
 /* --------------------------------------------------- bf16-storage variants of the path --
  * Same semantics, argument order and reference call sites as the *_f32 entry points above, on bf16 rows

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads the HIP runtime torch uses)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libstin_hip.so')
 
-c_i64, c_i32, c_int, c_f32 = ctypes.c_int64, ctypes.c_int32, ctypes.c_int, ctypes.c_float
+c_i64, c_i32, c_int, c_f32, c_f64 = ctypes.c_int64, ctypes.c_int32, ctypes.c_int, ctypes.c_float, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
 
 
@@ -74,7 +74,7 @@ SIGNATURES = {
     'stin_norm_bwd_coef_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     'stin_masked_l1_workspace_bytes': (c_size, [c_i64, c_int]),
     'stin_masked_l1_loss_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
-    'stin_adam_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_int,
+    'stin_adam_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64, c_int, c_int,
                               c_ptr]),
 }
 # bf16-storage variants: same argument lists as their *_f32 twins (pointers are void* here)

@@ -244,20 +244,22 @@ __global__ __launch_bounds__(256) void k_loss_final(const double* __restrict__ p
     if (threadIdx.x == 0) loss[0] = (float)(sm[0] * (double)inv_count);
 }
 
-// Adam with amsgrad over one flat parameter buffer (torch.optim.Adam semantics, weight_decay added to the gradient):
-//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; vmax = max(vmax, v)
-//   p -= lr / (1 - b1^t) * m / (sqrt(vmax) / sqrt(1 - b2^t) + eps)
+// Adam with amsgrad over one flat parameter buffer, the arithmetic of torch.optim.Adam's single-tensor path
+// (weight_decay added to the gradient; exp_avg by lerp; the scalar factors come from the host in double):
+//   m += (1-b1) (g - m) ; v = b2 v + (1-b2) g^2 ; vmax = max(vmax, v)
+//   p += (-lr / (1 - b1^t)) * m / (sqrt(vmax) / sqrt(1 - b2^t) + eps)
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, float* __restrict__ vmax, int64_t n, float lr,
-                                              float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                              int amsgrad) {
+                                              float* __restrict__ v, float* __restrict__ vmax, int64_t n, float neg_step_size,
+                                              float one_minus_b1, float b2, float one_minus_b2, float eps, float wd,
+                                              float bc2_sqrt, int amsgrad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float gi = g[i];
     const float pi = p[i];
     if (wd != 0.f) gi += wd * pi;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float m0 = m[i];
+    const float mi = m0 + one_minus_b1 * (gi - m0);
+    const float vi = b2 * v[i] + one_minus_b2 * gi * gi;
     m[i] = mi;
     v[i] = vi;
     float vh = vi;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
         vmax[i] = vh;
     }
     const float denom = sqrtf(vh) / bc2_sqrt + eps;
-    p[i] = pi - (lr / bc1) * (mi / denom);
+    p[i] = pi + neg_step_size * mi / denom;
 }
 }  // namespace
 
@@ -292,15 +294,17 @@ extern "C" int stin_masked_l1_loss_f32(const float* out, const float* color, con
     return stin_launch_status();
 }
 
-extern "C" int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int step, int amsgrad, stin_stream_t stream_) {
+extern "C" int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, int step, int amsgrad, stin_stream_t stream_) {
     stin_clear_stale_error();
     STIN_REQUIRE(n >= 0 && step >= 1, STIN_E_SIZE);
     if (n == 0) return STIN_OK;
     STIN_REQUIRE(p && g && m && v && (!amsgrad || vmax), STIN_E_NULL);
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, vmax, n, lr,
-                       beta1, beta2, eps, weight_decay, bc1, bc2s, amsgrad);
+    // bias corrections in double on the host, as torch computes them (python floats)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, vmax, n,
+                       (float)(-(lr / bc1)), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)weight_decay, (float)bc2s, amsgrad);
     return stin_launch_status();
 }

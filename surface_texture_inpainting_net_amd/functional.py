@@ -3,8 +3,8 @@ the nn.Modules in surfacetextureinpaintingnet.py are written on.
 
 Every function here runs on GPU tensors only and calls through the C ABI
 (include/stin_hip.h); there is no eager/CPU fallback.  The dense per-vertex GEMMs are
-the hand-written MFMA kernels too (gemm_nt / gemm_tn); STIN_GEMM_BACKEND=blas swaps in
-torch.mm purely as an A/B numerics aid.
+the hand-written MFMA kernels too (gemm_nt / gemm_tn); the library-GEMM A/B aid of round 1 lives in
+profiles/gemm_bench.py, outside the package.
 """
 import os
 
@@ -189,7 +189,7 @@ def colsum(x):
     return colreduce(RED_SUM, x, _One, None).view(-1)
 
 
-def instance_stats(x, groups):
+def instance_stats(x, groups, eps=EPS):
     """-> (mean, rstd) [B, C]: biased variance, eps inside the sqrt (F.instance_norm /
     FastInstanceNorm semantics, reference models/modules/fastinstancenorm.py:44-98)."""
     if groups.gid is None and x.shape[0] == 1:   # F.instance_norm's own check on the batch=None branch
@@ -197,10 +197,10 @@ def instance_stats(x, groups):
             torch.Size([1, x.shape[1], 1])))
     if not groups.quirk:
         # one pass: fp64 sum x and sum x^2 over each graph's rows (slices == graphs here)
-        return colreduce(RED_MOMENTS, x, groups, groups.ptr_sum)
+        return colreduce(RED_MOMENTS, x, groups, groups.ptr_sum, eps=eps)
     # linspace-slice quirk: sums over slices, centring through the graph id -> two passes as the reference does
     mean = colreduce(RED_SUM, x, groups, groups.ptr_sum, post=POST_SCALE)
-    rstd = colreduce(RED_CSQ, x, groups, groups.ptr_sum, mean=mean, post=POST_RSTD)
+    rstd = colreduce(RED_CSQ, x, groups, groups.ptr_sum, mean=mean, post=POST_RSTD, eps=eps)
     return mean, rstd
 
 
@@ -247,12 +247,8 @@ def instance_norm_act_bwd(x, gout, mean, rstd, groups, act=True, out=None):
     return dx
 
 
-# debugging aid for A/B numerics checks only: STIN_GEMM_BACKEND=blas routes the dense GEMMs to torch.mm
-_GEMM_BLAS_NT = os.environ.get('STIN_GEMM_BACKEND', 'mfma') in ('blas', 'blas_nt')
-_GEMM_BLAS_TN = os.environ.get('STIN_GEMM_BACKEND', 'mfma') in ('blas', 'blas_tn')
-
-
 GEMM_F32, GEMM_BF16X3, GEMM_BF16X6, GEMM_F16X3 = 0, 2, 3, 4
+PREC_NAMES = {GEMM_F32: 'fp32', GEMM_BF16X3: 'bf16x3', GEMM_BF16X6: 'bf16x6', GEMM_F16X3: 'fp16x3'}
 # matrix-core path per GEMM role (env override for A/B experiments: STIN_GEMM_FWD / STIN_GEMM_BWD = 0 | 2 | 3 | 4)
 # Defaults: forward GEMMs on the 2-piece fp16 split (3 MFMAs; rms 1-5e-7 against fp64 = the fp32 MFMA chain's
 # accuracy on unit-scale activations, 1.7x faster than it; whole-net forward error 5-6e-6 like fp32 and bf16x6,
@@ -261,10 +257,10 @@ GEMM_F32, GEMM_BF16X3, GEMM_BF16X6, GEMM_F16X3 = 0, 2, 3, 4
 PREC_FWD = int(os.environ.get('STIN_GEMM_FWD', GEMM_F16X3))
 PREC_BWD = int(os.environ.get('STIN_GEMM_BWD', GEMM_BF16X3))
 GEMM_W_PRESPLIT = 0x100            # nt: the weight operand already holds its two 16-bit pieces (stin_hip.h)
-WEIGHT_PRESPLIT = os.environ.get('STIN_WEIGHT_PRESPLIT', '1') != '0' and not _GEMM_BLAS_NT
+WEIGHT_PRESPLIT = os.environ.get('STIN_WEIGHT_PRESPLIT', '1') != '0'
 # one C call per GraphResnetBlock and direction (stin_edgeconv_block_fwd/bwd enqueue the same kernels in the same order
 # as the per-kernel path below): removes ~25 Python-level foreign calls per block.  STIN_BLOCK_CALL=0 = per-kernel path.
-USE_BLOCK_CALL = os.environ.get('STIN_BLOCK_CALL', '1') != '0' and not (_GEMM_BLAS_NT or _GEMM_BLAS_TN)
+USE_BLOCK_CALL = os.environ.get('STIN_BLOCK_CALL', '1') != '0'
 
 
 def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32, residual=None, out_dtype=None):
@@ -274,19 +270,6 @@ def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32, residu
     unless out_dtype=torch.float32."""
     if A.dtype == torch.bfloat16:
         return _gemm_nt_bf16(A, W, bias, out, row_mask, residual, out_dtype)
-    if _GEMM_BLAS_NT:
-        if bias is None:
-            r = torch.mm(A, W.t())
-        elif row_mask is None:
-            r = torch.addmm(bias, A, W.t())
-        else:
-            r = torch.mm(A, W.t()) + row_mask.reshape(-1, 1) * bias
-        if residual is not None:
-            r = r + residual
-        if out is not None:
-            out.copy_(r)
-            return out
-        return r
     A, lda = _mat(A)
     W, ldw = _mat(W)
     M, K = A.shape
@@ -351,12 +334,6 @@ def gemm_tn(G, X, ones_column=False, row_weight=None, precision=GEMM_F32):
               row_weight.stride(0) if row_weight is not None else 0, _ptr(out), Kp, _ptr(ws), ws_bytes, _stream(G),
               tag=(M, Nc, K))
         return out
-    if _GEMM_BLAS_TN:
-        r = torch.mm(G.t(), X)
-        if not ones_column:
-            return r
-        gs = G.sum(0) if row_weight is None else (G * row_weight.reshape(-1, 1)).sum(0)
-        return torch.cat([r, gs[:, None]], 1)
     lib = _lib.load()
     G, ldg = _mat(G)
     X, ldx = _mat(X)
@@ -378,11 +355,12 @@ class LinearFn(torch.autograd.Function):
     """y = x W^T + b on the MFMA kernels (the tail Linears and the generic filter paths)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, out_fp32=False):
+    def forward(ctx, x, weight, bias, out_fp32=False, precision=None):
         x, _ = _mat(x)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return gemm_nt(x, weight, bias, precision=PREC_FWD, out_dtype=torch.float32 if out_fp32 else None)
+        return gemm_nt(x, weight, bias, precision=PREC_FWD if precision is None else precision,
+                       out_dtype=torch.float32 if out_fp32 else None)
 
     @staticmethod
     def backward(ctx, g):
@@ -393,13 +371,25 @@ class LinearFn(torch.autograd.Function):
         dwb = gemm_tn(g, x, ones_column=ctx.has_bias, precision=PREC_BWD)
         dx = gemm_nt(g, weight.t().contiguous(), precision=PREC_BWD)
         if ctx.has_bias:
-            return dx, dwb[:, :-1].contiguous(), dwb[:, -1].contiguous(), None
-        return dx, dwb, None, None
+            return dx, dwb[:, :-1].contiguous(), dwb[:, -1].contiguous(), None, None
+        return dx, dwb, None, None, None
 
 
-def linear(x, weight, bias=None, out_fp32=False):
-    """x W^T + b.  out_fp32: fp32 result from bf16-storage activations (the network's final output)."""
-    return LinearFn.apply(x, weight, bias, out_fp32)
+def linear(x, weight, bias=None, out_fp32=False, precision=None):
+    """x W^T + b.  out_fp32: fp32 result from bf16-storage activations (the network's final output).
+    precision: forward matrix-core path (None = PREC_FWD); see forward_precision()."""
+    return LinearFn.apply(x, weight, bias, out_fp32, precision)
+
+
+def forward_precision(unbounded_input):
+    """Forward GEMM path for a layer.  fp16x3 (the default PREC_FWD) carries fp32-grade products for operands inside
+    fp16's range (|activation| < 8188, |weight| < 1023; out-of-range operands give inf/NaN, never a silently wrong
+    value) - true for everything downstream of an instance / batch / graph norm.  A layer fed by RAW data (the first
+    block: un-normalised vertex features) or living in a network built without norms gets bf16x6 instead: bf16 pieces
+    have fp32's exponent range, the 3-piece split is exact, and the first block's GEMMs are tiny (K = 12)."""
+    if unbounded_input and PREC_FWD == GEMM_F16X3:
+        return GEMM_BF16X6
+    return PREC_FWD
 
 
 # ----------------------------------------------------------------------- autograd ops
@@ -471,26 +461,49 @@ def _direct_grad_views(params):
     return out
 
 
+def _plain_autograd_may_defer():
+    """The deferred join is safe under plain autograd only while nothing outside this module can read a gradient before
+    the end of the backward pass.  DistributedDataParallel registers its reducer as C++ post-hooks on the AccumulateGrad
+    nodes - invisible to `p._backward_hooks` / `_post_accumulate_grad_hooks` - and copies each gradient into its bucket on
+    the compute stream as soon as autograd produces it.  DDP cannot exist without an initialised multi-rank process
+    group, so in that situation only the TrainStep bucket route (which bypasses autograd for these gradients) uses the
+    side stream; every other caller keeps the block on one stream."""
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
 def _wgrad_side_args(dev, keep_alive, params, direct=False, work=0):
     """-> (wgrad_stream, ev_dagg, ev_dy, ev_done, join) for stin_edgeconv_block_bwd.  The join with the compute stream is
-    deferred to the end of the backward pass when nothing can read the gradients earlier (every parameter is a leaf whose
-    .grad is None - autograd then adopts the returned tensor without a kernel - and has no hooks); otherwise in-call."""
+    deferred to the end of the backward pass when nothing can read the gradients earlier: the TrainStep bucket route
+    (`direct`), or plain single-process autograd with every parameter a leaf whose .grad is None (autograd then adopts
+    the returned tensor without a kernel) and without hooks; otherwise the block stays on one stream."""
     if not USE_WGRAD_STREAM or work > WGRAD_MAX_WORK:
         return 0, 0, 0, 0, 0
-    side = _wgrad_side(dev)
-    deferred = WGRAD_DEFER_JOIN and (direct or all(p is None or (p.is_leaf and p.grad is None and not p._backward_hooks and
-                                 not getattr(p, '_post_accumulate_grad_hooks', None)) for p in params))
+    deferred = WGRAD_DEFER_JOIN and (direct or (_plain_autograd_may_defer() and all(
+        p is None or (p.is_leaf and p.grad is None and not p._backward_hooks and
+                      not getattr(p, '_post_accumulate_grad_hooks', None)) for p in params)))
     if not deferred:
         # a join inside every call measured SLOWER than one stream (9.70 vs 9.45 ms per step): gradient accumulation,
-        # parameter hooks (DDP) and non-leaf weights simply keep the whole block on the compute stream
+        # parameter hooks, DDP and non-leaf weights simply keep the whole block on the compute stream
         return 0, 0, 0, 0, 0
-    if deferred:
-        # the side stream reads these after this call has returned: keep them referenced until the end-of-backward join
-        # (then they are freed in compute-stream order AFTER the join - no record_stream: its deferred frees made the
-        # caching allocator's pool grow by ~80 MB per step over hundreds of steps with changing scene sizes)
-        side.hold.append(keep_alive)
+    side = _wgrad_side(dev)
+    # the side stream reads (and, outside the bucket route, WRITES) these after this call has returned: keep them referenced
+    # until the join (then they are freed in compute-stream order AFTER the join - no record_stream: its deferred frees made
+    # the caching allocator's pool grow by ~80 MB per step over hundreds of steps with changing scene sizes)
+    side.hold.append(keep_alive)
     ev = side.next_events()
-    return side.stream.cuda_stream, ev[0].cuda_event, ev[1].cuda_event, ev[2].cuda_event, int(not deferred)
+    return side.stream.cuda_stream, ev[0].cuda_event, ev[1].cuda_event, ev[2].cuda_event, 0
+
+
+def wgrad_side_settle(dev):
+    """Defensive join for callers that own the step (TrainStep.forward_backward's finally): when a backward pass raised
+    after a block had put work on the weight-gradient stream, the autograd engine dropped the end-of-backward callbacks
+    and the join never ran - wait for the side stream now and release what it was reading / writing.  A no-op after a
+    normal pass (the join emptied `hold`)."""
+    side = _WGRAD_SIDE.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    if side is not None and side.hold:
+        torch.cuda.current_stream(dev).wait_event(side.last_done)
+        side.hold.clear()
 
 
 def _wgrad_deferred_join(dev, params, grads):
@@ -526,7 +539,8 @@ class EdgeConvBlockFn(torch.autograd.Function):
     support the mask).  Fast path: one C call per direction (stin_edgeconv_block_fwd / _bwd, same kernels, same order)."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, Ws, bs, edges, groups, trans_inv):
+    def forward(ctx, x, W1, b1, W2, b2, Ws, bs, edges, groups, trans_inv, eps=EPS, prec_fwd=None):
+        prec_fwd = PREC_FWD if prec_fwd is None else int(prec_fwd)
         x, _ = _mat(x)
         N, Cin = x.shape
         H, Cout = W1.shape[0], W2.shape[0]
@@ -543,7 +557,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
             xp = x
         # forward / backward weight operands, pre-split once here into the two 16-bit pieces the split GEMMs use
         # (instead of once per GEMM block); plain fp32 for the other precisions and for bf16-storage activations
-        fsp = PREC_FWD if (not b16 and PREC_FWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT) else 0
+        fsp = prec_fwd if (not b16 and prec_fwd in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT) else 0
         bsp = PREC_BWD if (not b16 and PREC_BWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT and Cout % 4 == 0) else 0
         fast = (USE_BLOCK_CALL and USE_EDGE_MASK and edge_mask_supported(H) and N > 1
                 and not KernelTimer.enabled)          # (the bench's per-kernel HIP-event brackets need the per-kernel path)
@@ -566,7 +580,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
             cd = edges.by_dst
             _call('stin_edgeconv_block_fwd', int(b16), _ptr(xp), xp.stride(0), N, Cin, Cp, H, Cout, int(has_shortcut),
                   int(trans_inv), _ptr(W1c), _ptr(b1), _ptr(W2c), _ptr(b2), _ptr(Ws), _ptr(bs), _ptr(cd.rowptr), _ptr(cd.col),
-                  _ptr(groups.ptr_sum), B, _ptr(groups.gid), _ptr(groups.inv_cnt), int(groups.quirk), float(EPS), int(PREC_FWD), fsp, bsp,
+                  _ptr(groups.ptr_sum), B, _ptr(groups.gid), _ptr(groups.inv_cnt), int(groups.quirk), float(eps), prec_fwd, fsp, bsp,
                   _ptr(wcatT), _ptr(w2T), _ptr(Y), Yw, _ptr(hE), H + pad, _ptr(mask), _ptr(agg), _ptr(mean), _ptr(rstd),
                   _ptr(out), Cout, _ptr(ws), ws_bytes, _stream(x))
             ctx.save_for_backward(xp, Y, hE, agg, mean, rstd, wcatT, w2T)
@@ -588,7 +602,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         _call('stin_edgeconv_pack_f32', _ptr(W1c), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2c), Cin, Cp, H, Cout,
               int(has_shortcut), int(trans_inv), _ptr(wcat), _ptr(bcat), _ptr(wcatT), _ptr(w2T), _ptr(w2s) if fsp else None,
               fsp, bsp, _stream(x))
-        pf = (PREC_FWD | GEMM_W_PRESPLIT) if fsp else PREC_FWD
+        pf = (prec_fwd | GEMM_W_PRESPLIT) if fsp else prec_fwd
         Y = gemm_nt(xp, wcat, bcat, precision=pf)
         hE = torch.empty(N, H + pad, dtype=x.dtype, device=dev)     # [h | (deg > 0) | pad]: rows stay 16-byte multiples
         # ReLU decisions as bits (E*H/8 bytes): backward then needs no recompute gathers
@@ -599,7 +613,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         mask = torch.empty(max(edges.n_edges, 1) * (H // 32), dtype=torch.int32, device=dev) if use_mask else None
         edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True, mask=mask)
         agg = gemm_nt(hE[:, :H], w2s if fsp else W2c, b2, row_mask=hE[:, H], precision=pf)
-        mean, rstd = instance_stats(agg, groups)
+        mean, rstd = instance_stats(agg, groups, eps)
         res = Y[:, 2 * H:] if has_shortcut else x
         out = norm_act_res_fwd(agg, mean, rstd, groups, res=res, act=True)
         ctx.save_for_backward(xp, Y, hE, agg, mean, rstd, wcatT, w2T)
@@ -636,7 +650,8 @@ class EdgeConvBlockFn(torch.autograd.Function):
             ws_bytes = lib.stin_edgeconv_block_bwd_workspace_bytes(N, Cp, H, Cout, int(ctx.has_shortcut), groups.B, int(b16))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             cs = edges.by_src
-            side = _wgrad_side_args(dev, (ws, x, hE, g), ctx.params, direct is not None, work=float(N) * Y.shape[1] * Cp)
+            side = _wgrad_side_args(dev, (ws, x, hE, g, dW1, db1, dW2, db2, dWs, dbs), ctx.params, direct is not None,
+                                    work=float(N) * Y.shape[1] * Cp)
             _call('stin_edgeconv_block_bwd', int(b16), _ptr(g), ldg, _ptr(x), x.stride(0), N, Cin, Cp, H, Cout,
                   int(ctx.has_shortcut), int(ctx.trans_inv), _ptr(Y), Y.stride(0), _ptr(hE), hE.stride(0), _ptr(ctx.mask),
                   _ptr(agg), _ptr(mean), _ptr(rstd), _ptr(wcatT), _ptr(w2T), _ptr(edges.by_dst.rowptr), _ptr(cs.rowptr),
@@ -647,12 +662,14 @@ class EdgeConvBlockFn(torch.autograd.Function):
             if side[0] and not side[4]:
                 _wgrad_deferred_join(dev, ctx.params, () if direct is not None else (dW1, db1, dW2, db2, dWs, dbs))
             if direct is not None:
+                # a bucket that reduces in segments hands every completed one to RCCL now (train_step.FlatGradBucket)
+                ctx.params[0]._stin_slot[0].block_done(_wgrad_side(dev).last_done if side[0] else None)
                 if dx is not None and Cp != Cin:
                     dx = dx[:, :Cin]
-                return dx, None, None, None, None, None, None, None, None, None
+                return (dx,) + (None,) * 11
             if dx is not None and Cp != Cin:
                 dx = dx[:, :Cin]
-            return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None
+            return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None, None, None
         dagg = instance_norm_act_bwd(agg, g, mean, rstd, groups, act=True)
         dw2b = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H], precision=PREC_BWD)   # [Cout, H + 1] = dW2 | db2
         dhE = gemm_nt(dagg, w2T, precision=ctx.prec_bwd_nt)                                             # [N, H] = dagg W2
@@ -684,7 +701,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         db2 = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b2 else None
         _call('stin_edgeconv_unpack_grads_f32', _ptr(dwb), _ptr(dw2b), Cin, Cp, H, Cout, int(ctx.has_shortcut),
               int(ctx.trans_inv), _ptr(dW1), _ptr(db1), _ptr(dWs), _ptr(dbs), _ptr(dW2), _ptr(db2), _stream(x))
-        return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None
+        return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None, None, None
 
 
 class EdgeReluMeanFn(torch.autograd.Function):
@@ -791,9 +808,9 @@ class InstanceNormActResFn(torch.autograd.Function):
     """y = res + act(InstanceNorm(x)) (res optional, act = ELU or identity)."""
 
     @staticmethod
-    def forward(ctx, x, res, groups, act):
+    def forward(ctx, x, res, groups, act, eps=EPS):
         x, _ = _mat(x)
-        mean, rstd = instance_stats(x, groups)
+        mean, rstd = instance_stats(x, groups, eps)
         y = norm_act_res_fwd(x, mean, rstd, groups, res=res, act=act)
         ctx.save_for_backward(x, mean, rstd)
         ctx.groups, ctx.act, ctx.has_res = groups, act, res is not None
@@ -803,7 +820,7 @@ class InstanceNormActResFn(torch.autograd.Function):
     def backward(ctx, g):
         x, mean, rstd = ctx.saved_tensors
         dx = instance_norm_act_bwd(x, g, mean, rstd, ctx.groups, act=ctx.act)
-        return dx, (g if ctx.has_res else None), None, None
+        return dx, (g if ctx.has_res else None), None, None, None
 
 
 class MaskedL1LossFn(torch.autograd.Function):

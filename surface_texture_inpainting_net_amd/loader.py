@@ -30,9 +30,26 @@ from .scene_io import load_scene
 _FEATURE_KEYS = ('x', 'color', 'mask', 'batch', 'name')
 
 
-def shard_indices(n, epoch, seed=0, shuffle=True, rank=0, world_size=1):
+def shard_indices(n, epoch, seed=0, shuffle=True, rank=0, world_size=1, sizes=None):
     """The item order of one epoch for one rank: seeded permutation of range(n), padded by wrap-around to a multiple of
-    world_size, every world_size-th element starting at rank (torch.utils.data.DistributedSampler semantics)."""
+    world_size, every world_size-th element starting at rank (torch.utils.data.DistributedSampler semantics).
+
+    sizes (optional, one number per item - e.g. the level-0 vertex count): SIZE-BALANCED sharding for the synchronous
+    gradient all-reduce.  ScanNet scenes spread over 12 k...28 k (crops) / 50 k...400 k (scenes) vertices and a step takes
+    as long as its slowest rank, so the items are sorted by size, cut into consecutive buckets of world_size items (the
+    ranks of one step get neighbours in size), the ORDER of the buckets is shuffled per epoch and the items of a bucket
+    are dealt to the ranks by a per-bucket seeded rotation (no rank always gets the largest of its bucket).  Same
+    coverage / padding guarantees as the plain form."""
+    if sizes is not None and world_size > 1 and n > 0:
+        assert len(sizes) == n
+        by_size = sorted(range(n), key=lambda i: (-float(sizes[i]), i))
+        total = (n + world_size - 1) // world_size * world_size
+        by_size = by_size + by_size[:total - n]
+        buckets = [by_size[b:b + world_size] for b in range(0, total, world_size)]
+        g = torch.Generator().manual_seed(int(seed) + int(epoch))
+        order = torch.randperm(len(buckets), generator=g).tolist() if shuffle else list(range(len(buckets)))
+        rot = torch.randint(0, world_size, (len(buckets),), generator=g).tolist() if shuffle else [0] * len(buckets)
+        return [buckets[b][(rank + rot[b]) % world_size] for b in order]
     if shuffle:
         g = torch.Generator().manual_seed(int(seed) + int(epoch))
         order = torch.randperm(n, generator=g).tolist()
@@ -127,12 +144,18 @@ class SceneLoader:
     """Iterate GPU-resident training batches: ``for sample in loader.epoch(e): loss = step(sample)``."""
 
     def __init__(self, items, device, batch_size=1, shuffle=True, seed=0, rank=0, world_size=1, prefetch=2,
-                 cache_bytes=32 << 30, end_level=3, cropped=False, model=None, host_cache_bytes=64 << 30, worker_threads=4, workers=2):
+                 cache_bytes=32 << 30, end_level=3, cropped=False, model=None, host_cache_bytes=64 << 30, worker_threads=4, workers=2,
+                 sizes=None):
         self.items = list(items)
         self.device = torch.device(device)
         self.batch_size, self.shuffle, self.seed = int(batch_size), bool(shuffle), int(seed)
         self.rank, self.world_size, self.prefetch = int(rank), int(world_size), max(1, int(prefetch))
         self.end_level, self.cropped = end_level, cropped
+        # per-item sizes (level-0 vertex counts) -> size-balanced rank sharding (shard_indices); in-memory items carry
+        # their size, file items need the caller's list (e.g. from the dataset index)
+        if sizes is None and self.world_size > 1 and all(isinstance(it, HierarchicalBatch) for it in self.items):
+            sizes = [int(it.x.shape[0]) for it in self.items]
+        self.sizes = None if sizes is None else [float(v) for v in sizes]
         self.model = model                                   # optional: lets the loader build the plan (model.prefetch_plan)
         self.worker_threads = max(1, int(worker_threads))    # intra-op threads of each WORKER thread's torch ops (collate ...)
         self.workers = max(1, int(workers))                  # worker threads preparing batches side by side (order is kept)
@@ -171,11 +194,11 @@ class SceneLoader:
         return scene
 
     def steps_per_epoch(self):
-        n = len(shard_indices(len(self.items), 0, self.seed, False, self.rank, self.world_size))
+        n = len(shard_indices(len(self.items), 0, self.seed, False, self.rank, self.world_size, self.sizes))
         return (n + self.batch_size - 1) // self.batch_size
 
     def _batch_ids(self, epoch):
-        idx = shard_indices(len(self.items), epoch, self.seed, self.shuffle, self.rank, self.world_size)
+        idx = shard_indices(len(self.items), epoch, self.seed, self.shuffle, self.rank, self.world_size, self.sizes)
         return [idx[b:b + self.batch_size] for b in range(0, len(idx), self.batch_size)]
 
     def _prepare(self, turn, ids):
@@ -192,7 +215,7 @@ class SceneLoader:
             slot.done.synchronize()                             # the uploads issued from this slot have left it
             slot.done = None
         pinned = HierarchicalBatch(**{k: (slot.stage(k, batch[k]) if torch.is_tensor(batch[k]) else batch[k]) for k in keys})
-        pinned._slot = slot
+        object.__setattr__(pinned, '_slot', slot)            # not a data key: stays out of the sample and the cache
         return ids, pinned
 
     def _cpu_batches(self, epoch):
@@ -212,7 +235,7 @@ class SceneLoader:
         for v in dev.values():
             if torch.is_tensor(v):
                 v.record_stream(main)
-        slot = getattr(cpu_batch, '_slot', None)
+        slot = cpu_batch.__dict__.get('_slot')
         if slot is not None:
             slot.done = self._copy_stream.record_event()        # the worker may overwrite the slot after this
         main.wait_stream(self._copy_stream)

@@ -73,10 +73,11 @@ class EdgeConv(nn.Module):
         edges = _as_edges(edge_index, x.shape[0])
         wcat, bcat, w2e = self.fused_weights()
         H = self.hidden()
-        Y = SF.linear(x, wcat, bcat)
+        prec = getattr(self, 'fwd_precision', None)
+        Y = SF.linear(x, wcat, bcat, precision=prec)
         h = SF.EdgeReluMeanFn.apply(Y[:, :H], Y[:, H:], edges)
         has_in = (edges.by_dst.rowptr[1:] > edges.by_dst.rowptr[:-1]).to(h.dtype).unsqueeze(1)
-        return SF.linear(h, self.nn[2].weight) + has_in * w2e[:, H]
+        return SF.linear(h, self.nn[2].weight, precision=prec) + has_in * w2e[:, H]
 
     def __repr__(self):
         return '{}(nn={}, aggr={})'.format(self.__class__.__name__, self.nn, self.aggr)
@@ -129,7 +130,8 @@ class SAGEConv(nn.Module):
             # agg[:, 3:9] - x_i[:, 3:9] * [deg_i > 0]
             has_in = (edges.by_dst.rowptr[1:] > edges.by_dst.rowptr[:-1]).to(x.dtype).unsqueeze(1)
             agg = torch.cat([agg[:, :3], agg[:, 3:9] - x[:, 3:9] * has_in, agg[:, 9:]], dim=1)
-        return SF.linear(agg, self.lin_l.weight, self.lin_l.bias) + SF.linear(x, self.lin_r.weight)
+        prec = getattr(self, 'fwd_precision', None)
+        return SF.linear(agg, self.lin_l.weight, self.lin_l.bias, precision=prec) + SF.linear(x, self.lin_r.weight, precision=prec)
 
 
 class SAGEConvTransInv(SAGEConv):
@@ -142,6 +144,7 @@ class SumSAGEConv(nn.Module):
         self.sage1 = module(*args, **kwargs)
 
     def forward(self, x, edge_index, size=None):
+        self.sage1.fwd_precision = getattr(self, 'fwd_precision', None)
         return self.sage1(x, edge_index, size)
 
 
@@ -168,7 +171,7 @@ class FastInstanceNorm(nn.Module):
 
     def forward(self, x, batch=None):
         groups = _as_groups(batch, x.shape[0], x.device, self.linspace_quirk)
-        return SF.InstanceNormActResFn.apply(x, None, groups, False)
+        return SF.InstanceNormActResFn.apply(x, None, groups, False, self.eps)
 
     def __repr__(self):
         return '{}({})'.format(self.__class__.__name__, self.num_features)

@@ -24,6 +24,9 @@ class GraphResnetBlock(nn.Module):
         super().__init__()
         self.dim_in, self.dim_out = dim_in, dim_out
         self.act = nn.ELU()
+        # True for a block fed by un-normalised data (the network's first block, or any block of a norm-free network):
+        # its forward GEMMs take the range-safe matrix-core path (functional.forward_precision)
+        self.unbounded_input = False
         if module is not None:
             self.first_filter = get_gcn_filter(dim_in, dim_out, inplace=inplace, bias=use_bias, module=module,
                                                double_input=double_input)
@@ -47,12 +50,15 @@ class GraphResnetBlock(nn.Module):
             return SF.EdgeConvBlockFn.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias,
                                             None if shortcut is None else shortcut.weight,
                                             None if shortcut is None else shortcut.bias, edges, groups,
-                                            self.first_filter.trans_inv)
+                                            self.first_filter.trans_inv, self.first_norm.eps,
+                                            SF.forward_precision(self.unbounded_input))
+        self.first_filter.fwd_precision = SF.forward_precision(self.unbounded_input)
         out = self.first_filter(x, edges)
-        res = SF.linear(x, self.shortcut.weight, self.shortcut.bias) if self.dim_in != self.dim_out else x
+        res = (SF.linear(x, self.shortcut.weight, self.shortcut.bias, precision=SF.forward_precision(self.unbounded_input))
+               if self.dim_in != self.dim_out else x)
         if isinstance(self.first_norm, M.FastInstanceNorm):
             groups = M._as_groups(batch, n, x.device, self.first_norm.linspace_quirk)
-            return SF.InstanceNormActResFn.apply(out, res, groups, True)
+            return SF.InstanceNormActResFn.apply(out, res, groups, True, self.first_norm.eps)
         return res + self.act(self.first_norm(out, batch))
 
 
@@ -133,6 +139,10 @@ class SurfaceTextureInpaintingNet(nn.Module):
         self.final_linear1 = nn.Linear(ngf, ngf, bias=use_bias)
         self.final_norm1 = self.norm(ngf)
         self.final_linear2 = nn.Linear(ngf, output_nc)
+        for m in self.modules():
+            if isinstance(m, GraphResnetBlock):
+                m.unbounded_input = not self.using_norm
+        self.input_blocks[0].unbounded_input = True                 # raw vertex features (fp16's range is not guaranteed)
         for m in self.modules():                                    # reference zeroes every Linear bias (:360-374)
             if isinstance(m, nn.Linear) and m.bias is not None:
                 nn.init.zeros_(m.bias)
@@ -227,12 +237,13 @@ class SurfaceTextureInpaintingNet(nn.Module):
             out = blk(out, edges, self._norm_arg(plan, tgt))
         for blk in self.output_blocks:
             out = blk(out, e0, self._norm_arg(plan, 0, whole_batch=True))
-        out = SF.linear(out, self.final_linear1.weight, self.final_linear1.bias)
+        tail_prec = SF.forward_precision(not self.using_norm)
+        out = SF.linear(out, self.final_linear1.weight, self.final_linear1.bias, precision=tail_prec)
         if self.norm is M.FastInstanceNorm:                         # per-graph branch even for B = 1 (:465, Q3)
-            out = SF.InstanceNormActResFn.apply(out, None, plan.norm_groups(0), True)
+            out = SF.InstanceNormActResFn.apply(out, None, plan.norm_groups(0), True, self.final_norm1.eps)
         else:
             out = F.elu(self.final_norm1(out, batch=sample.batch))
-        out = torch.tanh(SF.linear(out, self.final_linear2.weight, self.final_linear2.bias, out_fp32=True))
+        out = torch.tanh(SF.linear(out, self.final_linear2.weight, self.final_linear2.bias, out_fp32=True, precision=tail_prec))
         plan.validate()
         return out
 

@@ -1,15 +1,19 @@
 """The training step the reference's Inpainting3DTrainer runs around the hot path
-(trainers/inpainting3d_trainer.py:127-137, :156-177), restated for one process per GPU:
+(trainers/inpainting3d_trainer.py:127-137, :156-177, :199-201), restated for one process per GPU:
 
     out  = model(data)                                   # the HIP hot path
     pred = where(mask > 0, out, color)
     loss = mean(|pred - color| * 0.99 ** mask)           # use_mask_weighted_loss
-    loss.backward(); [all-reduce grads]; Adam(lr 7e-5, wd 0, amsgrad).step(); zero_grad(set_to_none)
+    (loss / num_cumulated_train_batches).backward()      # gradients accumulate over `accumulate` scenes (:170-172)
+    every `accumulate`-th scene: [all-reduce grads]; Adam(lr 7e-5, wd 0, amsgrad).step(); zero_grad(set_to_none)
+    lr_scheduler.step() per epoch (StepLR(20000, 0.5), :199-201) -> works on TrainStep.optimizer / set_lr()
 
 Data parallelism (new in this build; the reference asserts n_gpu == 1): one scene per rank, ONE
-flat fp32 gradient bucket all-reduced with RCCL over xGMI (torch.distributed backend "nccl"), then
-divided by the world size - the mean of per-scene means, i.e. the reference's
-num_cumulated_train_batches semantics (:170-177).
+flat fp32 gradient bucket summed with RCCL over xGMI (torch.distributed backend "nccl"); the 1 / world factor rides on
+the loss gradient (exact for 2 / 4 / 8 ranks), so the all-reduced bucket IS the mean of per-scene means - the
+reference's num_cumulated_train_batches semantics (:170-177) - without a separate division pass.  Large buckets (the
+67 M-parameter 5-level network: 268 MB) are reduced in segments as the backward pass completes them, on RCCL's own
+stream beside the remaining backward kernels (FlatGradBucket.enable_overlap).
 """
 import torch
 import torch.distributed as dist
@@ -27,6 +31,12 @@ def compute_loss(output, target, weights=None):
     return loss.mean()
 
 
+def _world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return 1
+
+
 class FlatGradBucket:
     """All parameter gradients as views into ONE contiguous fp32 buffer (16.8 MB for the 3-level
     config): a single large all-reduce per step instead of 74 small ones."""
@@ -36,11 +46,12 @@ class FlatGradBucket:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.views = []
+        self.views, self.offsets = [], []
         off = 0
         for i, p in enumerate(self.params):
             v = self.flat[off:off + p.numel()].view_as(p)
             self.views.append(v)
+            self.offsets.append(off)
             p.grad = v
             off += p.numel()
             if dev.type == 'cuda':
@@ -49,6 +60,16 @@ class FlatGradBucket:
                 p._stin_slot = (self, i)
         self.accepting = False
         self.written = [False] * len(self.params)
+        self.acc = None                       # gradient accumulation over several backward passes (TrainStep(accumulate=k))
+        # overlapped all-reduce (enable_overlap): segments = contiguous parameter ranges [lo, hi) in the order the
+        # backward pass completes them (reverse parameter order), each reduced as soon as its last gradient is written
+        self.overlap_min_bytes = None
+        self.segments = None
+        self._seg_next = 0
+        self._seg_work = []
+        self._group = None
+        self._comm_stream = None
+        self.allreduce_log = None             # list: (start, end) HIP events of the end-of-backward all-reduces (bench: allreduce_us)
 
     def zero(self):
         self.flat.zero_()
@@ -62,6 +83,8 @@ class FlatGradBucket:
             p.grad = None
         self.written = [False] * len(self.params)
         self.accepting = True
+        self._seg_next = 0
+        self._seg_work = []
 
     def gather_grads(self):
         """After backward: copy all gradients into the flat bucket with one multi-tensor copy and point
@@ -82,15 +105,116 @@ class FlatGradBucket:
         if views:
             torch._foreach_copy_(views, grads)
 
-    def all_reduce_mean(self, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    # ---- gradient accumulation (reference :170-177) -------------------------------------------------------------------
+    def accumulate(self, first, last):
+        """Called after gather_grads() of every micro-batch of an accumulation window: the direct-write path OVERWRITES
+        the bucket, so the running sum lives in `acc` (same left-to-right summation order as autograd's `.grad +=`)."""
+        if first and last:
+            return
+        if self.acc is None:
+            self.acc = torch.empty_like(self.flat)
+        if first:
+            self.acc.copy_(self.flat)
+        elif last:
+            torch.add(self.acc, self.flat, out=self.flat)
+        else:
+            self.acc.add_(self.flat)
+
+    # ---- all-reduce -----------------------------------------------------------------------------------------------------
+    def enable_overlap(self, group=None, min_bytes=32 << 20):
+        """Reduce the bucket in segments of >= min_bytes while the backward pass is still running.  The segments are
+        learned from the first step (which parameters the block backward writes directly); a bucket smaller than
+        2 * min_bytes keeps the single tail all-reduce (16.8 MB at 3 levels: ~100 us, nothing to hide)."""
+        self.overlap_min_bytes = int(min_bytes)
+        self._group = group
+        if self.flat.is_cuda and self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.flat.device)
+
+    def _learn_segments(self):
+        """Runs of directly written parameters, walked in reverse parameter order (= completion order of the backward
+        pass), cut into segments of >= overlap_min_bytes.  Parameters that reach the bucket through autograd (the tail
+        Linears, generic filters) are copied in by gather_grads() after backward and belong to the tail all-reduce."""
+        segs, hi, nbytes = [], None, 0
+        for i in range(len(self.params) - 1, -1, -1):
+            if not self.written[i]:
+                hi, nbytes = None, 0
+                continue
+            if hi is None:
+                hi, nbytes = i + 1, 0
+            nbytes += self.params[i].numel() * 4
+            if nbytes >= self.overlap_min_bytes:
+                segs.append((i, hi))
+                hi, nbytes = None, 0
+        total = self.flat.numel() * 4
+        self.segments = segs if total >= 2 * self.overlap_min_bytes else []
+
+    def _seg_slice(self, seg):
+        lo, hi = seg
+        return self.flat[self.offsets[lo]:self.offsets[hi - 1] + self.params[hi - 1].numel()]
+
+    def block_done(self, side_event=None):
+        """functional.EdgeConvBlockFn.backward calls this after it has ENQUEUED a block's direct gradient writes: every
+        segment whose parameters are all written is handed to RCCL now - on the communication stream, behind the compute
+        stream's position and the weight-gradient side stream's newest event - while backward continues."""
+        if not self.segments or self._seg_next >= len(self.segments) or _world(self._group) == 1:
+            return
+        while self._seg_next < len(self.segments):
+            lo, hi = self.segments[self._seg_next]
+            if not all(self.written[lo:hi]):
+                break
+            dev = self.flat.device
+            cs = self._comm_stream
+            cs.wait_stream(torch.cuda.current_stream(dev))
+            if side_event is not None:
+                cs.wait_event(side_event)
+            with torch.cuda.stream(cs):
+                w = dist.all_reduce(self._seg_slice((lo, hi)), op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+            self._seg_work.append(w)
+            self._seg_next += 1
+
+    def all_reduce(self, group=None, timed=False):
+        """Sum the bucket over the ranks (the loss gradient already carries 1 / world).  Segments launched during the
+        backward pass are only waited for; the rest of the bucket goes out in contiguous pieces now."""
+        if _world(group) == 1:
+            return
+        done = self.segments[:self._seg_next] if self.segments else []
+        for w in self._seg_work:
+            w.wait()                                            # the compute stream waits for RCCL's stream
+        if self._comm_stream is not None and self._seg_work:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._comm_stream)
+        self._seg_work = []
+        ev = None
+        if timed and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if not done:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+        else:
+            # the complement of the reduced segments, as contiguous flat ranges
+            n = self.flat.numel()
+            cuts = sorted((self.offsets[lo], self.offsets[hi - 1] + self.params[hi - 1].numel()) for lo, hi in done)
+            at = 0
+            for a, b in cuts + [(n, n)]:
+                if a > at:
+                    dist.all_reduce(self.flat[at:a], op=dist.ReduceOp.SUM, group=group)
+                at = max(at, b)
+        if ev is not None:
+            ev[1].record()
+            if self.allreduce_log is not None and len(self.allreduce_log) < 256:
+                self.allreduce_log.append(ev)
+        if self.overlap_min_bytes is not None and self.segments is None:
+            self._learn_segments()
+
+    def all_reduce_mean(self, group=None):
+        """Stand-alone form (gradients NOT pre-scaled by 1 / world): sum, then divide."""
+        if _world(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(_world(group))
 
 
 def broadcast_parameters(model, src=0, group=None):
     """Identical replicas: rank `src`'s parameters to every rank (one flat broadcast)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _world(group) == 1:
         return
     ps = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
     flat = torch.cat([p.reshape(-1).float() for p in ps])
@@ -101,15 +225,34 @@ def broadcast_parameters(model, src=0, group=None):
         off += p.numel()
 
 
-class FlatAdam:
+def replicas_identical(model, group=None):
+    """SURVEY §8e validation: parameters bit-identical across ranks (rank 0's flat copy compared on every rank, the
+    verdicts AND-reduced).  -> bool, the same on every rank."""
+    if _world(group) == 1:
+        return True
+    ps = [p.data for p in model.parameters()]
+    mine = torch.cat([p.reshape(-1).float() for p in ps])
+    ref = mine.clone()
+    dist.broadcast(ref, src=0, group=group)
+    ok = torch.tensor([1 if torch.equal(mine.view(torch.int32), ref.view(torch.int32)) else 0], dtype=torch.int32,
+                      device=mine.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(ok.item()))
+
+
+class FlatAdam(torch.optim.Optimizer):
     """Adam(amsgrad) over ONE flat parameter buffer: the parameters are re-pointed at views of `flat_p`, the moments
     live in flat buffers of the same size, and the update is a single HIP launch (stin_adam_f32) on the bucket's
     flat gradient - instead of torch's ~15 multi-tensor kernels per step.  Same arithmetic as
-    torch.optim.Adam(lr, betas, eps, weight_decay, amsgrad)."""
+    torch.optim.Adam(lr, betas, eps, weight_decay, amsgrad) (bias corrections in double on the host like torch).
+
+    A real torch.optim.Optimizer: `param_groups[0]['lr']` is what step() uses, so torch's LR schedulers (the reference's
+    StepLR, inpainting3d_trainer.py:46-48, :199-201) drive it unchanged, and state_dict() / load_state_dict() speak
+    torch.optim.Adam's per-parameter layout ('step', 'exp_avg', 'exp_avg_sq', 'max_exp_avg_sq' keyed by parameter
+    index) - the 'optimizer' entry of a reference checkpoint (base_trainer.py:150, :199) loads and saves unchanged."""
 
     def __init__(self, bucket, lr=7e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=True):
         self.bucket = bucket
-        self.lr, self.betas, self.eps, self.weight_decay, self.amsgrad = lr, betas, eps, weight_decay, amsgrad
         self.flat_p = torch.empty_like(bucket.flat)
         off = 0
         for p in bucket.params:
@@ -121,27 +264,96 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros_like(bucket.flat)
         self.max_exp_avg_sq = torch.zeros_like(bucket.flat)
         self.step_count = 0
+        super().__init__(bucket.params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+        if len(self.param_groups) != 1:
+            raise ValueError('FlatAdam runs one parameter group')
 
-    def step(self):
+    # the hyper-parameters live in param_groups[0] (schedulers write there); attribute access for convenience
+    @property
+    def lr(self):
+        return self.param_groups[0]['lr']
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]['lr'] = float(value)
+
+    def zero_grad(self, set_to_none=True):
+        self.bucket.zero()
+
+    @torch.no_grad()
+    def step(self, closure=None):
         from . import functional as SF
+        g = self.param_groups[0]
         self.step_count += 1
-        SF.adam_step(self.flat_p, self.bucket.flat, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, self.lr,
-                     self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, self.amsgrad)
+        SF.adam_step(self.flat_p, self.bucket.flat, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq, g['lr'],
+                     g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self.step_count, g['amsgrad'])
+
+    def _views(self, flat):
+        out, off = [], 0
+        for p in self.bucket.params:
+            out.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return out
 
     def state_dict(self):
-        return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
-                'max_exp_avg_sq': self.max_exp_avg_sq, 'lr': self.lr}
+        """torch.optim.Adam's layout: {'state': {i: {'step', 'exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'}}, 'param_groups'}
+        (empty 'state' before the first step, like torch)."""
+        groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]
+        groups[0]['params'] = list(range(len(self.bucket.params)))
+        state = {}
+        if self.step_count > 0:
+            m, v, vm = self._views(self.exp_avg), self._views(self.exp_avg_sq), self._views(self.max_exp_avg_sq)
+            for i in range(len(self.bucket.params)):
+                state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': m[i].clone(), 'exp_avg_sq': v[i].clone()}
+                if self.param_groups[0]['amsgrad']:
+                    state[i]['max_exp_avg_sq'] = vm[i].clone()
+        return {'state': state, 'param_groups': groups}
+
+    def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.bucket.params):
+            raise ValueError('optimizer state_dict does not match the parameter list (%d groups, %d parameters expected)'
+                             % (1, len(self.bucket.params)))
+        for k, v in groups[0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v
+        state = sd['state']
+        m, v, vm = self._views(self.exp_avg), self._views(self.exp_avg_sq), self._views(self.max_exp_avg_sq)
+        steps = set()
+        for buf in (self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq):
+            buf.zero_()
+        for j, i in enumerate(groups[0]['params']):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            steps.add(int(float(st['step'])))
+            m[j].copy_(st['exp_avg'])
+            v[j].copy_(st['exp_avg_sq'])
+            if 'max_exp_avg_sq' in st:
+                vm[j].copy_(st['max_exp_avg_sq'])
+        if len(steps) > 1:
+            raise ValueError('per-parameter step counts differ (%s): one flat update cannot continue them' % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
 
 
 class TrainStep:
     """model + Adam(amsgrad) + flat-bucket gradient all-reduce; ``step(sample) -> loss`` (a 0-dim
     tensor, no host sync).  On the GPU the loss (+ its gradient) and the optimizer update are one HIP
-    kernel each; on the CPU (the gloo tests of the harness) the same arithmetic runs through torch."""
+    kernel each; on the CPU (the gloo tests of the harness) the same arithmetic runs through torch.
 
-    def __init__(self, model, lr=7e-5, weight_decay=0.0, amsgrad=True, use_mask_weighted_loss=True, group=None):
+    accumulate = the reference's num_cumulated_train_batches (:170-177): the loss of every call is divided by it, the
+    gradients of `accumulate` consecutive calls are summed, and only the last call of a window all-reduces and runs the
+    optimizer.  `optimizer` is a torch.optim.Optimizer either way (LR schedulers attach to it; set_lr() for manual
+    schedules)."""
+
+    def __init__(self, model, lr=7e-5, weight_decay=0.0, amsgrad=True, use_mask_weighted_loss=True, group=None,
+                 accumulate=1, overlap_allreduce_min_bytes=32 << 20, time_allreduce=False):
         self.model = model
         self.group = group
         self.use_mask_weighted_loss = use_mask_weighted_loss
+        self.accumulate = max(1, int(accumulate))
+        self._micro = 0
+        self.time_allreduce = time_allreduce
         broadcast_parameters(model, 0, group)
         # a training loop must not stall the host once per step: out-of-range indices of a scene are reported by the
         # NEXT step (or by finish()) instead of inside the forward call that used them
@@ -151,10 +363,17 @@ class TrainStep:
         self.on_gpu = self.bucket.flat.is_cuda
         if self.on_gpu:
             self.optimizer = FlatAdam(self.bucket, lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
+            if overlap_allreduce_min_bytes and _world(group) > 1 and self.accumulate == 1:
+                self.bucket.enable_overlap(group, overlap_allreduce_min_bytes)
         else:
             self.optimizer = torch.optim.Adam(self.bucket.params, lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
 
-    def forward_backward(self, sample):
+    def set_lr(self, lr):
+        for g in self.optimizer.param_groups:
+            g['lr'] = float(lr)
+
+    def forward_backward(self, sample, grad_scale=1.0):
+        """One forward + loss + backward; the bucket then holds d(loss * grad_scale)/dw of THIS sample."""
         self.bucket.detach_grads()
         try:
             if self.on_gpu:
@@ -163,9 +382,15 @@ class TrainStep:
             else:
                 pred = graph_forward(self.model, sample)
                 loss = compute_loss(pred, sample.color, sample.mask if self.use_mask_weighted_loss else None)
-            loss.backward()
+            if grad_scale == 1.0:
+                loss.backward()
+            else:
+                loss.backward(torch.full_like(loss, grad_scale))
         finally:
             self.bucket.accepting = False           # also when forward / backward raised: no stray direct writes later
+            if self.on_gpu:
+                from . import functional as SF
+                SF.wgrad_side_settle(self.bucket.flat.device)   # an aborted backward never ran its end-of-backward join
         self.bucket.gather_grads()
         return loss.detach()
 
@@ -176,7 +401,12 @@ class TrainStep:
             check_deferred(wait=True)
 
     def __call__(self, sample):
-        loss = self.forward_backward(sample)
-        self.bucket.all_reduce_mean(self.group)
-        self.optimizer.step()
+        k = self.accumulate
+        first, last = self._micro == 0, self._micro == k - 1
+        loss = self.forward_backward(sample, grad_scale=1.0 / (k * _world(self.group)))
+        self.bucket.accumulate(first, last)
+        self._micro = 0 if last else self._micro + 1
+        if last:
+            self.bucket.all_reduce(self.group, timed=self.time_allreduce)
+            self.optimizer.step()
         return loss
