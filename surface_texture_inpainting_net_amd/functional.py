@@ -487,9 +487,9 @@ def _wgrad_side_args(dev, keep_alive, params, direct=False, work=0):
         # parameter hooks, DDP and non-leaf weights simply keep the whole block on the compute stream
         return 0, 0, 0, 0, 0
     side = _wgrad_side(dev)
-    # the side stream reads (and, outside the bucket route, WRITES) these after this call has returned: keep them referenced
-    # until the join (then they are freed in compute-stream order AFTER the join - no record_stream: its deferred frees made
-    # the caching allocator's pool grow by ~80 MB per step over hundreds of steps with changing scene sizes)
+    # the side stream reads these after this call has returned: keep them referenced until the join (then they are freed in
+    # compute-stream order AFTER the join - no record_stream: its deferred frees made the caching allocator's pool grow by
+    # ~80 MB per step over hundreds of steps with changing scene sizes)
     side.hold.append(keep_alive)
     ev = side.next_events()
     return side.stream.cuda_stream, ev[0].cuda_event, ev[1].cuda_event, ev[2].cuda_event, 0
@@ -650,8 +650,16 @@ class EdgeConvBlockFn(torch.autograd.Function):
             ws_bytes = lib.stin_edgeconv_block_bwd_workspace_bytes(N, Cp, H, Cout, int(ctx.has_shortcut), groups.B, int(b16))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             cs = edges.by_src
-            side = _wgrad_side_args(dev, (ws, x, hE, g, dW1, db1, dW2, db2, dWs, dbs), ctx.params, direct is not None,
-                                    work=float(N) * Y.shape[1] * Cp)
+            side = _wgrad_side_args(dev, (ws, x, hE, g), ctx.params, direct is not None, work=float(N) * Y.shape[1] * Cp)
+            if side[0] and direct is None:
+                # the side stream WRITES these fresh tensors after this call has returned.  They must not be referenced from
+                # here (autograd adopts a returned gradient only when it holds the sole reference - otherwise it copies it on
+                # the compute stream, before the join); record_stream makes the allocator wait for the side stream should
+                # an aborted backward free them early (a few MB of weights: no pool growth, unlike the activations)
+                ss = _wgrad_side(dev).stream
+                for t in (dW1, db1, dW2, db2, dWs, dbs):
+                    if t is not None:
+                        t.record_stream(ss)
             _call('stin_edgeconv_block_bwd', int(b16), _ptr(g), ldg, _ptr(x), x.stride(0), N, Cin, Cp, H, Cout,
                   int(ctx.has_shortcut), int(ctx.trans_inv), _ptr(Y), Y.stride(0), _ptr(hE), hE.stride(0), _ptr(ctx.mask),
                   _ptr(agg), _ptr(mean), _ptr(rstd), _ptr(wcatT), _ptr(w2T), _ptr(edges.by_dst.rowptr), _ptr(cs.rowptr),
