@@ -597,20 +597,20 @@ def test_mid_size_full_width_model_vs_oracle():
     got = net(sd)
     stin_oracle.compute_loss(torch.where((sd.mask > 0).expand_as(sd.color), got, sd.color), sd.color, sd.mask).backward()
     assert float((got.detach().cpu() - want.detach()).abs().max()) <= FWD_TOL
-    # Gradients at full width: fp32 re-association flips a handful of near-tie arg-max (max pool) and
-    # ReLU decisions (out of ~1e7), each of which re-routes one gradient entry - a DISCRETE change that
-    # moves individual weight gradients by O(1/sqrt(N)) ~ 1 %.  Measured on this very case against an
-    # fp64 run of the oracle: the fp32 CPU oracle itself is up to 8e-4 of the gradient scale away from
-    # the fp64 truth, this path 4e-3 or 4e-4 depending only on which GEMM rounding pattern is used.
-    # So: a loose per-tensor max-abs bound plus a tight bound on the global relative L2 error.
+    # Gradients at full width: fp32 re-association flips a handful of near-tie arg-max (max pool) and ReLU decisions (out of
+    # ~1e7), each of which re-routes one gradient entry - a DISCRETE change.  tests/test_full_size_parity.py measures it
+    # against an fp64 run of the oracle on this very case: fp32 CPU oracle 2.4e-4 relative L2 / 8.4e-4 worst entry, this
+    # path 6.9e-4 / 7.5e-4 with the shipped split-16-bit GEMMs, 8.1e-4 / 8.2e-4 with exact fp32 GEMMs, identical with
+    # bf16x6 backward GEMMs - flip noise, not GEMM precision.  SURVEY 8d's bar (relative 1e-3 on weight gradients) is met
+    # at the full 200k size (3.0e-4); at 12k vertices each flip weighs more, hence 1.5e-3 / 3e-3 here.
     scale = max(float(p.grad.abs().max()) for p in ref.parameters())
     num = den = 0.0
     for (k, p), q in zip(net.named_parameters(), ref.parameters()):
         d = p.grad.cpu() - q.grad
-        assert float(d.abs().max()) <= 1e-2 * scale, k
+        assert float(d.abs().max()) <= 3e-3 * scale, k
         num += float(d.double().pow(2).sum())
         den += float(q.grad.double().pow(2).sum())
-    assert (num / den) ** 0.5 <= 3e-3
+    assert (num / den) ** 0.5 <= 1.5e-3
 
 
 def test_plan_prefetch_on_side_streams_equals_lazy_build():
