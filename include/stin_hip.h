@@ -246,6 +246,16 @@ int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_
                                       k-group [hi x 4 | lo x 4] in the 16 bytes of the fp32 values it replaces (same
                                       shape / ld / footprint; made by stin_gemm_split_weights_f32 or the pack kernel) -
                                       the weight split is then done once per step instead of once per block    */
+#define STIN_GEMM_W_FRAG 0x400     /* nt, OR-ed into PRESPLIT: the pre-split W is stored in MFMA FRAGMENT order where the shape
+                                      takes it (stin_gemm_w_is_frag(Nc, K): the shapes of the resident-strip kernel - K % 64 == 0,
+                                      Nc % 32 == 0, 128 <= K <= 256, Nc >= 320; other shapes keep the k-group form above, so the
+                                      flag may be set unconditionally): for the 32-column tile t
+                                      and the 16-wide k-step s, 2 KB at byte ((t * K/16 + s) * 64 + lane) * 32 hold lane
+                                      (k-half h, column r) = h * 32 + r's [hi x 8 | lo x 8] of k = 16 s + 8 h .. + 7 - what the
+                                      resident-strip kernel loads straight into its B fragments (same footprint as fp32; ldw
+                                      is ignored).  Producer and consumer must agree: pass the same flag to
+                                      stin_gemm_split_weights_f32 / stin_edgeconv_pack_f32 and to stin_gemm_nt_f32             */
+int stin_gemm_w_is_frag(int Nc, int K);
 int stin_gemm_split_weights_f32(const float* W, int64_t ldw, int Nc, int K, int precision, float* out, int64_t ldo,
                                 stin_stream_t stream);
 int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
@@ -295,8 +305,9 @@ int stin_bn_running_stats_f32(const float* mean, const float* rstd, int C, float
  *   dw2b [Cout, H+1] (optional) -> contiguous dW2 [Cout, H], db2 [Cout].
  * (models/modules/edge_conv_filter.py:46-52, models/surfacetextureinpaintingnet.py:505-506)
  * norm_bwd_coef: k = -rstd^3 T1 inv_cnt, m = -rstd S0 inv_cnt for stin_norm_act_bwd_f32.
- * fwd_split / bwd_split (0, STIN_GEMM_F16X3 or STIN_GEMM_BF16X3): write the forward operands (wcat, and a copy w2s
- * [Cout, H] of W2) / the backward operands (wcatT, w2T) directly in the STIN_GEMM_W_PRESPLIT form of that precision.
+ * fwd_split / bwd_split (0, STIN_GEMM_F16X3 or STIN_GEMM_BF16X3, optionally | STIN_GEMM_W_FRAG): write the forward
+ * operands (wcat, and a copy w2s [Cout, H] of W2) / the backward operands (wcatT, w2T) directly in the
+ * STIN_GEMM_W_PRESPLIT form of that precision (each operand in fragment order where its shape allows, see W_FRAG).
  */
 int stin_edgeconv_pack_f32(const float* W1, const float* b1, const float* Ws, const float* bs, const float* W2,
                            int Cin, int Cp, int H, int Cout, int has_shortcut, int trans_inv, float* wcat,

@@ -69,6 +69,7 @@ SIGNATURES = {
     'stin_edgeconv_pack_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr,
                                        c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr]),
     'stin_gemm_split_weights_f32': (c_int, [c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
+    'stin_gemm_w_is_frag': (c_int, [c_int, c_int]),
     'stin_edgeconv_unpack_grads_f32': (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr,
                                                c_ptr, c_ptr, c_ptr, c_ptr]),
     'stin_norm_bwd_coef_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr]),

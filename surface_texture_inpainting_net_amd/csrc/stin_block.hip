@@ -68,7 +68,7 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
                                     fwd_split ? w2s : nullptr, fwd_split, bwd_split, stream));
     const float* w2_op = fwd_split ? w2s : W2;
     const int wbf = (storage == 1 && fwd_split) ? STIN_GEMM_W_BF16 : 0;
-    const int pf = fwd_split ? (prec_fwd | STIN_GEMM_W_PRESPLIT) : prec_fwd;
+    const int pf = fwd_split ? (prec_fwd | STIN_GEMM_W_PRESPLIT | (fwd_split & STIN_GEMM_W_FRAG)) : prec_fwd;
     const void* res = has_shortcut ? col_off(static_cast<const void*>(Y), 2 * (int64_t)H, storage) : x;
     const int64_t ld_res = has_shortcut ? ldy : ldx;
     if (storage == 0) {
@@ -175,7 +175,7 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
     void* red_ws = carve(p, red_bytes);
     void* tn_ws = p;
     const size_t tn_bytes = workspace_bytes - (size_t)(p - static_cast<char*>(workspace));
-    const int pb = bwd_split ? (prec_bwd | STIN_GEMM_W_PRESPLIT) : prec_bwd;
+    const int pb = bwd_split ? (prec_bwd | STIN_GEMM_W_PRESPLIT | (bwd_split & STIN_GEMM_W_FRAG)) : prec_bwd;
     hipStream_t hs = (hipStream_t)stream;
     // weight-gradient GEMMs are off the critical path dx <- g: with a wgrad_stream they run beside the edge-stage /
     // dx kernels of this block (and the head of the next one), ordered by the caller's events

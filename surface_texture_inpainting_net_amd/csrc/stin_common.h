@@ -20,6 +20,15 @@ static inline int stin_launch_status() {
     return e == hipSuccess ? STIN_OK : (int)e;
 }
 
+// Shapes whose pre-split NT weight operand is stored in MFMA fragment order under STIN_GEMM_W_FRAG (stin_hip.h), i.e. the
+// shapes the resident-strip kernel takes.  Layout constraints: K % 64 == 0, Nc % 32 == 0.  Selection (measured per shape on
+// MI355X, profiles/r02_gemm_shapes.md): one resident K chunk (K <= 256) with enough work per staged strip (K >= 128) and
+// at least 2.5 column panels (Nc >= 320) - 5-15 % faster there; narrower outputs leave waves of the 128-column panel idle,
+// longer K would add its chunks through memory, and both stay on the tiled kernel.
+__host__ __device__ static inline bool stin_w_frag_shape(int Nc, int K) {
+    return K % 64 == 0 && Nc % 32 == 0 && K >= 128 && K <= 256 && Nc >= 320;
+}
+
 static inline bool stin_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Lanes that cooperate on one feature row: smallest power of two >= ceil(C/4), capped at a wave.

@@ -12,6 +12,7 @@
 // A[i = l&31][k = l>>5], B operand B[k = l>>5][j = l&31]; C/D reg r of lane l is
 // row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
 #include <cstdlib>
+#include <type_traits>
 #include "stin_common.h"
 
 namespace {
@@ -377,6 +378,259 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
                                          (res != nullptr ? res[row * ld_res + col] : 0.f);
             }
         }
+    }
+}
+
+// ------------------------------------------------------------ NT, split 16-bit, resident row strip
+// The tall-skinny shapes of this network (M = 1e4..1e6 rows, K <= 1280, Nc <= 1280) spend their time moving operands, not
+// multiplying: with 64x64 output tiles every A tile is fetched from L2 and split into its 16-bit pieces once per COLUMN
+// block (16 times at Nc = 1024), every block pays a load-latency prologue for 8 k-steps of work, and a per-k-step barrier
+// keeps the waves of a block in lock-step.  This kernel turns the loop nest around:
+//   * a block of 4 waves owns a STRIP of 64 rows and keeps the split A strip (one K chunk of <= 256) resident in LDS: every A
+//     element crosses the fabric once per strip and is split once (64 KB at K = 256: two blocks per CU, one stages while
+//     the other multiplies).  LDS image: [piece][k-step of 16][row][2 x 16 B], the two 16-byte k-halves of a row swapped
+//     for rows with bit 3 set - conflict-free ds_read_b128 fragments whose address is ONE per-lane register plus immediates;
+//   * the weight operand comes pre-split in MFMA FRAGMENT ORDER (STIN_GEMM_W_FRAG, stin_pack.hip): the B fragment of a
+//     32-column tile and 16-wide k-step is 2 KB contiguous, lane l's 32 bytes = [hi x 8 | lo x 8], so each wave fetches its
+//     own fragments straight from L2 into registers with two fully coalesced 16-byte loads per lane (scalar base + lane
+//     offset) - no LDS staging, no barrier: wave w computes columns [32 w, 32 w + 32) of a 128-column panel for all 64
+//     rows (2 accumulator tiles, 6 MFMAs per fragment), and the waves run free of each other until the strip changes;
+//   * the fragment loads are a 4-deep register ring inside a panel (a fragment is requested 4 k-steps = 24 MFMAs before its
+//     use); what a wave cannot hide at a panel or strip boundary the second block on the CU does;
+//   * work = (strip, 128-column panel) units in strip-major order, dealt to a grid sized to the chip (blocks resident at
+//     once) in contiguous ranges: every block gets the same number of units +-1, a range that crosses a strip boundary
+//     stages two strips.  M = 18 063 rows no longer means "283 row tiles on 256 CUs".
+// K longer than the resident chunk is processed chunk by chunk: the first chunk stores C, later chunks add to it.
+// Same arithmetic, same k order and same epilogue expression as k_gemm_nt_bf16s<.., NS = 2, .., WPRE = true>: bit-identical
+// results while K fits one chunk (tests/test_hip_parity.py::test_gemm_nt_strip_kernel_equals_tiled_kernel).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int ST_MT = 2;                            // 32-row MFMA tiles per wave: strips of 64 rows
+constexpr int ST_BM = 32 * ST_MT, ST_PANEL = 128, ST_THREADS = 256, ST_RING = 4;
+constexpr int ST_STEP_BYTES = ST_BM * 32;           // LDS bytes of one piece of one k-step (64 rows x 32 B)
+
+// fragment of one k-step: 2 x 16 bytes per lane at base + lane * 32 (base wave-uniform -> scalar registers)
+struct StFrag {
+    u32x4 hi, lo;
+};
+__device__ __forceinline__ StFrag st_wload(const unsigned char* base, unsigned lane_off) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(base + lane_off);
+    StFrag f;
+    f.hi = p[0];
+    f.lo = p[1];
+    return f;
+}
+
+template <typename PT>
+__global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __restrict__ A, int64_t lda,
+                                                              const float* __restrict__ Wf,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ row_mask, int64_t ld_mask,
+                                                              const float* __restrict__ res, int64_t ld_res, int64_t M,
+                                                              int Nc, int K, float* __restrict__ C, int64_t ldc, int KC,
+                                                              int64_t units, int P) {
+    typedef typename PieceTraits<PT>::vec8 vec8;
+    constexpr float ASCALE = PieceTraits<PT>::ascale, WSCALE = PieceTraits<PT>::wscale;
+    constexpr int BM = ST_BM, MT = ST_MT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
+    const int plane_bytes = (KC / 16) * ST_STEP_BYTES;                    // one piece of the resident chunk
+    float* bias_s = reinterpret_cast<float*>(strip_smem + 2 * plane_bytes);   // [Nc rounded up to 128]
+    float* mask_s = bias_s + P * ST_PANEL;                                // [BM]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform: the sequence logic stays scalar
+    const int kh = lane >> 5, li = lane & 31;
+    const int kq = tid & 7, r0 = tid >> 3;                                // staging: float4 index along k, first row (32 rows per pass)
+    const int KS_total = K / 16;                                          // k-steps of the whole K (K is a multiple of 64)
+    const int nchunk = (K + KC - 1) / KC;
+
+    const int64_t u0 = (int64_t)blockIdx.x * units / gridDim.x, u1 = (int64_t)(blockIdx.x + 1) * units / gridDim.x;
+    if (u0 >= u1) return;
+    for (int c = tid; c < P * ST_PANEL; c += ST_THREADS) bias_s[c] = (bias != nullptr && c < Nc) ? bias[c] : 0.f;
+
+    // ---- the sequence of (strip, chunk, panel) this block walks
+    struct Seq {
+        int64_t u, s;        // first unit of the current strip segment, strip index
+        int pa, pb;          // panels [pa, pb) of that strip
+        int c, p;            // chunk, panel
+        bool live;
+    };
+    auto ks_of = [&](int c) { const int len = K - c * KC; return (len < KC ? len : KC) / 16; };
+    auto seq_begin = [&]() {
+        Seq q;
+        q.u = u0;
+        q.s = u0 / P;
+        q.pa = (int)(u0 % P);
+        q.pb = (u1 - u0 < P - q.pa) ? q.pa + (int)(u1 - u0) : P;
+        q.c = 0;
+        q.p = q.pa;
+        q.live = true;
+        return q;
+    };
+    auto seq_next_panel = [&](Seq& q) {          // live = false at the end of the block's range
+        if (++q.p < q.pb) return;
+        q.p = q.pa;
+        if (++q.c < nchunk) return;
+        q.c = 0;
+        q.u += q.pb - q.pa;
+        if (q.u >= u1) {
+            q.live = false;
+            return;
+        }
+        ++q.s;
+        q.pa = 0;
+        q.pb = (u1 - q.u < P) ? (int)(u1 - q.u) : P;
+        q.p = 0;
+    };
+    auto frag_base = [&](const Seq& q) {         // first fragment of the panel's chunk for this wave's column tile (uniform)
+        int tile = q.p * 4 + wave;
+        if (tile * 32 >= Nc) tile = Nc / 32 - 1;                          // (a panel past Nc: fetch something valid, store nothing)
+        return reinterpret_cast<const unsigned char*>(Wf) + ((int64_t)tile * KS_total + q.c * (KC / 16)) * 2048;
+    };
+    const unsigned lane_off = (unsigned)lane * 32u;
+
+    Seq run = seq_begin();
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // A fragment of (row tile i, k-step ks, piece p): a_frag + p * plane_bytes + ks * ST_STEP_BYTES + i * 1024
+    const unsigned char* a_frag = strip_smem + li * 32 + ((kh ^ ((li >> 3) & 1)) << 4);
+    int staged_c = -1;
+    int64_t staged_s = -1;
+    while (run.live) {
+        // ---- (strip, chunk) changed: every wave is done with the old strip -> stage the new one (split once)
+        if (run.s != staged_s || run.c != staged_c) {
+            __syncthreads();
+            const int KTc = ks_of(run.c) / 2;
+            for (int kt0 = 0; kt0 < KTc; kt0 += 4) {    // four k-tiles (4 x MT float4 per thread) in flight
+                float4 ra[4][MT];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int ktc = kt0 + h < KTc ? kt0 + h : KTc - 1;
+                    const int k = run.c * KC + ktc * 32 + kq * 4;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        const int64_t row = run.s * BM + r0 + t * 32;
+                        const float4 v = ld4(A + (row < M ? row : M - 1) * lda + k);
+                        ra[h][t] = row < M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    if (kt0 + h >= KTc) break;
+                    const int ks = (kt0 + h) * 2 + (kq >> 2), kh_ = (kq >> 1) & 1;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        const int row = r0 + t * 32;
+                        PT* dst = reinterpret_cast<PT*>(strip_smem + ks * ST_STEP_BYTES + row * 32 + ((kh_ ^ ((row >> 3) & 1)) << 4) + (kq & 1) * 8);
+                        split_store<2, PT>(ra[h][t], dst, plane_bytes / 2, ASCALE);
+                    }
+                }
+            }
+            if (row_mask != nullptr && tid < BM) {
+                const int64_t row = run.s * BM + tid;
+                mask_s[tid] = row_mask[(row < M ? row : M - 1) * ld_mask];
+            }
+            staged_s = run.s;
+            staged_c = run.c;
+            __syncthreads();
+        }
+        // ---- one panel: groups of ST_RING k-steps, 3 MT MFMAs per step; the ring slot a step has consumed is refilled with
+        // the fragment ST_RING steps further along.  The ring does not reach across panels: a wave stalls once per panel
+        // on its first fragments (and on its last panel's stores, which are older in the in-order memory queue) while the
+        // other wave of the SIMD - the CU holds two blocks - keeps the matrix pipe busy.
+        const int G = ks_of(run.c) / ST_RING;
+        const unsigned char* wrun = frag_base(run);
+        StFrag wf[ST_RING];
+#pragma unroll
+        for (int j = 0; j < ST_RING; ++j) wf[j] = st_wload(wrun + j * 2048, lane_off);
+        auto kgroup = [&](const unsigned char* ag, const unsigned char* fetch, auto REFILL) {
+#pragma unroll
+            for (int j = 0; j < ST_RING; ++j) {
+                vec8 a0[MT], a1[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    a0[i] = *reinterpret_cast<const vec8*>(ag + j * ST_STEP_BYTES + i * 1024);
+                    a1[i] = *reinterpret_cast<const vec8*>(ag + plane_bytes + j * ST_STEP_BYTES + i * 1024);
+                }
+                const vec8 b0 = __builtin_bit_cast(vec8, wf[j].hi), b1 = __builtin_bit_cast(vec8, wf[j].lo);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    acc[i] = mfma_k16(a0[i], b1, acc[i]);
+                    acc[i] = mfma_k16(a1[i], b0, acc[i]);
+                    acc[i] = mfma_k16(a0[i], b0, acc[i]);
+                }
+                if (decltype(REFILL)::value) wf[j] = st_wload(fetch + j * 2048, lane_off);
+            }
+        };
+        for (int g = 0; g + 1 < G; ++g)
+            kgroup(a_frag + g * (ST_RING * ST_STEP_BYTES), wrun + (g + 1) * (ST_RING * 2048), std::true_type());
+        kgroup(a_frag + (G - 1) * (ST_RING * ST_STEP_BYTES), wrun, std::false_type());
+        // ---- epilogue of the panel's chunk
+        const int col0 = run.p * ST_PANEL + wave * 32;                    // wave-uniform
+        const bool tile_ok = col0 < Nc;                                   // Nc is a multiple of 32: a whole tile is in or out
+        const bool full_rows = (run.s + 1) * BM <= M;
+        const float sc = 1.f / (ASCALE * WSCALE);
+        if (run.c == 0 && res == nullptr && tile_ok && full_rows) {
+            // the common case loads nothing: 32 stores, row base pointers wave-uniform (scalar), the lane's offset one register
+            const float bv = bias_s[col0 + li];
+            float* cbase = C + run.s * BM * ldc + col0;
+            const unsigned coff = (unsigned)(4 * kh) * (unsigned)ldc + (unsigned)li;
+            if (row_mask != nullptr) {
+                float mk[MT][16];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mk[i][r] = mask_s[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* rp = cbase + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc;
+                        rp[coff] = acc[i][r] * sc + bv * mk[i][r] + 0.f;
+                        acc[i][r] = 0.f;
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* rp = cbase + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc;
+                        rp[coff] = acc[i][r] * sc + bv + 0.f;
+                        acc[i][r] = 0.f;
+                    }
+            }
+        } else {
+            // partial strip / tile past Nc / residual / later K chunk: every load first (clamped addresses), then the stores
+            const int col = col0 + li;
+            const int cc = tile_ok ? col : 0;
+            const float bv = bias_s[cc];
+            float ld[MT][16];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = run.s * BM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int64_t rc = row < M ? row : M - 1;
+                    ld[i][r] = run.c > 0 ? C[rc * ldc + cc] : (res != nullptr ? res[rc * ld_res + cc] : 0.f);
+                }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int64_t row = run.s * BM + lr;
+                    float v;
+                    if (run.c == 0) v = acc[i][r] * sc + (row_mask != nullptr ? bv * mask_s[lr] : bv) + ld[i][r];
+                    else v = ld[i][r] + acc[i][r] * sc;                   // later K chunk: add to what this lane stored before
+                    if (row < M && tile_ok) C[row * ldc + col] = v;
+                    acc[i][r] = 0.f;
+                }
+        }
+        seq_next_panel(run);
     }
 }
 
@@ -1172,6 +1426,16 @@ inline int stin_nt_force_tile() {
     return e ? atoi(e) : 0;
 }
 
+inline int stin_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 inline int tn_rows_per_chunk(int64_t M, int tiles) {
     // ~512 blocks (2 resident per CU, one round; measured best of 256..1536), chunks a multiple of the LDS slab
     static const int target = getenv("STIN_TN_BLOCKS") ? atoi(getenv("STIN_TN_BLOCKS")) : 512;   // tuning aid
@@ -1194,7 +1458,8 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
     STIN_REQUIRE(residual == nullptr || ld_res >= Nc, STIN_E_SIZE);
     const bool wpre = (precision & STIN_GEMM_W_PRESPLIT) != 0;
-    precision &= ~STIN_GEMM_W_PRESPLIT;
+    const bool wfrag = wpre && (precision & STIN_GEMM_W_FRAG) != 0 && stin_w_frag_shape(Nc, K);
+    precision &= ~(STIN_GEMM_W_PRESPLIT | STIN_GEMM_W_FRAG);
     STIN_REQUIRE(precision == STIN_GEMM_F32 || precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6 ||
                      precision == STIN_GEMM_F16X3,
                  STIN_E_UNSUPPORTED);
@@ -1224,7 +1489,35 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
         else if (force_tile == 2) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);  \
         else STIN_NT(KERNEL, 64, 64, 2, 2, ##__VA_ARGS__);                                     \
     } while (0)
-    if (wpre) {
+    if (wfrag) {
+        // resident-strip kernel (k_gemm_nt_strip): the fragment-order weight operand cannot be read by any other kernel
+        STIN_REQUIRE(vec && ldc % 4 == 0 && stin_aligned16(C) && (residual == nullptr || (ld_res % 4 == 0 && stin_aligned16(residual))),
+                     STIN_E_ALIGN);
+        const int KC = K < 256 ? K : 256;                             // resident K chunk: 64 rows x 256 k x 4 B = 64 KB -> 2 blocks per CU
+        const int P = (Nc + ST_PANEL - 1) / ST_PANEL;
+        const size_t lds = (size_t)2 * (KC / 32) * ST_BM * 64 + (size_t)P * ST_PANEL * 4 + ST_BM * 4;
+        const int64_t units = ((M + ST_BM - 1) / ST_BM) * P;
+        int occ = (int)(160 * 1024 / lds);
+        if (occ > 8) occ = 8;
+        if (occ < 1) occ = 1;
+        const char* e_occ = getenv("STIN_STRIP_OCC");                 // tuning aid
+        if (e_occ && atoi(e_occ) > 0) occ = atoi(e_occ);
+        int64_t grid = (int64_t)stin_cu_count() * occ;
+        if (grid > units) grid = units;
+#define STIN_STRIP(PT_)                                                                                                   \
+    do {                                                                                                                  \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set) {                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_strip<PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((k_gemm_nt_strip<PT_>), dim3((unsigned)grid), dim3(ST_THREADS), lds, stream, A, lda, W, bias, row_mask, \
+                           ld_mask, residual, ld_res, M, Nc, K, C, ldc, KC, units, P);                                   \
+    } while (0)
+        if (precision == STIN_GEMM_BF16X3) STIN_STRIP(__bf16);
+        else STIN_STRIP(_Float16);
+#undef STIN_STRIP
+    } else if (wpre) {
         // pre-split W: the 16-byte vector path only (K % 4 == 0, aligned rows) - one tile shape, the data is per-network
         STIN_REQUIRE(vec, STIN_E_ALIGN);
         if (force_tile == 1 || (force_tile == 0 && big_tile)) {

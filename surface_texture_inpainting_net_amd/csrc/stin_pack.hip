@@ -10,7 +10,29 @@ constexpr int BLOCK = 256;
 // kernel would otherwise compute for every block that stages the tile.  Same footprint as fp32: the 16 bytes of the
 // k-group 4g..4g+3 of a row hold [hi x 4 | lo x 4]; piece type / pre-scale as in stin_gemm.hip (fp16: x 64, bf16: x 1).
 // mode 0 = plain fp32; STIN_GEMM_W_BF16 = plain bf16 (the weight operand of the bf16-storage GEMMs).
-__device__ __forceinline__ void put_weight(float* __restrict__ base, int64_t row_off, int c, float v, int mode) {
+// With STIN_GEMM_W_FRAG in `mode` and a shape the strip kernel takes (nc rows, kk columns: stin_w_frag_shape) the two pieces go to
+// the MFMA fragment order documented at STIN_GEMM_W_FRAG in stin_hip.h instead (r = the element's row).
+__device__ __forceinline__ void put_weight(float* __restrict__ base, int64_t row_off, int c, float v, int mode, int r = 0,
+                                           int nc = 0, int kk = 0) {
+    if ((mode & STIN_GEMM_W_FRAG) && stin_w_frag_shape(nc, kk)) {
+        const int prec = mode & ~STIN_GEMM_W_FRAG;
+        const int64_t lane_slot = ((int64_t)(r >> 5) * (kk >> 4) + (c >> 4)) * 64 + ((c >> 3) & 1) * 32 + (r & 31);
+        uint16_t* h = reinterpret_cast<uint16_t*>(base) + lane_slot * 16 + (c & 7);
+        if (prec == STIN_GEMM_F16X3) {
+            const float s = v * 64.f;
+            const _Float16 hi = (_Float16)s;
+            const _Float16 lo = (_Float16)(s - (float)hi);
+            h[0] = *reinterpret_cast<const uint16_t*>(&hi);
+            h[8] = *reinterpret_cast<const uint16_t*>(&lo);
+        } else {
+            const __bf16 hi = (__bf16)v;
+            const __bf16 lo = (__bf16)(v - (float)hi);
+            h[0] = *reinterpret_cast<const uint16_t*>(&hi);
+            h[8] = *reinterpret_cast<const uint16_t*>(&lo);
+        }
+        return;
+    }
+    mode &= ~STIN_GEMM_W_FRAG;
     if (mode == 0) {
         base[row_off + c] = v;
         return;
@@ -39,7 +61,7 @@ __global__ void k_split_weights(const float* __restrict__ W, int64_t ldw, int Nc
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)Nc * K) return;
     const int r = (int)(t / K), c = (int)(t % K);
-    put_weight(out, (int64_t)r * ldo, c, W[(int64_t)r * ldw + c], mode);
+    put_weight(out, (int64_t)r * ldo, c, W[(int64_t)r * ldw + c], mode, r, Nc, K);
 }
 
 // wcat [Yw, Cin] = [Wa - Wb ; Wb ; Ws]   (trans_inv: [-W1 ; W1 ; Ws]),  bcat [Yw] = [b1 ; 0 ; bs],
@@ -63,15 +85,15 @@ __global__ void k_pack(const float* __restrict__ W1, const float* __restrict__ b
             else if (r < 2 * H) v = trans_inv ? W1[(int64_t)(r - H) * ld1 + c] : W1[(int64_t)(r - H) * ld1 + Cin + c];
             else v = Ws[(int64_t)(r - 2 * H) * Cin + c];
         }
-        put_weight(wcat, (int64_t)r * Cp, c, v, fwd_mode);
-        put_weight(wcatT, (int64_t)c * Yw, r, v, bwd_mode);
+        put_weight(wcat, (int64_t)r * Cp, c, v, fwd_mode, r, Yw, Cp);
+        put_weight(wcatT, (int64_t)c * Yw, r, v, bwd_mode, c, Cp, Yw);
         if (c == 0) bcat[r] = r < H ? (b1 != nullptr ? b1[r] : 0.f) : (r < 2 * H ? 0.f : (bs != nullptr ? bs[r - 2 * H] : 0.f));
     } else if (t < n_w + n_2) {
         const int64_t u = t - n_w;
         const int k = (int)(u / Cout), o = (int)(u % Cout);      // w2T[k][o] = W2[o][k]
         const float v = W2[(int64_t)o * H + k];
-        put_weight(w2T, (int64_t)k * Cout, o, v, bwd_mode);
-        if (w2s != nullptr) put_weight(w2s, (int64_t)o * H, k, v, fwd_mode);
+        put_weight(w2T, (int64_t)k * Cout, o, v, bwd_mode, k, H, Cout);
+        if (w2s != nullptr) put_weight(w2s, (int64_t)o * H, k, v, fwd_mode, o, Cout, H);
     }
 }
 
@@ -129,7 +151,13 @@ __global__ void k_norm_coef_m_quirk(const float* __restrict__ S0, const float* _
 }
 }  // namespace
 
-static inline bool split_mode_ok(int m) { return m == 0 || m == STIN_GEMM_BF16X3 || m == STIN_GEMM_F16X3; }
+static inline bool split_mode_ok(int m) {
+    if (m == 0) return true;
+    m &= ~STIN_GEMM_W_FRAG;
+    return m == STIN_GEMM_BF16X3 || m == STIN_GEMM_F16X3;
+}
+
+extern "C" int stin_gemm_w_is_frag(int Nc, int K) { return stin_w_frag_shape(Nc, K) ? 1 : 0; }
 
 extern "C" int stin_gemm_split_weights_f32(const float* W, int64_t ldw, int Nc, int K, int precision, float* out, int64_t ldo,
                                            stin_stream_t stream_) {

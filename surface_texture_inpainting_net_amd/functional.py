@@ -257,6 +257,9 @@ PREC_NAMES = {GEMM_F32: 'fp32', GEMM_BF16X3: 'bf16x3', GEMM_BF16X6: 'bf16x6', GE
 PREC_FWD = int(os.environ.get('STIN_GEMM_FWD', GEMM_F16X3))
 PREC_BWD = int(os.environ.get('STIN_GEMM_BWD', GEMM_BF16X3))
 GEMM_W_PRESPLIT = 0x100            # nt: the weight operand already holds its two 16-bit pieces (stin_hip.h)
+# pre-split operands in MFMA fragment order where the shape allows (stin_hip.h STIN_GEMM_W_FRAG): what the resident-strip NT
+# kernel reads.  STIN_NT_STRIP=0 keeps the k-group layout and with it the tiled kernel (A/B aid).
+GEMM_W_FRAG = 0x400 if os.environ.get('STIN_NT_STRIP', '1') != '0' else 0
 WEIGHT_PRESPLIT = os.environ.get('STIN_WEIGHT_PRESPLIT', '1') != '0'
 # one C call per GraphResnetBlock and direction (stin_edgeconv_block_fwd/bwd enqueue the same kernels in the same order
 # as the per-kernel path below): removes ~25 Python-level foreign calls per block.  STIN_BLOCK_CALL=0 = per-kernel path.
@@ -307,7 +310,8 @@ def _gemm_nt_bf16(A, W, bias, out, row_mask, residual, out_dtype):
 
 
 def split_weights(W, precision):
-    """fp32 W [Nc, K] -> the STIN_GEMM_W_PRESPLIT form for `precision` (GEMM_BF16X3 or GEMM_F16X3), same shape."""
+    """fp32 W [Nc, K] -> the STIN_GEMM_W_PRESPLIT form for `precision` (GEMM_BF16X3 or GEMM_F16X3, optionally
+    | GEMM_W_FRAG: fragment order where the shape allows - pass the same flag to gemm_nt), same shape."""
     W, ldw = _mat(W)
     out = torch.empty_like(W, memory_format=torch.contiguous_format)
     _call('stin_gemm_split_weights_f32', _ptr(W), ldw, W.shape[0], W.shape[1], int(precision), _ptr(out), W.shape[1],
@@ -557,8 +561,8 @@ class EdgeConvBlockFn(torch.autograd.Function):
             xp = x
         # forward / backward weight operands, pre-split once here into the two 16-bit pieces the split GEMMs use
         # (instead of once per GEMM block); plain fp32 for the other precisions and for bf16-storage activations
-        fsp = prec_fwd if (not b16 and prec_fwd in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT) else 0
-        bsp = PREC_BWD if (not b16 and PREC_BWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT and Cout % 4 == 0) else 0
+        fsp = (prec_fwd | GEMM_W_FRAG) if (not b16 and prec_fwd in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT) else 0
+        bsp = (PREC_BWD | GEMM_W_FRAG) if (not b16 and PREC_BWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT and Cout % 4 == 0) else 0
         fast = (USE_BLOCK_CALL and USE_EDGE_MASK and edge_mask_supported(H) and N > 1
                 and not KernelTimer.enabled)          # (the bench's per-kernel HIP-event brackets need the per-kernel path)
         ctx.fast = fast
@@ -602,7 +606,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         _call('stin_edgeconv_pack_f32', _ptr(W1c), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2c), Cin, Cp, H, Cout,
               int(has_shortcut), int(trans_inv), _ptr(wcat), _ptr(bcat), _ptr(wcatT), _ptr(w2T), _ptr(w2s) if fsp else None,
               fsp, bsp, _stream(x))
-        pf = (prec_fwd | GEMM_W_PRESPLIT) if fsp else prec_fwd
+        pf = (prec_fwd | GEMM_W_PRESPLIT | GEMM_W_FRAG) if fsp else prec_fwd
         Y = gemm_nt(xp, wcat, bcat, precision=pf)
         hE = torch.empty(N, H + pad, dtype=x.dtype, device=dev)     # [h | (deg > 0) | pad]: rows stay 16-byte multiples
         # ReLU decisions as bits (E*H/8 bytes): backward then needs no recompute gathers
@@ -622,7 +626,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut, ctx.trans_inv = edges, groups, H, has_shortcut, trans_inv
         ctx.has_b1, ctx.has_b2, ctx.has_bs = b1 is not None, b2 is not None, bs is not None
         ctx.w1_shape = tuple(W1.shape)
-        ctx.prec_bwd_nt = (PREC_BWD | GEMM_W_PRESPLIT) if bsp else PREC_BWD
+        ctx.prec_bwd_nt = (PREC_BWD | GEMM_W_PRESPLIT | GEMM_W_FRAG) if bsp else PREC_BWD
         ctx.bsp = bsp
         return out
 

@@ -230,6 +230,43 @@ def test_gemm_nt_precision_modes(M, Nc, K):
     assert float((tiny - (want - b.double())).abs().max()) / scale <= 2e-5
 
 
+@pytest.mark.parametrize('M,Nc,K', [(1, 320, 128), (37, 320, 192), (300, 352, 128), (4097, 320, 128), (5000, 1024, 256), (18063, 640, 256),
+                                    (2500, 1280, 128), (64, 384, 256), (129, 1024, 128), (777, 1280, 256), (2049, 96, 576),
+                                    (130, 64, 36), (1000, 256, 640), (3001, 128, 320)])
+def test_gemm_nt_strip_kernel_equals_tiled_kernel(M, Nc, K):
+    """The resident-strip NT kernel (k_gemm_nt_strip: 64-row strips resident in LDS, weight fragments straight from L2 in
+    MFMA fragment order, unit ranges) against the tiled kernel on the k-group layout: same arithmetic in the same order ->
+    bit-identical.  Shapes the strip kernel does not take (stin_gemm_w_is_frag) keep the k-group layout and the tiled
+    kernel under the same flag.  Both against fp64."""
+    g = torch.Generator().manual_seed(M + Nc + K)
+    A = torch.randn(M + 3, K + 4, generator=g).to(DEV)[1:M + 1, :K]            # a strided view: lda != K
+    W = (torch.randn(Nc, K, generator=g) * 0.1).to(DEV)
+    b = torch.randn(Nc, generator=g).to(DEV)
+    mask = (torch.rand(M, 3, generator=g) < 0.7).float().to(DEV)[:, 1]
+    res = torch.randn(M, Nc, generator=g).to(DEV)
+    want = A.double() @ W.double().t()
+    scale = float(want.abs().max()) + 1.0
+    FR = 0x400
+    frag = K % 64 == 0 and Nc % 32 == 0 and 128 <= K <= 256 and Nc >= 320
+    assert bool(_lib_load().stin_gemm_w_is_frag(Nc, K)) == frag
+    for prec in (SF.GEMM_F16X3, SF.GEMM_BF16X3):
+        Wk, Wf = SF.split_weights(W, prec), SF.split_weights(W, prec | FR)
+        assert torch.equal(Wk, Wf) == (not frag)
+        for kw in (dict(), dict(bias=b), dict(bias=b, row_mask=mask), dict(residual=res), dict(bias=b, residual=res)):
+            tiled = SF.gemm_nt(A, Wk, precision=prec | SF.GEMM_W_PRESPLIT, **kw)
+            for _ in range(2):                                  # twice: the ring / unit logic must not depend on what ran before
+                strip = SF.gemm_nt(A, Wf, precision=prec | SF.GEMM_W_PRESPLIT | FR, **kw)
+                assert torch.equal(strip, tiled), (prec, sorted(kw))
+        ref = want + b.double() * mask.double()[:, None]
+        tol = 3e-6 if prec == SF.GEMM_F16X3 else 2e-5
+        assert float((SF.gemm_nt(A, Wf, b, row_mask=mask, precision=prec | SF.GEMM_W_PRESPLIT | FR).double() - ref).abs().max()) <= tol * scale
+
+
+def _lib_load():
+    from surface_texture_inpainting_net_amd import _lib
+    return _lib.load()
+
+
 def test_gemm_nt_on_strided_views_and_linear_autograd():
     g = torch.Generator().manual_seed(3)
     big = torch.randn(500, 200, generator=g).to(DEV)
