@@ -367,6 +367,68 @@ def g10_singleconvmeshnet():
         print('g10_singleconvmeshnet', pooling, 'loss', float(loss), 'params', sum(p.numel() for p in net.parameters()))
 
 
+def g11_scene_reader():
+    """the reference's OWN reader.  A synthetic scene is written in the on-disk schema of
+    preprocessing/graph_level_generation.py:492-536 (graphs/<scene>.pt, masks/<name>/<scene>/<id>.npz) and read back by
+    ScanNetGraphColorDataSet.__getitem__ (datasets/scannetcolorgraph_dataloader.py:83-156, with the config's
+    CoordsNormalization transform) - as a full validation scene and as a training crop (the two trace conventions,
+    :124-128).  The fixture holds the file CONTENT (the saved tensors) and the sample the reference assembled from it."""
+    import tempfile
+    from surface_texture_inpainting_net_amd.scene_io import save_scene_like_reference
+    mod = ref_import.load_scannet_color_dataset_module()
+    import transform
+    d = {}
+    with tempfile.TemporaryDirectory() as root:
+        for tag, is_train, dil in (('full', False, (2, 4, 8)), ('crop', True, (2,))):
+            s = make_synthetic_mesh(350, 3, seed=11 + is_train, dilations=(2, 4) if not is_train else (2,))
+            scene = 'scene0042_00' if not is_train else 'scene0042_00_3'
+            os.makedirs(os.path.join(root, 'graphs'), exist_ok=True)
+            os.makedirs(os.path.join(root, 'masks', 'rand', scene), exist_ok=True)
+            gp = os.path.join(root, 'graphs', scene + '.pt')
+            mp = os.path.join(root, 'masks', 'rand', scene, '7.npz')
+            save_scene_like_reference(s, gp, mp, dilation_dists=dil)       # dist 8 empty -> the reader's fall-back (:143-145)
+            saved = torch.load(gp, weights_only=False)
+            if is_train:                                                    # crops carry no trace to the original mesh (:124-126)
+                saved['traces'] = saved['traces'][1:]
+                torch.save(saved, gp)
+            ds = object.__new__(mod.ScanNetGraphColorDataSet)               # the index (glob over ScanNet split files) is not under test
+            ds._root_dir, ds._mask_name, ds._end_level = root, 'rand', 3
+            ds._is_train, ds._no_train_cropped = is_train, False
+            ds._transform = [transform.CoordsNormalization([1.5, 1.5, 1.5])]
+            ds._transform = (lambda ts: (lambda smp: [smp := t(smp) for t in ts][-1]))(ds._transform)
+            ds.index2filenames = np.asarray([scene])
+            ds.index2maskfilenames = [{7: '7.npz'}]
+            smp = ds[0]
+            assert smp.name == scene
+            for k in smp.keys:
+                v = smp[k]
+                if torch.is_tensor(v):
+                    d['%s.s.%s' % (tag, k)] = _np(v)
+            for k in ('vertices', 'edges', 'traces'):
+                for i, v in enumerate(saved[k]):
+                    d['%s.f.%s.%d' % (tag, k, i)] = _np(v)
+            for lvl, sets in enumerate(saved['dilated_edges']):
+                if sets is not None:
+                    for i, v in enumerate(sets):
+                        d['%s.f.dil.%d.%d' % (tag, lvl, i)] = _np(v) if torch.is_tensor(v) else np.zeros((0, 2), dtype=np.int64)
+            d['%s.f.dilation_dists' % tag] = np.asarray(saved['dilation_dists'])
+            with open(mp, 'rb') as f:
+                d['%s.f.vertex_mask' % tag] = np.load(f, allow_pickle=True)['vertex_mask']
+    np.savez_compressed(os.path.join(OUT, 'g11_scene_reader.npz'), **d)
+    print('g11_scene_reader', len(d), 'arrays')
+
+
+def g12_batchnorm_step(stin, trainer_mod):
+    """norm='batch' (models/surfacetextureinpaintingnet.py:236-241) through one REAL training step of the reference:
+    forward + backward run the checkpointed encoder / bottleneck / decoder blocks twice (:429, :438, :451, :454), so their
+    BatchNorm running statistics are updated twice and num_batches_tracked ends at 2 (bottleneck momentum sqrt(0.1),
+    :496-499); the fixture's post-step state_dict (sd1.*) pins exactly that, plus output, loss, gradients, Adam update."""
+    s = make_synthetic_mesh(420, 3, seed=12, dilations=(2,))
+    cfg = dict(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconvtransinv', norm='batch', n_blocks=2, n_levels=2,
+               pooling_type='max', dilations=[1, 2], checkpoint_bottleneck=True)
+    _model_fixture('g12_batchnorm_step', stin, trainer_mod, cfg, s, seed=1212, adam_step=True)
+
+
 def param_counts(stin):
     """The structural constants SURVEY.md §8(c) records."""
     out = {}
@@ -397,6 +459,8 @@ def main():
     g8_metrics()
     g9_preprocessing()
     g10_singleconvmeshnet()
+    g11_scene_reader()
+    g12_batchnorm_step(stin, trainer_mod)
     param_counts(stin)
 
 

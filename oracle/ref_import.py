@@ -115,3 +115,31 @@ def load_trainer3d_module():
     _stub('termcolor', colored=lambda s, *a, **k: s)
     _stub('git', Repo=object)
     return importlib.import_module('trainers.inpainting3d_trainer')
+
+
+def load_scannet_color_dataset_module():
+    """-> datasets.scannetcolorgraph_dataloader (the reference's 3-D inpainting dataset) under stubs for the libraries it
+    imports but __getitem__ does not use (open3d, torchvision, easydict, PyG loaders); `transform` is the reference's own
+    package (CoordsNormalization is applied to the sample), `utils.data_utils.HierarchicalData` its own sample class."""
+    setup()
+    class _Easy(dict):
+        __getattr__ = dict.get
+    _stub('open3d')
+    _stub('termcolor', colored=lambda s, *a, **k: s)
+    _stub('git', Repo=object)
+    tv = _stub('torchvision')
+    tv.transforms = _stub('torchvision.transforms', Compose=lambda ts: ts)
+    _stub('easydict', EasyDict=_Easy)
+    import torch_geometric.data as tgd
+    if not hasattr(tgd, 'DataListLoader'):
+        tgd.DataListLoader = object
+    if 'transform' not in sys.modules:
+        m = types.ModuleType('transform')
+        m.__path__ = [os.path.join(REFERENCE_ROOT, 'transform')]
+        sys.modules['transform'] = m
+        for f in ('coords_normalization',):
+            sub = importlib.import_module('transform.' + f)
+            for k, v in sub.__dict__.items():
+                if not k.startswith('_'):
+                    setattr(m, k, v)
+    return importlib.import_module('datasets.scannetcolorgraph_dataloader')

@@ -178,8 +178,12 @@ class OracleBlock(nn.Module):
     """GraphResnetBlock, models/surfacetextureinpaintingnet.py:474-521: one conv ->
     norm -> ELU, residual add with a Linear shortcut when Cin != Cout."""
 
-    def __init__(self, cin, cout, filter_type, norm, first=False, is_checkpointed=False):
+    def __init__(self, cin, cout, filter_type, norm, first=False, is_checkpointed=False, recomputed=False):
         super().__init__()
+        # recomputed: the reference wraps this block in torch.utils.checkpoint (:429, :438, :451, :454), i.e. its forward
+        # runs a SECOND time inside backward.  Numerically that is a no-op except for BatchNorm's running statistics
+        # (norm='batch'): they are updated twice per training step (and num_batches_tracked += 2).
+        self.recomputed = recomputed
         self.first_filter = _Filter(cin, cout, filter_type, first)
         mom = math.sqrt(0.1) if (is_checkpointed and norm == 'batch') else 0.1
         self.first_norm = _Norm(norm, cout, mom)
@@ -188,7 +192,16 @@ class OracleBlock(nn.Module):
         self.cin, self.cout = cin, cout
 
     def forward(self, x, edge_index, batch=None):
-        out = F.elu(self.first_norm(self.first_filter(x, edge_index), batch))
+        conv = self.first_filter(x, edge_index)
+        if self.recomputed and self.first_norm.kind == 'batch' and self.training and conv.requires_grad:
+            detached = conv.detach()
+
+            def _recompute(grad, norm=self.first_norm, t=detached, b=batch):
+                with torch.no_grad():                               # the recompute pass of the reference's checkpoint, run
+                    norm(t, b)                                      # when backward reaches the block: statistics once more
+                return grad
+            conv.register_hook(_recompute)
+        out = F.elu(self.first_norm(conv, batch))
         if self.cin != self.cout:
             x = self.shortcut(x)
         return x + out
@@ -197,7 +210,8 @@ class OracleBlock(nn.Module):
 class OracleSTINet(nn.Module):
     """SurfaceTextureInpaintingNet, models/surfacetextureinpaintingnet.py:208-471,
     same constructor meaning and state_dict keys; activation checkpointing (:429,
-    :438, :451, :454) is a memory device with no numeric effect and is omitted."""
+    :438, :451, :454) is a memory device whose only numeric effect - BatchNorm running
+    statistics updated by the recompute pass too - is restated in OracleBlock."""
 
     def __init__(self, input_nc, output_nc, filter_type, ngf=64, norm_type='instance', n_blocks=6,
                  n_levels=2, n_repeated_io_convs=1, pooling_type='mean', checkpoint_bottleneck=False,
@@ -219,13 +233,15 @@ class OracleSTINet(nn.Module):
         enc = []
         for i in range(n_levels):                                                            # :316-325
             cin = ngf * 2 ** i + (num_embedding if (i == 0 and use_label_embedding) else 0)
-            enc.append(mk(cin, ngf * 2 ** (i + 1)))
+            enc.append(mk(cin, ngf * 2 ** (i + 1), recomputed=True))
         self.encoder_blocks = nn.ModuleList(enc)
         w = ngf * 2 ** n_levels
         self.bottleneck_blocks = nn.ModuleList(
-            [mk(w, w, is_checkpointed=checkpoint_bottleneck) for _ in range(n_blocks)])      # :327-331
+            [mk(w, w, is_checkpointed=checkpoint_bottleneck,
+                recomputed=checkpoint_bottleneck and (i + 1) % num_blocks_per_uncheckpointed_block == 0)
+             for i in range(n_blocks)])                                                      # :327-331, :433-440
         self.decoder_blocks = nn.ModuleList(
-            [mk(ngf * 2 ** (n_levels - i), ngf * 2 ** (n_levels - i) // 2) for i in range(n_levels)])  # :333-338
+            [mk(ngf * 2 ** (n_levels - i), ngf * 2 ** (n_levels - i) // 2, recomputed=True) for i in range(n_levels)])  # :333-338
         self.output_blocks = nn.ModuleList([mk(ngf, ngf) for _ in range(n_repeated_io_convs)])  # :342-352
         self.final_linear1 = nn.Linear(ngf, ngf)
         self.final_norm1 = _Norm(norm, ngf)

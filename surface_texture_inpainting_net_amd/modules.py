@@ -177,6 +177,58 @@ class FastInstanceNorm(nn.Module):
         return '{}({})'.format(self.__class__.__name__, self.num_features)
 
 
+class _GraphNormFn(torch.autograd.Function):
+    """y = w (x - a mu[g]) r[g] + b with mu = mean(x), r = 1/sqrt(mean(x^2) + eps) over the linspace row slices of the
+    reference (singlebatchgroupnorm.py:46-71) - forward and backward on the library's kernels: slice sums by
+    stin_colreduce (sum x; sum x^2 as CSQ around a zero mean), the affine normalisation as stin_norm_act_res_fwd with
+    per-group rows [a mu, w r] (+ the bias row), the backward reductions sum G (x - a mu), sum G by the DOT mode and
+    dx = (w r)[g] G + k[s] x + m[s] by stin_norm_act_bwd.  No [N, C] framework kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mean_scale, groups, eps):
+        x, _ = SF._mat(x)
+        n_rows, C = x.shape
+        B = groups.B
+        if B == 1:
+            inv_n = torch.full((1, 1), 1.0 / float(n_rows), device=x.device)
+        else:
+            inv_n = 1.0 / (groups.ptr_sum[1:] - groups.ptr_sum[:-1]).to(torch.float32).unsqueeze(1)
+        zero = torch.zeros(B, C, dtype=torch.float32, device=x.device)
+        mu = SF.colreduce(SF.RED_SUM, x, groups, groups.ptr_sum) * inv_n                    # [B, C] per slice
+        q = SF.colreduce(SF.RED_CSQ, x, groups, groups.ptr_sum, mean=zero) * inv_n          # sum x^2: CSQ around a zero mean
+        r = torch.rsqrt(q + eps)
+        m = (mu * mean_scale).contiguous()
+        wr = (r * weight).contiguous()
+        u = SF.norm_act_res_fwd(x, m, wr, groups, res=None, act=False)                      # (x - m[g]) * (w r)[g]
+        y = u.add_(bias)                                                                    # in place: one row broadcast
+        ctx.save_for_backward(x, weight, mean_scale, mu, r, m, wr, inv_n)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, G):
+        x, weight, mean_scale, mu, r, m, wr, inv_n = ctx.saved_tensors
+        groups = ctx.groups
+        G, _ = SF._mat(G)
+        zero = torch.zeros_like(r)
+        # per TRUE group (rows with gid == g): T1 = sum G (x - m[g]), S0 = sum G
+        T1, S0 = SF.colreduce(SF.RED_DOT_ELU, x, groups, groups.ptr_true, gout=G, mean=m, rstd=zero)
+        dbias = S0.sum(0)
+        dweight = (r * T1).sum(0)
+        dm = -(wr * S0)                                   # d/d(a mu[g])
+        dr = weight * T1
+        dscale = (dm * mu).sum(0)
+        dmu = dm * mean_scale
+        dq = -0.5 * r * r * r * dr
+        k = (2.0 * dq * inv_n).contiguous()               # applied through the SLICE id: the statistics ran over slices
+        mm = (dmu * inv_n).contiguous()
+        dx = torch.empty_like(x)
+        SF._call('stin_norm_act_bwd' + SF._sfx(x), SF._ptr(x), x.stride(0), SF._ptr(G), G.stride(0), SF._ptr(zero), SF._ptr(zero),
+                 SF._ptr(wr), SF._ptr(k), SF._ptr(mm), SF._ptr(groups.gid), SF._ptr(groups.sid), x.shape[0], x.shape[1], 0,
+                 SF._ptr(dx), dx.stride(0), SF._stream(x))
+        return dx, dweight, dbias, dscale, None, None
+
+
 class SingleBatchGraphNorm(nn.Module):
     """weight * (x - mean_scale * mean) / sqrt(mean(x^2) + eps) + bias over linspace row
     slices - the reference's GraphNorm variant incl. its raw-x^2 variance
@@ -191,17 +243,7 @@ class SingleBatchGraphNorm(nn.Module):
 
     def forward(self, x, batch=None):
         groups = _as_groups(batch, x.shape[0], x.device, True)
-        if groups.B == 1:
-            n = torch.full((1, 1), float(x.shape[0]), device=x.device)
-        else:
-            n = (groups.ptr_sum[1:] - groups.ptr_sum[:-1]).to(x.dtype).unsqueeze(1)
-        mean = SF.SliceSumFn.apply(x, groups) / n
-        ex2 = SF.SliceSumFn.apply(x * x, groups) / n
-        if groups.gid is not None:
-            mean = mean.index_select(0, groups.gid.long())
-            ex2 = ex2.index_select(0, groups.gid.long())
-        out = x - mean * self.mean_scale
-        return self.weight * out / (ex2 + self.eps).sqrt() + self.bias
+        return _GraphNormFn.apply(x, self.weight, self.bias, self.mean_scale, groups, float(self.eps))
 
     def __repr__(self):
         return '{}({})'.format(self.__class__.__name__, self.in_channels)
@@ -209,14 +251,17 @@ class SingleBatchGraphNorm(nn.Module):
 
 class BatchNorm2Param(nn.Module):
     """PyG BatchNorm (BatchNorm1d held as ``.module``) that ignores ``batch``
-    (models/surfacetextureinpaintingnet.py:236-241)."""
+    (models/surfacetextureinpaintingnet.py:236-241), on the library's kernels: fp64-accumulated column moments, the
+    affine normalisation and its backward as one pass each (stin_bn_act_fwd / _bwd), running statistics in one launch.
+    recomputed: the reference checkpoints the enclosing block, so backward updates the running statistics once more."""
 
     def __init__(self, in_channels, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
         super().__init__()
         self.module = nn.BatchNorm1d(in_channels, eps, momentum, affine, track_running_stats)
 
-    def forward(self, x, batch=None):
-        return self.module(x)
+    def forward(self, x, batch=None, recomputed=False):
+        from .singleconvmeshnet import batch_norm_rows
+        return batch_norm_rows(x, self.module, relu=False, recomputed=recomputed)
 
 
 class Identity(nn.Module):

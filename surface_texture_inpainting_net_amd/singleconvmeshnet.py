@@ -112,12 +112,12 @@ class _RowStatsNormFn(torch.autograd.Function):
     as non-differentiable outputs for the running statistics: BatchNorm1d's training-mode normalisation."""
 
     @staticmethod
-    def forward(ctx, x, groups, eps):
+    def forward(ctx, x, groups, eps, bn2=None):
         x, _ = SF._mat(x)
         mean, rstd = SF.instance_stats(x, groups) if eps == SF.EPS else SF.colreduce(SF.RED_MOMENTS, x, groups, groups.ptr_sum, eps=eps)
         y = SF.norm_act_res_fwd(x, mean, rstd, groups, res=None, act=False)
         ctx.save_for_backward(x, mean, rstd)
-        ctx.groups = groups
+        ctx.groups, ctx.bn2 = groups, bn2
         m1, r1 = mean.view(-1), rstd.view(-1)
         ctx.mark_non_differentiable(m1, r1)
         return y, m1, r1
@@ -125,7 +125,9 @@ class _RowStatsNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gm, _gv):
         x, mean, rstd = ctx.saved_tensors
-        return SF.instance_norm_act_bwd(x, g, mean, rstd, ctx.groups, act=False), None, None
+        if ctx.bn2 is not None:
+            _update_running(ctx.bn2, mean.view(-1), rstd.view(-1), x.shape[0])
+        return SF.instance_norm_act_bwd(x, g, mean, rstd, ctx.groups, act=False), None, None, None
 
 
 class _BatchNormActFn(torch.autograd.Function):
@@ -134,7 +136,7 @@ class _BatchNormActFn(torch.autograd.Function):
     of their gradients live inside those kernels instead of separate elementwise / reduce launches."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, relu):
+    def forward(ctx, x, gamma, beta, groups, eps, relu, bn2=None):
         x, ldx = SF._mat(x)
         n, c = x.shape
         mean, rstd = SF.colreduce(SF.RED_MOMENTS, x, groups, groups.ptr_sum, eps=eps)
@@ -143,7 +145,7 @@ class _BatchNormActFn(torch.autograd.Function):
         SF._call('stin_bn_act_fwd_f32', SF._ptr(x), ldx, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gamma), SF._ptr(beta), n, c,
                  int(relu), SF._ptr(y), c, SF._stream(x))
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
-        ctx.groups, ctx.relu = groups, relu
+        ctx.groups, ctx.relu, ctx.bn2 = groups, relu, bn2
         m1, r1 = mean.view(-1), rstd.view(-1)
         ctx.mark_non_differentiable(m1, r1)
         return y, m1, r1
@@ -154,13 +156,15 @@ class _BatchNormActFn(torch.autograd.Function):
         x, ldx = SF._mat(x)
         g, ldg = SF._mat(g)
         n, c = x.shape
+        if ctx.bn2 is not None:      # the reference recomputes this block's forward here (torch.utils.checkpoint): its BatchNorm
+            _update_running(ctx.bn2, mean.view(-1), rstd.view(-1), n)      # running statistics take the batch a second time
         gb = torch.stack([gamma, beta])                                     # coef = [gamma ; beta]
         P, Q = SF.colreduce(SF.RED_DOT_BN_RELU if ctx.relu else SF.RED_DOT_BN, x, ctx.groups, ctx.groups.ptr_sum, gout=g,
                             mean=mean, rstd=rstd, coef=gb)
         dx = torch.empty(n, c, dtype=x.dtype, device=x.device)
         SF._call('stin_bn_act_bwd_f32', SF._ptr(x), ldx, SF._ptr(g), ldg, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gamma),
                  SF._ptr(beta), SF._ptr(P), SF._ptr(Q), 1.0 / n, n, c, int(ctx.relu), SF._ptr(dx), c, SF._stream(x))
-        return dx, P.view(-1), Q.view(-1), None, None, None
+        return dx, P.view(-1), Q.view(-1), None, None, None, None
 
 
 class _BatchNormMeanFn(torch.autograd.Function):
@@ -171,7 +175,7 @@ class _BatchNormMeanFn(torch.autograd.Function):
     more passes over [E, C]."""
 
     @staticmethod
-    def forward(ctx, m, gamma, beta, ei, groups_e, groups_n, eps):
+    def forward(ctx, m, gamma, beta, ei, groups_e, groups_n, eps, bn2=None):
         m, ldm = SF._mat(m)
         e, c = m.shape
         mean, rstd = SF.colreduce(SF.RED_MOMENTS, m, groups_e, groups_e.ptr_sum, eps=eps)
@@ -182,7 +186,7 @@ class _BatchNormMeanFn(torch.autograd.Function):
                  SF._ptr(out), c, SF._stream(m))
         out.mul_(ei.has_in)
         ctx.save_for_backward(m, agg, mean, rstd, gamma, beta)
-        ctx.ei, ctx.groups_n = ei, groups_n
+        ctx.ei, ctx.groups_n, ctx.bn2 = ei, groups_n, bn2
         m1, r1 = mean.view(-1), rstd.view(-1)
         ctx.mark_non_differentiable(m1, r1)
         return out, m1, r1
@@ -193,13 +197,15 @@ class _BatchNormMeanFn(torch.autograd.Function):
         ei = ctx.ei
         m, ldm = SF._mat(m)
         e, c = m.shape
+        if ctx.bn2 is not None:
+            _update_running(ctx.bn2, mean.view(-1), rstd.view(-1), e)
         g = g * ei.has_in                                                 # rows without in-edges produced a constant 0
         P, Q = SF.colreduce(SF.RED_DOT_BN, agg, ctx.groups_n, ctx.groups_n.ptr_sum, gout=g, mean=mean, rstd=rstd,
                             coef=torch.stack([gamma, beta]))
         dm = torch.empty(e, c, dtype=m.dtype, device=m.device)
         SF._call('stin_bn_mean_bwd_f32', SF._ptr(m), ldm, SF._ptr(g), c, SF._ptr(ei.dst32), SF._ptr(ei.by_dst.inv_deg), SF._ptr(mean),
                  SF._ptr(rstd), SF._ptr(gamma), SF._ptr(P), SF._ptr(Q), 1.0 / max(e, 1), e, c, SF._ptr(dm), c, SF._stream(m))
-        return dm, P.view(-1), Q.view(-1), None, None, None, None
+        return dm, P.view(-1), Q.view(-1), None, None, None, None, None
 
 
 _SINGLE_GROUPS = {}
@@ -231,32 +237,48 @@ def _update_running(bn, mean, rstd, n):
                  float(mom), SF._ptr(bn.running_mean), SF._ptr(bn.running_var), SF._stream(mean))
 
 
-def batch_norm_mean(m, bn, ei):
+def _second_pass(bn, recomputed):
+    """The module whose running statistics backward updates once more: set when the reference wraps the enclosing block in
+    torch.utils.checkpoint (its forward, BatchNorm included, runs a second time inside backward)."""
+    return bn if (recomputed and bn.training and bn.track_running_stats and torch.is_grad_enabled()) else None
+
+
+def batch_norm_mean(m, bn, ei, recomputed=False):
     """scatter_mean(bn(m), edge_index[1]) for an affine BatchNorm1d in training mode (running statistics updated as
     nn.BatchNorm1d does), fused; None when this fast path does not apply."""
     e = m.shape[0]
     if not (bn.training and bn.affine and m.dtype == torch.float32 and e > 1):
         return None
     out, mean, rstd = _BatchNormMeanFn.apply(m, bn.weight, bn.bias, ei, _all_rows(e, m.device), _all_rows(ei.n, m.device),
-                                             float(bn.eps))
+                                             float(bn.eps), _second_pass(bn, recomputed))
     _update_running(bn, mean, rstd, e)
     return out
 
 
-def batch_norm_rows(x, bn, relu=False):
+def batch_norm_rows(x, bn, relu=False, recomputed=False):
     """nn.BatchNorm1d semantics on [rows, C] (training: batch statistics over all rows + running-stat update with the
     unbiased variance; eval: running statistics), statistics by the fp64-accumulating column-reduction kernels;
-    `relu=True` applies the following ReLU in the same kernels."""
+    `relu=True` applies the following ReLU in the same kernels.  recomputed: see _second_pass."""
     if bn.training or not bn.track_running_stats:
         n = x.shape[0]
         fused = bn.affine and x.dtype == torch.float32 and n > 0
         if fused:
-            y, mean, rstd = _BatchNormActFn.apply(x, bn.weight, bn.bias, _all_rows(n, x.device), float(bn.eps), bool(relu))
+            y, mean, rstd = _BatchNormActFn.apply(x, bn.weight, bn.bias, _all_rows(n, x.device), float(bn.eps), bool(relu),
+                                                  _second_pass(bn, recomputed))
         else:
-            y, mean, rstd = _RowStatsNormFn.apply(x, _all_rows(n, x.device), float(bn.eps))
+            y, mean, rstd = _RowStatsNormFn.apply(x, _all_rows(n, x.device), float(bn.eps), _second_pass(bn, recomputed))
         _update_running(bn, mean, rstd, n)
         if fused:
             return y
+    elif bn.affine and x.dtype == torch.float32 and x.shape[0] > 0 and not (torch.is_grad_enabled() and x.requires_grad):
+        # inference: one HIP pass with the running statistics (rstd from running_var: a [C] vector op)
+        x, ldx = SF._mat(x)
+        n, c = x.shape
+        y = torch.empty(n, c, dtype=x.dtype, device=x.device)
+        rstd = torch.rsqrt(bn.running_var + bn.eps)
+        SF._call('stin_bn_act_fwd_f32', SF._ptr(x), ldx, SF._ptr(bn.running_mean), SF._ptr(rstd), SF._ptr(bn.weight.detach()),
+                 SF._ptr(bn.bias.detach()), n, c, int(relu), SF._ptr(y), c, SF._stream(x))
+        return y
     else:
         y = (x - bn.running_mean) * torch.rsqrt(bn.running_var + bn.eps)
     if bn.affine:
@@ -271,6 +293,7 @@ class EdgeConvBN(nn.Module):
     def __init__(self, cin, cout, trans_inv=False):
         super().__init__()
         self.trans_inv = trans_inv
+        self.recomputed = False      # True where the reference checkpoints the enclosing block (running statistics: _second_pass)
         self.nn = nn.Sequential(nn.Linear(cin if trans_inv else 2 * cin, 2 * cout, bias=False), nn.BatchNorm1d(2 * cout),
                                 nn.ReLU(), nn.Linear(2 * cout, cout, bias=False), nn.BatchNorm1d(cout))
 
@@ -288,11 +311,11 @@ class EdgeConvBN(nn.Module):
             pre = _GatherAddFn.apply(y, ei)               # [E, 2 cout] = A[dst] + B[src]
         else:
             pre = _GatherRowsFn.apply(y[:, :h2], ei.dst32, ei.by_dst) + _GatherRowsFn.apply(y[:, h2:], ei.src32, ei.by_src)
-        h = batch_norm_rows(pre, bn1, relu=True)                           # [E, 2 cout]
+        h = batch_norm_rows(pre, bn1, relu=True, recomputed=self.recomputed)   # [E, 2 cout]
         m = SF.linear(h, lin2.weight)                                      # per-EDGE GEMM, [E, cout]
-        out = batch_norm_mean(m, bn2, ei)                                  # BN2 + mean over the in-edges, fused
+        out = batch_norm_mean(m, bn2, ei, recomputed=self.recomputed)      # BN2 + mean over the in-edges, fused
         if out is None:
-            out = _ScatterMeanFn.apply(batch_norm_rows(m, bn2), ei)
+            out = _ScatterMeanFn.apply(batch_norm_rows(m, bn2, recomputed=self.recomputed), ei)
         return out
 
     def __repr__(self):
@@ -331,6 +354,13 @@ class SingleConvMeshNet(nn.Module):
                 cur = fs
         self.left_geo_cnns = nn.ModuleList(left)
         self.right_geo_cnns = nn.ModuleList(right)
+        # the reference runs left blocks of levels >= 1 and every right block but the last-executed (level 0) one under
+        # torch.utils.checkpoint (models/singleconvmeshnet.py:124-126, :139-144): a second forward inside backward, which
+        # numerically only touches the BatchNorm running statistics (two updates per training step)
+        L = len(filter_sizes)
+        for blk in list(self.left_geo_cnns[1:]) + [self.right_geo_cnns[-level] for level in range(1, L - 1)]:
+            for f in blk.filters:
+                f.recomputed = True
         f0 = filter_sizes[0]
         self.final_convs = nn.ModuleList([nn.Sequential(nn.Linear(f0, f0 // 2), nn.BatchNorm1d(f0 // 2), nn.ReLU(),
                                                         nn.Linear(f0 // 2, num_classes))])

@@ -24,6 +24,9 @@ class GraphResnetBlock(nn.Module):
         super().__init__()
         self.dim_in, self.dim_out = dim_in, dim_out
         self.act = nn.ELU()
+        # True where the reference wraps the block in torch.utils.checkpoint (:429, :438, :451, :454): its forward runs a
+        # second time inside backward, which numerically only matters for BatchNorm running statistics (norm='batch')
+        self.recomputed = False
         # True for a block fed by un-normalised data (the network's first block, or any block of a norm-free network):
         # its forward GEMMs take the range-safe matrix-core path (functional.forward_precision)
         self.unbounded_input = False
@@ -59,6 +62,8 @@ class GraphResnetBlock(nn.Module):
         if isinstance(self.first_norm, M.FastInstanceNorm):
             groups = M._as_groups(batch, n, x.device, self.first_norm.linspace_quirk)
             return SF.InstanceNormActResFn.apply(out, res, groups, True, self.first_norm.eps)
+        if isinstance(self.first_norm, M.BatchNorm2Param):
+            return res + self.act(self.first_norm(out, batch, recomputed=self.recomputed))
         return res + self.act(self.first_norm(out, batch))
 
 
@@ -143,6 +148,10 @@ class SurfaceTextureInpaintingNet(nn.Module):
             if isinstance(m, GraphResnetBlock):
                 m.unbounded_input = not self.using_norm
         self.input_blocks[0].unbounded_input = True                 # raw vertex features (fp16's range is not guaranteed)
+        for blk in list(self.encoder_blocks) + list(self.decoder_blocks):
+            blk.recomputed = True
+        for i, blk in enumerate(self.bottleneck_blocks):
+            blk.recomputed = bool(self.checkpoint_bottleneck) and (i + 1) % self.num_blocks_per_uncheckpointed_block == 0
         for m in self.modules():                                    # reference zeroes every Linear bias (:360-374)
             if isinstance(m, nn.Linear) and m.bias is not None:
                 nn.init.zeros_(m.bias)

@@ -11,6 +11,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 MODEL_FIXTURES = ['g1_imagegraph_edgeconv', 'g2_3level_transinv_max', 'g2_3level_transinv_mean',
                   'g3_batch2_unequal', 'g5_sageconv', 'g5_sageconvtransinv', 'g6_graphnorm', 'g7_train_step']
+# (g12_batchnorm_step has its own protocol - two forward calls - and its own tests)
 
 
 def load_npz(name):

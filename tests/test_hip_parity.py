@@ -389,6 +389,7 @@ def test_instance_norm_variants_against_reference_fixture():
         (y * torch.linspace(-1, 1, y.numel()).view_as(y).to(DEV)).sum().backward()
         assert float((xx.grad.cpu() - z['gn.%s.gx' % tag]).abs().max()) <= 5e-5, tag
         assert float((gn.weight.grad.cpu() - z['gn.%s.gweight' % tag]).abs().max()) <= 5e-5
+        assert float((gn.mean_scale.grad.cpu() - z['gn.%s.gmean_scale' % tag]).abs().max()) <= 5e-5
         gn.zero_grad()
 
 
@@ -514,6 +515,48 @@ def test_train_step_against_reference_fixture():
     for k, v in step.model.state_dict().items():
         ok = fx.grads[k].abs() > 1e-5
         assert torch.allclose(v.cpu()[ok], fx.state_dict_after[k][ok], rtol=0, atol=5e-7), k
+
+
+def test_batchnorm_training_step_against_reference_fixture():
+    """norm='batch' on the library's BatchNorm kernels through the reference's real training step (fixture g12): output,
+    loss, gradients, the Adam update and the running statistics - which the reference's checkpointed blocks update TWICE
+    per step (their forward is recomputed inside backward; this build updates them a second time in backward instead)."""
+    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    fx = ModelFixture('g12_batchnorm_step')
+    net = S.define_G(**fx.cfg)
+    net.load_state_dict(fx.state_dict)
+    net = net.to(DEV).train()
+    s = fx.sample(DEV)
+    out = net(s)                                              # fixture protocol: one forward-only call in train mode first
+    assert float((out.detach().cpu() - fx.out).abs().max()) <= FWD_TOL
+    step = TrainStep(net, lr=7e-5, amsgrad=True)
+    loss = step(s)
+    assert abs(float(loss) - float(fx.loss)) <= 2e-6
+    flat = step.bucket.flat.cpu()
+    off = 0
+    scale = max(float(g.abs().max()) for g in fx.grads.values())
+    for k, p in net.named_parameters():
+        g = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+        assert float((g - fx.grads[k]).abs().max()) <= 1e-3 * scale, k
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    for k, v in fx.state_dict_after.items():
+        if k.endswith('num_batches_tracked'):
+            assert int(sd[k]) == int(v), k
+        elif 'running_' in k:
+            assert float((sd[k] - v).abs().max()) <= 2e-6 + 1e-5 * float(v.abs().max()), k
+        else:
+            ok = fx.grads[k].abs() > 1e-5 if k in fx.grads else torch.ones_like(v, dtype=torch.bool)
+            assert torch.allclose(sd[k][ok], v[ok], rtol=0, atol=5e-7), k
+    net.eval()                                                # inference: running statistics through the same kernels
+    with torch.no_grad():
+        ev = net(s)
+    ref = stin_oracle.define_G(**fx.cfg)
+    ref.load_state_dict({k: v for k, v in sd.items()})
+    ref.eval()
+    with torch.no_grad():
+        want = ref(fx.sample())
+    assert float((ev.cpu() - want).abs().max()) <= FWD_TOL
 
 
 def test_fused_masked_l1_loss_matches_trainer_formula():

@@ -101,6 +101,86 @@ def test_oracle_metrics_fixture():
     assert torch.allclose(stin_oracle.graph_total_variation(z['pred'], z['ei']), z['tv'], rtol=1e-6)
 
 
+def _g11_saved(z, tag):
+    """The dict of a graphs/<scene>.pt file rebuilt from the fixture's file-content arrays."""
+    def lst(prefix):
+        out, i = [], 0
+        while '%s.f.%s.%d' % (tag, prefix, i) in z:
+            out.append(torch.from_numpy(z['%s.f.%s.%d' % (tag, prefix, i)]))
+            i += 1
+        return out
+    vertices, edges, traces = lst('vertices'), lst('edges'), lst('traces')
+    dil = []
+    for lvl in range(len(edges)):
+        sets, i = [], 0
+        while '%s.f.dil.%d.%d' % (tag, lvl, i) in z:
+            a = z['%s.f.dil.%d.%d' % (tag, lvl, i)]
+            sets.append(torch.from_numpy(a) if a.shape[0] else [])
+            i += 1
+        dil.append(sets if sets else None)
+    return {'vertices': vertices, 'edges': edges, 'traces': traces, 'dilated_edges': dil,
+            'dilation_dists': [int(v) for v in z['%s.f.dilation_dists' % tag]]}
+
+
+@pytest.mark.parametrize('tag,cropped', [('full', False), ('crop', True)])
+def test_scene_reader_equals_the_reference_reader(tag, cropped, tmp_path):
+    """scene_io against the reference's OWN ScanNetGraphColorDataSet.__getitem__ (fixture g11, generated by running it on
+    these very file contents, CoordsNormalization included): full validation scene and training crop (the two trace
+    conventions, datasets/scannetcolorgraph_dataloader.py:124-128), the empty-dilation fall-back (:143-145)."""
+    from surface_texture_inpainting_net_amd.scene_io import load_scene, sample_from_tensors
+    import numpy as np
+    z = load_npz('g11_scene_reader')
+    saved = _g11_saved(z, tag)
+    got = sample_from_tensors(saved, z['%s.f.vertex_mask' % tag], end_level=3, cropped=cropped)
+    # ... and through real files in the on-disk schema
+    gp, mp = str(tmp_path / 'scene.pt'), str(tmp_path / '7.npz')
+    torch.save(saved, gp)
+    np.savez(mp, vertex_mask=z['%s.f.vertex_mask' % tag])
+    from_disk = load_scene(gp, mp, end_level=3, cropped=cropped)
+    want = {k[len(tag) + 3:]: torch.from_numpy(v) for k, v in z.items() if k.startswith(tag + '.s.')}
+    assert len(want) >= 10
+    for smp in (got, from_disk):
+        for k, v in want.items():
+            if k == 'num_vertices':
+                assert smp[k].reshape(-1).tolist() == v.reshape(-1).tolist() and smp[k].dtype == torch.int32
+            elif v.is_floating_point():
+                assert smp[k].dtype == v.dtype and torch.equal(smp[k], v), k       # same operations in the same order: exact
+            else:
+                assert torch.equal(smp[k], v.to(smp[k].dtype)), k
+        extra = set(smp.keys()) - set(want) - {'batch', 'name'}
+        assert not extra, extra
+    if tag == 'full':                                          # dist 8 was empty on disk: the reference reuses dist 4
+        assert torch.equal(want['hierarchy_dil_8_edge_index_2'], want['hierarchy_dil_4_edge_index_2'])
+
+
+def test_oracle_batchnorm_step_fixture():
+    """norm='batch' through a REAL training step of the reference (fixture g12): its checkpointed encoder / bottleneck /
+    decoder blocks run their forward twice, so their BatchNorm running statistics take the batch twice per step.  Fixture
+    protocol: one forward-only call in train mode, then forward + loss + backward + Adam."""
+    fx = ModelFixture('g12_batchnorm_step')
+    net = stin_oracle.define_G(**fx.cfg)
+    net.load_state_dict(fx.state_dict)
+    net.train()
+    s = fx.sample()
+    out = net(s)
+    assert float((out - fx.out).abs().max()) <= 1e-6
+    opt = torch.optim.Adam(net.parameters(), lr=7e-5, weight_decay=0, amsgrad=True)
+    loss = stin_oracle.compute_loss(stin_oracle.graph_forward(net, s), s.color, s.mask)
+    loss.backward()
+    assert abs(float(loss) - float(fx.loss)) <= 1e-6
+    for k, p in net.named_parameters():
+        assert float((p.grad - fx.grads[k]).abs().max()) <= 2e-6 + 1e-4 * float(fx.grads[k].abs().max()), k
+    opt.step()
+    sd = net.state_dict()
+    counts = {k: int(v) for k, v in fx.state_dict_after.items() if k.endswith('num_batches_tracked')}
+    assert sorted(set(counts.values())) == [2, 3], 'recomputed blocks count one more batch'
+    for k, v in fx.state_dict_after.items():
+        if k.endswith('num_batches_tracked'):
+            assert int(sd[k]) == int(v), k
+        elif 'running_' in k:
+            assert float((sd[k] - v).abs().max()) <= 1e-6, k
+
+
 @pytest.mark.reference
 def test_oracle_against_live_reference_random_config():
     """Build-container only: run the reference's own class side by side (fresh seed)."""
