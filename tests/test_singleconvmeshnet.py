@@ -71,7 +71,7 @@ def test_hip_singleconvmeshnet_matches_reference_fixture(pooling):
     # backward = where the reference recomputes its checkpointed blocks (left levels >= 1, right blocks but the last one,
     # models/singleconvmeshnet.py:124-126, :139-144): their BatchNorm statistics take the batch a second time
     twice = {k: v.cpu() for k, v in net.state_dict().items() if k in once}
-    recomputed = [k for k in once if k.startswith(('left_geo_cnns.1.', 'left_geo_cnns.2.', 'right_geo_cnns.0.'))]
+    recomputed = [k for k in once if k.startswith(('left_geo_cnns.1.', 'left_geo_cnns.2.', 'right_geo_cnns.1.'))]
     assert recomputed and len(recomputed) < len(once)
     m = 0.1
     for k in once:
@@ -79,10 +79,9 @@ def test_hip_singleconvmeshnet_matches_reference_fixture(pooling):
             assert torch.equal(twice[k], once[k]), k
         elif k.endswith('num_batches_tracked'):
             assert int(twice[k]) == 2 and int(once[k]) == 1, k
-        elif k.endswith('running_mean'):                       # r1 = m mu;  r2 = (1 - m) r1 + m mu
-            assert torch.allclose(twice[k], (2 - m) * once[k], rtol=1e-5, atol=1e-7), k
-        else:                                                  # v1 = (1 - m) + m v;  v2 = (1 - m) v1 + m v
-            assert torch.allclose(twice[k], (1 - m) * once[k] + (once[k] - (1 - m)), rtol=1e-5, atol=1e-7), k
+        else:      # x1 = (1 - m) x0 + m b and x2 = (1 - m) x1 + m b with the same batch value b  =>  x2 = (2 - m) x1 - (1 - m) x0
+            assert torch.allclose(twice[k], (2 - m) * once[k] - (1 - m) * state[k], rtol=1e-5, atol=1e-6), k
+    net.load_state_dict({**net.state_dict(), **{k: v.to('cuda:0') for k, v in once.items()}})    # the fixture's eval state
     net.eval()
     with torch.no_grad():
         assert float((net(s).cpu() - torch.from_numpy(g['out_eval'])).abs().max()) <= 1e-4
