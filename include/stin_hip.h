@@ -336,6 +336,12 @@ size_t stin_masked_l1_workspace_bytes(int64_t N, int C);
 int stin_masked_l1_loss_f32(const float* out, const float* color, const int64_t* mask, int64_t N, int C,
                             int use_weight, float* loss, float* grad, void* workspace, size_t workspace_bytes,
                             stin_stream_t stream);
+/* graph total variation, the per-step smoothness metric of the trainer (utils/metrics/graph_metrics.py:34-38,
+ * trainers/inpainting3d_trainer.py:254-263): out[0] = sum_e sum_c |x[src_e, c] - x[dst_e, c]| / (N * C) over the
+ * destination CSR the forward pass has built (rowptr_dst / col_dst), fp64 partial sums in a fixed order. */
+size_t stin_total_variation_workspace_bytes(int64_t N);
+int stin_total_variation_f32(const float* x, int64_t ldx, const int32_t* rowptr_dst, const int32_t* col_dst, int64_t N, int C,
+                             float* out, void* workspace, size_t workspace_bytes, stin_stream_t stream);
 int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int step, int amsgrad, stin_stream_t stream);
 

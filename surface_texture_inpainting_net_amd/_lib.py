@@ -75,6 +75,8 @@ SIGNATURES = {
     'stin_norm_bwd_coef_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     'stin_masked_l1_workspace_bytes': (c_size, [c_i64, c_int]),
     'stin_masked_l1_loss_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    'stin_total_variation_workspace_bytes': (c_size, [c_i64]),
+    'stin_total_variation_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size, c_ptr]),
     'stin_adam_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64, c_int, c_int,
                               c_ptr]),
 }

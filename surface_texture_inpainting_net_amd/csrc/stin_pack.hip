@@ -272,6 +272,33 @@ __global__ __launch_bounds__(256) void k_loss_final(const double* __restrict__ p
     if (threadIdx.x == 0) loss[0] = (float)(sm[0] * (double)inv_count);
 }
 
+// graph total variation (utils/metrics/graph_metrics.py:34-38): sum over the directed edges of |x_src - x_dst| over all
+// channels.  One thread per destination row walks its in-edges (C is 1 or 3 for the metric: a row is one 4..12-byte gather);
+// fp64 block partials in a fixed order, k_loss_final sums them and applies 1 / (N * C).
+__global__ __launch_bounds__(256) void k_total_variation(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col, int64_t N, int C,
+                                                         double* __restrict__ partial) {
+    __shared__ double sm[256];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = 0.0;
+    if (i < N) {
+        const float* xi = x + i * ldx;
+        for (int32_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+            const float* xj = x + (int64_t)col[e] * ldx;
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s += fabsf(xj[c] - xi[c]);
+            acc += (double)s;
+        }
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
 // Adam with amsgrad over one flat parameter buffer, the arithmetic of torch.optim.Adam's single-tensor path
 // (weight_decay added to the gradient; exp_avg by lerp; the scalar factors come from the host in double):
 //   m += (1-b1) (g - m) ; v = b2 v + (1-b2) g^2 ; vmax = max(vmax, v)
@@ -319,6 +346,25 @@ extern "C" int stin_masked_l1_loss_f32(const float* out, const float* color, con
     hipLaunchKernelGGL(k_masked_l1, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, out, color, mask, N, C,
                        use_weight, inv, grad, partial);
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, (hipStream_t)stream_, partial, blocks, inv, loss);
+    return stin_launch_status();
+}
+
+extern "C" size_t stin_total_variation_workspace_bytes(int64_t N) {
+    if (N < 0) return 0;
+    return (size_t)((N + 255) / 256 + 1) * sizeof(double) + 256;
+}
+
+extern "C" int stin_total_variation_f32(const float* x, int64_t ldx, const int32_t* rowptr_dst, const int32_t* col_dst, int64_t N,
+                                        int C, float* out, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N > 0 && C > 0 && ldx >= C, STIN_E_SIZE);
+    STIN_REQUIRE(x && rowptr_dst && out && workspace, STIN_E_NULL);
+    STIN_REQUIRE(workspace_bytes >= stin_total_variation_workspace_bytes(N), STIN_E_WORKSPACE);
+    double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int blocks = (int)((N + 255) / 256);
+    hipLaunchKernelGGL(k_total_variation, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, x, ldx, rowptr_dst, col_dst, N,
+                       C, partial);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(256), 0, (hipStream_t)stream_, partial, blocks, 1.0f / ((float)N * (float)C), out);
     return stin_launch_status();
 }
 

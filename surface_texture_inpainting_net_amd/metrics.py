@@ -35,14 +35,20 @@ def graph_laplace_variance(x, edge_index):
 
 
 def graph_total_variation(x, edge_index):
-    """sum_e |x_src - x_dst| / (N * C)   (graph_metrics.py:34-38).  Per vertex i the in-edges contribute
-    sum_j |x_j - x_i|; evaluated as a gather-free identity over the destination CSR is not possible for an
-    absolute value, so this uses the CSR column list directly."""
+    """sum_e |x_src - x_dst| / (N * C)   (graph_metrics.py:34-38): one HIP pass over the destination CSR (each vertex walks
+    its in-edges), fp64 partial sums in a fixed order - no [E, C] temporaries, no host sync."""
+    from . import _lib
+    from .plan import _ptr, _stream
     e = _edges(edge_index, x.shape[0])
+    x, ldx = SF._mat(x.detach().float())
     n, c = x.shape
-    deg = (e.by_dst.rowptr[1:] - e.by_dst.rowptr[:-1]).long()
-    dst = torch.repeat_interleave(torch.arange(n, device=x.device), deg)
-    return torch.abs(x[e.by_dst.col.long()] - x[dst]).sum() / (n * c)
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws_bytes = lib.stin_total_variation_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    SF._call('stin_total_variation_f32', _ptr(x), ldx, _ptr(e.by_dst.rowptr), _ptr(e.by_dst.col), n, c, _ptr(out), _ptr(ws),
+             ws_bytes, _stream(x))
+    return out[0]
 
 
 def psnr(x, y, data_range=1.0, convert_to_greyscale=False):
