@@ -8,8 +8,15 @@ Two layers of checks, all through the C ABI:
   * GEMMs against fp64 on the bf16-rounded operands (fp32 accumulation: error bound independent of bf16);
   * whole network (shipped 3-D config, 15 blocks) against the fp32 CPU oracle - the STATED tolerance of the bf16
     mode: tanh output max-abs <= 0.15 and mean-abs <= 2e-2 (measured 7.8e-2 / 9.9e-3), loss within 1 % (measured
-    2e-4), weight gradients within 25 % relative L2 (measured 16 %: ~60 bf16 roundings of 2^-9 in sequence plus the
-    ReLU / arg-max decisions they flip).  Keeping the pre-norm tensor in fp32 does not change these numbers.
+    2e-4), weight gradients within 25 % relative L2 (measured 16 %).
+    Why the gradient bar is not tighter, and why no "mixed" variant is shipped (tests/tools/bf16_design_probe.py,
+    profiles/r02_bf16_sensitivity.md): this network's gradient responds to a forward perturbation of relative size e like
+    sqrt(e), not e - ReLU and arg-max (max pool) decisions flip in proportion to e and each flip moves a gradient entry
+    by O(1).  fp32 reordering (e = 6e-8) already gives 7e-4 against the reference formulation; ONE bf16 rounding per block
+    (block input only, fp32 everything else, fp32 residual stream) gives 9.5 %, the pre-activations Y alone 11 %, all
+    tensors 16 %; every backward rounding together < 0.5 %.  A 5 % bar is therefore out of reach of ANY 16-bit storage
+    of a forward tensor (fp16's 2^-11 would halve it), and keeping the residual stream in fp32 buys 16 % -> 15 %.  What
+    certifies the mode is the training curve: test_bf16_training_curve_tracks_fp32.
 """
 import pytest
 import torch
@@ -239,6 +246,31 @@ def test_bf16_network_is_deterministic_and_trains():
     step = TrainStep(net, lr=1e-3)
     losses = [float(step(s)) for _ in range(8)]
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+def test_bf16_training_curve_tracks_fp32():
+    """200 Adam steps (lr 5e-5) of the shipped 3-D config on a 20 164-vertex mesh with a smooth (learnable) colour field and
+    four hole masks, same initial weights and data order: bf16 storage against fp32 storage, with fp32 storage + exact-fp32
+    GEMMs as the CONTROL (two fp32 evaluation orders drift apart too - the network's decisions amplify any perturbation, see
+    tests/tools/bf16_design_probe.py).  Measured on MI355X: control +1.0 % / +1.9 %, bf16 +2.1 % / +0.1 % (seeds 3 / 4) in the
+    mean loss of the last 50 steps.  Stated bar: bf16 within 4 % of fp32 there, and within 1 % over the first 50 steps (where
+    the trajectories have not separated yet)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('bf16_training_curve', os.path.join(os.path.dirname(__file__), 'tools',
+                                                                                    'bf16_training_curve.py'))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    samples = [s.to(DEV) for s in tool.learnable_samples(20_000)]
+    curves = {m: tool.curve(samples, 200, m, seed=3, lr=5e-5) for m in ('f32', 'f32-exact-gemm', 'bf16')}
+    head = {m: float(c[:50].mean()) for m, c in curves.items()}
+    tail = {m: float(c[-50:].mean()) for m, c in curves.items()}
+    print('\nmean loss steps 0-49 %s\nmean loss steps 150-199 %s' % (head, tail))
+    assert all(bool(torch.isfinite(c).all()) for c in curves.values())
+    assert tail['f32'] < 0.25 * head['f32'], 'the task must actually train'
+    assert abs(head['bf16'] - head['f32']) <= 1e-2 * head['f32']
+    assert abs(tail['bf16'] - tail['f32']) <= 4e-2 * tail['f32']
+    assert abs(tail['f32-exact-gemm'] - tail['f32']) <= 4e-2 * tail['f32'], 'control drifted: the bar above is not meaningful'
 
 
 def test_bf16_mode_is_refused_for_unsupported_variants():
