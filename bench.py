@@ -241,6 +241,8 @@ def main():
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--time-gemms', action='store_true', help='bracket every MFMA GEMM launch INSIDE the timed region too '
                     '(the default line times the GEMMs in a separate pass after it)')
+    ap.add_argument('--no-prefetch-plan', action='store_true', help='build each step\'s CSR plan on the compute stream at first '
+                    'use instead of one step ahead on the plan side streams')
     ap.add_argument('--cache-plan', action='store_true', help='reuse the CSR plan across steps (NOT the headline)')
     ap.add_argument('--crops', type=int, default=0,
                     help='BASELINE config 3: a collated batch of this many unequal crops (12-28k vertices each) per step '
@@ -298,9 +300,15 @@ def main():
     n0 = sample.x.shape[0]
     e0 = sample.edge_index.shape[1]
 
+    pending_plan = [None]
+
     def one_step():
         if not args.cache_plan:
-            sample._plan_cache = None                       # rebuild the CSR plan: part of the step
+            # a fresh CSR plan per step (part of the step).  As a loader with one batch of look-ahead does
+            # (TrainStep.prefetch), the plan of step k+1 is built on the plan side streams while step k runs; the
+            # first step builds its own at first use.  --no-prefetch-plan: every step builds its plan on the compute stream.
+            sample._plan_cache = pending_plan[0]
+            pending_plan[0] = None if args.no_prefetch_plan else net.build_plan(sample)
         return step(sample)
 
     def fence():
@@ -428,6 +436,7 @@ def main():
                                       '(fp32 accumulate / statistics / weights)'),
                        'vertices_per_gpu': n0, 'edges_per_gpu': e0, 'levels': args.levels, 'params': sum(p.numel() for p in net.parameters()),
                        'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan,
+                       'plan_prefetched_one_step_ahead': not (args.cache_plan or args.no_prefetch_plan),
                        'crops_per_step': args.crops or None},
             'gemm_precision': ({'fwd': SF.PREC_NAMES[SF.PREC_FWD], 'bwd': SF.PREC_NAMES[SF.PREC_BWD],
                                 'note': 'fp32 storage, operands split into 16-bit pieces on the MFMA path (fp16x3: 22-bit '

@@ -209,6 +209,7 @@ class GraphPlan:
         self._bad.record_stream(main)
         self._bad_ready = s0.record_event()
         main.wait_event(self._bad_ready)
+        self._pending = []
         self._edges = {}
         self._pools = {}
         self._norms = {}
@@ -218,12 +219,14 @@ class GraphPlan:
         self._validated = False
         self._flag_host = None
 
-    def prefetch(self, edge_items=(), pool_levels=(), inputs_ready=False):
+    def prefetch(self, edge_items=(), pool_levels=(), inputs_ready=False, join=True):
         """Build the listed edge sets [(key, level), ...] and pool maps [level, ...] NOW, side by side on a pool of HIP
         streams, instead of one after the other at first use on the compute stream.  The compute stream then waits
         for them once.  inputs_ready=True asserts that the sample's index tensors are already complete in memory (a
         loader handed over resident tensors): the builds then do not wait for work still queued on the compute stream
-        and overlap with it (the previous step's tail); otherwise they start after everything queued so far."""
+        and overlap with it (the previous step's tail); otherwise they start after everything queued so far.
+        join=False leaves the compute stream alone: it waits for the builds when the plan is first USED (a plan built
+        for the NEXT step while the current one is still being enqueued - TrainStep.prefetch)."""
         todo = [('e', k, l) for (k, l) in edge_items if k not in self._edges]
         todo += [('p', l, l) for l in pool_levels if l not in self._pools]
         if not todo:
@@ -248,13 +251,26 @@ class GraphPlan:
                     obj = self._pools[level] = PoolMap(trace, self.level_sizes[level - 1], self.level_sizes[level], self._bad)
             for t in obj.tensors():
                 t.record_stream(main)            # allocated on s, consumed on the compute stream: defer reuse accordingly
-        for s in used:
-            main.wait_stream(s)
+        if join:
+            for s in used:
+                main.wait_stream(s)
+        else:
+            self._pending += [s.record_event() for s in used]
         self._validated = False
         return self
 
+    def join(self):
+        """Make the current stream wait for builds started with prefetch(join=False)."""
+        if self._pending:
+            main = torch.cuda.current_stream(self.device)
+            for ev in self._pending:
+                main.wait_event(ev)
+            self._pending = []
+
     # ---- lazily built pieces ------------------------------------------------------
     def edges(self, key, level):
+        if self._pending:
+            self.join()
         if key not in self._edges:
             ei = self._sample.edge_index if key == 'edge_index' else self._sample[key]
             self._edges[key] = EdgeSet(ei, self.level_sizes[level], self._bad)
@@ -270,6 +286,8 @@ class GraphPlan:
 
     def pool(self, level):
         """level >= 1: map from level-1 (fine) to level (coarse)."""
+        if self._pending:
+            self.join()
         if level not in self._pools:
             trace = self._sample['hierarchy_trace_index_%d' % level]
             self._pools[level] = PoolMap(trace, self.level_sizes[level - 1], self.level_sizes[level], self._bad)

@@ -215,6 +215,15 @@ class SurfaceTextureInpaintingNet(nn.Module):
         plan.prefetch(edges, pools, inputs_ready=inputs_ready)
         return plan
 
+    def build_plan(self, sample, inputs_ready=True):
+        """A NEW, complete GraphPlan of `sample`, built on the side streams WITHOUT making the compute stream wait (it
+        waits when the plan is first used) and without touching the sample's cached plan: the data pipeline's way to
+        prepare step k+1 while step k runs.  Hand it over with `sample._plan_cache = plan` (TrainStep.prefetch does)."""
+        from .plan import GraphPlan
+        plan = GraphPlan(sample, linspace_quirk=self.compat_linspace_norm, validation=self.plan_validation)
+        edges, pools = self._plan_items()
+        return plan.prefetch(edges, pools, inputs_ready=inputs_ready, join=False)
+
     def forward(self, sample):
         check_deferred()                                                      # deferred index checks of earlier calls
         plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm,      # pieces not prefetched are built at first use

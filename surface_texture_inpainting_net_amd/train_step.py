@@ -372,6 +372,15 @@ class TrainStep:
         for g in self.optimizer.param_groups:
             g['lr'] = float(lr)
 
+    def prefetch(self, sample):
+        """Start building the CSR plan of a sample a LATER call will train on (the loader's next batch, already resident
+        on the GPU): the build runs on the plan side streams beside the step being enqueued / executed and the compute
+        stream waits for it only when that sample's forward starts."""
+        model = self.model.module if hasattr(self.model, 'module') else self.model
+        if getattr(sample, '_plan_cache', None) is None and hasattr(model, 'build_plan'):
+            sample._plan_cache = model.build_plan(sample)
+        return sample
+
     def forward_backward(self, sample, grad_scale=1.0):
         """One forward + loss + backward; the bucket then holds d(loss * grad_scale)/dw of THIS sample."""
         self.bucket.detach_grads()

@@ -266,3 +266,39 @@ def test_fused_block_survives_torch_checkpoint(use_reentrant):
         assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
         for a, b in zip(gp0, gp1):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_plan_prefetched_one_step_ahead_gives_the_same_training_run():
+    """TrainStep.prefetch builds the next sample's CSR plan on side streams while the current step runs; the compute
+    stream joins it at first use.  Losses and weights after 4 steps must equal the run that builds every plan in place."""
+    from surface_texture_inpainting_net_amd import surfacetextureinpaintingnet as S
+    cfg = dict(input_nc=10, output_nc=3, ngf=32, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 4])
+    meshes = [make_synthetic_mesh(3000 + 500 * i, 3, seed=20 + i, dilations=(2, 4)) for i in range(3)]
+
+    def run(prefetch):
+        torch.manual_seed(5)
+        net = S.define_G(**cfg).to('cuda:0')
+        step = TrainStep(net, lr=1e-3)
+        samples = [m.to('cuda:0') for m in meshes]
+        losses = []
+        for k in range(4):
+            s = samples[k % 3]
+            s._plan_cache = None if not prefetch else s._plan_cache
+            if prefetch and k == 0:
+                step.prefetch(s)
+            nxt = samples[(k + 1) % 3]
+            nxt._plan_cache = None
+            if prefetch:
+                step.prefetch(nxt)                       # before the step that overlaps it is enqueued
+                assert nxt._plan_cache is not None and nxt._plan_cache._pending
+            losses.append(float(step(s)))
+            assert not (s._plan_cache._pending)
+        step.finish()
+        return losses, [p.detach().clone() for p in net.parameters()]
+
+    l0, w0 = run(False)
+    l1, w1 = run(True)
+    assert l0 == l1
+    assert all(torch.equal(a, b) for a, b in zip(w0, w1))
