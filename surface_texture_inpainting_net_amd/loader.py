@@ -238,6 +238,7 @@ class SceneLoader:
         slot = cpu_batch.__dict__.get('_slot')
         if slot is not None:
             slot.done = self._copy_stream.record_event()        # the worker may overwrite the slot after this
+        uploaded = self._copy_stream.record_event()
         main.wait_stream(self._copy_stream)
         if entry is not None:                                 # resident graph part + its plan: nothing to upload or build
             graph, plan, _ = entry
@@ -255,8 +256,15 @@ class SceneLoader:
         if 'num_vertices' in cpu_batch:
             out._nv_host = cpu_batch['num_vertices'].clone()    # level sizes for the plan without a device sync (a copy:
                                                                 # the staging slot is overwritten by a later batch)
+        # the batch is handed out while the previous step is still executing (the host runs ahead of the GPU): with a model
+        # the whole CSR plan is built NOW on the plan side streams, after the upload and beside that step, and the compute
+        # stream joins it when this batch's forward starts
+        plan = None
+        if self.model is not None and hasattr(self.model, 'build_plan'):
+            plan = out._plan_cache = self.model.build_plan(out, after=uploaded)
         if self.cache is not None:
-            plan = self.model.prefetch_plan(out) if self.model is not None else _plan.plan_for(out)
+            if plan is None:
+                plan = self.model.prefetch_plan(out) if self.model is not None else _plan.plan_for(out)
             graph = {k: v for k, v in dev.items() if k not in _FEATURE_KEYS}
             self._pending = (key, graph, plan)
         return out

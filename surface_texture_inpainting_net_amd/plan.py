@@ -219,12 +219,13 @@ class GraphPlan:
         self._validated = False
         self._flag_host = None
 
-    def prefetch(self, edge_items=(), pool_levels=(), inputs_ready=False, join=True):
+    def prefetch(self, edge_items=(), pool_levels=(), inputs_ready=False, join=True, after=None):
         """Build the listed edge sets [(key, level), ...] and pool maps [level, ...] NOW, side by side on a pool of HIP
         streams, instead of one after the other at first use on the compute stream.  The compute stream then waits
         for them once.  inputs_ready=True asserts that the sample's index tensors are already complete in memory (a
         loader handed over resident tensors): the builds then do not wait for work still queued on the compute stream
         and overlap with it (the previous step's tail); otherwise they start after everything queued so far.
+        after = an event the index tensors are complete at (a loader's upload stream): the builds wait for it instead.
         join=False leaves the compute stream alone: it waits for the builds when the plan is first USED (a plan built
         for the NEXT step while the current one is still being enqueued - TrainStep.prefetch)."""
         todo = [('e', k, l) for (k, l) in edge_items if k not in self._edges]
@@ -238,7 +239,10 @@ class GraphPlan:
             s = streams[i % len(streams)]
             if s not in used:
                 used.append(s)
-                if inputs_ready:
+                if after is not None:
+                    s.wait_event(after)
+                    s.wait_event(self._bad_ready)
+                elif inputs_ready:
                     s.wait_event(self._bad_ready)
                 else:
                     s.wait_stream(main)

@@ -215,14 +215,15 @@ class SurfaceTextureInpaintingNet(nn.Module):
         plan.prefetch(edges, pools, inputs_ready=inputs_ready)
         return plan
 
-    def build_plan(self, sample, inputs_ready=True):
+    def build_plan(self, sample, inputs_ready=True, after=None):
         """A NEW, complete GraphPlan of `sample`, built on the side streams WITHOUT making the compute stream wait (it
         waits when the plan is first used) and without touching the sample's cached plan: the data pipeline's way to
-        prepare step k+1 while step k runs.  Hand it over with `sample._plan_cache = plan` (TrainStep.prefetch does)."""
+        prepare step k+1 while step k runs.  Hand it over with `sample._plan_cache = plan` (TrainStep.prefetch and
+        loader.SceneLoader do).  after = event of the stream that uploads the sample's index tensors, if one does."""
         from .plan import GraphPlan
         plan = GraphPlan(sample, linspace_quirk=self.compat_linspace_norm, validation=self.plan_validation)
         edges, pools = self._plan_items()
-        return plan.prefetch(edges, pools, inputs_ready=inputs_ready, join=False)
+        return plan.prefetch(edges, pools, inputs_ready=inputs_ready, join=False, after=after)
 
     def forward(self, sample):
         check_deferred()                                                      # deferred index checks of earlier calls

@@ -60,6 +60,17 @@ def test_resident_graph_cache_reuses_plans_and_gives_identical_results():
         scenes[1]['x'] = scenes[1].x * 0.5
         b = list(ld.epoch(0))[1]
         assert torch.equal(net(b), net(scenes[1].to(dev)))
+        # with a model the loader builds each batch's plan ahead (side streams, after the upload, joined at first use),
+        # with and without the resident cache
+        for cache_bytes in (0, 1 << 30):
+            ahead = SceneLoader(scenes, dev, shuffle=False, cache_bytes=cache_bytes, model=net)
+            for epoch in range(2):
+                for i, b in enumerate(ahead.epoch(epoch)):
+                    assert b._plan_cache is not None
+                    assert epoch == 1 and cache_bytes or b._plan_cache._pending, 'a fresh plan is handed over un-joined'
+                    out = net(b)
+                    assert i == 1 or torch.equal(out, want[i])
+                    assert not b._plan_cache._pending
         # a cache too small for anything must behave like no cache
         tiny = SceneLoader(scenes, dev, shuffle=False, cache_bytes=1024)
         for epoch in range(2):
