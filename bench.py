@@ -27,6 +27,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import surface_texture_inpainting_net_amd  # noqa: E402,F401  (sets its HIP runtime flag before the first GPU call)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md, chip-level parameters)
 MFMA_16BIT_PEAK_TF = 2500.0    # dense bf16 / f16 MFMA peak (same guide); the fp32-storage GEMMs issue 3 such MFMAs per product
@@ -241,6 +242,8 @@ def main():
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--time-gemms', action='store_true', help='bracket every MFMA GEMM launch INSIDE the timed region too '
                     '(the default line times the GEMMs in a separate pass after it)')
+    ap.add_argument('--graph', action='store_true', help='TrainStep(graph=True): plan build + fwd + loss + bwd captured into one HIP '
+                    'graph and replayed (for launch-bound configurations; the per-kernel HIP-event brackets are not available)')
     ap.add_argument('--no-prefetch-plan', action='store_true', help='build each step\'s CSR plan on the compute stream at first '
                     'use instead of one step ahead on the plan side streams')
     ap.add_argument('--cache-plan', action='store_true', help='reuse the CSR plan across steps (NOT the headline)')
@@ -290,7 +293,7 @@ def main():
     net = S.define_G(**cfg).to(device)
     if args.dtype == 'bf16':
         net.set_activation_dtype(torch.bfloat16)
-    step = TrainStep(net, lr=7e-5, amsgrad=True, time_allreduce=world > 1)
+    step = TrainStep(net, lr=7e-5, amsgrad=True, time_allreduce=world > 1, graph=args.graph)
     if args.crops > 0:
         from surface_texture_inpainting_net_amd.data import collate
         sizes = [12_000 + (16_000 * i) // max(args.crops - 1, 1) for i in range(args.crops)]
@@ -308,7 +311,7 @@ def main():
             # (TrainStep.prefetch), the plan of step k+1 is built on the plan side streams while step k runs; the
             # first step builds its own at first use.  --no-prefetch-plan: every step builds its plan on the compute stream.
             sample._plan_cache = pending_plan[0]
-            pending_plan[0] = None if args.no_prefetch_plan else net.build_plan(sample)
+            pending_plan[0] = None if (args.no_prefetch_plan or args.graph) else net.build_plan(sample)
         return step(sample)
 
     def fence():
@@ -330,19 +333,33 @@ def main():
     timed = edge_names + (gemm_names if args.time_gemms else [])
     # HIP-event brackets need the per-kernel host path (the whole-block C calls enqueue their kernels natively) and event
     # pairs are not free: bracket the edge launches of about one timed step in ten, the rest runs un-instrumented.
+    def eager_step():
+        """one_step() through the per-launch host path even with --graph (HIP-event brackets cannot sit inside a replay)."""
+        g, step.graph = step.graph, False
+        try:
+            return one_step()
+        finally:
+            step.graph = g
+
     SF.KernelTimer.start(timed, max_records=1_000_000)
-    one_step()                                              # one more untimed step: counts the bracketed launches per step
+    eager_step()                                            # one more untimed step: counts the bracketed launches per step
     per_step = max(1, len(SF.KernelTimer.records))
     SF.KernelTimer.stop()
     fence()
     step.bucket.allreduce_log = []
-    SF.KernelTimer.start(timed, max_records=1_000_000 if args.time_gemms else per_step * max(1, args.steps // 10))
+    if not args.graph:
+        SF.KernelTimer.start(timed, max_records=1_000_000 if args.time_gemms else per_step * max(1, args.steps // 10))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
     dt_enqueue = time.perf_counter() - t0                   # host side done (everything enqueued); the GPU may still be running
     fence()
     dt = time.perf_counter() - t0
+    if args.graph:                                          # kernel brackets from two eager steps AFTER the timed replays
+        SF.KernelTimer.start(timed, max_records=1_000_000)
+        for _ in range(2):
+            eager_step()
+        fence()
     ktimes = SF.KernelTimer.stop()
     step.finish()                                           # deferred index checks of the timed steps (all clean)
     allreduce_us = None
@@ -370,7 +387,7 @@ def main():
         gemm_steps = 2.0
         SF.KernelTimer.start(gemm_names, max_records=1_000_000)
         for _ in range(int(gemm_steps)):
-            one_step()
+            eager_step()
         gtimes = SF.KernelTimer.stop()
     gc.enable()
     rank_ms = [dt / args.steps * 1e3]
@@ -436,7 +453,8 @@ def main():
                                       '(fp32 accumulate / statistics / weights)'),
                        'vertices_per_gpu': n0, 'edges_per_gpu': e0, 'levels': args.levels, 'params': sum(p.numel() for p in net.parameters()),
                        'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan,
-                       'plan_prefetched_one_step_ahead': not (args.cache_plan or args.no_prefetch_plan),
+                       'plan_prefetched_one_step_ahead': not (args.cache_plan or args.no_prefetch_plan or args.graph),
+                       'hip_graph': bool(args.graph),
                        'crops_per_step': args.crops or None},
             'gemm_precision': ({'fwd': SF.PREC_NAMES[SF.PREC_FWD], 'bwd': SF.PREC_NAMES[SF.PREC_BWD],
                                 'note': 'fp32 storage, operands split into 16-bit pieces on the MFMA path (fp16x3: 22-bit '

@@ -404,6 +404,10 @@ WGRAD_DEFER_JOIN = os.environ.get('STIN_WGRAD_DEFER', '1') == '1'
 # whole chip busy for hundreds of microseconds and only slows the critical-path kernels it runs beside (measured: 500 k
 # vertices / 4 levels +4.7 %, every block <= 1.5e10; 1 M vertices / 3 levels -13 %, every block >= 2e10)
 WGRAD_MAX_WORK = float(os.environ.get('STIN_WGRAD_MAX_WORK', 1.6e10))
+# ... and below this a step is launch-bound on the host, where the second stream only adds host work (3 event records / waits
+# per block): 40 k vertices 4.2-4.8 ms per step without vs 5.4-5.5 with (every block <= 1.6e9), 60 k equal, 100 k 6.09 without
+# vs 5.60 with (bottleneck blocks 2.4e9), batch of 8 crops / 4 levels 9.8 vs 9.3
+WGRAD_MIN_WORK = float(os.environ.get('STIN_WGRAD_MIN_WORK', 2.0e9))
 _WGRAD_SIDE = {}
 
 
@@ -481,7 +485,7 @@ def _wgrad_side_args(dev, keep_alive, params, direct=False, work=0):
     deferred to the end of the backward pass when nothing can read the gradients earlier: the TrainStep bucket route
     (`direct`), or plain single-process autograd with every parameter a leaf whose .grad is None (autograd then adopts
     the returned tensor without a kernel) and without hooks; otherwise the block stays on one stream."""
-    if not USE_WGRAD_STREAM or work > WGRAD_MAX_WORK:
+    if not USE_WGRAD_STREAM or work > WGRAD_MAX_WORK or work < WGRAD_MIN_WORK:
         return 0, 0, 0, 0, 0
     deferred = WGRAD_DEFER_JOIN and (direct or (_plain_autograd_may_defer() and all(
         p is None or (p.is_leaf and p.grad is None and not p._backward_hooks and

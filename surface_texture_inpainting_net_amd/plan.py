@@ -10,6 +10,8 @@ object, shared by all blocks of a level:
   * per level: instance-norm row groups (gid / slice ids) for batched samples.
 Indices are int64 at the Python boundary (as in the reference) and int32 inside.
 """
+import collections
+
 import torch
 
 from . import _lib
@@ -34,14 +36,38 @@ def _ptr(t):
     return p
 
 
+_CONSTANTS = collections.OrderedDict()        # (device, dtype, shape, bytes) -> device tensor, LRU
+_CONSTANTS_MAX = 1024
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def _upload(host_tensor, device):
-    """Small host tensor -> device without stalling the host: pinned staging buffer + non-blocking copy (the caching
-    host allocator keeps the staging block alive until the copy has run)."""
+    """Small host tensor (row-pointer arrays, 1 / count vectors: tens of values) -> read-only device constant without
+    stalling the host: pinned staging buffer + non-blocking copy (the caching host allocator keeps the staging block
+    alive until the copy has run).  Constants are kept in a small LRU keyed by their bytes: a batch composition seen
+    before costs a dict lookup, and a step being captured into a HIP graph (train_step.TrainStep(graph=True)) - where
+    host-to-device copies cannot be recorded - finds the arrays its eager warm-up pass uploaded."""
     if torch.device(device).type != 'cuda':
         return host_tensor.to(device)
+    host_tensor = host_tensor.contiguous()
+    key = (str(device), host_tensor.dtype, tuple(host_tensor.shape), host_tensor.numpy().tobytes())
+    hit = _CONSTANTS.get(key)
+    if hit is not None:
+        _CONSTANTS.move_to_end(key)
+        return hit
+    if _capturing():
+        raise RuntimeError('a host array must be uploaded while a HIP graph is being captured: run the step once eagerly '
+                           'on a sample of the same composition first (TrainStep(graph=True) does)')
     pinned = torch.empty(host_tensor.shape, dtype=host_tensor.dtype, pin_memory=True)
     pinned.copy_(host_tensor)
-    return pinned.to(device, non_blocking=True)
+    dev = pinned.to(device, non_blocking=True)
+    _CONSTANTS[key] = dev
+    while len(_CONSTANTS) > _CONSTANTS_MAX:
+        _CONSTANTS.popitem(last=False)
+    return dev
 
 
 _SIDE_STREAMS = {}
@@ -203,12 +229,16 @@ class GraphPlan:
         # out-of-range flag, zeroed on a side stream so that side-stream builds (prefetch) never have to wait for the
         # compute still queued on the main stream; the main stream joins it here (one event wait)
         main = torch.cuda.current_stream(self.device)
-        s0 = _side_streams(self.device)[0]
-        with torch.cuda.stream(s0):
+        if _capturing():                                  # inside a HIP-graph capture everything stays on the captured stream
             self._bad = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._bad.record_stream(main)
-        self._bad_ready = s0.record_event()
-        main.wait_event(self._bad_ready)
+            self._bad_ready = None
+        else:
+            s0 = _side_streams(self.device)[0]
+            with torch.cuda.stream(s0):
+                self._bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._bad.record_stream(main)
+            self._bad_ready = s0.record_event()
+            main.wait_event(self._bad_ready)
         self._pending = []
         self._edges = {}
         self._pools = {}
@@ -231,6 +261,8 @@ class GraphPlan:
         todo = [('e', k, l) for (k, l) in edge_items if k not in self._edges]
         todo += [('p', l, l) for l in pool_levels if l not in self._pools]
         if not todo:
+            return self
+        if _capturing():                                  # captured step: built at first use on the captured stream
             return self
         main = torch.cuda.current_stream(self.device)
         streams = _side_streams(self.device)

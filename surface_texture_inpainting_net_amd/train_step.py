@@ -336,6 +336,84 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count = steps.pop() if steps else 0
 
 
+def _sample_signature(sample):
+    """What a captured step depends on besides tensor CONTENTS: every tensor's name / shape / dtype and the per-graph level
+    sizes (the host-side num_vertices table: instance-norm row ranges are built from it on the host)."""
+    sig = []
+    for k in sorted(sample.keys()):
+        v = sample[k]
+        sig.append((k, tuple(v.shape), str(v.dtype)) if torch.is_tensor(v) else (k, repr(v)))
+    nv = getattr(sample, '_nv_host', None)
+    if nv is None and 'num_vertices' in sample.keys():
+        nv = sample['num_vertices'].detach().cpu()            # foreign sample types: one host sync per step
+    return tuple(sig), (None if nv is None else tuple(int(x) for x in nv.reshape(-1)))
+
+
+class _CapturedStep:
+    """plan build + forward + masked L1 + backward of ONE sample signature as a HIP graph: static input tensors the
+    incoming sample is copied into, the loss tensor and the plan's out-of-range flag as outputs."""
+
+    def __init__(self, owner, sample, grad_scale, pool):
+        from .data import HierarchicalBatch
+        from .plan import GraphPlan, check_deferred
+        dev = owner.bucket.flat.device
+        self.keys = [k for k in sample.keys() if torch.is_tensor(sample[k])]
+        static = HierarchicalBatch(**{k: (sample[k].clone() if torch.is_tensor(sample[k]) else sample[k]) for k in sample.keys()})
+        static._nv_host = getattr(sample, '_nv_host', None)
+        if static._nv_host is None and 'num_vertices' in sample.keys():
+            static._nv_host = sample['num_vertices'].detach().cpu()
+        self.static = static
+        self.dst = [static[k] for k in self.keys]
+        model = owner.model.module if hasattr(owner.model, 'module') else owner.model
+        check_deferred(wait=True)                       # nothing of an earlier step may be polled from inside the capture
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, pool=pool):
+            # the plan is part of the step (the sample's indices change from replay to replay); its index validation
+            # cannot poll an event from inside a capture, so the flag is an output checked after every replay
+            plan = GraphPlan(static, linspace_quirk=getattr(model, 'compat_linspace_norm', True), validate=False)
+            static._plan_cache = plan
+            self.loss = owner.forward_backward(static, grad_scale)
+            self.bad = plan._bad
+        # index validation: the plan's out-of-range flag is re-zeroed by every replay, so replays add it into a running
+        # total; the total travels to pinned host memory whenever the previous copy has landed (the host never waits)
+        self.bad_total = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.flag_event = None
+        self.pool = self.graph.pool()
+
+    def run(self, sample):
+        src = [sample[k] for k in self.keys]
+        if any(a.data_ptr() != b.data_ptr() for a, b in zip(self.dst, src)):
+            torch._foreach_copy_(self.dst, src)
+        self.graph.replay()
+        self.bad_total.add_(self.bad)
+        if self._check(wait=False):
+            self.flag_host.copy_(self.bad_total, non_blocking=True)
+            self.flag_event = torch.cuda.current_stream().record_event()
+        return self.loss.clone()                        # the graph's own output tensor is overwritten by the next replay
+
+    def _check(self, wait):
+        """-> True when no flag copy is in flight any more (raises if one of the replays so far saw a bad index)."""
+        if self.flag_event is not None:
+            if not wait and not self.flag_event.query():
+                return False
+            self.flag_event.synchronize()
+            self.flag_event = None
+        if int(self.flag_host[0]) != 0:
+            self.flag_host.zero_()
+            self.bad_total.zero_()
+            raise IndexError('edge / trace index out of range for the level sizes in sample.num_vertices '
+                             '(reported after the captured step that used the sample)')
+        return True
+
+    def finish(self):
+        self._check(wait=True)
+        self.flag_host.copy_(self.bad_total, non_blocking=True)
+        self.flag_event = torch.cuda.current_stream().record_event()
+        self._check(wait=True)
+
+
 class TrainStep:
     """model + Adam(amsgrad) + flat-bucket gradient all-reduce; ``step(sample) -> loss`` (a 0-dim
     tensor, no host sync).  On the GPU the loss (+ its gradient) and the optimizer update are one HIP
@@ -344,10 +422,18 @@ class TrainStep:
     accumulate = the reference's num_cumulated_train_batches (:170-177): the loss of every call is divided by it, the
     gradients of `accumulate` consecutive calls are summed, and only the last call of a window all-reduces and runs the
     optimizer.  `optimizer` is a torch.optim.Optimizer either way (LR schedulers attach to it; set_lr() for manual
-    schedules)."""
+    schedules).
+
+    graph=True (GPU, accumulate == 1): plan build + forward + loss + backward are captured into ONE HIP graph per sample
+    signature (tensor shapes + per-graph level sizes) and replayed - ~420 kernel launches become one graph launch, which is
+    what a launch-bound step (a 20k-vertex crop, a batch of crops) needs.  The first step of a signature runs eagerly
+    (warm-up: lazy initialisations, host-side constants, index validation), the second captures, later ones copy the
+    sample into the graph's input tensors and replay.  The gradient all-reduce and the Adam update stay outside the
+    graph (Adam's bias corrections are host scalars that change every step).  Up to `graph_cache` signatures are kept
+    (least recently used dropped), all in one memory pool."""
 
     def __init__(self, model, lr=7e-5, weight_decay=0.0, amsgrad=True, use_mask_weighted_loss=True, group=None,
-                 accumulate=1, overlap_allreduce_min_bytes=32 << 20, time_allreduce=False):
+                 accumulate=1, overlap_allreduce_min_bytes=32 << 20, time_allreduce=False, graph=False, graph_cache=8):
         self.model = model
         self.group = group
         self.use_mask_weighted_loss = use_mask_weighted_loss
@@ -361,10 +447,25 @@ class TrainStep:
             model.plan_validation = 'deferred'
         self.bucket = FlatGradBucket(model.parameters())
         self.on_gpu = self.bucket.flat.is_cuda
+        self.graph = bool(graph)
+        if self.graph and not (self.on_gpu and self.accumulate == 1):
+            raise ValueError('graph=True needs a GPU model and accumulate == 1')
+        if self.graph:
+            from . import GRAPH_REPLAY_SAFE
+            import os
+            if not GRAPH_REPLAY_SAFE or os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') != '0':
+                raise RuntimeError('graph=True: the HIP runtime was initialised before this package could set '
+                                   'DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (ROCm 7.2 graph replays fault without it, see '
+                                   'surface_texture_inpainting_net_amd/__init__.py): import the package - or export the '
+                                   'variable - before the first GPU call')
+        import collections
+        self._captured = collections.OrderedDict()      # signature -> 'warm' | _CapturedStep
+        self._graph_cache = max(1, int(graph_cache))
+        self._graph_pool = None
         if self.on_gpu:
             self.optimizer = FlatAdam(self.bucket, lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
-            if overlap_allreduce_min_bytes and _world(group) > 1 and self.accumulate == 1:
-                self.bucket.enable_overlap(group, overlap_allreduce_min_bytes)
+            if overlap_allreduce_min_bytes and _world(group) > 1 and self.accumulate == 1 and not self.graph:
+                self.bucket.enable_overlap(group, overlap_allreduce_min_bytes)     # (RCCL calls are not captured)
         else:
             self.optimizer = torch.optim.Adam(self.bucket.params, lr=lr, weight_decay=weight_decay, amsgrad=amsgrad)
 
@@ -403,16 +504,35 @@ class TrainStep:
         self.bucket.gather_grads()
         return loss.detach()
 
+    def _graphed_forward_backward(self, sample, grad_scale):
+        sig = _sample_signature(sample)
+        ent = self._captured.get(sig)
+        if ent is None:                                  # first visit: eager (also validates the indices the usual way)
+            self._captured[sig] = 'warm'
+            while len(self._captured) > self._graph_cache:
+                self._captured.popitem(last=False)
+            return self.forward_backward(sample, grad_scale)
+        self._captured.move_to_end(sig)
+        if ent == 'warm':
+            ent = self._captured[sig] = _CapturedStep(self, sample, grad_scale, self._graph_pool)
+            if self._graph_pool is None:
+                self._graph_pool = ent.pool
+        return ent.run(sample)
+
     def finish(self):
         """Resolve the deferred index checks of the steps run so far (waits for the GPU)."""
         if self.on_gpu:
             from .plan import check_deferred
             check_deferred(wait=True)
+            for ent in self._captured.values():
+                if ent != 'warm':
+                    ent.finish()
 
     def __call__(self, sample):
         k = self.accumulate
         first, last = self._micro == 0, self._micro == k - 1
-        loss = self.forward_backward(sample, grad_scale=1.0 / (k * _world(self.group)))
+        scale = 1.0 / (k * _world(self.group))
+        loss = self._graphed_forward_backward(sample, scale) if self.graph else self.forward_backward(sample, scale)
         self.bucket.accumulate(first, last)
         self._micro = 0 if last else self._micro + 1
         if last:

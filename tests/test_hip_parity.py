@@ -784,7 +784,8 @@ def test_weight_gradient_side_stream_is_bit_identical_in_every_autograd_mode():
             net(s).square().mean().backward()
         return [p.grad.clone() for p in params]
 
-    old = SF.USE_WGRAD_STREAM
+    old, old_min = SF.USE_WGRAD_STREAM, SF.WGRAD_MIN_WORK
+    SF.WGRAD_MIN_WORK = 0.0                      # (a 40k-vertex step would otherwise stay on one stream: launch-bound)
     try:
         for mode in ('backward', 'accumulate', 'grad'):
             SF.USE_WGRAD_STREAM = False
@@ -794,7 +795,7 @@ def test_weight_gradient_side_stream_is_bit_identical_in_every_autograd_mode():
                 got = grads(mode)
                 assert all(torch.equal(a, b) for a, b in zip(got, want)), mode
     finally:
-        SF.USE_WGRAD_STREAM = old
+        SF.USE_WGRAD_STREAM, SF.WGRAD_MIN_WORK = old, old_min
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
