@@ -248,8 +248,9 @@ int stin_norm_act_bwd_f32(const float* x, int64_t ldx, const float* gout, int64_
                                       the weight split is then done once per step instead of once per block    */
 #define STIN_GEMM_W_FRAG 0x400     /* nt, OR-ed into PRESPLIT: the pre-split W is stored in MFMA FRAGMENT order where the shape
                                       takes it (stin_gemm_w_is_frag(Nc, K): the shapes of the resident-strip kernel - K % 64 == 0,
-                                      Nc % 32 == 0, 128 <= K <= 256, Nc >= 320; other shapes keep the k-group form above, so the
-                                      flag may be set unconditionally): for the 32-column tile t
+                                      Nc % 32 == 0, 128 <= K <= 256, Nc >= 320 - and of the all-columns kernel - Nc = 256 with
+                                      K >= 512 or Nc = 128 with K >= 256, K % 64 == 0; other shapes keep the k-group form above,
+                                      so the flag may be set unconditionally): for the 32-column tile t
                                       and the 16-wide k-step s, 2 KB at byte ((t * K/16 + s) * 64 + lane) * 32 hold lane
                                       (k-half h, column r) = h * 32 + r's [hi x 8 | lo x 8] of k = 16 s + 8 h .. + 7 - what the
                                       resident-strip kernel loads straight into its B fragments (same footprint as fp32; ldw

@@ -25,8 +25,12 @@ static inline int stin_launch_status() {
 // MI355X, profiles/r02_gemm_shapes.md): one resident K chunk (K <= 256) with enough work per staged strip (K >= 128) and
 // at least 2.5 column panels (Nc >= 320) - 5-15 % faster there; narrower outputs leave waves of the 128-column panel idle,
 // longer K would add its chunks through memory, and both stay on the tiled kernel.
+// Narrow outputs with a long reduction (Nc = 256 and K >= 512, Nc = 128 and K >= 256; K a multiple of 64) go to the
+// all-columns kernel (k_gemm_nt_wide), which reads the same layout; shorter K measured slower there than on the 64x64 tiling.
 __host__ __device__ static inline bool stin_w_frag_shape(int Nc, int K) {
-    return K % 64 == 0 && Nc % 32 == 0 && K >= 128 && K <= 256 && Nc >= 320;
+    if (K % 64 != 0) return false;
+    if ((Nc == 256 && K >= 512) || (Nc == 128 && K >= 256)) return true;
+    return Nc % 32 == 0 && K >= 128 && K <= 256 && Nc >= 320;
 }
 
 static inline bool stin_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -634,6 +634,165 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Narrow outputs (Nc = 128 or 256 columns) with any K: the block owns ALL columns of its rows.  A 64x64 tiling reads and
+// splits every A tile once per 64-column block (4x at Nc = 256) and runs 3 MFMAs per 4 LDS fragment reads; here
+//   * 4 waves as (4 / NW) x NW, each 64 rows x 64 columns (2 x 2 accumulator tiles, 12 MFMAs per 16-wide k-step against
+//     4 A-fragment reads from LDS and 4 B-fragment loads), NW = Nc / 64: BM = 64 rows at Nc = 256, 128 rows at Nc = 128;
+//   * A is streamed ONCE: 64-wide K chunks, split into the two 16-bit pieces once and double-buffered in LDS in the strip
+//     kernel's image ([piece][k-step][row][2 x 16 B swizzled]); the next chunk's global loads are in flight during the 48
+//     MFMAs of the current one, one barrier per chunk;
+//   * the weight operand is read in MFMA FRAGMENT order straight from L2 (as in k_gemm_nt_strip), a 4-step register ring
+//     that runs ahead across chunk boundaries;
+//   * accumulators live across the whole K: no partial sums through memory, same k order and epilogue expression as the
+//     other split kernels -> bit-identical results (tests/test_hip_parity.py::test_gemm_nt_strip_kernel_equals_tiled_kernel).
+// Measured (profiles/r02_gemm_shapes.md, r02_pmc_nt_wide.md): 60 211 x 256 x 640 91 -> 79 us, 60 211 x 128 x 256 37 -> 34 us,
+// 18 063 x 256 x 1024 52 -> 52 us.  At 18 063 rows the grid is 283 blocks on 256 CUs - one wave per SIMD, so every LDS /
+// L2 wait and the split's VALU work is exposed: a wave lives 72 k cycles for 24.6 k cycles of MFMA issue (counters: 47 % issue
+// stall, 26 % s_waitcnt / barrier) - the same wall time as the 64x64 tiling reaches with 4x the waves and 3.4x the instructions.
+// Rotating the K order per block (L2 channel hot-spotting) and padding the row pitch (4 KB) changed nothing.
+constexpr int WD_KC = 64, WD_STEPS = WD_KC / 16, WD_THREADS = 256;
+
+template <typename PT, int NW>
+__global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __restrict__ A, int64_t lda,
+                                                             const float* __restrict__ Wf,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ row_mask, int64_t ld_mask,
+                                                             const float* __restrict__ res, int64_t ld_res, int64_t M,
+                                                             int K, float* __restrict__ C, int64_t ldc) {
+    typedef typename PieceTraits<PT>::vec8 vec8;
+    constexpr float ASCALE = PieceTraits<PT>::ascale, WSCALE = PieceTraits<PT>::wscale;
+    constexpr int WAVES_M = 4 / NW, BM = 64 * WAVES_M, PASSES = BM / 32;       // staging: 32 rows per pass
+    constexpr int STEP_BYTES = BM * 32, PLANE = WD_STEPS * STEP_BYTES, BUF = 2 * PLANE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+    __shared__ float mask_s[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NW, wn = wave % NW;                                  // wave-uniform
+    const int kh = lane >> 5, li = lane & 31;
+    const int kq = tid & 7, r0 = tid >> 3;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int nchunk = K / WD_KC, KS_total = K / 16;
+
+    if (row_mask != nullptr && tid < BM) {
+        const int64_t row = row0 + tid;
+        mask_s[tid] = row_mask[(row < M ? row : M - 1) * ld_mask];
+    }
+
+    float4 ra[2][PASSES];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < PASSES; ++t) {
+                const int64_t row = row0 + r0 + t * 32;
+                // rows past M read row M - 1 (valid memory): their accumulators are never stored, so no zeroing - a select
+                // here would make the compiler wait for the load right where it is issued
+                ra[h][t] = ld4(A + (row < M ? row : M - 1) * lda + c * WD_KC + h * 32 + kq * 4);
+            }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ks = h * 2 + (kq >> 2), kh_ = (kq >> 1) & 1;
+#pragma unroll
+            for (int t = 0; t < PASSES; ++t) {
+                const int row = r0 + t * 32;
+                PT* dst = reinterpret_cast<PT*>(smem + buf * BUF + ks * STEP_BYTES + row * 32 + ((kh_ ^ ((row >> 3) & 1)) << 4) + (kq & 1) * 8);
+                split_store<2, PT>(ra[h][t], dst, PLANE / 2, ASCALE);
+            }
+        }
+    };
+
+    // B fragments of this wave's two 32-column tiles: step ks of tile t at ((t * KS_total + ks) * 2048) + lane * 32
+    const unsigned char* wb0 = reinterpret_cast<const unsigned char*>(Wf) + (int64_t)(wn * 2) * KS_total * 2048;
+    const unsigned char* wb1 = wb0 + (int64_t)KS_total * 2048;
+    const unsigned lane_off = (unsigned)lane * 32u;
+    StFrag wf[WD_STEPS][2];
+#pragma unroll
+    for (int j = 0; j < WD_STEPS; ++j) {
+        wf[j][0] = st_wload(wb0 + j * 2048, lane_off);
+        wf[j][1] = st_wload(wb1 + j * 2048, lane_off);
+    }
+    gload(0);
+    sstore(0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const unsigned char* a_frag = smem + (wm * 64 + li) * 32 + ((kh ^ ((li >> 3) & 1)) << 4);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const bool more = c + 1 < nchunk;                                      // block-uniform
+        if (more) gload(c + 1);
+        const unsigned char* ab = a_frag + (c & 1) * BUF;
+        // refill target of the ring: the same step of the next chunk (clamped at the end of K: fetched, never used)
+        const int nxt = (more ? c + 1 : c) * WD_STEPS;
+#pragma unroll
+        for (int j = 0; j < WD_STEPS; ++j) {
+            vec8 a0[2], a1[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a0[i] = *reinterpret_cast<const vec8*>(ab + j * STEP_BYTES + i * 1024);
+                a1[i] = *reinterpret_cast<const vec8*>(ab + PLANE + j * STEP_BYTES + i * 1024);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const vec8 b0 = __builtin_bit_cast(vec8, wf[j][t].hi), b1 = __builtin_bit_cast(vec8, wf[j][t].lo);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[i][t] = mfma_k16(a0[i], b1, acc[i][t]);
+                    acc[i][t] = mfma_k16(a1[i], b0, acc[i][t]);
+                    acc[i][t] = mfma_k16(a0[i], b0, acc[i][t]);
+                }
+            }
+            wf[j][0] = st_wload(wb0 + (int64_t)(nxt + j) * 2048, lane_off);
+            wf[j][1] = st_wload(wb1 + (int64_t)(nxt + j) * 2048, lane_off);
+        }
+        if (more) sstore((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: v = acc / (ascale wscale) + bias [* row mask] + residual
+    const float sc = 1.f / (ASCALE * WSCALE);
+    const bool full_rows = row0 + BM <= M;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = wn * 64 + t * 32 + li;
+        const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr0 = wm * 64 + i * 32 + 4 * kh;
+            if (full_rows) {
+                float ld[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ld[r] = res != nullptr ? res[(row0 + lr0 + (r & 3) + 8 * (r >> 2)) * ld_res + col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = lr0 + (r & 3) + 8 * (r >> 2);
+                    C[(row0 + lr) * ldc + col] = acc[i][t][r] * sc + (row_mask != nullptr ? bv * mask_s[lr] : bv) + ld[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = lr0 + (r & 3) + 8 * (r >> 2);
+                    const int64_t row = row0 + lr;
+                    if (row < M)
+                        C[row * ldc + col] = acc[i][t][r] * sc + (row_mask != nullptr ? bv * mask_s[lr] : bv) +
+                                             (res != nullptr ? res[row * ld_res + col] : 0.f);
+                }
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- TN
 // dW tile TI x TJ per 256-thread block, reduction over a chunk of rows m.  Both operands are
 // row-major with m as the slow index, so a 32-row slab of G (TI columns) and X (TJ columns) is staged
@@ -1489,7 +1648,21 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
         else if (force_tile == 2) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);  \
         else STIN_NT(KERNEL, 64, 64, 2, 2, ##__VA_ARGS__);                                     \
     } while (0)
-    if (wfrag) {
+    if (wfrag && Nc <= 256) {
+        // all-columns kernel (k_gemm_nt_wide): Nc = 128 / 256, the fragment-order weight operand cannot be read by any other kernel
+        STIN_REQUIRE(vec, STIN_E_ALIGN);
+#define STIN_WIDE(PT_, NW_)                                                                                               \
+    hipLaunchKernelGGL((k_gemm_nt_wide<PT_, NW_>), dim3((unsigned)((M + 64 * (4 / NW_) - 1) / (64 * (4 / NW_)))), dim3(WD_THREADS), 0, \
+                       stream, A, lda, W, bias, row_mask, ld_mask, residual, ld_res, M, K, C, ldc)
+        if (precision == STIN_GEMM_BF16X3) {
+            if (Nc == 256) STIN_WIDE(__bf16, 4);
+            else STIN_WIDE(__bf16, 2);
+        } else {
+            if (Nc == 256) STIN_WIDE(_Float16, 4);
+            else STIN_WIDE(_Float16, 2);
+        }
+#undef STIN_WIDE
+    } else if (wfrag) {
         // resident-strip kernel (k_gemm_nt_strip): the fragment-order weight operand cannot be read by any other kernel
         STIN_REQUIRE(vec && ldc % 4 == 0 && stin_aligned16(C) && (residual == nullptr || (ld_res % 4 == 0 && stin_aligned16(residual))),
                      STIN_E_ALIGN);

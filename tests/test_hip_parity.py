@@ -232,12 +232,15 @@ def test_gemm_nt_precision_modes(M, Nc, K):
 
 @pytest.mark.parametrize('M,Nc,K', [(1, 320, 128), (37, 320, 192), (300, 352, 128), (4097, 320, 128), (5000, 1024, 256), (18063, 640, 256),
                                     (2500, 1280, 128), (64, 384, 256), (129, 1024, 128), (777, 1280, 256), (2049, 96, 576),
-                                    (130, 64, 36), (1000, 256, 640), (3001, 128, 320)])
+                                    (130, 64, 36), (1000, 256, 640), (3001, 128, 320), (1, 256, 128), (63, 256, 1024),
+                                    (18063, 256, 1024), (18063, 256, 512), (20001, 128, 256), (4100, 128, 1280), (200, 256, 64),
+                                    (129, 128, 192), (515, 192, 256)])
 def test_gemm_nt_strip_kernel_equals_tiled_kernel(M, Nc, K):
-    """The resident-strip NT kernel (k_gemm_nt_strip: 64-row strips resident in LDS, weight fragments straight from L2 in
-    MFMA fragment order, unit ranges) against the tiled kernel on the k-group layout: same arithmetic in the same order ->
-    bit-identical.  Shapes the strip kernel does not take (stin_gemm_w_is_frag) keep the k-group layout and the tiled
-    kernel under the same flag.  Both against fp64."""
+    """The NT kernels that read the weight operand in MFMA fragment order straight from L2 - the resident-strip kernel
+    (k_gemm_nt_strip: 64-row strips resident in LDS, Nc >= 320, K <= 256) and the all-columns kernel (k_gemm_nt_wide:
+    Nc = 128 / 256, any K, A streamed once through a double-buffered LDS chunk) - against the tiled kernel on the k-group
+    layout: same arithmetic in the same order -> bit-identical.  Shapes neither takes (stin_gemm_w_is_frag) keep the
+    k-group layout and the tiled kernel under the same flag.  Both against fp64."""
     g = torch.Generator().manual_seed(M + Nc + K)
     A = torch.randn(M + 3, K + 4, generator=g).to(DEV)[1:M + 1, :K]            # a strided view: lda != K
     W = (torch.randn(Nc, K, generator=g) * 0.1).to(DEV)
@@ -247,7 +250,7 @@ def test_gemm_nt_strip_kernel_equals_tiled_kernel(M, Nc, K):
     want = A.double() @ W.double().t()
     scale = float(want.abs().max()) + 1.0
     FR = 0x400
-    frag = K % 64 == 0 and Nc % 32 == 0 and 128 <= K <= 256 and Nc >= 320
+    frag = K % 64 == 0 and ((Nc == 256 and K >= 512) or (Nc == 128 and K >= 256) or (Nc % 32 == 0 and 128 <= K <= 256 and Nc >= 320))
     assert bool(_lib_load().stin_gemm_w_is_frag(Nc, K)) == frag
     for prec in (SF.GEMM_F16X3, SF.GEMM_BF16X3):
         Wk, Wf = SF.split_weights(W, prec), SF.split_weights(W, prec | FR)
@@ -257,6 +260,11 @@ def test_gemm_nt_strip_kernel_equals_tiled_kernel(M, Nc, K):
             for _ in range(2):                                  # twice: the ring / unit logic must not depend on what ran before
                 strip = SF.gemm_nt(A, Wf, precision=prec | SF.GEMM_W_PRESPLIT | FR, **kw)
                 assert torch.equal(strip, tiled), (prec, sorted(kw))
+        wide = torch.full((M + 2, Nc + 8), 3.0, device=DEV)                  # output as a view into a wider matrix
+        SF.gemm_nt(A, Wf, b, residual=res, out=wide[1:M + 1, 4:Nc + 4], precision=prec | SF.GEMM_W_PRESPLIT | FR)
+        assert torch.equal(wide[1:M + 1, 4:Nc + 4], SF.gemm_nt(A, Wk, b, residual=res, precision=prec | SF.GEMM_W_PRESPLIT))
+        wide[1:M + 1, 4:Nc + 4] = 3.0
+        assert float((wide - 3.0).abs().max()) == 0.0
         ref = want + b.double() * mask.double()[:, None]
         tol = 3e-6 if prec == SF.GEMM_F16X3 else 2e-5
         assert float((SF.gemm_nt(A, Wf, b, row_mask=mask, precision=prec | SF.GEMM_W_PRESPLIT | FR).double() - ref).abs().max()) <= tol * scale
