@@ -646,11 +646,15 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
 //     that runs ahead across chunk boundaries;
 //   * accumulators live across the whole K: no partial sums through memory, same k order and epilogue expression as the
 //     other split kernels -> bit-identical results (tests/test_hip_parity.py::test_gemm_nt_strip_kernel_equals_tiled_kernel).
-// Measured (profiles/r02_gemm_shapes.md, r02_pmc_nt_wide.md): 60 211 x 256 x 640 91 -> 79 us, 60 211 x 128 x 256 37 -> 34 us,
-// 18 063 x 256 x 1024 52 -> 52 us.  At 18 063 rows the grid is 283 blocks on 256 CUs - one wave per SIMD, so every LDS /
-// L2 wait and the split's VALU work is exposed: a wave lives 72 k cycles for 24.6 k cycles of MFMA issue (counters: 47 % issue
-// stall, 26 % s_waitcnt / barrier) - the same wall time as the 64x64 tiling reaches with 4x the waves and 3.4x the instructions.
-// Rotating the K order per block (L2 channel hot-spotting) and padding the row pitch (4 KB) changed nothing.
+// Measured (profiles/r02_gemm_shapes.md): 18 063 x 256 x 1024 52 -> 45 us, 18 063 x 256 x 512 36 -> 31, 18 063 x 128 x 1280
+// 43 -> 37, 60 211 x 256 x 640 91 -> 72, 60 211 x 128 x 256 37 -> 31.  At 18 063 rows the grid is 283 blocks on 256 CUs - one wave
+// per SIMD, so nothing hides a stall for free.  Compile-time ablations of the plain loop (load chunk c+1, 48 MFMAs, split +
+// store, barrier): MFMA issue 12.6 us + weight-fragment waits 10 + A staging 8 + the rest 21 = the measured 52 - the costs
+// ADD UP.  Hence the explicit software pipeline below (-6 us).  What remains of the 45: 27 of the 256 CUs run two blocks
+// whose waves share the matrix pipes - a 2 x 12 us MFMA makespan - plus launch / prologue / epilogue (~12 us).  Tried and
+// dropped: a second group of 4 waves per block splitting K (two waves per SIMD; the block-wide barrier keeps the groups in
+// lock-step: 59 us), rotating the K order per block (L2 channel hot spots: no change), padding the 4 KB row pitch (no change);
+// SQ counters of the first version: profiles/r02_pmc_nt_wide.md.
 constexpr int WD_KC = 64, WD_STEPS = WD_KC / 16, WD_THREADS = 256;
 
 template <typename PT, int NW>
@@ -680,8 +684,13 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
         mask_s[tid] = row_mask[(row < M ? row : M - 1) * ld_mask];
     }
 
-    float4 ra[2][PASSES];
-    auto gload = [&](int c) {
+    // Software pipeline (one wave per SIMD at M = 18 k: nothing else hides a stall).  Measured by ablation at 18 063 x 256 x
+    // 1024: MFMA issue 12.6 us, weight-fragment waits 10, A staging 8, fixed 21 - and in the straightforward loop they ADD UP
+    // (52 us).  So the staging work of chunk c+1 is spread over the MFMA groups of chunk c (split + LDS store of one 16-byte
+    // piece after the first MFMAs of every k-step), its global loads are issued a whole chunk earlier (two register sets),
+    // and the A fragments of k-step j+1 are read from LDS while k-step j multiplies.
+    float4 ra[2][2][PASSES];                                                   // [register set][k-tile of the chunk][row pass]
+    auto gload = [&](float4 (&r)[2][PASSES], int c) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -689,20 +698,14 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
                 const int64_t row = row0 + r0 + t * 32;
                 // rows past M read row M - 1 (valid memory): their accumulators are never stored, so no zeroing - a select
                 // here would make the compiler wait for the load right where it is issued
-                ra[h][t] = ld4(A + (row < M ? row : M - 1) * lda + c * WD_KC + h * 32 + kq * 4);
+                r[h][t] = ld4(A + (row < M ? row : M - 1) * lda + c * WD_KC + h * 32 + kq * 4);
             }
     };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ks = h * 2 + (kq >> 2), kh_ = (kq >> 1) & 1;
-#pragma unroll
-            for (int t = 0; t < PASSES; ++t) {
-                const int row = r0 + t * 32;
-                PT* dst = reinterpret_cast<PT*>(smem + buf * BUF + ks * STEP_BYTES + row * 32 + ((kh_ ^ ((row >> 3) & 1)) << 4) + (kq & 1) * 8);
-                split_store<2, PT>(ra[h][t], dst, PLANE / 2, ASCALE);
-            }
-        }
+    auto sstore_piece = [&](const float4 (&r)[2][PASSES], int buf, int h, int t) {
+        const int ks = h * 2 + (kq >> 2), kh_ = (kq >> 1) & 1;
+        const int row = r0 + t * 32;
+        PT* dst = reinterpret_cast<PT*>(smem + buf * BUF + ks * STEP_BYTES + row * 32 + ((kh_ ^ ((row >> 3) & 1)) << 4) + (kq & 1) * 8);
+        split_store<2, PT>(r[h][t], dst, PLANE / 2, ASCALE);
     };
 
     // B fragments of this wave's two 32-column tiles: step ks of tile t at ((t * KS_total + ks) * 2048) + lane * 32
@@ -715,8 +718,12 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
         wf[j][0] = st_wload(wb0 + j * 2048, lane_off);
         wf[j][1] = st_wload(wb1 + j * 2048, lane_off);
     }
-    gload(0);
-    sstore(0);
+    gload(ra[0], 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < PASSES; ++t) sstore_piece(ra[0], 0, h, t);
+    gload(ra[1], nchunk > 1 ? 1 : 0);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -727,37 +734,64 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const unsigned char* a_frag = smem + (wm * 64 + li) * 32 + ((kh ^ ((li >> 3) & 1)) << 4);
-    __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const bool more = c + 1 < nchunk;                                      // block-uniform
-        if (more) gload(c + 1);
+    struct AFrag {
+        vec8 a0[2], a1[2];
+    };
+    auto aread = [&](const unsigned char* ab, int j) {
+        AFrag f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.a0[i] = *reinterpret_cast<const vec8*>(ab + j * STEP_BYTES + i * 1024);
+            f.a1[i] = *reinterpret_cast<const vec8*>(ab + PLANE + j * STEP_BYTES + i * 1024);
+        }
+        return f;
+    };
+    // one chunk: compute from buffer (c & 1); meanwhile split + store `stage` (chunk c + 1, loaded an iteration ago) into the
+    // other buffer and request chunk c + 2 into `fetch` (the set whose content was stored during the previous iteration)
+    // (branch-free body: past the end of K the fetches re-read the last chunk and the staging writes a buffer nobody reads
+    // any more - conditionals between the MFMAs made the compiler shuttle the accumulators between AGPRs and VGPRs)
+    auto chunk = [&](int c, const float4 (&stage)[2][PASSES], float4 (&fetch)[2][PASSES]) {
+        gload(fetch, c + 2 < nchunk ? c + 2 : nchunk - 1);
         const unsigned char* ab = a_frag + (c & 1) * BUF;
-        // refill target of the ring: the same step of the next chunk (clamped at the end of K: fetched, never used)
-        const int nxt = (more ? c + 1 : c) * WD_STEPS;
+        const int nxt = (c + 1 < nchunk ? c + 1 : c) * WD_STEPS;               // ring refill: same step of the next chunk (clamped)
+        AFrag cur = aread(ab, 0);
 #pragma unroll
         for (int j = 0; j < WD_STEPS; ++j) {
-            vec8 a0[2], a1[2];
+            AFrag nx = cur;
+            if (j + 1 < WD_STEPS) nx = aread(ab, j + 1);                       // next k-step's fragments in flight during this one
+            const vec8 b00 = __builtin_bit_cast(vec8, wf[j][0].hi), b01 = __builtin_bit_cast(vec8, wf[j][0].lo);
+            const vec8 b10 = __builtin_bit_cast(vec8, wf[j][1].hi), b11 = __builtin_bit_cast(vec8, wf[j][1].lo);
+            acc[0][0] = mfma_k16(cur.a0[0], b01, acc[0][0]);
+            acc[0][0] = mfma_k16(cur.a1[0], b00, acc[0][0]);
+            acc[0][0] = mfma_k16(cur.a0[0], b00, acc[0][0]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a0[i] = *reinterpret_cast<const vec8*>(ab + j * STEP_BYTES + i * 1024);
-                a1[i] = *reinterpret_cast<const vec8*>(ab + PLANE + j * STEP_BYTES + i * 1024);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const vec8 b0 = __builtin_bit_cast(vec8, wf[j][t].hi), b1 = __builtin_bit_cast(vec8, wf[j][t].lo);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    acc[i][t] = mfma_k16(a0[i], b1, acc[i][t]);
-                    acc[i][t] = mfma_k16(a1[i], b0, acc[i][t]);
-                    acc[i][t] = mfma_k16(a0[i], b0, acc[i][t]);
-                }
-            }
+            for (int q = 0; q < PASSES / 2; ++q)                               // this k-step's share of the staging
+                sstore_piece(stage, (c + 1) & 1, j >> 1, (j & 1) * (PASSES / 2) + q);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = mfma_k16(cur.a0[1], b01, acc[1][0]);
+            acc[1][0] = mfma_k16(cur.a1[1], b00, acc[1][0]);
+            acc[1][0] = mfma_k16(cur.a0[1], b00, acc[1][0]);
             wf[j][0] = st_wload(wb0 + (int64_t)(nxt + j) * 2048, lane_off);
+            acc[0][1] = mfma_k16(cur.a0[0], b11, acc[0][1]);
+            acc[0][1] = mfma_k16(cur.a1[0], b10, acc[0][1]);
+            acc[0][1] = mfma_k16(cur.a0[0], b10, acc[0][1]);
+            acc[1][1] = mfma_k16(cur.a0[1], b11, acc[1][1]);
+            acc[1][1] = mfma_k16(cur.a1[1], b10, acc[1][1]);
+            acc[1][1] = mfma_k16(cur.a0[1], b10, acc[1][1]);
             wf[j][1] = st_wload(wb1 + (int64_t)(nxt + j) * 2048, lane_off);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nx;
         }
-        if (more) sstore((c + 1) & 1);
         __syncthreads();
+    };
+    __syncthreads();
+    int c = 0;
+    for (; c + 1 < nchunk; c += 2) {
+        chunk(c, ra[1], ra[0]);
+        chunk(c + 1, ra[0], ra[1]);
     }
+    if (c < nchunk) chunk(c, ra[1], ra[0]);
 
     // ---- epilogue: v = acc / (ascale wscale) + bias [* row mask] + residual
     const float sc = 1.f / (ASCALE * WSCALE);
