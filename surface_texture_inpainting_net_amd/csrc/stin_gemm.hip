@@ -1040,10 +1040,16 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
     float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);                  // bias-gradient partial (columns of this thread's G patch)
 
-    float4 patch[NPASS][4];
-    float pw[4];
-    bool pv[4];
-    auto load_slab = [&](int64_t m0) {
+    // Two register sets (128x128 tiles): the loads of slab s + 2 are issued while slab s multiplies - one slab of cover (24 MFMAs
+    // = 0.35 us per wave) is less than an HBM / Infinity-Cache load takes under load.  Pays for M >= 60 k; at M = 18 k the
+    // kernel is bound by the LDS round trip of the transposing split (2 barriers, 32 KB written + 64 KB read per slab), not by loads.
+    struct Slab {
+        float4 patch[NPASS][4];
+        float pw[4];
+        bool pv[4];
+    };
+    Slab S0, S1;
+    auto load_slab = [&](Slab& P, int64_t m0) {
 #pragma unroll
         for (int s = 0; s < NPASS; ++s) {
             const int item = tid + s * BLOCK;
@@ -1070,20 +1076,19 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
                         if (col + 3 < lim) v.w = p[3];
                     }
                 }
-                patch[s][r] = v;
+                P.patch[s][r] = v;
                 // row weight of the bias-gradient column: a PLAIN load (clamped row, no select on the loaded value), so that
                 // the compiler does not have to drain the prefetched patch loads before the MFMAs; masked in store_slab
                 if (s == 0) {
                     const int64_t rc = row < me ? row : me - 1;
                     const float* wp = (want_bias && row_w != nullptr) ? row_w + rc * ld_w : G;   // always a valid address
-                    pw[r] = *wp;
-                    pv[r] = row < me;
+                    P.pw[r] = *wp;
+                    P.pv[r] = row < me;
                 }
             }
         }
     };
-    auto store_slab = [&](int buf) {
-        (void)buf;
+    auto store_slab = [&](const Slab& P) {
 #pragma unroll
         for (int s = 0; s < NPASS; ++s) {
             const int item = tid + s * BLOCK;
@@ -1094,19 +1099,19 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
             if (s == 0 && isG) {                                   // 2*TI >= 128: pass 0 holds every G patch of TI=128; see below for TI=64
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float w = (want_bias && pv[r]) ? (row_w != nullptr ? pw[r] : 1.f) : 0.f;
-                    bs.x += w * patch[s][r].x;
-                    bs.y += w * patch[s][r].y;
-                    bs.z += w * patch[s][r].z;
-                    bs.w += w * patch[s][r].w;
+                    const float w = (want_bias && P.pv[r]) ? (row_w != nullptr ? P.pw[r] : 1.f) : 0.f;
+                    bs.x += w * P.patch[s][r].x;
+                    bs.y += w * P.patch[s][r].y;
+                    bs.z += w * P.patch[s][r].z;
+                    bs.w += w * P.patch[s][r].w;
                 }
             }
             __bf16* dst = isG ? &Gt[0][c4 * 4][rg * 4] : &Xt[0][c4 * 4][rg * 4];
             const int plane = (isG ? TI : TJ) * TNB_PITCH;
-            float col[4][4] = {{patch[s][0].x, patch[s][1].x, patch[s][2].x, patch[s][3].x},
-                               {patch[s][0].y, patch[s][1].y, patch[s][2].y, patch[s][3].y},
-                               {patch[s][0].z, patch[s][1].z, patch[s][2].z, patch[s][3].z},
-                               {patch[s][0].w, patch[s][1].w, patch[s][2].w, patch[s][3].w}};
+            float col[4][4] = {{P.patch[s][0].x, P.patch[s][1].x, P.patch[s][2].x, P.patch[s][3].x},
+                               {P.patch[s][0].y, P.patch[s][1].y, P.patch[s][2].y, P.patch[s][3].y},
+                               {P.patch[s][0].z, P.patch[s][1].z, P.patch[s][2].z, P.patch[s][3].z},
+                               {P.patch[s][0].w, P.patch[s][1].w, P.patch[s][2].w, P.patch[s][3].w}};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -1124,12 +1129,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
     };
 
     const int kh = lane >> 5, li = lane & 31;
-    load_slab(mb);
-    for (int64_t m0 = mb; m0 < me; m0 += TNB_R) {
-        __syncthreads();                                           // previous slab's fragment reads are done
-        store_slab(0);
-        __syncthreads();
-        if (m0 + TNB_R < me) load_slab(m0 + TNB_R);                // next slab's global loads in flight during the MFMAs
+    auto multiply = [&]() {
 #pragma unroll
         for (int ks = 0; ks < TNB_R; ks += 16) {
             bf16x8 a[NS][MT], c[NS][NT];
@@ -1155,6 +1155,33 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][t], c[0][u], acc[t][u], 0, 0, 0);
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][t], c[0][u], acc[t][u], 0, 0, 0);
                 }
+        }
+    };
+    // 128x128 tiles only: the second register set costs the narrower tiles a wave of occupancy (measured: 200 704 x 320 x 12
+    // 91 -> 118 us with it, while 60 211 x 640 x 256 goes 161 -> 139 and 200 704 x 320 x 128 186 -> 143)
+    constexpr bool DEEP = (TI == 128 && TJ == 128);
+    load_slab(S0, mb);
+    if (DEEP) {
+        load_slab(S1, mb + TNB_R);                                 // (rows >= me load nothing)
+        // (branch-free body: with an odd slab count the last half-iteration multiplies a slab of zeros)
+        auto step = [&](Slab& P, int64_t m0) {
+            __syncthreads();                                       // previous slab's fragment reads are done
+            store_slab(P);
+            __syncthreads();
+            load_slab(P, m0 + 2 * TNB_R);                          // two slabs ahead
+            multiply();
+        };
+        for (int64_t m0 = mb; m0 < me; m0 += 2 * TNB_R) {
+            step(S0, m0);
+            step(S1, m0 + TNB_R);
+        }
+    } else {
+        for (int64_t m0 = mb; m0 < me; m0 += TNB_R) {
+            __syncthreads();
+            store_slab(S0);
+            __syncthreads();
+            if (m0 + TNB_R < me) load_slab(S0, m0 + TNB_R);        // next slab's global loads in flight during the MFMAs
+            multiply();
         }
     }
 
