@@ -136,6 +136,12 @@ int stin_edge_relu_mean_bwd_dst_mask_f32(const float* G, int64_t ldg, const uint
 int stin_edge_relu_mean_bwd_src_mask_f32(const float* G, int64_t ldg, const float* w_src, const uint32_t* mask,
                                          const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot,
                                          int64_t N, int H, float* dB, int64_t lddb, stin_stream_t stream);
+/* bwd_dst_mask and bwd_src_mask in ONE launch (the dB blocks first, then the dA blocks); results bit-identical to the two
+ * calls above.  fp32 rows. */
+int stin_edge_relu_mean_bwd_mask_f32(const float* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst,
+                                     const float* w_src, const int32_t* rowptr_src, const int32_t* col_src,
+                                     const int32_t* xslot, int64_t N, int H, float* dA, int64_t ldda, float* dB,
+                                     int64_t lddb, stin_stream_t stream);
 int stin_edge_relu_mean_bwd_dst_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
                                     const float* G, int64_t ldg, const int32_t* rowptr,
                                     const int32_t* col, int64_t N, int H, float* dA, int64_t ldda,

@@ -217,9 +217,8 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         STIN_TRY(stin_gemm_nt_f32(static_cast<const float*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H, Cout,
                                   static_cast<float*>(dhE), H, pb, stream));
         // edge stage backward from the saved ReLU mask -> dY = [dA | dB | g]
-        STIN_TRY(stin_edge_relu_mean_bwd_dst_mask_f32(static_cast<const float*>(dhE), H, mask, rowptr_dst, N, H, dYf, Yw, stream));
-        STIN_TRY(stin_edge_relu_mean_bwd_src_mask_f32(static_cast<const float*>(dhE), H, w_src, mask, rowptr_src, col_src, xslot, N,
-                                                      H, dYf + H, Yw, stream));
+        STIN_TRY(stin_edge_relu_mean_bwd_mask_f32(static_cast<const float*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src, col_src,
+                                                 xslot, N, H, dYf, Yw, dYf + H, Yw, stream));
         if (has_shortcut && N > 0) {
             hipError_t e = hipMemcpy2DAsync(dYf + 2 * H, (size_t)Yw * 4, gf, (size_t)ldg * 4, (size_t)Cout * 4, (size_t)N,
                                             hipMemcpyDeviceToDevice, hs);

@@ -141,6 +141,11 @@ def test_edge_stage_saved_mask_backward_equals_recompute(H):
     SF.edge_relu_mean_bwd_src_mask(Gr, mask, es, dB1)
     assert torch.equal(dA0, dA1)
     assert torch.equal(dB0, dB1)
+    # both halves in one launch, written into column slices of one wider matrix as the block backward does
+    dY = torch.full((n, 2 * H + 8), 7.0, device=DEV)
+    SF.edge_relu_mean_bwd_mask(Gr, mask, es, dY[:, :H], dY[:, H:2 * H])
+    assert torch.equal(dY[:, :H], dA1) and torch.equal(dY[:, H:2 * H], dB1)
+    assert float((dY[:, 2 * H:] - 7.0).abs().max()) == 0.0
 
 
 def test_edge_stage_on_column_slices_and_indicator():
