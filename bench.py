@@ -55,9 +55,10 @@ def edge_bytes(kernel, n, e, h):
         return e * h // 8 + 2 * n * h * s + 4 * (n + 1)
     if kernel == 'stin_edge_relu_mean_bwd_src_mask_f32':  # gather G per edge + its mask words, col/xslot/inv_deg, write dB
         return e * h * s + e * h // 8 + 12 * e + n * h * s + 4 * (n + 1)
-    if kernel == 'stin_edge_relu_mean_bwd_mask_f32':      # both of the above in one launch (fp32 rows)
-        return (edge_bytes('stin_edge_relu_mean_bwd_dst_mask_f32', n, e, h) +
-                edge_bytes('stin_edge_relu_mean_bwd_src_mask_f32', n, e, h))
+    if kernel == 'stin_edge_relu_mean_bwd_mask_f32':      # both of the above in one launch
+        sfx = '_bf16' if s == 2 else '_f32'
+        return (edge_bytes('stin_edge_relu_mean_bwd_dst_mask' + sfx, n, e, h) +
+                edge_bytes('stin_edge_relu_mean_bwd_src_mask' + sfx, n, e, h))
     raise KeyError(kernel)
 
 
@@ -333,7 +334,7 @@ def main():
     sfx = '_' + args.dtype
     edge_names = ['stin_edge_relu_mean_fwd' + sfx, 'stin_edge_relu_mean_bwd_dst_f32', 'stin_edge_relu_mean_bwd_src_f32',
                   'stin_edge_relu_mean_bwd_dst_mask' + sfx, 'stin_edge_relu_mean_bwd_src_mask' + sfx,
-                  'stin_edge_relu_mean_bwd_mask_f32']
+                  'stin_edge_relu_mean_bwd_mask' + sfx]
     gemm_names = ['stin_gemm_nt' + sfx, 'stin_gemm_tn' + sfx]
     timed = edge_names + (gemm_names if args.time_gemms else [])
     # HIP-event brackets need the per-kernel host path (the whole-block C calls enqueue their kernels natively) and event

@@ -378,6 +378,10 @@ int stin_edge_relu_mean_bwd_dst_mask_bf16(const stin_bf16_t* G, int64_t ldg, con
 int stin_edge_relu_mean_bwd_src_mask_bf16(const stin_bf16_t* G, int64_t ldg, const float* w_src, const uint32_t* mask,
                                           const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot,
                                           int64_t N, int H, stin_bf16_t* dB, int64_t lddb, stin_stream_t stream);
+int stin_edge_relu_mean_bwd_mask_bf16(const stin_bf16_t* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst,
+                                      const float* w_src, const int32_t* rowptr_src, const int32_t* col_src,
+                                      const int32_t* xslot, int64_t N, int H, stin_bf16_t* dA, int64_t ldda,
+                                      stin_bf16_t* dB, int64_t lddb, stin_stream_t stream);
 int stin_pool_max_fwd_bf16(const stin_bf16_t* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
                            int64_t n_coarse, int C, stin_bf16_t* out, int64_t ldo, int32_t* arg, stin_stream_t stream);
 int stin_pool_max_bwd_bf16(const stin_bf16_t* g, int64_t ldg, const int32_t* arg, const int32_t* trace,

@@ -84,7 +84,7 @@ SIGNATURES = {
 }
 # bf16-storage variants: same argument lists as their *_f32 twins (pointers are void* here)
 for _n in ('stin_segment_sum', 'stin_edge_relu_mean_fwd', 'stin_edge_relu_mean_bwd_dst_mask',
-           'stin_edge_relu_mean_bwd_src_mask', 'stin_pool_max_fwd', 'stin_pool_max_bwd', 'stin_gather_rows',
+           'stin_edge_relu_mean_bwd_src_mask', 'stin_edge_relu_mean_bwd_mask', 'stin_pool_max_fwd', 'stin_pool_max_bwd', 'stin_gather_rows',
            'stin_colreduce', 'stin_norm_act_res_fwd', 'stin_norm_act_bwd'):
     SIGNATURES[_n + '_bf16'] = SIGNATURES[_n + '_f32']
 SIGNATURES['stin_gemm_nt_bf16'] = SIGNATURES['stin_gemm_nt_f32']          # last int = c_is_f32 instead of precision

@@ -257,10 +257,8 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         const int wbb = (Cp % 8 == 0 && Cout % 8 == 0) ? STIN_GEMM_W_BF16 : 0;   // as written by the forward call's pack
         STIN_TRY(stin_gemm_nt_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H,
                                    Cout, dhE, H, wbb, stream));
-        STIN_TRY(stin_edge_relu_mean_bwd_dst_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, mask, rowptr_dst, N, H, dYh, Yw,
-                                                       stream));
-        STIN_TRY(stin_edge_relu_mean_bwd_src_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, w_src, mask, rowptr_src, col_src,
-                                                       xslot, N, H, dYh + H, Yw, stream));
+        STIN_TRY(stin_edge_relu_mean_bwd_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src,
+                                                  col_src, xslot, N, H, dYh, Yw, dYh + H, Yw, stream));
         if (has_shortcut && N > 0) {
             hipError_t e = hipMemcpy2DAsync(dYh + 2 * H, (size_t)Yw * 2, gh, (size_t)ldg * 2, (size_t)Cout * 2, (size_t)N,
                                             hipMemcpyDeviceToDevice, hs);

@@ -402,9 +402,10 @@ template <int G>
 struct Lane8 {
     int lg;
     int64_t row;
-    __device__ __forceinline__ Lane8() {
+    __device__ __forceinline__ Lane8() : Lane8(blockIdx.x) {}
+    __device__ __forceinline__ explicit Lane8(unsigned vblock) {
         lg = threadIdx.x % G;
-        row = (int64_t)blockIdx.x * (BLOCK / G) + threadIdx.x / G;
+        row = (int64_t)vblock * (BLOCK / G) + threadIdx.x / G;
     }
     __device__ __forceinline__ int chan(int k) const { return (k * G + lg) * 8; }
 };
@@ -504,11 +505,11 @@ __device__ __forceinline__ void mask_words8(const uint32_t* __restrict__ m, int 
 }
 
 template <int G, int VPL, int U>
-__global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask8(const stin_bf16* __restrict__ Gr, int64_t ldg,
-                                                              const uint32_t* __restrict__ mask,
-                                                              const int32_t* __restrict__ rowptr, int64_t N, int H,
-                                                              stin_bf16* __restrict__ dA, int64_t ldda) {
-    Lane8<G> L;
+__device__ __forceinline__ void edge_bwd_dst_mask8_body(unsigned vblock, const stin_bf16* __restrict__ Gr, int64_t ldg,
+                                                        const uint32_t* __restrict__ mask,
+                                                        const int32_t* __restrict__ rowptr, int64_t N, int H,
+                                                        stin_bf16* __restrict__ dA, int64_t ldda) {
+    Lane8<G> L(vblock);
     if (L.row >= N) return;
     const int beg = rowptr[L.row], end = rowptr[L.row + 1];
     const int mwords = H >> 5;
@@ -551,16 +552,23 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask8(const stin_bf16* _
             st8(dA + L.row * ldda + L.chan(k), o);
         }
 }
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask8(const stin_bf16* __restrict__ Gr, int64_t ldg,
+                                                              const uint32_t* __restrict__ mask,
+                                                              const int32_t* __restrict__ rowptr, int64_t N, int H,
+                                                              stin_bf16* __restrict__ dA, int64_t ldda) {
+    edge_bwd_dst_mask8_body<G, VPL, U>(blockIdx.x, Gr, ldg, mask, rowptr, N, H, dA, ldda);
+}
 
 template <int G, int VPL, int U>
-__global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask8(const stin_bf16* __restrict__ Gr, int64_t ldg,
-                                                              const float* __restrict__ w_slot,
-                                                              const uint32_t* __restrict__ mask,
-                                                              const int32_t* __restrict__ rowptr,
-                                                              const int32_t* __restrict__ col,
-                                                              const int32_t* __restrict__ xslot, int64_t N, int H,
-                                                              stin_bf16* __restrict__ dB, int64_t lddb) {
-    Lane8<G> L;
+__device__ __forceinline__ void edge_bwd_src_mask8_body(unsigned vblock, const stin_bf16* __restrict__ Gr, int64_t ldg,
+                                                        const float* __restrict__ w_slot,
+                                                        const uint32_t* __restrict__ mask,
+                                                        const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col,
+                                                        const int32_t* __restrict__ xslot, int64_t N, int H,
+                                                        stin_bf16* __restrict__ dB, int64_t lddb) {
+    Lane8<G> L(vblock);
     if (L.row >= N) return;
     const int beg = rowptr[L.row], end = rowptr[L.row + 1];
     const int mwords = H >> 5;
@@ -598,6 +606,32 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask8(const stin_bf16* _
 #pragma unroll
     for (int k = 0; k < VPL; ++k)
         if (on[k]) st8(dB + L.row * lddb + L.chan(k), acc[k]);
+}
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask8(const stin_bf16* __restrict__ Gr, int64_t ldg,
+                                                              const float* __restrict__ w_slot,
+                                                              const uint32_t* __restrict__ mask,
+                                                              const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ col,
+                                                              const int32_t* __restrict__ xslot, int64_t N, int H,
+                                                              stin_bf16* __restrict__ dB, int64_t lddb) {
+    edge_bwd_src_mask8_body<G, VPL, U>(blockIdx.x, Gr, ldg, w_slot, mask, rowptr, col, xslot, N, H, dB, lddb);
+}
+// dB blocks then dA blocks in one launch, as k_edge_bwd_mask_pair does for fp32 rows
+template <int G, int VPL, int UD, int US>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_pair8(const stin_bf16* __restrict__ Gr, int64_t ldg,
+                                                               const uint32_t* __restrict__ mask,
+                                                               const int32_t* __restrict__ rowptr_dst,
+                                                               const float* __restrict__ w_slot,
+                                                               const int32_t* __restrict__ rowptr_src,
+                                                               const int32_t* __restrict__ col_src,
+                                                               const int32_t* __restrict__ xslot, int64_t N, int H,
+                                                               stin_bf16* __restrict__ dA, int64_t ldda,
+                                                               stin_bf16* __restrict__ dB, int64_t lddb, unsigned nb) {
+    if (blockIdx.x < nb)
+        edge_bwd_src_mask8_body<G, VPL, US>(blockIdx.x, Gr, ldg, w_slot, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
+    else
+        edge_bwd_dst_mask8_body<G, VPL, UD>(blockIdx.x - nb, Gr, ldg, mask, rowptr_dst, N, H, dA, ldda);
 }
 
 // H in {128, 256, 512, 1024, 2048}: G = H/8 capped at 64, VPL = H / (8 G); U as in STIN_DISPATCH for the same row bytes
@@ -1013,6 +1047,29 @@ int edge_bwd_mask_pair_impl(const float* G, int64_t ldg, const uint32_t* mask, c
     return stin_launch_status();
 }
 
+int edge_bwd_mask_pair8_impl(const stin_bf16* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst,
+                             const float* w_src, const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot,
+                             int64_t N, int H, stin_bf16* dA, int64_t ldda, stin_bf16* dB, int64_t lddb, hipStream_t stream) {
+    STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && ldda >= H && lddb >= H, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(G && mask && rowptr_dst && w_src && rowptr_src && col_src && xslot && dA && dB, STIN_E_NULL);
+    STIN_REQUIRE(mask_shape_ok(H), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(wide8_ok(H, {G, dA, dB}, {ldg, ldda, lddb}), STIN_E_ALIGN);    // the geometry the forward kernel wrote the mask in
+#define STIN_PAIR8(G_, V_, UD_, US_)                                                                                          \
+    do {                                                                                                                      \
+        const unsigned nb = grid_rows(N, G_);                                                                                 \
+        hipLaunchKernelGGL((k_edge_bwd_mask_pair8<G_, V_, UD_, US_>), dim3(2 * nb), dim3(BLOCK), 0, stream, G, ldg, mask,     \
+                           rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb);                       \
+    } while (0)
+    if (H == 128) STIN_PAIR8(16, 1, 6, 2);            // (UD, US) as the separate kernels' dispatch
+    else if (H == 256) STIN_PAIR8(32, 1, 3, 2);
+    else if (H == 512) STIN_PAIR8(64, 1, 3, 2);
+    else if (H == 1024) STIN_PAIR8(64, 2, 2, 1);
+    else STIN_PAIR8(64, 4, 1, 1);
+#undef STIN_PAIR8
+    return stin_launch_status();
+}
+
 template <typename T>
 int segment_sum_impl(const T* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col, int64_t N, int C, int mean,
                      T* out, int64_t ld_out, hipStream_t stream) {
@@ -1179,6 +1236,16 @@ extern "C" int stin_edge_relu_mean_bwd_mask_f32(const float* G, int64_t ldg, con
     stin_clear_stale_error();
     return edge_bwd_mask_pair_impl(G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb,
                                    (hipStream_t)stream);
+}
+
+extern "C" int stin_edge_relu_mean_bwd_mask_bf16(const stin_bf16_t* G, int64_t ldg, const uint32_t* mask,
+                                                const int32_t* rowptr_dst, const float* w_src, const int32_t* rowptr_src,
+                                                const int32_t* col_src, const int32_t* xslot, int64_t N, int H,
+                                                stin_bf16_t* dA, int64_t ldda, stin_bf16_t* dB, int64_t lddb,
+                                                stin_stream_t stream) {
+    stin_clear_stale_error();
+    return edge_bwd_mask_pair8_impl(b16(G), ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, b16(dA), ldda,
+                                    b16(dB), lddb, (hipStream_t)stream);
 }
 
 extern "C" int stin_segment_sum_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col,

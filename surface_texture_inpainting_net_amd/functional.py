@@ -113,15 +113,12 @@ def edge_relu_mean_bwd_src_mask(G, mask, edges, dB):
 
 
 def edge_relu_mean_bwd_mask(G, mask, edges, dA, dB):
-    """dA and dB of the mask backward in one launch (fp32 rows; bit-identical to the two separate kernels)."""
-    if G.dtype != torch.float32:
-        edge_relu_mean_bwd_dst_mask(G, mask, edges.by_dst, dA)
-        return dA, edge_relu_mean_bwd_src_mask(G, mask, edges, dB)
+    """dA and dB of the mask backward in one launch (bit-identical to the two separate kernels)."""
     G, ldg = _mat(G)
     cs = edges.by_src
     _same(G, dA)
     _same(G, dB)
-    _call('stin_edge_relu_mean_bwd_mask_f32', _ptr(G), ldg, _ptr(mask), _ptr(edges.by_dst.rowptr), _ptr(edges.w_src),
+    _call('stin_edge_relu_mean_bwd_mask' + _sfx(G), _ptr(G), ldg, _ptr(mask), _ptr(edges.by_dst.rowptr), _ptr(edges.w_src),
           _ptr(cs.rowptr), _ptr(cs.col), _ptr(edges.xslot), G.shape[0], G.shape[1], _ptr(dA), dA.stride(0), _ptr(dB),
           dB.stride(0), _stream(G), tag=(G.shape[0], cs.n_entries, G.shape[1]))
     return dA, dB

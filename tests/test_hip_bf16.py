@@ -76,6 +76,11 @@ def test_edge_stage_bf16_equals_rounded_fp32_kernels(H):
     SF.edge_relu_mean_bwd_src_mask(G.float(), m32, es, dB32)
     assert torch.equal(dA16, dA32.to(BF))
     assert torch.equal(dB16, dB32.to(BF))
+    # both halves in one launch (what the block backward calls), into column slices of one wider matrix
+    dY = torch.full((n, 2 * H + 8), 7.0, dtype=BF, device=DEV)
+    SF.edge_relu_mean_bwd_mask(G, m16, es, dY[:, :H], dY[:, H:2 * H])
+    assert torch.equal(dY[:, :H], dA16) and torch.equal(dY[:, H:2 * H], dB16)
+    assert float((dY[:, 2 * H:].float() - 7.0).abs().max()) == 0.0
 
 
 def test_edge_stage_bf16_on_column_slices_of_a_wider_matrix():
