@@ -137,11 +137,13 @@ int stin_edge_relu_mean_bwd_src_mask_f32(const float* G, int64_t ldg, const floa
                                          const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot,
                                          int64_t N, int H, float* dB, int64_t lddb, stin_stream_t stream);
 /* bwd_dst_mask and bwd_src_mask in ONE launch (the dB blocks first, then the dA blocks); results bit-identical to the two
- * calls above.  fp32 rows. */
+ * calls above.  Optional rider (copy_src != NULL): copy_dst[i, :C_copy] = copy_src[i, :C_copy] for all N rows in the same
+ * launch (C_copy <= H, multiple of 4 (bf16: 8), 16-byte aligned rows) - the block backward's dY[:, 2H:] = g. */
 int stin_edge_relu_mean_bwd_mask_f32(const float* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst,
                                      const float* w_src, const int32_t* rowptr_src, const int32_t* col_src,
                                      const int32_t* xslot, int64_t N, int H, float* dA, int64_t ldda, float* dB,
-                                     int64_t lddb, stin_stream_t stream);
+                                     int64_t lddb, const float* copy_src, int64_t ld_copy_src, float* copy_dst,
+                                     int64_t ld_copy_dst, int C_copy, stin_stream_t stream);
 int stin_edge_relu_mean_bwd_dst_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
                                     const float* G, int64_t ldg, const int32_t* rowptr,
                                     const int32_t* col, int64_t N, int H, float* dA, int64_t ldda,
@@ -381,7 +383,8 @@ int stin_edge_relu_mean_bwd_src_mask_bf16(const stin_bf16_t* G, int64_t ldg, con
 int stin_edge_relu_mean_bwd_mask_bf16(const stin_bf16_t* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst,
                                       const float* w_src, const int32_t* rowptr_src, const int32_t* col_src,
                                       const int32_t* xslot, int64_t N, int H, stin_bf16_t* dA, int64_t ldda,
-                                      stin_bf16_t* dB, int64_t lddb, stin_stream_t stream);
+                                      stin_bf16_t* dB, int64_t lddb, const stin_bf16_t* copy_src, int64_t ld_copy_src,
+                                      stin_bf16_t* copy_dst, int64_t ld_copy_dst, int C_copy, stin_stream_t stream);
 int stin_pool_max_fwd_bf16(const stin_bf16_t* x, int64_t ldx, const int32_t* rowptr, const int32_t* col,
                            int64_t n_coarse, int C, stin_bf16_t* out, int64_t ldo, int32_t* arg, stin_stream_t stream);
 int stin_pool_max_bwd_bf16(const stin_bf16_t* g, int64_t ldg, const int32_t* arg, const int32_t* trace,

@@ -46,7 +46,7 @@ SIGNATURES = {
     'stin_edge_relu_mean_bwd_src_mask_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr,
                                                      c_i64, c_ptr]),
     'stin_edge_relu_mean_bwd_mask_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr,
-                                                 c_i64, c_ptr, c_i64, c_ptr]),
+                                                 c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr]),
     'stin_edge_relu_mean_bwd_dst_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int,
                                                 c_ptr, c_i64, c_ptr]),
     'stin_edge_relu_mean_bwd_src_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64,

@@ -217,9 +217,13 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         STIN_TRY(stin_gemm_nt_f32(static_cast<const float*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H, Cout,
                                   static_cast<float*>(dhE), H, pb, stream));
         // edge stage backward from the saved ReLU mask -> dY = [dA | dB | g]
+        // (a shortcut block's dY[:, 2H:] = g rides on the same launch when the rows allow 16-byte copies, else one 2-D memcpy)
+        const bool ride = has_shortcut && N > 0 && Cout % 4 == 0 && ldg % 4 == 0 && Yw % 4 == 0 && stin_aligned16(gf) &&
+                          stin_aligned16(dYf + 2 * H);
         STIN_TRY(stin_edge_relu_mean_bwd_mask_f32(static_cast<const float*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src, col_src,
-                                                 xslot, N, H, dYf, Yw, dYf + H, Yw, stream));
-        if (has_shortcut && N > 0) {
+                                                 xslot, N, H, dYf, Yw, dYf + H, Yw, ride ? gf : nullptr, ldg,
+                                                 ride ? dYf + 2 * H : nullptr, Yw, ride ? Cout : 0, stream));
+        if (has_shortcut && N > 0 && !ride) {
             hipError_t e = hipMemcpy2DAsync(dYf + 2 * H, (size_t)Yw * 4, gf, (size_t)ldg * 4, (size_t)Cout * 4, (size_t)N,
                                             hipMemcpyDeviceToDevice, hs);
             if (e != hipSuccess) return (int)e;
@@ -257,9 +261,12 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         const int wbb = (Cp % 8 == 0 && Cout % 8 == 0) ? STIN_GEMM_W_BF16 : 0;   // as written by the forward call's pack
         STIN_TRY(stin_gemm_nt_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H,
                                    Cout, dhE, H, wbb, stream));
+        const bool ride = has_shortcut && N > 0 && Cout % 8 == 0 && ldg % 8 == 0 && Yw % 8 == 0 && stin_aligned16(gh) &&
+                          stin_aligned16(dYh + 2 * H);
         STIN_TRY(stin_edge_relu_mean_bwd_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src,
-                                                  col_src, xslot, N, H, dYh, Yw, dYh + H, Yw, stream));
-        if (has_shortcut && N > 0) {
+                                                  col_src, xslot, N, H, dYh, Yw, dYh + H, Yw, ride ? gh : nullptr, ldg,
+                                                  ride ? dYh + 2 * H : nullptr, Yw, ride ? Cout : 0, stream));
+        if (has_shortcut && N > 0 && !ride) {
             hipError_t e = hipMemcpy2DAsync(dYh + 2 * H, (size_t)Yw * 2, gh, (size_t)ldg * 2, (size_t)Cout * 2, (size_t)N,
                                             hipMemcpyDeviceToDevice, hs);
             if (e != hipSuccess) return (int)e;

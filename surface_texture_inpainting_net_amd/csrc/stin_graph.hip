@@ -359,11 +359,23 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_pair(const T* __restric
                                                               const int32_t* __restrict__ col_src,
                                                               const int32_t* __restrict__ xslot, int64_t N, int H,
                                                               T* __restrict__ dA, int64_t ldda, T* __restrict__ dB,
-                                                              int64_t lddb, unsigned nb) {
-    if (blockIdx.x < nb)
+                                                              int64_t lddb, unsigned nb, const T* __restrict__ cp_src,
+                                                              int64_t ld_cps, T* __restrict__ cp_dst, int64_t ld_cpd, int Ccp) {
+    if (blockIdx.x < nb) {
         edge_bwd_src_mask_body<T, G, VPL, US>(blockIdx.x, Gr, ldg, w_slot, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
-    else
+    } else {
+        // optional row copy riding on the streaming role (the block backward's dY[:, 2H:] = g of a shortcut block: one
+        // 2-D memcpy launch less); Ccp <= H channels, 4 per lane
+        if (cp_src != nullptr) {
+            Lane<G, VPL> L(blockIdx.x - nb);
+            if (L.row < N) {
+#pragma unroll
+                for (int k = 0; k < VPL; ++k)
+                    if (L.chan(k) < Ccp) st4(cp_dst + L.row * ld_cpd + L.chan(k), ld4(cp_src + L.row * ld_cps + L.chan(k)));
+            }
+        }
         edge_bwd_dst_mask_body<T, G, VPL, UD>(blockIdx.x - nb, Gr, ldg, mask, rowptr_dst, N, H, dA, ldda);
+    }
 }
 
 // ===================================================== bf16 rows, 8 channels (16 bytes) per lane
@@ -627,11 +639,24 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_pair8(const stin_bf16* 
                                                                const int32_t* __restrict__ col_src,
                                                                const int32_t* __restrict__ xslot, int64_t N, int H,
                                                                stin_bf16* __restrict__ dA, int64_t ldda,
-                                                               stin_bf16* __restrict__ dB, int64_t lddb, unsigned nb) {
-    if (blockIdx.x < nb)
+                                                               stin_bf16* __restrict__ dB, int64_t lddb, unsigned nb,
+                                                               const stin_bf16* __restrict__ cp_src, int64_t ld_cps,
+                                                               stin_bf16* __restrict__ cp_dst, int64_t ld_cpd, int Ccp) {
+    if (blockIdx.x < nb) {
         edge_bwd_src_mask8_body<G, VPL, US>(blockIdx.x, Gr, ldg, w_slot, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
-    else
+    } else {
+        if (cp_src != nullptr) {                           // optional row copy, 8 channels (16 bytes) per lane
+            Lane8<G> L(blockIdx.x - nb);
+            if (L.row < N) {
+#pragma unroll
+                for (int k = 0; k < VPL; ++k)
+                    if (L.chan(k) < Ccp)
+                        *reinterpret_cast<uint4*>(cp_dst + L.row * ld_cpd + L.chan(k)) =
+                            *reinterpret_cast<const uint4*>(cp_src + L.row * ld_cps + L.chan(k));
+            }
+        }
         edge_bwd_dst_mask8_body<G, VPL, UD>(blockIdx.x - nb, Gr, ldg, mask, rowptr_dst, N, H, dA, ldda);
+    }
 }
 
 // H in {128, 256, 512, 1024, 2048}: G = H/8 capped at 64, VPL = H / (8 G); U as in STIN_DISPATCH for the same row bytes
@@ -1027,9 +1052,14 @@ int edge_bwd_src_mask_impl(const T* G, int64_t ldg, const float* w_src, const ui
 // fp32 rows only (the block backward's path); unroll factors per (G, VPL) are STIN_DISPATCH's with DIV 1 (dA) and 2 (dB)
 int edge_bwd_mask_pair_impl(const float* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst, const float* w_src,
                             const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot, int64_t N, int H,
-                            float* dA, int64_t ldda, float* dB, int64_t lddb, hipStream_t stream) {
+                            float* dA, int64_t ldda, float* dB, int64_t lddb, const float* cp_src, int64_t ld_cps, float* cp_dst,
+                            int64_t ld_cpd, int Ccp, hipStream_t stream) {
     using T = float;
     STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && ldda >= H && lddb >= H, STIN_E_SIZE);
+    if (cp_src != nullptr) {
+        STIN_REQUIRE(cp_dst != nullptr && Ccp > 0 && Ccp <= H && Ccp % 4 == 0 && ld_cps >= Ccp && ld_cpd >= Ccp, STIN_E_SIZE);
+        STIN_REQUIRE(stin_aligned16(cp_src) && stin_aligned16(cp_dst) && ld_cps % 4 == 0 && ld_cpd % 4 == 0, STIN_E_ALIGN);
+    }
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(G && mask && rowptr_dst && w_src && rowptr_src && col_src && xslot && dA && dB, STIN_E_NULL);
     STIN_REQUIRE(mask_shape_ok(H) && vec_ok<T>(H, {G, dA, dB}, {ldg, ldda, lddb}), STIN_E_UNSUPPORTED);
@@ -1037,7 +1067,8 @@ int edge_bwd_mask_pair_impl(const float* G, int64_t ldg, const uint32_t* mask, c
     const unsigned nb = grid_rows(N, g);
 #define STIN_PAIR(G_, VPL_, BASE_)                                                                                       \
     hipLaunchKernelGGL((k_edge_bwd_mask_pair<T, G_, VPL_, STIN_U(BASE_, 1), STIN_U(BASE_, 2)>), dim3(2 * nb), dim3(BLOCK), 0,  \
-                       stream, G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb)
+                       stream, G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src,       \
+                       ld_cps, cp_dst, ld_cpd, Ccp)
     if (g == 32) STIN_PAIR(32, 1, 6);                 // H = 128
     else if (vpl == 1) STIN_PAIR(64, 1, 4);           // 256
     else if (vpl == 2) STIN_PAIR(64, 2, 2);           // 512
@@ -1049,8 +1080,13 @@ int edge_bwd_mask_pair_impl(const float* G, int64_t ldg, const uint32_t* mask, c
 
 int edge_bwd_mask_pair8_impl(const stin_bf16* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst,
                              const float* w_src, const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot,
-                             int64_t N, int H, stin_bf16* dA, int64_t ldda, stin_bf16* dB, int64_t lddb, hipStream_t stream) {
+                             int64_t N, int H, stin_bf16* dA, int64_t ldda, stin_bf16* dB, int64_t lddb, const stin_bf16* cp_src,
+                             int64_t ld_cps, stin_bf16* cp_dst, int64_t ld_cpd, int Ccp, hipStream_t stream) {
     STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && ldda >= H && lddb >= H, STIN_E_SIZE);
+    if (cp_src != nullptr) {
+        STIN_REQUIRE(cp_dst != nullptr && Ccp > 0 && Ccp <= H && Ccp % 8 == 0 && ld_cps >= Ccp && ld_cpd >= Ccp, STIN_E_SIZE);
+        STIN_REQUIRE(stin_aligned16(cp_src) && stin_aligned16(cp_dst) && ld_cps % 8 == 0 && ld_cpd % 8 == 0, STIN_E_ALIGN);
+    }
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(G && mask && rowptr_dst && w_src && rowptr_src && col_src && xslot && dA && dB, STIN_E_NULL);
     STIN_REQUIRE(mask_shape_ok(H), STIN_E_UNSUPPORTED);
@@ -1059,7 +1095,8 @@ int edge_bwd_mask_pair8_impl(const stin_bf16* G, int64_t ldg, const uint32_t* ma
     do {                                                                                                                      \
         const unsigned nb = grid_rows(N, G_);                                                                                 \
         hipLaunchKernelGGL((k_edge_bwd_mask_pair8<G_, V_, UD_, US_>), dim3(2 * nb), dim3(BLOCK), 0, stream, G, ldg, mask,     \
-                           rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb);                       \
+                           rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src, ld_cps,        \
+                           cp_dst, ld_cpd, Ccp);                                                                               \
     } while (0)
     if (H == 128) STIN_PAIR8(16, 1, 6, 2);            // (UD, US) as the separate kernels' dispatch
     else if (H == 256) STIN_PAIR8(32, 1, 3, 2);
@@ -1232,20 +1269,23 @@ extern "C" int stin_edge_relu_mean_bwd_src_mask_bf16(const stin_bf16_t* G, int64
 extern "C" int stin_edge_relu_mean_bwd_mask_f32(const float* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst,
                                                const float* w_src, const int32_t* rowptr_src, const int32_t* col_src,
                                                const int32_t* xslot, int64_t N, int H, float* dA, int64_t ldda, float* dB,
-                                               int64_t lddb, stin_stream_t stream) {
+                                               int64_t lddb, const float* copy_src, int64_t ld_copy_src, float* copy_dst,
+                                               int64_t ld_copy_dst, int C_copy, stin_stream_t stream) {
     stin_clear_stale_error();
     return edge_bwd_mask_pair_impl(G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb,
-                                   (hipStream_t)stream);
+                                   copy_src, ld_copy_src, copy_dst, ld_copy_dst, C_copy, (hipStream_t)stream);
 }
 
 extern "C" int stin_edge_relu_mean_bwd_mask_bf16(const stin_bf16_t* G, int64_t ldg, const uint32_t* mask,
                                                 const int32_t* rowptr_dst, const float* w_src, const int32_t* rowptr_src,
                                                 const int32_t* col_src, const int32_t* xslot, int64_t N, int H,
                                                 stin_bf16_t* dA, int64_t ldda, stin_bf16_t* dB, int64_t lddb,
-                                                stin_stream_t stream) {
+                                                const stin_bf16_t* copy_src, int64_t ld_copy_src, stin_bf16_t* copy_dst,
+                                                int64_t ld_copy_dst, int C_copy, stin_stream_t stream) {
     stin_clear_stale_error();
     return edge_bwd_mask_pair8_impl(b16(G), ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, b16(dA), ldda,
-                                    b16(dB), lddb, (hipStream_t)stream);
+                                    b16(dB), lddb, b16(copy_src), ld_copy_src, b16(copy_dst), ld_copy_dst, C_copy,
+                                    (hipStream_t)stream);
 }
 
 extern "C" int stin_segment_sum_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col,

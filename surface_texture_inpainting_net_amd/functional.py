@@ -112,15 +112,20 @@ def edge_relu_mean_bwd_src_mask(G, mask, edges, dB):
     return dB
 
 
-def edge_relu_mean_bwd_mask(G, mask, edges, dA, dB):
-    """dA and dB of the mask backward in one launch (bit-identical to the two separate kernels)."""
+def edge_relu_mean_bwd_mask(G, mask, edges, dA, dB, copy_src=None, copy_dst=None):
+    """dA and dB of the mask backward in one launch (bit-identical to the two separate kernels); optionally
+    copy_dst[:, :] = copy_src (row views of the same height) in the same launch."""
     G, ldg = _mat(G)
     cs = edges.by_src
     _same(G, dA)
     _same(G, dB)
+    cp = (None, 0, None, 0, 0)
+    if copy_src is not None:
+        _same(G, copy_src, copy_dst)
+        cp = (_ptr(copy_src), copy_src.stride(0), _ptr(copy_dst), copy_dst.stride(0), copy_src.shape[1])
     _call('stin_edge_relu_mean_bwd_mask' + _sfx(G), _ptr(G), ldg, _ptr(mask), _ptr(edges.by_dst.rowptr), _ptr(edges.w_src),
           _ptr(cs.rowptr), _ptr(cs.col), _ptr(edges.xslot), G.shape[0], G.shape[1], _ptr(dA), dA.stride(0), _ptr(dB),
-          dB.stride(0), _stream(G), tag=(G.shape[0], cs.n_entries, G.shape[1]))
+          dB.stride(0), *cp, _stream(G), tag=(G.shape[0], cs.n_entries, G.shape[1]))
     return dA, dB
 
 
@@ -710,7 +715,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
             edge_relu_mean_bwd_dst(A, B, dhE, edges.by_dst, dY[:, :H])
             edge_relu_mean_bwd_src(A, B, dhE, edges.inv_deg, edges.by_src, dY[:, H:2 * H])
         if ctx.has_shortcut:
-            dY[:, 2 * H:].copy_(g)
+            dY[:, 2 * H:].copy_(g)                  # (the whole-block C call lets this ride on the edge launch)
         dwb = gemm_tn(dY, x, ones_column=True, precision=PREC_BWD)           # [Yw, Cin + 1]: packed weight grad | bias grad
         # dx = dY Wcat (+ g: the identity-residual path, added in the GEMM epilogue); skipped when the block input
         # needs no gradient (the network input of the first block)

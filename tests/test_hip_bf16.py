@@ -81,6 +81,11 @@ def test_edge_stage_bf16_equals_rounded_fp32_kernels(H):
     SF.edge_relu_mean_bwd_mask(G, m16, es, dY[:, :H], dY[:, H:2 * H])
     assert torch.equal(dY[:, :H], dA16) and torch.equal(dY[:, H:2 * H], dB16)
     assert float((dY[:, 2 * H:].float() - 7.0).abs().max()) == 0.0
+    dZ = torch.full((n, 2 * H + H // 2 + 8), 7.0, dtype=BF, device=DEV)
+    src = _rand((n, H), 9)[:, :H // 2]
+    SF.edge_relu_mean_bwd_mask(G, m16, es, dZ[:, :H], dZ[:, H:2 * H], copy_src=src, copy_dst=dZ[:, 2 * H:2 * H + H // 2])
+    assert torch.equal(dZ[:, :H], dA16) and torch.equal(dZ[:, H:2 * H], dB16) and torch.equal(dZ[:, 2 * H:2 * H + H // 2], src)
+    assert float((dZ[:, 2 * H + H // 2:].float() - 7.0).abs().max()) == 0.0
 
 
 def test_edge_stage_bf16_on_column_slices_of_a_wider_matrix():

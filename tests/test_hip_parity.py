@@ -146,6 +146,12 @@ def test_edge_stage_saved_mask_backward_equals_recompute(H):
     SF.edge_relu_mean_bwd_mask(Gr, mask, es, dY[:, :H], dY[:, H:2 * H])
     assert torch.equal(dY[:, :H], dA1) and torch.equal(dY[:, H:2 * H], dB1)
     assert float((dY[:, 2 * H:] - 7.0).abs().max()) == 0.0
+    # ... with the row-copy rider (the shortcut gradient of the block backward): H / 2 channels from a strided source
+    dZ = torch.full((n, 2 * H + H // 2 + 4), 7.0, device=DEV)
+    src = torch.randn(n, H, device=DEV)[:, :H // 2]
+    SF.edge_relu_mean_bwd_mask(Gr, mask, es, dZ[:, :H], dZ[:, H:2 * H], copy_src=src, copy_dst=dZ[:, 2 * H:2 * H + H // 2])
+    assert torch.equal(dZ[:, :H], dA1) and torch.equal(dZ[:, H:2 * H], dB1) and torch.equal(dZ[:, 2 * H:2 * H + H // 2], src)
+    assert float((dZ[:, 2 * H + H // 2:] - 7.0).abs().max()) == 0.0
 
 
 def test_edge_stage_on_column_slices_and_indicator():
