@@ -318,6 +318,16 @@ int stin_bn_running_stats_f32(const float* mean, const float* rstd, int C, float
  * operands (wcat, and a copy w2s [Cout, H] of W2) / the backward operands (wcatT, w2T) directly in the
  * STIN_GEMM_W_PRESPLIT form of that precision (each operand in fragment order where its shape allows, see W_FRAG).
  */
+/* pack_many: the pack of EVERY block of a network in one launch.  `jobs_device` = n_jobs records in DEVICE memory (the
+ * arguments of stin_edgeconv_pack_f32 as a struct; written once per model - the pointers do not change from step to step),
+ * max_elems = max over the jobs of Yw * Cp + H * Cout.  The same argument rules as stin_edgeconv_pack_f32 apply per job
+ * (not re-checked on the device).  stin_edgeconv_block_fwd then takes STIN_BLOCK_PACKED in fwd_split. */
+typedef struct stin_pack_job {
+    const float *W1, *b1, *Ws, *bs, *W2;
+    float *wcat, *bcat, *wcatT, *w2T, *w2s;
+    int Cin, Cp, H, Cout, has_shortcut, trans_inv, fwd_split, bwd_split;
+} stin_pack_job_t;                                   /* 10 pointers + 8 ints = 112 bytes */
+int stin_edgeconv_pack_many_f32(const stin_pack_job_t* jobs_device, int n_jobs, int64_t max_elems, stin_stream_t stream);
 int stin_edgeconv_pack_f32(const float* W1, const float* b1, const float* Ws, const float* bs, const float* W2,
                            int Cin, int Cp, int H, int Cout, int has_shortcut, int trans_inv, float* wcat,
                            float* bcat, float* wcatT, float* w2T, float* w2s, int fwd_split, int bwd_split,
@@ -432,7 +442,13 @@ int stin_gemm_tn_bf16(const stin_bf16_t* G, int64_t ldg, const stin_bf16_t* X, i
  *        caller's next enqueue; with join == 0 the CALLER must order any reader of dW1..dbs after ev_done and keep the
  *        workspace (and x, hE, g) alive until then.  The three events are caller-owned hipEvent_t.
  */
+#define STIN_BLOCK_PACKED 0x800   /* OR-ed into stin_edgeconv_block_fwd's fwd_split: the caller has already run the pack (e.g.
+                                     stin_edgeconv_pack_many_f32) with the same modes into wcatT / w2T and into THIS workspace
+                                     at the offsets stin_edgeconv_block_fwd_pack_offsets reports - the call then skips it    */
 size_t stin_edgeconv_block_fwd_workspace_bytes(int Cin, int Cp, int H, int Cout, int has_shortcut, int B);
+/* byte offsets of wcat [Yw, Cp], w2s [Cout, H] and bcat [Yw] from the workspace pointer rounded UP to 256 bytes */
+int stin_edgeconv_block_fwd_pack_offsets(int Cp, int H, int Cout, int has_shortcut, size_t* off_wcat, size_t* off_w2s,
+                                         size_t* off_bcat);
 int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, int64_t N, int Cin, int Cp, int H, int Cout,
                             int has_shortcut, int trans_inv, const float* W1, const float* b1, const float* W2,
                             const float* b2, const float* Ws, const float* bs, const int32_t* rowptr_dst,

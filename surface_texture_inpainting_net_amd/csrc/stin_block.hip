@@ -36,6 +36,16 @@ extern "C" size_t stin_edgeconv_block_fwd_workspace_bytes(int Cin, int Cp, int H
     return up256(Yw * Cp * 4) + up256((size_t)Cout * H * 4) + up256(Yw * 4) + up256(stin_colreduce_workspace_bytes(Cout, B)) + 256;
 }
 
+extern "C" int stin_edgeconv_block_fwd_pack_offsets(int Cp, int H, int Cout, int has_shortcut, size_t* off_wcat, size_t* off_w2s,
+                                                    size_t* off_bcat) {
+    if (Cp <= 0 || H <= 0 || Cout <= 0 || !off_wcat || !off_w2s || !off_bcat) return STIN_E_SIZE;
+    const size_t Yw = 2 * (size_t)H + (has_shortcut ? Cout : 0);
+    *off_wcat = 0;                                                  // the carve order of stin_edgeconv_block_fwd
+    *off_w2s = up256(Yw * Cp * 4);
+    *off_bcat = *off_w2s + up256((size_t)Cout * H * 4);
+    return STIN_OK;
+}
+
 // Forward.  storage: 0 = fp32 rows, 1 = bf16 rows (x, Y, hE, agg, out).  Saved for backward by the caller: x, Y, hE,
 // mask, agg, mean, rstd, wcatT, w2T.  Requirements of this fast path (the caller falls back to the individual entry
 // points otherwise): saved ReLU mask supported for H.  slice_quirk: statistics over the reference's linspace slices
@@ -63,9 +73,12 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
 
     // bf16 rows: the GEMM weight operands are written as bf16 once here (half the bytes every tile load, no conversion)
     // when every reduction length is a multiple of 8; fwd_split / bwd_split then carry STIN_GEMM_W_BF16
+    const bool packed = storage == 0 && (fwd_split & STIN_BLOCK_PACKED) != 0;      // the caller ran the pack (pack_many)
+    fwd_split &= ~STIN_BLOCK_PACKED;
     if (storage == 1) fwd_split = bwd_split = (Cp % 8 == 0 && Cout % 8 == 0) ? STIN_GEMM_W_BF16 : 0;
-    STIN_TRY(stin_edgeconv_pack_f32(W1, b1, Ws, bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T,
-                                    fwd_split ? w2s : nullptr, fwd_split, bwd_split, stream));
+    if (!packed)
+        STIN_TRY(stin_edgeconv_pack_f32(W1, b1, Ws, bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T,
+                                        fwd_split ? w2s : nullptr, fwd_split, bwd_split, stream));
     const float* w2_op = fwd_split ? w2s : W2;
     const int wbf = (storage == 1 && fwd_split) ? STIN_GEMM_W_BF16 : 0;
     const int pf = fwd_split ? (prec_fwd | STIN_GEMM_W_PRESPLIT | (fwd_split & STIN_GEMM_W_FRAG)) : prec_fwd;

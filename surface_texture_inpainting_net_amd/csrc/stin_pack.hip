@@ -68,15 +68,15 @@ __global__ void k_split_weights(const float* __restrict__ W, int64_t ldw, int Nc
 // wcatT [Cin, Yw] = wcat^T,  w2T [H, Cout] = W2^T,  w2s [Cout, H] = W2 (only when pre-split).  Yw = 2H (+ Cout with a
 // shortcut).  fwd_mode / bwd_mode: the storage form (put_weight) of the forward operands (wcat, w2s) and of the
 // backward operands (wcatT, w2T).
-__global__ void k_pack(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ Ws,
-                       const float* __restrict__ bs, const float* __restrict__ W2, int Cin, int Cp, int H, int Cout,
-                       int has_shortcut, int trans_inv, float* __restrict__ wcat, float* __restrict__ bcat,
-                       float* __restrict__ wcatT, float* __restrict__ w2T, float* __restrict__ w2s, int fwd_mode,
-                       int bwd_mode) {
+__device__ __forceinline__ void pack_body(int64_t t, const float* __restrict__ W1, const float* __restrict__ b1,
+                                          const float* __restrict__ Ws, const float* __restrict__ bs,
+                                          const float* __restrict__ W2, int Cin, int Cp, int H, int Cout, int has_shortcut,
+                                          int trans_inv, float* __restrict__ wcat, float* __restrict__ bcat,
+                                          float* __restrict__ wcatT, float* __restrict__ w2T, float* __restrict__ w2s,
+                                          int fwd_mode, int bwd_mode) {
     const int Yw = 2 * H + (has_shortcut ? Cout : 0);
     const int ld1 = trans_inv ? Cin : 2 * Cin;
     const int64_t n_w = (int64_t)Yw * Cp, n_2 = (int64_t)H * Cout;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_w) {
         const int r = (int)(t / Cp), c = (int)(t % Cp);
         float v = 0.f;                                   // zero padding columns c >= Cin (inner dimension padded to Cp)
@@ -95,6 +95,22 @@ __global__ void k_pack(const float* __restrict__ W1, const float* __restrict__ b
         put_weight(w2T, (int64_t)k * Cout, o, v, bwd_mode, k, H, Cout);
         if (w2s != nullptr) put_weight(w2s, (int64_t)o * H, k, v, fwd_mode, o, Cout, H);
     }
+}
+
+__global__ void k_pack(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ Ws,
+                       const float* __restrict__ bs, const float* __restrict__ W2, int Cin, int Cp, int H, int Cout,
+                       int has_shortcut, int trans_inv, float* __restrict__ wcat, float* __restrict__ bcat,
+                       float* __restrict__ wcatT, float* __restrict__ w2T, float* __restrict__ w2s, int fwd_mode,
+                       int bwd_mode) {
+    pack_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, W1, b1, Ws, bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat,
+              bcat, wcatT, w2T, w2s, fwd_mode, bwd_mode);
+}
+
+// Every block of a network in ONE launch: blockIdx.y picks the job (a table in device memory, written once per model).
+__global__ void k_pack_many(const stin_pack_job_t* __restrict__ jobs) {
+    const stin_pack_job_t j = jobs[blockIdx.y];
+    pack_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, j.W1, j.b1, j.Ws, j.bs, j.W2, j.Cin, j.Cp, j.H, j.Cout,
+              j.has_shortcut, j.trans_inv, j.wcat, j.bcat, j.wcatT, j.w2T, j.w2s, j.fwd_split, j.bwd_split);
 }
 
 // dwb [Yw, Cin + 1] (weight grad | bias grad of the packed operand) -> grads of the reference-layout
@@ -187,6 +203,17 @@ extern "C" int stin_edgeconv_pack_f32(const float* W1, const float* b1, const fl
     const int64_t n = (int64_t)Yw * Cp + (int64_t)H * Cout;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream_, W1, b1, Ws,
                        bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T, w2s, fwd_split, bwd_split);
+    return stin_launch_status();
+}
+
+extern "C" int stin_edgeconv_pack_many_f32(const stin_pack_job_t* jobs_device, int n_jobs, int64_t max_elems,
+                                           stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(n_jobs >= 0 && max_elems >= 0 && n_jobs <= 65535, STIN_E_SIZE);
+    if (n_jobs == 0 || max_elems == 0) return STIN_OK;
+    STIN_REQUIRE(jobs_device != nullptr, STIN_E_NULL);
+    hipLaunchKernelGGL(k_pack_many, dim3((unsigned)((max_elems + BLOCK - 1) / BLOCK), (unsigned)n_jobs), dim3(BLOCK), 0,
+                       (hipStream_t)stream_, jobs_device);
     return stin_launch_status();
 }
 

@@ -550,6 +550,65 @@ def _wgrad_deferred_join(dev, params, grads):
     torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
+def block_split_modes(prec_fwd, b16, Cout):
+    """(fwd_split, bwd_split) of one fused block: the storage form of its forward / backward weight operands."""
+    fsp = (prec_fwd | GEMM_W_FRAG) if (not b16 and prec_fwd in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT) else 0
+    bsp = (PREC_BWD | GEMM_W_FRAG) if (not b16 and PREC_BWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT and Cout % 4 == 0) else 0
+    return fsp, bsp
+
+
+BLOCK_PACKED = 0x800
+USE_PACK_MANY = os.environ.get('STIN_PACK_MANY', '1') != '0'
+
+
+class PackSet:
+    """The weight packs of ALL fused blocks of a network in one launch per step (stin_edgeconv_pack_many_f32) instead of
+    one tiny launch at the head of every block: persistent per-block operand buffers (the block call's forward workspace
+    and wcatT | w2T), a job table in device memory written once.  specs: [(W1, b1, W2, b2, Ws, bs, trans_inv, prec_fwd, B)]
+    in block order, fp32 storage.  Valid while the parameters stay where they are (`matches`)."""
+
+    def __init__(self, specs, dev):
+        import ctypes
+        import struct
+        lib = _lib.load()
+        self.key = self.key_of(specs)
+        self.buffers = []                      # per block: (ws, wts, fwd_split, bwd_split)
+        blob, self.max_elems = b'', 0
+        for (W1, b1, W2, b2, Ws, bs, trans_inv, prec_fwd, B) in specs:
+            H, Cout = W1.shape[0], W2.shape[0]
+            Cin = W1.shape[1] if trans_inv else W1.shape[1] // 2
+            Cp = (Cin + 3) // 4 * 4
+            has_sc = Ws is not None
+            Yw = 2 * H + (Cout if has_sc else 0)
+            fsp, bsp = block_split_modes(prec_fwd, False, Cout)
+            ws = torch.empty(lib.stin_edgeconv_block_fwd_workspace_bytes(Cin, Cp, H, Cout, int(has_sc), B), dtype=torch.uint8, device=dev)
+            wts = torch.empty(Yw * Cp + H * Cout, dtype=torch.float32, device=dev)
+            off = [ctypes.c_size_t(0) for _ in range(3)]
+            _lib.check(lib.stin_edgeconv_block_fwd_pack_offsets(Cp, H, Cout, int(has_sc), *[ctypes.byref(o) for o in off]),
+                       'stin_edgeconv_block_fwd_pack_offsets')
+            base = (ws.data_ptr() + 255) & ~255
+            wcat, w2s, bcat = (base + o.value for o in off)
+            W1c, W2c = W1.contiguous(), W2.contiguous()
+            assert W1c.data_ptr() == W1.data_ptr() and W2c.data_ptr() == W2.data_ptr(), 'pack_many needs contiguous weights'
+            blob += struct.pack('<10Q8i', _ptr(W1), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2), wcat, bcat, _ptr(wts),
+                                _ptr(wts) + 4 * Yw * Cp, w2s if fsp else 0, Cin, Cp, H, Cout, int(has_sc), int(trans_inv), fsp, bsp)
+            self.max_elems = max(self.max_elems, Yw * Cp + H * Cout)
+            self.buffers.append((ws, wts, fsp, bsp))
+        self.jobs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        self.n = len(specs)
+
+    @staticmethod
+    def key_of(specs):
+        return tuple((_ptr(W1), _ptr(b1), _ptr(W2), _ptr(Ws), _ptr(bs), tuple(W1.shape), tuple(W2.shape), bool(t), int(pf), int(B),
+                      PREC_BWD, WEIGHT_PRESPLIT, GEMM_W_FRAG) for (W1, b1, W2, b2, Ws, bs, t, pf, B) in specs)
+
+    def matches(self, specs):
+        return self.key == self.key_of(specs)
+
+    def run(self):
+        _call('stin_edgeconv_pack_many_f32', _ptr(self.jobs), self.n, self.max_elems, _stream(self.jobs))
+
+
 class EdgeConvBlockFn(torch.autograd.Function):
     """One GraphResnetBlock with an EdgeConv(mean) filter and instance norm, fused at the
     autograd level (reference models/surfacetextureinpaintingnet.py:507-521), taking the
@@ -564,7 +623,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
     support the mask).  Fast path: one C call per direction (stin_edgeconv_block_fwd / _bwd, same kernels, same order)."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, Ws, bs, edges, groups, trans_inv, eps=EPS, prec_fwd=None):
+    def forward(ctx, x, W1, b1, W2, b2, Ws, bs, edges, groups, trans_inv, eps=EPS, prec_fwd=None, prepacked=None):
         prec_fwd = PREC_FWD if prec_fwd is None else int(prec_fwd)
         x, _ = _mat(x)
         N, Cin = x.shape
@@ -582,15 +641,18 @@ class EdgeConvBlockFn(torch.autograd.Function):
             xp = x
         # forward / backward weight operands, pre-split once here into the two 16-bit pieces the split GEMMs use
         # (instead of once per GEMM block); plain fp32 for the other precisions and for bf16-storage activations
-        fsp = (prec_fwd | GEMM_W_FRAG) if (not b16 and prec_fwd in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT) else 0
-        bsp = (PREC_BWD | GEMM_W_FRAG) if (not b16 and PREC_BWD in (GEMM_BF16X3, GEMM_F16X3) and WEIGHT_PRESPLIT and Cout % 4 == 0) else 0
+        fsp, bsp = block_split_modes(prec_fwd, b16, Cout)
         fast = (USE_BLOCK_CALL and USE_EDGE_MASK and edge_mask_supported(H) and N > 1
                 and not KernelTimer.enabled)          # (the bench's per-kernel HIP-event brackets need the per-kernel path)
         ctx.fast = fast
         if fast:
             lib = _lib.load()
             B = groups.B
-            wts = torch.empty(Yw * Cp + H * Cout, dtype=torch.float32, device=dev)       # backward weight operands
+            packed = 0
+            if prepacked is not None and not b16 and prepacked[2] == fsp and prepacked[3] == bsp:
+                ws, wts, packed = prepacked[0], prepacked[1], BLOCK_PACKED       # operands already packed (PackSet.run)
+            else:
+                wts = torch.empty(Yw * Cp + H * Cout, dtype=torch.float32, device=dev)   # backward weight operands
             wcatT, w2T = wts[:Yw * Cp].view(Cp, Yw), wts[Yw * Cp:].view(H, Cout)
             Y = torch.empty(N, Yw, dtype=x.dtype, device=dev)
             hE = torch.empty(N, H + pad, dtype=x.dtype, device=dev)
@@ -600,12 +662,16 @@ class EdgeConvBlockFn(torch.autograd.Function):
             mean, rstd = stats[0], stats[1]
             out = torch.empty(N, Cout, dtype=x.dtype, device=dev)
             ws_bytes = lib.stin_edgeconv_block_fwd_workspace_bytes(Cin, Cp, H, Cout, int(has_shortcut), B)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            if not packed:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            elif ws.numel() < ws_bytes:
+                raise RuntimeError('prepacked workspace too small for this batch (PackSet built for another batch size)')
             W1c, W2c = W1.contiguous(), W2.contiguous()
             cd = edges.by_dst
             _call('stin_edgeconv_block_fwd', int(b16), _ptr(xp), xp.stride(0), N, Cin, Cp, H, Cout, int(has_shortcut),
                   int(trans_inv), _ptr(W1c), _ptr(b1), _ptr(W2c), _ptr(b2), _ptr(Ws), _ptr(bs), _ptr(cd.rowptr), _ptr(cd.col),
-                  _ptr(groups.ptr_sum), B, _ptr(groups.gid), _ptr(groups.inv_cnt), int(groups.quirk), float(eps), prec_fwd, fsp, bsp,
+                  _ptr(groups.ptr_sum), B, _ptr(groups.gid), _ptr(groups.inv_cnt), int(groups.quirk), float(eps), prec_fwd,
+                  fsp | packed, bsp,
                   _ptr(wcatT), _ptr(w2T), _ptr(Y), Yw, _ptr(hE), H + pad, _ptr(mask), _ptr(agg), _ptr(mean), _ptr(rstd),
                   _ptr(out), Cout, _ptr(ws), ws_bytes, _stream(x))
             ctx.save_for_backward(xp, Y, hE, agg, mean, rstd, wcatT, w2T)
@@ -699,10 +765,10 @@ class EdgeConvBlockFn(torch.autograd.Function):
                 ctx.params[0]._stin_slot[0].block_done(_wgrad_side(dev).last_done if side[0] else None)
                 if dx is not None and Cp != Cin:
                     dx = dx[:, :Cin]
-                return (dx,) + (None,) * 11
+                return (dx,) + (None,) * 12
             if dx is not None and Cp != Cin:
                 dx = dx[:, :Cin]
-            return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None, None, None
+            return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None, None, None, None
         dagg = instance_norm_act_bwd(agg, g, mean, rstd, groups, act=True)
         dw2b = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H], precision=PREC_BWD)   # [Cout, H + 1] = dW2 | db2
         dhE = gemm_nt(dagg, w2T, precision=ctx.prec_bwd_nt)                                             # [N, H] = dagg W2
@@ -733,7 +799,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         db2 = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b2 else None
         _call('stin_edgeconv_unpack_grads_f32', _ptr(dwb), _ptr(dw2b), Cin, Cp, H, Cout, int(ctx.has_shortcut),
               int(ctx.trans_inv), _ptr(dW1), _ptr(db1), _ptr(dWs), _ptr(dbs), _ptr(dW2), _ptr(db2), _stream(x))
-        return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None, None, None
+        return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None, None, None, None
 
 
 class EdgeReluMeanFn(torch.autograd.Function):

@@ -27,6 +27,7 @@ class GraphResnetBlock(nn.Module):
         # True where the reference wraps the block in torch.utils.checkpoint (:429, :438, :451, :454): its forward runs a
         # second time inside backward, which numerically only matters for BatchNorm running statistics (norm='batch')
         self.recomputed = False
+        self._prepacked = None        # (workspace, wcatT | w2T, fwd_split, bwd_split) of functional.PackSet, set by the network
         # True for a block fed by un-normalised data (the network's first block, or any block of a norm-free network):
         # its forward GEMMs take the range-safe matrix-core path (functional.forward_precision)
         self.unbounded_input = False
@@ -42,6 +43,16 @@ class GraphResnetBlock(nn.Module):
         if dim_in != dim_out:
             self.shortcut = nn.Linear(dim_in, dim_out)
 
+    def pack_spec(self, B):
+        """The arguments of this block's weight pack (functional.PackSet), or None when the block is not the fused kind."""
+        if not (isinstance(self.first_filter, M.EdgeConv) and isinstance(self.first_norm, M.FastInstanceNorm)):
+            return None
+        shortcut = self.shortcut if self.dim_in != self.dim_out else None
+        lin1, lin2 = self.first_filter.nn[0], self.first_filter.nn[2]
+        return (lin1.weight, lin1.bias, lin2.weight, lin2.bias, None if shortcut is None else shortcut.weight,
+                None if shortcut is None else shortcut.bias, self.first_filter.trans_inv,
+                SF.forward_precision(self.unbounded_input), int(B))
+
     def forward(self, x, edges, batch=None):
         n = x.shape[0]
         edges = M._as_edges(edges, n)
@@ -54,7 +65,7 @@ class GraphResnetBlock(nn.Module):
                                             None if shortcut is None else shortcut.weight,
                                             None if shortcut is None else shortcut.bias, edges, groups,
                                             self.first_filter.trans_inv, self.first_norm.eps,
-                                            SF.forward_precision(self.unbounded_input))
+                                            SF.forward_precision(self.unbounded_input), self._prepacked)
         self.first_filter.fwd_precision = SF.forward_precision(self.unbounded_input)
         out = self.first_filter(x, edges)
         res = (SF.linear(x, self.shortcut.weight, self.shortcut.bias, precision=SF.forward_precision(self.unbounded_input))
@@ -90,6 +101,7 @@ class SurfaceTextureInpaintingNet(nn.Module):
             self.norm, self.using_norm = M.SingleBatchGraphNorm, True
         else:
             self.norm, self.using_norm = M.Identity, False
+        self._pack_set = None
         self._pooling_type = pooling_type
         self.checkpoint_bottleneck = checkpoint_bottleneck          # accepted for config compatibility: the HIP
         self.num_blocks_per_uncheckpointed_block = num_blocks_per_uncheckpointed_block  # blocks save only per-vertex
@@ -181,6 +193,29 @@ class SurfaceTextureInpaintingNet(nn.Module):
     def _unpooling(self, vertex_features, pool_map):
         return SF.UnpoolFn.apply(vertex_features, pool_map)
 
+    def _pack_weights(self, x, num_graphs):
+        """All fused blocks' weight operands in ONE launch (functional.PackSet) instead of one tiny launch at the head of
+        every block: 15 launches of ~8 us on the critical path become one.  fp32 storage on the whole-block path only."""
+        blocks = [b for grp in (self.input_blocks, self.encoder_blocks, self.bottleneck_blocks, self.decoder_blocks,
+                                self.output_blocks) for b in grp]
+        use = (SF.USE_PACK_MANY and SF.USE_BLOCK_CALL and SF.USE_EDGE_MASK and not SF.KernelTimer.enabled and x.is_cuda and
+               x.dtype == torch.float32 and self.norm is M.FastInstanceNorm)
+        specs = None
+        if use:
+            whole = set(id(b) for b in list(self.input_blocks) + list(self.output_blocks))       # norm over the whole batch: B = 1
+            specs = [b.pack_spec(1 if id(b) in whole else num_graphs) for b in blocks]
+            use = all(sp is not None for sp in specs)
+        if not use:
+            for b in blocks:
+                b._prepacked = None
+            return
+        ps = self._pack_set
+        if ps is None or not ps.matches(specs):
+            ps = self._pack_set = SF.PackSet(specs, x.device)
+        ps.run()
+        for b, buf in zip(blocks, ps.buffers):
+            b._prepacked = buf
+
     def _norm_arg(self, plan, level, whole_batch=False):
         """What a block's norm receives: NormGroups for the instance norm; for the other norms the
         reference's `batch` tensor / None."""
@@ -234,6 +269,7 @@ class SurfaceTextureInpaintingNet(nn.Module):
         if self.activation_dtype != out.dtype:
             out = out.to(self.activation_dtype)
         e0 = plan.edges('edge_index', 0)
+        self._pack_weights(out, plan.num_graphs)
         for blk in self.input_blocks:                               # norm over the WHOLE batch (reference :406-407)
             out = blk(out, e0, self._norm_arg(plan, 0, whole_batch=True))
         for i, blk in enumerate(self.encoder_blocks):

@@ -817,6 +817,43 @@ def test_weight_gradient_side_stream_is_bit_identical_in_every_autograd_mode():
         SF.USE_WGRAD_STREAM, SF.WGRAD_MIN_WORK = old, old_min
 
 
+@pytest.mark.parametrize('batched', [False, True])
+def test_pack_many_equals_the_per_block_pack(batched):
+    """functional.PackSet: the weight operands of every fused block packed by ONE launch at the start of forward (persistent
+    buffers, job table in device memory) - outputs and gradients bit-identical to the per-block pack, over two steps with a
+    weight update in between (the table must keep pointing at the live parameters) and after moving to another batch size."""
+    from surface_texture_inpainting_net_amd.data import collate
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 1])
+    if batched:
+        samples = [collate([make_synthetic_mesh(n, 3, seed=70 + i, dilations=(2,)) for i, n in enumerate(ns)]).to(DEV)
+                   for ns in ((900, 1500, 700), (1200, 800))]
+    else:
+        samples = [make_synthetic_mesh(n, 3, seed=70 + n, dilations=(2,)).to(DEV) for n in (5000, 3100)]
+
+    def run(flag):
+        old = SF.USE_PACK_MANY
+        SF.USE_PACK_MANY = flag
+        try:
+            torch.manual_seed(9)
+            net = S.define_G(**cfg).to(DEV)
+            opt = torch.optim.SGD(net.parameters(), lr=0.05)
+            outs = []
+            for s in samples + samples[:1]:
+                opt.zero_grad(set_to_none=True)
+                out = net(s)
+                out.square().mean().backward()
+                outs += [out.detach().clone()] + [p.grad.clone() for p in net.parameters()]
+                opt.step()
+            assert (net._pack_set is not None) == flag
+            return outs
+        finally:
+            SF.USE_PACK_MANY = old
+
+    want, got = run(False), run(True)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('batched', [False, True])
 def test_block_call_equals_per_kernel_path_bitwise(batched, dtype):
