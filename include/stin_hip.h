@@ -364,6 +364,19 @@ int stin_total_variation_f32(const float* x, int64_t ldx, const int32_t* rowptr_
 int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int step, int amsgrad, stin_stream_t stream);
 
+/* GEMM + first stage of the instance-norm statistics of its output (the all-columns NT kernel's blocks own whole rows):
+ * colstats [groups][2][Nc] doubles = per 64-row group the column sums of the stored values and of their squares;
+ * groups = stin_gemm_nt_colstats_groups(M, Nc, K, precision) (0: shape / precision not supported - Nc = 128 / 256 in
+ * fragment order only).  stin_moments_final_f32 turns them into mean / rstd of ONE instance (inv_cnt[0] = 1 / M).
+ * Replaces GEMM2 + stin_colreduce_f32(MOMENTS) of a single-graph block (fastinstancenorm.py:44-98 on the conv output). */
+int64_t stin_gemm_nt_colstats_groups(int64_t M, int Nc, int K, int precision);
+int stin_gemm_nt_colstats_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                              const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
+                              int Nc, int K, float* C, int64_t ldc, int precision, double* colstats, size_t colstats_bytes,
+                              stin_stream_t stream);
+int stin_moments_final_f32(const double* partial, int64_t groups, int C, const float* inv_cnt, float eps, float* mean,
+                           float* rstd, stin_stream_t stream);
+
 /* --------------------------------------------------- bf16-storage variants of the path --
  * Same semantics, argument order and reference call sites as the *_f32 entry points above, on bf16 rows
  * (stin_bf16_t, see the typedef).  What stays fp32: instance-norm statistics (fp64 accumulation), inv_deg / w_src /

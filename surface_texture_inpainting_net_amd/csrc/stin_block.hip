@@ -90,9 +90,20 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
         STIN_TRY(stin_gemm_nt_f32(static_cast<const float*>(x), ldx, wcat, Cp, bcat, nullptr, 0, nullptr, 0, N, Yw, Cp, Yf, ldy,
                                   pf, stream));
         STIN_TRY(stin_edge_relu_mean_fwd_f32(Yf, ldy, Yf + H, ldy, rowptr_dst, col_dst, N, H, hf, ldh, 1, mask, stream));
-        STIN_TRY(stin_gemm_nt_f32(hf, ldh, w2_op, H, b2, hf + H, ldh, nullptr, 0, N, Cout, H, static_cast<float*>(agg), Cout,
-                                  pf, stream));
-        if (!slice_quirk) {
+        // one graph, all-columns GEMM shape: the column sums of agg come out of GEMM2's epilogue (no pass over agg for them)
+        const int64_t stat_groups = (B == 1 && gid == nullptr && !slice_quirk) ? stin_gemm_nt_colstats_groups(N, Cout, H, pf) : 0;
+        const bool fused_stats = stat_groups > 0 && (size_t)stat_groups * 2 * Cout * sizeof(double) + 256 <= red_bytes;
+        if (fused_stats) {
+            double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(red_ws) + 255) & ~(uintptr_t)255);
+            STIN_TRY(stin_gemm_nt_colstats_f32(hf, ldh, w2_op, H, b2, hf + H, ldh, nullptr, 0, N, Cout, H, static_cast<float*>(agg),
+                                               Cout, pf, partial, (size_t)stat_groups * 2 * Cout * sizeof(double), stream));
+            STIN_TRY(stin_moments_final_f32(partial, stat_groups, Cout, inv_cnt, eps, mean, rstd, stream));
+        } else {
+            STIN_TRY(stin_gemm_nt_f32(hf, ldh, w2_op, H, b2, hf + H, ldh, nullptr, 0, N, Cout, H, static_cast<float*>(agg), Cout,
+                                      pf, stream));
+        }
+        if (fused_stats) {
+        } else if (!slice_quirk) {
             STIN_TRY(stin_colreduce_f32(STIN_RED_MOMENTS, static_cast<const float*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum, B,
                                         gid, nullptr, nullptr, nullptr, nullptr, STIN_POST_NONE, inv_cnt, eps, mean, rstd, red_ws,
                                         red_bytes, stream));

@@ -663,7 +663,8 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ row_mask, int64_t ld_mask,
                                                              const float* __restrict__ res, int64_t ld_res, int64_t M,
-                                                             int K, float* __restrict__ C, int64_t ldc) {
+                                                             int K, float* __restrict__ C, int64_t ldc,
+                                                             double* __restrict__ colstats) {
     typedef typename PieceTraits<PT>::vec8 vec8;
     constexpr float ASCALE = PieceTraits<PT>::ascale, WSCALE = PieceTraits<PT>::wscale;
     constexpr int WAVES_M = 4 / NW, BM = 64 * WAVES_M, PASSES = BM / 32;       // staging: 32 rows per pass
@@ -794,12 +795,16 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
     if (c < nchunk) chunk(c, ra[1], ra[0]);
 
     // ---- epilogue: v = acc / (ascale wscale) + bias [* row mask] + residual
+    // colstats (optional): per 64-row group (blockIdx * WAVES_M + wm) the column sums of the STORED values and of their
+    // squares in fp64, [group][2][Nc] - the first stage of the instance-norm statistics (stin_moments_final_f32 is the second),
+    // fixed summation order: rows of the lane in storage order, then the two 32-lane halves.
     const float sc = 1.f / (ASCALE * WSCALE);
     const bool full_rows = row0 + BM <= M;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int col = wn * 64 + t * 32 + li;
         const float bv = bias != nullptr ? bias[col] : 0.f;
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int lr0 = wm * 64 + i * 32 + 4 * kh;
@@ -811,17 +816,39 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int lr = lr0 + (r & 3) + 8 * (r >> 2);
-                    C[(row0 + lr) * ldc + col] = acc[i][t][r] * sc + (row_mask != nullptr ? bv * mask_s[lr] : bv) + ld[r];
+                    const float v = acc[i][t][r] * sc + (row_mask != nullptr ? bv * mask_s[lr] : bv) + ld[r];
+                    C[(row0 + lr) * ldc + col] = v;
+                    if (colstats != nullptr) {
+                        const double d = (double)v;
+                        s1 += d;
+                        s2 += d * d;
+                    }
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int lr = lr0 + (r & 3) + 8 * (r >> 2);
                     const int64_t row = row0 + lr;
-                    if (row < M)
-                        C[row * ldc + col] = acc[i][t][r] * sc + (row_mask != nullptr ? bv * mask_s[lr] : bv) +
-                                             (res != nullptr ? res[row * ld_res + col] : 0.f);
+                    if (row < M) {
+                        const float v = acc[i][t][r] * sc + (row_mask != nullptr ? bv * mask_s[lr] : bv) +
+                                        (res != nullptr ? res[row * ld_res + col] : 0.f);
+                        C[row * ldc + col] = v;
+                        if (colstats != nullptr) {
+                            const double d = (double)v;
+                            s1 += d;
+                            s2 += d * d;
+                        }
+                    }
                 }
+            }
+        }
+        if (colstats != nullptr) {                                             // block-uniform
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (kh == 0) {
+                double* dst = colstats + ((int64_t)blockIdx.x * WAVES_M + wm) * 2 * (NW * 64) + col;
+                dst[0] = s1;
+                dst[NW * 64] = s2;
             }
         }
     }
@@ -1670,9 +1697,10 @@ inline int tn_rows_per_chunk(int64_t M, int tiles) {
 
 }  // namespace
 
-extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
-                                const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
-                                int Nc, int K, float* C, int64_t ldc, int precision, stin_stream_t stream_) {
+// colstats != NULL: the launch must be the all-columns kernel (its blocks own whole rows) - STIN_E_UNSUPPORTED otherwise
+static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                            const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
+                            int Nc, int K, float* C, int64_t ldc, int precision, double* colstats, stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
@@ -1709,12 +1737,13 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
         else if (force_tile == 2) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);  \
         else STIN_NT(KERNEL, 64, 64, 2, 2, ##__VA_ARGS__);                                     \
     } while (0)
+    STIN_REQUIRE(colstats == nullptr || (wfrag && Nc <= 256), STIN_E_UNSUPPORTED);
     if (wfrag && Nc <= 256) {
         // all-columns kernel (k_gemm_nt_wide): Nc = 128 / 256, the fragment-order weight operand cannot be read by any other kernel
         STIN_REQUIRE(vec, STIN_E_ALIGN);
 #define STIN_WIDE(PT_, NW_)                                                                                               \
     hipLaunchKernelGGL((k_gemm_nt_wide<PT_, NW_>), dim3((unsigned)((M + 64 * (4 / NW_) - 1) / (64 * (4 / NW_)))), dim3(WD_THREADS), 0, \
-                       stream, A, lda, W, bias, row_mask, ld_mask, residual, ld_res, M, K, C, ldc)
+                       stream, A, lda, W, bias, row_mask, ld_mask, residual, ld_res, M, K, C, ldc, colstats)
         if (precision == STIN_GEMM_BF16X3) {
             if (Nc == 256) STIN_WIDE(__bf16, 4);
             else STIN_WIDE(__bf16, 2);
@@ -1775,6 +1804,32 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
 #undef STIN_NT
 #undef STIN_NT_ARGS
     return stin_launch_status();
+}
+
+extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                                const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
+                                int Nc, int K, float* C, int64_t ldc, int precision, stin_stream_t stream) {
+    return gemm_nt_f32_impl(A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc, precision, nullptr, stream);
+}
+
+// The GEMM plus the FIRST stage of the instance-norm statistics of its output: colstats [groups][2][Nc] doubles, groups =
+// ceil(M / 64) (stin_gemm_nt_colstats_groups; 0 = this shape / precision does not support it: only the all-columns kernel's
+// blocks own whole rows).  Second stage: stin_moments_final_f32.
+extern "C" int64_t stin_gemm_nt_colstats_groups(int64_t M, int Nc, int K, int precision) {
+    const bool ok = (precision & STIN_GEMM_W_PRESPLIT) && (precision & STIN_GEMM_W_FRAG) && Nc <= 256 && stin_w_frag_shape(Nc, K);
+    const int p = precision & ~(STIN_GEMM_W_PRESPLIT | STIN_GEMM_W_FRAG);
+    if (!ok || M <= 0 || (p != STIN_GEMM_BF16X3 && p != STIN_GEMM_F16X3)) return 0;
+    return (M + 63) / 64;
+}
+extern "C" int stin_gemm_nt_colstats_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                                         const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res,
+                                         int64_t M, int Nc, int K, float* C, int64_t ldc, int precision, double* colstats,
+                                         size_t colstats_bytes, stin_stream_t stream) {
+    const int64_t groups = stin_gemm_nt_colstats_groups(M, Nc, K, precision);
+    STIN_REQUIRE(groups > 0, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(colstats != nullptr, STIN_E_NULL);
+    STIN_REQUIRE(colstats_bytes >= (size_t)groups * 2 * (size_t)Nc * sizeof(double), STIN_E_WORKSPACE);
+    return gemm_nt_f32_impl(A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc, precision, colstats, stream);
 }
 
 extern "C" size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int ones_column) {

@@ -499,6 +499,19 @@ extern "C" int stin_colreduce_bf16(int mode, const stin_bf16_t* x, int64_t ldx, 
                                      inv_cnt, eps, out0, out1, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// Second stage of the fused GEMM + statistics (stin_gemm_nt_colstats_f32): partial [groups][2][C] doubles (sum, sum of
+// squares per row group) -> mean, rstd [C] of ONE instance of N rows (inv_cnt[0] = 1 / N), same final arithmetic as the
+// MOMENTS mode of stin_colreduce_f32.
+extern "C" int stin_moments_final_f32(const double* partial, int64_t groups, int C, const float* inv_cnt, float eps, float* mean,
+                                      float* rstd, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(groups > 0 && groups <= INT32_MAX && C > 0, STIN_E_SIZE);
+    STIN_REQUIRE(partial && inv_cnt && mean && rstd, STIN_E_NULL);
+    hipLaunchKernelGGL(k_moments_final, dim3((unsigned)((C + FIN_COLS - 1) / FIN_COLS), 1u, 1u), dim3(BLOCK), 0, (hipStream_t)stream,
+                       partial, (int)groups, C, 1, inv_cnt, eps, mean, rstd);
+    return stin_launch_status();
+}
+
 extern "C" int stin_norm_act_res_fwd_f32(const float* x, int64_t ldx, const float* mean, const float* rstd,
                                          const int32_t* gid, const float* res, int64_t ldres, int64_t N, int C, int act,
                                          float* y, int64_t ldy, stin_stream_t stream) {

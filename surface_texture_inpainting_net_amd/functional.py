@@ -283,6 +283,31 @@ WEIGHT_PRESPLIT = os.environ.get('STIN_WEIGHT_PRESPLIT', '1') != '0'
 USE_BLOCK_CALL = os.environ.get('STIN_BLOCK_CALL', '1') != '0'
 
 
+def gemm_nt_colstats(A, W, bias, row_mask, precision, n_cols):
+    """hE W2^T + masked bias AND the first stage of the column statistics of the result in one launch, or None when this
+    shape / precision has no all-columns kernel.  -> (C, partial [groups, 2, n_cols] float64)."""
+    A, lda = _mat(A)
+    M, K = A.shape
+    lib = _lib.load()
+    groups = int(lib.stin_gemm_nt_colstats_groups(M, n_cols, K, int(precision))) if A.dtype == torch.float32 else 0
+    if groups <= 0 or groups > 1024:
+        return None
+    C = torch.empty(M, n_cols, dtype=torch.float32, device=A.device)
+    partial = torch.empty(groups, 2, n_cols, dtype=torch.float64, device=A.device)
+    mk, ldm = (row_mask, row_mask.stride(0)) if row_mask is not None else (None, 0)
+    _call('stin_gemm_nt_colstats_f32', _ptr(A), lda, _ptr(W), K, _ptr(bias), _ptr(mk), ldm, None, 0, M, n_cols, K, _ptr(C), n_cols,
+          int(precision), _ptr(partial), partial.numel() * 8, _stream(A), tag=(M, n_cols, K))
+    return C, partial
+
+
+def moments_final(partial, inv_cnt, eps=EPS):
+    """Second stage: mean, rstd [1, C] of one instance (inv_cnt [1] = 1 / rows)."""
+    groups, _, C = partial.shape
+    out = torch.empty(2, 1, C, dtype=torch.float32, device=partial.device)
+    _call('stin_moments_final_f32', _ptr(partial), groups, C, _ptr(inv_cnt), float(eps), _ptr(out[0]), _ptr(out[1]), _stream(partial))
+    return out[0], out[1]
+
+
 def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32, residual=None, out_dtype=None):
     """A[M, K] . W[Nc, K]^T + bias * row_mask -> [M, Nc]  (hand-written MFMA kernels).
     row_mask: optional [M] column view (stride = its row pitch) multiplying the bias per row.
@@ -703,8 +728,15 @@ class EdgeConvBlockFn(torch.autograd.Function):
                                       '{128, 256, 512, 1024, 2048} (or STIN_EDGE_MASK=0)' % H)
         mask = torch.empty(max(edges.n_edges, 1) * (H // 32), dtype=torch.int32, device=dev) if use_mask else None
         edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True, mask=mask)
-        agg = gemm_nt(hE[:, :H], w2s if fsp else W2c, b2, row_mask=hE[:, H], precision=pf)
-        mean, rstd = instance_stats(agg, groups, eps)
+        fused = None
+        if fsp and groups.B == 1 and groups.gid is None and not groups.quirk and N > 1:
+            fused = gemm_nt_colstats(hE[:, :H], w2s, b2, hE[:, H], pf, Cout)       # GEMM2 + column sums in one launch
+        if fused is not None:
+            agg = fused[0]
+            mean, rstd = moments_final(fused[1], groups.inv_cnt, eps)
+        else:
+            agg = gemm_nt(hE[:, :H], w2s if fsp else W2c, b2, row_mask=hE[:, H], precision=pf)
+            mean, rstd = instance_stats(agg, groups, eps)
         res = Y[:, 2 * H:] if has_shortcut else x
         out = norm_act_res_fwd(agg, mean, rstd, groups, res=res, act=True)
         ctx.save_for_backward(xp, Y, hE, agg, mean, rstd, wcatT, w2T)

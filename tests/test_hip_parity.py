@@ -281,6 +281,39 @@ def test_gemm_nt_strip_kernel_equals_tiled_kernel(M, Nc, K):
         assert float((SF.gemm_nt(A, Wf, b, row_mask=mask, precision=prec | SF.GEMM_W_PRESPLIT | FR).double() - ref).abs().max()) <= tol * scale
 
 
+@pytest.mark.parametrize('M,Nc,K', [(18063, 256, 512), (60211, 128, 256), (130, 256, 512), (64, 128, 256), (4097, 256, 1024)])
+def test_gemm_nt_with_fused_column_statistics(M, Nc, K):
+    """stin_gemm_nt_colstats_f32: GEMM2 of a block plus the first stage of the instance-norm statistics of its output in one
+    launch.  The output equals the plain call bit for bit; the per-group sums are the fp64 column sums of the stored fp32
+    values (exact up to fp64 rounding); mean / rstd equal the two-kernel colreduce route to fp32 rounding."""
+    from surface_texture_inpainting_net_amd.plan import NormGroups
+    g = torch.Generator().manual_seed(M + Nc)
+    A = torch.rand(M, K + 4, generator=g).to(DEV)
+    W = (torch.randn(Nc, K, generator=g) * 0.1).to(DEV)
+    b = torch.randn(Nc, generator=g).to(DEV)
+    prec = SF.GEMM_F16X3 | SF.GEMM_W_PRESPLIT | 0x400
+    Wf = SF.split_weights(W, SF.GEMM_F16X3 | 0x400)
+    plain = SF.gemm_nt(A[:, :K], Wf, b, row_mask=A[:, K], precision=prec)
+    got = SF.gemm_nt_colstats(A[:, :K], Wf, b, A[:, K], prec, Nc)
+    assert got is not None
+    C, partial = got
+    assert torch.equal(C, plain)
+    groups = (M + 63) // 64
+    assert partial.shape == (groups, 2, Nc)
+    pad = torch.zeros(groups * 64, Nc, dtype=torch.float64, device=DEV)
+    pad[:M] = C.double()
+    want = pad.view(groups, 64, Nc)
+    assert float((partial[:, 0] - want.sum(1)).abs().max()) <= 1e-11 * 64 * float(C.abs().max())
+    assert float((partial[:, 1] - (want * want).sum(1)).abs().max()) <= 1e-11 * 64 * float(C.abs().max()) ** 2
+    ng = NormGroups(M, torch.device(DEV))
+    mean, rstd = SF.moments_final(partial, ng.inv_cnt)
+    mean2, rstd2 = SF.instance_stats(C, ng)
+    assert float((mean - mean2).abs().max()) <= 1e-6 * float(mean2.abs().max()) + 1e-9
+    assert float((rstd / rstd2 - 1).abs().max()) <= 1e-6
+    # shapes without an all-columns kernel: no fused form
+    assert SF.gemm_nt_colstats(A[:, :K], SF.split_weights(W, SF.GEMM_F16X3), b, A[:, K], SF.GEMM_F16X3 | SF.GEMM_W_PRESPLIT, Nc) is None
+
+
 def _lib_load():
     from surface_texture_inpainting_net_amd import _lib
     return _lib.load()
