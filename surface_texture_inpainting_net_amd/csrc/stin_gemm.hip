@@ -845,7 +845,7 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
         if (colstats != nullptr) {                                             // block-uniform
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
-            if (kh == 0) {
+            if (kh == 0 && row0 + wm * 64 < M) {                               // (a 64-row group wholly past M does not exist)
                 double* dst = colstats + ((int64_t)blockIdx.x * WAVES_M + wm) * 2 * (NW * 64) + col;
                 dst[0] = s1;
                 dst[NW * 64] = s2;

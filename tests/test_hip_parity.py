@@ -281,7 +281,8 @@ def test_gemm_nt_strip_kernel_equals_tiled_kernel(M, Nc, K):
         assert float((SF.gemm_nt(A, Wf, b, row_mask=mask, precision=prec | SF.GEMM_W_PRESPLIT | FR).double() - ref).abs().max()) <= tol * scale
 
 
-@pytest.mark.parametrize('M,Nc,K', [(18063, 256, 512), (60211, 128, 256), (130, 256, 512), (64, 128, 256), (4097, 256, 1024)])
+@pytest.mark.parametrize('M,Nc,K', [(18063, 256, 512), (60211, 128, 256), (130, 256, 512), (64, 128, 256), (4097, 256, 1024),
+                                    (129, 128, 256), (190, 128, 512)])
 def test_gemm_nt_with_fused_column_statistics(M, Nc, K):
     """stin_gemm_nt_colstats_f32: GEMM2 of a block plus the first stage of the instance-norm statistics of its output in one
     launch.  The output equals the plain call bit for bit; the per-group sums are the fp64 column sums of the stored fp32
@@ -298,6 +299,11 @@ def test_gemm_nt_with_fused_column_statistics(M, Nc, K):
     assert got is not None
     C, partial = got
     assert torch.equal(C, plain)
+    # no write past the [groups, 2, Nc] buffer (a 128-row block whose second 64-row group lies past M must not store one)
+    guard = torch.full((partial.numel() + 4096,), -7.0, dtype=torch.float64, device=DEV)
+    SF._call('stin_gemm_nt_colstats_f32', SF._ptr(A), A.stride(0), SF._ptr(Wf), K, SF._ptr(b), SF._ptr(A[:, K]), A.stride(0), None, 0,
+             M, Nc, K, SF._ptr(C), Nc, prec, SF._ptr(guard), partial.numel() * 8, SF._stream(A))
+    assert torch.equal(guard[:partial.numel()].view_as(partial), partial) and float((guard[partial.numel():] + 7.0).abs().max()) == 0.0
     groups = (M + 63) // 64
     assert partial.shape == (groups, 2, Nc)
     pad = torch.zeros(groups * 64, Nc, dtype=torch.float64, device=DEV)
