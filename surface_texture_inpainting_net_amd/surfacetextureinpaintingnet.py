@@ -101,7 +101,7 @@ class SurfaceTextureInpaintingNet(nn.Module):
             self.norm, self.using_norm = M.SingleBatchGraphNorm, True
         else:
             self.norm, self.using_norm = M.Identity, False
-        self._pack_set = None
+        self._pack_set, self._pack_key, self._pack_probe = None, None, None
         self._pooling_type = pooling_type
         self.checkpoint_bottleneck = checkpoint_bottleneck          # accepted for config compatibility: the HIP
         self.num_blocks_per_uncheckpointed_block = num_blocks_per_uncheckpointed_block  # blocks save only per-vertex
@@ -196,16 +196,30 @@ class SurfaceTextureInpaintingNet(nn.Module):
     def _pack_weights(self, x, num_graphs):
         """All fused blocks' weight operands in ONE launch (functional.PackSet) instead of one tiny launch at the head of
         every block: 15 launches of ~8 us on the critical path become one.  fp32 storage on the whole-block path only."""
-        blocks = [b for grp in (self.input_blocks, self.encoder_blocks, self.bottleneck_blocks, self.decoder_blocks,
-                                self.output_blocks) for b in grp]
         use = (SF.USE_PACK_MANY and SF.USE_BLOCK_CALL and SF.USE_EDGE_MASK and not SF.KernelTimer.enabled and x.is_cuda and
                x.dtype == torch.float32 and self.norm is M.FastInstanceNorm)
+        # cheap per-step validity check of the cached set (the full parameter-pointer comparison costs ~0.3 ms of host time per
+        # step): the parameters of a module move together (.to(), FlatAdam re-pointing), so the first and the last one stand for all
+        first, last = self._pack_probe if self._pack_probe is not None else (None, None)
+        if first is None:
+            ps_ = list(self.parameters())
+            first, last = self._pack_probe = (ps_[0], ps_[-1])
+        key = (use, first.data_ptr(), last.data_ptr(), int(num_graphs), SF.PREC_FWD, SF.PREC_BWD, SF.GEMM_W_FRAG, SF.WEIGHT_PRESPLIT)
+        if key == self._pack_key:
+            if use:
+                self._pack_set.run()
+            return
+        self._pack_key = key
+        blocks = [b for grp in (self.input_blocks, self.encoder_blocks, self.bottleneck_blocks, self.decoder_blocks,
+                                self.output_blocks) for b in grp]
         specs = None
         if use:
             whole = set(id(b) for b in list(self.input_blocks) + list(self.output_blocks))       # norm over the whole batch: B = 1
             specs = [b.pack_spec(1 if id(b) in whole else num_graphs) for b in blocks]
             use = all(sp is not None for sp in specs)
         if not use:
+            self._pack_key = (False,) + key[1:]
+            self._pack_set = None
             for b in blocks:
                 b._prepacked = None
             return
