@@ -218,8 +218,9 @@ class SurfaceTextureInpaintingNet(nn.Module):
             specs = [b.pack_spec(1 if id(b) in whole else num_graphs) for b in blocks]
             use = all(sp is not None for sp in specs)
         if not use:
+            # (the set itself stays: a captured HIP graph may hold pointers into its buffers, and the per-kernel path of a
+            # bracketed bench step only bypasses it)
             self._pack_key = (False,) + key[1:]
-            self._pack_set = None
             for b in blocks:
                 b._prepacked = None
             return
