@@ -3,6 +3,7 @@
 // Contract: include/stin_hip.h.  All of these are HBM-streaming kernels: 16-byte loads,
 // one pass over [N, C] per call.
 #include "stin_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -401,7 +402,9 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
     const int CV = C / VW;
     const int CG = CV < BLOCK ? CV : BLOCK;
     const int RL = BLOCK / CG;
-    int64_t want = (N / B + (int64_t)RL * 16 - 1) / ((int64_t)RL * 16);
+    // row iterations per block: 8 (2 blocks per CU at the 18 k-row level) measured 0.3 % faster on the step than 16; 32 is 2 % slower
+    static const int rows_mul = (getenv("STIN_RED_ROWS") && atoi(getenv("STIN_RED_ROWS")) > 0) ? atoi(getenv("STIN_RED_ROWS")) : 8;
+    int64_t want = (N / B + (int64_t)RL * rows_mul - 1) / ((int64_t)RL * rows_mul);
     int cap = MAX_SLABS / B;
     if (cap < 1) cap = 1;
     int nch = (int)(want < 1 ? 1 : (want > cap ? cap : want));
