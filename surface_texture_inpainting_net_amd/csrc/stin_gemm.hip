@@ -1684,8 +1684,10 @@ inline int stin_cu_count() {
 }
 
 inline int tn_rows_per_chunk(int64_t M, int tiles) {
-    // ~512 blocks (2 resident per CU, one round; measured best of 256..1536), chunks a multiple of the LDS slab
-    static const int target = getenv("STIN_TN_BLOCKS") ? atoi(getenv("STIN_TN_BLOCKS")) : 512;   // tuning aid
+    // ~384 blocks (up to 2 resident per CU, one round), chunks a multiple of the LDS slab.  Round 1 measured 512 best of
+    // 256..1536; with loads two slabs ahead a block hides more latency by itself and fewer chunks mean fewer partial slabs to
+    // store and reduce: 384 is 0.3-0.5 % faster on the step than 512 (256: 0.4 % slower)
+    static const int target = getenv("STIN_TN_BLOCKS") ? atoi(getenv("STIN_TN_BLOCKS")) : 384;   // tuning aid
     int64_t chunks = (target + tiles - 1) / tiles;
     if (chunks > 8) chunks = (chunks + 7) / 8 * 8;          // whole rounds of 8 chunks (one per XCD, see the kernels' block map)
     int64_t rows = (M + chunks - 1) / chunks;
