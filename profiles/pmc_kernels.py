@@ -23,20 +23,24 @@ e = plan.edges('edge_index', 0)
 n, H = s.x.shape[0], 128
 A, B, G = (torch.randn(n, H, device=dev) for _ in range(3))
 out = torch.empty(n, H, device=dev)
+out2 = torch.empty(n, H, device=dev)
 mask = torch.empty(e.n_edges * (H // 32), dtype=torch.int32, device=dev)
 for _ in range(5):
     SF.edge_relu_mean_fwd(A, B, e.by_dst, out, mask=mask)          # as the training step runs it (writes the mask)
     SF.edge_relu_mean_bwd_dst_mask(G, mask, e.by_dst, out)
     SF.edge_relu_mean_bwd_src_mask(G, mask, e, out)
+    SF.edge_relu_mean_bwd_mask(G, mask, e, out, out2)               # round 2: both halves in one launch (what the step runs)
     SF.edge_relu_mean_bwd_dst(A, B, G, e.by_dst, out)               # recompute forms (STIN_EDGE_MASK=0)
     SF.edge_relu_mean_bwd_src(A, B, G, e.inv_deg, e.by_src, out)
 # bf16-storage twins of the training-step kernels
 A16, B16, G16 = A.bfloat16(), B.bfloat16(), G.bfloat16()
 out16 = torch.empty(n, H, dtype=torch.bfloat16, device=dev)
+out16b = torch.empty(n, H, dtype=torch.bfloat16, device=dev)
 for _ in range(5):
     SF.edge_relu_mean_fwd(A16, B16, e.by_dst, out16, mask=mask)
     SF.edge_relu_mean_bwd_dst_mask(G16, mask, e.by_dst, out16)
     SF.edge_relu_mean_bwd_src_mask(G16, mask, e, out16)
+    SF.edge_relu_mean_bwd_mask(G16, mask, e, out16, out16b)
 # standalone scatter-add: src[E, 64] -> out[N, 64], index in arbitrary edge order
 g = torch.Generator().manual_seed(0)
 idx = torch.randint(0, 200_000, (1_200_000,), generator=g).to(dev)
