@@ -338,7 +338,7 @@ def main():
     gemm_names = ['stin_gemm_nt' + sfx, 'stin_gemm_tn' + sfx]
     timed = edge_names + (gemm_names if args.time_gemms else [])
     # HIP-event brackets need the per-kernel host path (the whole-block C calls enqueue their kernels natively) and event
-    # pairs are not free: bracket the edge launches of about one timed step in ten, the rest runs un-instrumented.
+    # pairs are not free: bracket the edge launches of the FIRST timed step, the rest runs un-instrumented.
     def eager_step():
         """one_step() through the per-launch host path even with --graph (HIP-event brackets cannot sit inside a replay)."""
         g, step.graph = step.graph, False
@@ -354,7 +354,8 @@ def main():
     fence()
     step.bucket.allreduce_log = []
     if not args.graph:
-        SF.KernelTimer.start(timed, max_records=1_000_000 if args.time_gemms else per_step * max(1, args.steps // 10))
+        # (ONE bracketed step per run: a bracketed step takes the per-kernel host path and costs ~1.5 ms more than a plain one)
+        SF.KernelTimer.start(timed, max_records=1_000_000 if args.time_gemms else per_step)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
