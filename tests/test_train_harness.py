@@ -395,3 +395,23 @@ def test_captured_step_reports_out_of_range_indices():
     step(bad)                                           # replay on the bad indices: the kernels leave the pair out
     with pytest.raises(IndexError):
         step.finish()
+
+
+def test_graph_mode_guards_and_sample_signature():
+    """Host logic of TrainStep(graph=True) that needs no GPU: it refuses CPU models and gradient accumulation, and the capture
+    key separates samples by tensor shapes / dtypes and by the per-graph level sizes, not by tensor contents."""
+    from surface_texture_inpainting_net_amd.train_step import _sample_signature
+    net = stin_oracle.define_G(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconv', norm='instance', n_blocks=1, n_levels=1,
+                               pooling_type='max')
+    with pytest.raises(ValueError):
+        TrainStep(net, graph=True)
+    a = make_synthetic_mesh(300, 2, seed=1)
+    b = make_synthetic_mesh(300, 2, seed=1)
+    b['x'] = b.x * 2.0                                           # other contents, same signature
+    c = make_synthetic_mesh(340, 2, seed=1)
+    assert _sample_signature(a) == _sample_signature(b)
+    assert _sample_signature(a) != _sample_signature(c)
+    d = make_synthetic_mesh(300, 2, seed=1)
+    d['num_vertices'] = d.num_vertices + 0                       # same values
+    d._nv_host = None
+    assert _sample_signature(a)[1] == _sample_signature(d)[1]
