@@ -27,7 +27,9 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-import surface_texture_inpainting_net_amd  # noqa: E402,F401  (sets its HIP runtime flag before the first GPU call)
+import surface_texture_inpainting_net_amd  # noqa: E402
+if '--graph' in sys.argv:                       # opt-in ROCm 7.2 graph-replay workaround: must precede the first GPU call
+    surface_texture_inpainting_net_amd.enable_graph_replay()
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md, chip-level parameters)
 MFMA_16BIT_PEAK_TF = 2500.0    # dense bf16 / f16 MFMA peak (same guide); the fp32-storage GEMMs issue 3 such MFMAs per product

@@ -133,7 +133,9 @@ def load_scannet_color_dataset_module():
     import torch_geometric.data as tgd
     if not hasattr(tgd, 'DataListLoader'):
         tgd.DataListLoader = object
-    if 'transform' not in sys.modules:
+    # (load_imagegraph_dataset_class leaves an EMPTY stub `transform` behind - the image dataset never calls it; this
+    # dataset applies transform.CoordsNormalization, so a stub without it is replaced by the reference's own package)
+    if not hasattr(sys.modules.get('transform'), 'CoordsNormalization'):
         m = types.ModuleType('transform')
         m.__path__ = [os.path.join(REFERENCE_ROOT, 'transform')]
         sys.modules['transform'] = m

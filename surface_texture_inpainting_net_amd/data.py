@@ -16,6 +16,13 @@ _LEVEL_KEY = re.compile(r'^hierarchy_(?:dil_\d+_)?(?:edge|trace)_index_(\d+)$')
 _DIL_KEY = re.compile(r'^hierarchy_dil_(\d+)_edge_index_(\d+)$')
 
 
+def sample_keys(sample):
+    """The key list of a sample object: `keys` is a METHOD on this build's HierarchicalBatch (and on PyG >= 2.4) and a
+    PROPERTY on the PyG 2.0.x Data / Batch objects the reference feeds its model (utils/data_utils.py:11-42)."""
+    k = sample.keys
+    return list(k() if callable(k) else k)
+
+
 class HierarchicalBatch:
     """Attribute + item bag of tensors; ``.to(device)`` moves every tensor."""
 
@@ -98,7 +105,7 @@ def collate(samples, fix_dilated_offsets=True):
     with the PyG collate semantics the reference relies on: tensors whose key
     contains 'index' are concatenated along the LAST dim, others along dim 0;
     ``num_vertices`` is stacked to [B, L]; ``batch`` [N0] int64 is added."""
-    keys = samples[0].keys()
+    keys = sample_keys(samples[0])
     out = HierarchicalBatch()
     offsets = {k: 0 for k in keys}
     parts = {k: [] for k in keys}

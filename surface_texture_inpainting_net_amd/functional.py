@@ -794,7 +794,11 @@ class EdgeConvBlockFn(torch.autograd.Function):
                 _wgrad_deferred_join(dev, ctx.params, () if direct is not None else (dW1, db1, dW2, db2, dWs, dbs))
             if direct is not None:
                 # a bucket that reduces in segments hands every completed one to RCCL now (train_step.FlatGradBucket)
-                ctx.params[0]._stin_slot[0].block_done(_wgrad_side(dev).last_done if side[0] else None)
+                # behind the side stream's NEWEST event whenever any block of THIS backward pass has put weight-gradient work
+                # there (`hold` is emptied by the end-of-backward join) - not only when this block did: a segment spans
+                # several blocks, and an earlier one may have used the side stream while the block completing it did not
+                sd = _WGRAD_SIDE.get(dev.index if dev.index is not None else torch.cuda.current_device())
+                ctx.params[0]._stin_slot[0].block_done(sd.last_done if (sd is not None and sd.hold) else None)
                 if dx is not None and Cp != Cin:
                     dx = dx[:, :Cin]
                 return (dx,) + (None,) * 12

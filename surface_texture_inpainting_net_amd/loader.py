@@ -24,7 +24,7 @@ import threading
 import torch
 
 from . import plan as _plan
-from .data import HierarchicalBatch, collate
+from .data import HierarchicalBatch, collate, sample_keys
 from .scene_io import load_scene
 
 _FEATURE_KEYS = ('x', 'color', 'mask', 'batch', 'name')
@@ -182,7 +182,7 @@ class SceneLoader:
                 return hit[0]
         scene = load_scene(it[0], it[1], end_level=self.end_level, cropped=self.cropped)
         if self._host_cache_cap:
-            nb = _tensor_bytes({k: scene[k] for k in scene.keys()})
+            nb = _tensor_bytes({k: scene[k] for k in sample_keys(scene)})
             if nb <= self._host_cache_cap:
                 with self._host_lock:
                     while self._host_cache_used + nb > self._host_cache_cap and self._host_cache:
@@ -209,7 +209,7 @@ class SceneLoader:
             return ids, batch
         key = ids[0] if self.cache is not None else None
         cached = key is not None and key in self.cache._d       # peek (no LRU update from a worker thread)
-        keys = [k for k in batch.keys() if (k in _FEATURE_KEYS or not cached)]
+        keys = [k for k in sample_keys(batch) if (k in _FEATURE_KEYS or not cached)]
         slot = self._ring[turn % len(self._ring)]
         if slot.done is not None:
             slot.done.synchronize()                             # the uploads issued from this slot have left it
@@ -231,7 +231,7 @@ class SceneLoader:
         entry = self.cache.get(key) if key is not None else None
         with torch.cuda.stream(self._copy_stream):
             dev = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v)
-                   for k, v in ((k, cpu_batch[k]) for k in cpu_batch.keys())}
+                   for k, v in ((k, cpu_batch[k]) for k in sample_keys(cpu_batch))}
         for v in dev.values():
             if torch.is_tensor(v):
                 v.record_stream(main)
@@ -271,7 +271,7 @@ class SceneLoader:
 
     def _reload(self, ids):
         s = self._load(ids[0])
-        yield HierarchicalBatch(**{k: (s[k].pin_memory() if torch.is_tensor(s[k]) else s[k]) for k in s.keys()})
+        yield HierarchicalBatch(**{k: (s[k].pin_memory() if torch.is_tensor(s[k]) else s[k]) for k in sample_keys(s)})
 
     def _commit_pending(self):
         """Insert the previous step's graph into the cache once its plan is complete (all lazily built pieces exist)."""

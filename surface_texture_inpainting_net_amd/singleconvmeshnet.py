@@ -270,8 +270,10 @@ def batch_norm_rows(x, bn, relu=False, recomputed=False):
         _update_running(bn, mean, rstd, n)
         if fused:
             return y
-    elif bn.affine and x.dtype == torch.float32 and x.shape[0] > 0 and not (torch.is_grad_enabled() and x.requires_grad):
-        # inference: one HIP pass with the running statistics (rstd from running_var: a [C] vector op)
+    elif (bn.affine and x.dtype == torch.float32 and x.shape[0] > 0 and not (
+            torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad))):
+        # inference: one HIP pass with the running statistics (rstd from running_var: a [C] vector op).  Not taken when
+        # ANYTHING here can receive a gradient - frozen-statistics BN with a trainable affine keeps torch's expression
         x, ldx = SF._mat(x)
         n, c = x.shape
         y = torch.empty(n, c, dtype=x.dtype, device=x.device)

@@ -198,13 +198,26 @@ class SurfaceTextureInpaintingNet(nn.Module):
         every block: 15 launches of ~8 us on the critical path become one.  fp32 storage on the whole-block path only."""
         use = (SF.USE_PACK_MANY and SF.USE_BLOCK_CALL and SF.USE_EDGE_MASK and not SF.KernelTimer.enabled and x.is_cuda and
                x.dtype == torch.float32 and self.norm is M.FastInstanceNorm)
-        # cheap per-step validity check of the cached set (the full parameter-pointer comparison costs ~0.3 ms of host time per
-        # step): the parameters of a module move together (.to(), FlatAdam re-pointing), so the first and the last one stand for all
-        first, last = self._pack_probe if self._pack_probe is not None else (None, None)
-        if first is None:
-            ps_ = list(self.parameters())
-            first, last = self._pack_probe = (ps_[0], ps_[-1])
-        key = (use, first.data_ptr(), last.data_ptr(), int(num_graphs), SF.PREC_FWD, SF.PREC_BWD, SF.GEMM_W_FRAG, SF.WEIGHT_PRESPLIT)
+        # per-step validity check of the cached set: the data pointers of EVERY packed tensor, read from the modules'
+        # parameter tables each step (never from cached Parameter objects) - load_state_dict(assign=True), module surgery
+        # (`lin.weight = nn.Parameter(...)`, a replaced filter / shortcut module) and `p.data = ...` on any one of them all
+        # change the key.  ~90 dict lookups + data_ptr() calls: ~25 us of host time per step.
+        probe = self._pack_probe
+        if probe is None:
+            probe = self._pack_probe = [b for grp in (self.input_blocks, self.encoder_blocks, self.bottleneck_blocks,
+                                                      self.decoder_blocks, self.output_blocks) for b in grp]
+        ptrs = []
+        for b in probe:
+            mods = b._modules
+            flt = mods['first_filter']
+            seq = flt._modules.get('nn')
+            lins = (seq._modules.get('0'), seq._modules.get('2'), mods.get('shortcut')) if seq is not None else (mods.get('shortcut'),)
+            for lin in lins:
+                if lin is not None:
+                    for t in lin._parameters.values():
+                        if t is not None:
+                            ptrs.append(t.data_ptr())
+        key = (use, tuple(ptrs), int(num_graphs), SF.PREC_FWD, SF.PREC_BWD, SF.GEMM_W_FRAG, SF.WEIGHT_PRESPLIT)
         if key == self._pack_key:
             if use:
                 self._pack_set.run()

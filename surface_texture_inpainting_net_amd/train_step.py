@@ -336,15 +336,22 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count = steps.pop() if steps else 0
 
 
+from .data import sample_keys as _keys  # noqa: E402
+
+
 def _sample_signature(sample):
     """What a captured step depends on besides tensor CONTENTS: every tensor's name / shape / dtype and the per-graph level
     sizes (the host-side num_vertices table: instance-norm row ranges are built from it on the host)."""
     sig = []
-    for k in sorted(sample.keys()):
+    keys = _keys(sample)
+    for k in sorted(keys):
         v = sample[k]
-        sig.append((k, tuple(v.shape), str(v.dtype)) if torch.is_tensor(v) else (k, repr(v)))
+        if torch.is_tensor(v):
+            sig.append((k, tuple(v.shape), str(v.dtype)))
+        elif isinstance(v, (bool, int, float)):          # structural scalars; labels such as `name` do not shape the step
+            sig.append((k, v))
     nv = getattr(sample, '_nv_host', None)
-    if nv is None and 'num_vertices' in sample.keys():
+    if nv is None and 'num_vertices' in keys:
         nv = sample['num_vertices'].detach().cpu()            # foreign sample types: one host sync per step
     return tuple(sig), (None if nv is None else tuple(int(x) for x in nv.reshape(-1)))
 
@@ -357,10 +364,11 @@ class _CapturedStep:
         from .data import HierarchicalBatch
         from .plan import GraphPlan, check_deferred
         dev = owner.bucket.flat.device
-        self.keys = [k for k in sample.keys() if torch.is_tensor(sample[k])]
-        static = HierarchicalBatch(**{k: (sample[k].clone() if torch.is_tensor(sample[k]) else sample[k]) for k in sample.keys()})
+        keys = _keys(sample)
+        self.keys = [k for k in keys if torch.is_tensor(sample[k])]
+        static = HierarchicalBatch(**{k: (sample[k].clone() if torch.is_tensor(sample[k]) else sample[k]) for k in keys})
         static._nv_host = getattr(sample, '_nv_host', None)
-        if static._nv_host is None and 'num_vertices' in sample.keys():
+        if static._nv_host is None and 'num_vertices' in keys:
             static._nv_host = sample['num_vertices'].detach().cpu()
         self.static = static
         self.dst = [static[k] for k in self.keys]
@@ -452,13 +460,14 @@ class TrainStep:
         if self.graph and not (self.on_gpu and self.accumulate == 1):
             raise ValueError('graph=True needs a GPU model and accumulate == 1')
         if self.graph:
-            from . import GRAPH_REPLAY_SAFE
+            from . import graph_replay_safe
+            GRAPH_REPLAY_SAFE = graph_replay_safe()
             import os
             if not GRAPH_REPLAY_SAFE or os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') != '0':
-                raise RuntimeError('graph=True: the HIP runtime was initialised before this package could set '
-                                   'DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (ROCm 7.2 graph replays fault without it, see '
-                                   'surface_texture_inpainting_net_amd/__init__.py): import the package - or export the '
-                                   'variable - before the first GPU call')
+                raise RuntimeError('graph=True: ROCm 7.2 graph replays fault unless DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is in the '
+                                   'environment when the HIP runtime initialises (surface_texture_inpainting_net_amd/'
+                                   '__init__.py): call surface_texture_inpainting_net_amd.enable_graph_replay() - or export '
+                                   'STIN_GRAPH_REPLAY=1 / the variable itself - before the first GPU call')
         import collections
         self._captured = collections.OrderedDict()      # signature -> 'warm' | _CapturedStep
         self._graph_cache = max(1, int(graph_cache))
@@ -509,10 +518,13 @@ class TrainStep:
         sig = _sample_signature(sample)
         ent = self._captured.get(sig)
         if ent is None:                                  # first visit: eager (also validates the indices the usual way)
-            self._captured[sig] = 'warm'
+            loss = self.forward_backward(sample, grad_scale)
+            self._captured[sig] = 'warm'                 # only a COMPLETED eager step is a warm-up (lazy inits, constant uploads)
             while len(self._captured) > self._graph_cache:
-                self._captured.popitem(last=False)
-            return self.forward_backward(sample, grad_scale)
+                _, old = self._captured.popitem(last=False)
+                if old != 'warm':
+                    old.finish()                         # its replays' out-of-range flag is reported before the entry goes
+            return loss
         self._captured.move_to_end(sig)
         if ent == 'warm':
             ent = self._captured[sig] = _CapturedStep(self, sample, grad_scale, self._graph_pool)

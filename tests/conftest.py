@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # TrainStep(graph=True) tests: the ROCm 7.2 graph-replay workaround must be in the environment BEFORE the first HIP call
+    # of the process (torch.cuda.is_available() below is one) - an opt-in of the package, see its __init__
+    import surface_texture_inpainting_net_amd as pkg
+    pkg.enable_graph_replay()
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'reference: needs /root/reference (build container only); skipped elsewhere')
 

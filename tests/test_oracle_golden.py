@@ -222,3 +222,36 @@ def test_seeded_init_equals_reference_for_product_and_oracle():
         sd = other.state_dict()
         assert list(sd.keys()) == list(ref_sd.keys())
         assert all(torch.equal(sd[k], ref_sd[k]) for k in sd)
+
+
+@pytest.mark.reference
+def test_pinning_recipe_runs_end_to_end_and_reproduces_every_fixture(tmp_path):
+    """`python oracle/make_golden.py` as documented: main() in ONE process (the g1 loader's stub modules must not break
+    the g11 loader), every array of every fixture compared with the committed tests/golden/ (integers and bytes
+    identical, floats to 1e-6: BLAS summation order of the host)."""
+    import json
+    import os
+    from oracle import make_golden
+    from _golden import GOLDEN as GOLDEN_DIR
+    old = make_golden.OUT
+    make_golden.OUT = str(tmp_path)
+    try:
+        make_golden.main()
+    finally:
+        make_golden.OUT = old
+    committed = sorted(f for f in os.listdir(GOLDEN_DIR) if f.endswith(('.npz', '.json')))
+    assert sorted(os.listdir(tmp_path)) == committed
+    for f in committed:
+        if f.endswith('.json'):
+            assert json.load(open(os.path.join(tmp_path, f))) == json.load(open(os.path.join(GOLDEN_DIR, f))), f
+            continue
+        new, ref = np.load(os.path.join(tmp_path, f), allow_pickle=True), np.load(os.path.join(GOLDEN_DIR, f), allow_pickle=True)
+        assert sorted(new.files) == sorted(ref.files), f
+        for k in ref.files:
+            a, b = new[k], ref[k]
+            assert a.shape == b.shape and a.dtype == b.dtype, (f, k)
+            if np.issubdtype(a.dtype, np.floating):
+                scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+                assert float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) <= 1e-6 * scale if b.size else True, (f, k)
+            else:
+                assert np.array_equal(a, b), (f, k)

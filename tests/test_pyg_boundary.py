@@ -1,0 +1,142 @@
+"""The drop-in boundary fed with a PyG-SEMANTICS sample object instead of this build's HierarchicalBatch.
+
+The reference hands its model a PyG 2.0.x `Batch` of `HierarchicalData` (utils/data_utils.py:11-42), read by attribute
+AND by item (models/surfacetextureinpaintingnet.py:404-455).  PyG itself is absent from the image; oracle/pyg_shim
+restates the object semantics that matter at the boundary:
+  * `sample.keys` is a PROPERTY (not a method);
+  * `sample.<name> = value` lands in the data store, except `_`-prefixed names, which stay private attributes
+    (so `sample._plan_cache = plan` never shows up as a data key);
+  * `.to(device)` moves the tensors IN PLACE and returns the same object;
+  * `Batch.from_data_list` collates with each item's `__inc__` / `__cat_dim__`.
+The same fixture batch goes through both containers: outputs must be bit-identical, the plan is built and cached once.
+"""
+import os
+import re
+import sys
+
+import pytest
+import torch
+
+from _golden import ModelFixture
+from oracle import stin_oracle
+
+_SHIM = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', 'pyg_shim')
+if _SHIM not in sys.path:
+    sys.path.insert(0, _SHIM)
+from torch_geometric.data import Batch, Data  # noqa: E402  (oracle/pyg_shim: test infrastructure)
+
+from surface_texture_inpainting_net_amd import surfacetextureinpaintingnet as S  # noqa: E402
+from surface_texture_inpainting_net_amd.data import collate, sample_keys  # noqa: E402
+from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh  # noqa: E402
+
+DEV = 'cuda:0'
+_LEVELLED = re.compile(r'^hierarchy_(?:edge|trace)_index_(\d+)$')
+
+
+class _HierData(Data):
+    """The collate rules of the reference's HierarchicalData (utils/data_utils.py:24-42) on the shim's Data: `num_vertices`
+    is stacked, `edge_index` advances by N0, hierarchy_{edge,trace}_index_l by num_vertices[l], features by nothing, and
+    every other '*index*' key (the dilated sets) by PyG's default num_nodes = N0."""
+
+    def __cat_dim__(self, key, value, *a, **k):
+        return None if key == 'num_vertices' else super().__cat_dim__(key, value, *a, **k)
+
+    def __inc__(self, key, value, *a, **k):
+        if key == 'edge_index':
+            return self.num_vertices[0]
+        if key in ('x', 'color', 'pos', 'mask', 'labels'):
+            return 0
+        m = _LEVELLED.match(key)
+        if m is not None and 1 <= int(m.group(1)) < len(self.num_vertices):
+            return self.num_vertices[int(m.group(1))]
+        return super().__inc__(key, value, *a, **k)
+
+
+def _as_pyg(sample):
+    b = Batch()
+    for k in sample_keys(sample):
+        setattr(b, k, sample[k].clone() if torch.is_tensor(sample[k]) else sample[k])
+    return b
+
+
+def test_shim_objects_have_pyg20_semantics():
+    d = Data(x=torch.zeros(3, 2), edge_index=torch.zeros(2, 0, dtype=torch.long))
+    assert not callable(d.keys) and sorted(d.keys) == ['edge_index', 'x']
+    d.extra = torch.ones(1)
+    d._private = 7
+    assert 'extra' in d.keys and '_private' not in d.keys and d._private == 7 and d['extra'] is d.extra
+    assert d.to('cpu') is d
+
+
+def test_reference_collate_rules_equal_build_collate_without_dilated_sets():
+    """`Batch.from_data_list` over _HierData (the reference's own __inc__ rules) against data.collate: identical tensors
+    for every key the two agree on by design (dilated sets excluded: the reference's N0 offset is the Q4 bug, covered by
+    collate(fix_dilated_offsets=False) in test_abi_and_host)."""
+    graphs = [make_synthetic_mesh(n, 3, seed=70 + i, dilations=()) for i, n in enumerate((210, 330, 150))]
+    items = []
+    for g in graphs:
+        h = _HierData()
+        for k in sample_keys(g):
+            setattr(h, k, g[k].reshape(-1) if k == 'num_vertices' else g[k])     # the dataset stores the level sizes 1-D
+        items.append(h)
+    pyg = Batch.from_data_list(items)
+    ours = collate(graphs)
+    assert sorted(pyg.keys) == sorted(sample_keys(ours))
+    for k in sample_keys(ours):
+        assert torch.equal(pyg[k], ours[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['g3_batch2_unequal', 'g2_3level_transinv_max'])
+def test_model_reads_a_pyg_semantics_batch_bit_identically(name):
+    from surface_texture_inpainting_net_amd.plan import GraphPlan
+    fx = ModelFixture(name)
+    net = S.define_G(**fx.cfg)
+    net.load_state_dict(fx.state_dict)
+    net = net.to(DEV)
+    ours = fx.sample(DEV)
+    pyg = _as_pyg(fx.sample())
+    assert pyg.to(DEV) is pyg and pyg.x.is_cuda                    # PyG moves in place
+    keys_before = sorted(pyg.keys)
+    want = net(ours)
+    got = net(pyg)
+    assert torch.equal(got, want)
+    assert float((got.detach().cpu() - fx.out).abs().max()) <= 1e-4
+    # the plan was cached on the foreign object, outside its data store, and is reused by the next call
+    plan = pyg._plan_cache
+    assert isinstance(plan, GraphPlan) and sorted(pyg.keys) == keys_before
+    assert torch.equal(net(pyg), want) and pyg._plan_cache is plan
+    # gradients through the foreign container
+    grads = []
+    for s in (ours, pyg):
+        net.zero_grad(set_to_none=True)
+        out = net(s)
+        stin_oracle.compute_loss(torch.where((s.mask > 0).expand_as(s.color), out, s.color), s.color, s.mask).backward()
+        grads.append([p.grad.clone() for p in net.parameters()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('graph', [False, True])
+def test_train_step_on_a_pyg_semantics_batch(graph):
+    """TrainStep eager and graph=True on the shim Batch: same losses and weights as on HierarchicalBatch, bit for bit."""
+    import surface_texture_inpainting_net_amd as pkg
+    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    if graph and not pkg.graph_replay_safe():
+        pytest.skip('HIP runtime initialised without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0')
+    fx = ModelFixture('g3_batch2_unequal')
+    results = []
+    for foreign in (False, True):
+        torch.manual_seed(5)
+        net = S.define_G(**fx.cfg)
+        net.load_state_dict(fx.state_dict)
+        net = net.to(DEV)
+        step = TrainStep(net, lr=1e-3, graph=graph)
+        s = _as_pyg(fx.sample()).to(DEV) if foreign else fx.sample(DEV)
+        losses = [float(step(s)) for _ in range(4)]
+        step.finish()
+        results.append((losses, [p.detach().clone() for p in net.parameters()]))
+    assert results[0][0] == results[1][0]
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b)

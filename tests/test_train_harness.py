@@ -148,10 +148,15 @@ def test_bench_self_launches_two_ranks_from_a_plain_python_invocation():
     assert out['value'] > 0 and abs(out['ms_per_step'] - max(out['distributed']['ms_per_step_per_rank'])) < 1e-6
 
 
-def _overlap_worker(rank, world, port, out_dir, min_bytes):
+def _overlap_worker(rank, world, port, out_dir, min_bytes, mix=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     torch.cuda.set_device(0)
+    if mix:
+        # force the MIX the advisor flagged: every block takes the weight-gradient side stream except the ones above
+        # max-work (here the level-0 decoder block), so a segment can be completed by a block that did not use the stream
+        from surface_texture_inpainting_net_amd import functional as SF
+        SF.WGRAD_MIN_WORK, SF.WGRAD_MAX_WORK = 0.0, 6e7
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from surface_texture_inpainting_net_amd import surfacetextureinpaintingnet as S
     cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
@@ -167,7 +172,7 @@ def _overlap_worker(rank, world, port, out_dir, min_bytes):
         segs.append(len(step.bucket.segments or []))
     step.finish()
     torch.save({'grads': grads, 'segs': segs, 'p': torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()},
-               os.path.join(out_dir, 'r%d_%d.pt' % (rank, min_bytes)))
+               os.path.join(out_dir, 'r%d_%d%s.pt' % (rank, min_bytes, '_mix' if mix else '')))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -188,6 +193,15 @@ def test_segmented_allreduce_during_backward_equals_the_single_tail_allreduce(tm
             assert torch.equal(a, b)                      # two ranks: a + b is order-independent -> bit-identical
         assert torch.equal(res[0][r]['p'], res[256 << 10][r]['p'])
     assert torch.equal(res[0][0]['p'], res[0][1]['p']) and torch.equal(res[0][0]['grads'][2], res[0][1]['grads'][2])
+    # blocks on and off the weight-gradient side stream inside one segment (STIN_WGRAD_MIN_WORK = 0, one block above
+    # STIN_WGRAD_MAX_WORK): the segment's all-reduce must still wait for the side stream's newest event
+    mp.spawn(_overlap_worker, args=(2, _free_port(), str(tmp_path), 256 << 10, True), nprocs=2, join=True)
+    for r in range(2):
+        mixed = torch.load(tmp_path / ('r%d_%d_mix.pt' % (r, 256 << 10)))
+        assert mixed['segs'][1] >= 2
+        for a, b in zip(res[0][r]['grads'], mixed['grads']):
+            assert torch.equal(a, b)
+        assert torch.equal(res[0][r]['p'], mixed['p'])
 
 
 @pytest.mark.gpu
