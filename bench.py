@@ -118,9 +118,13 @@ def scatter_add_standalone(device, n=200_000, e=1_200_000, c=64, iters=30):
 
 
 def cpu_baseline(n0_target, levels, seed):
-    """The CPU oracle (op-for-op unfused PyG form) timed on this box's host cores, on a bounded sample
-    (~10-30 s of CPU work).  Thread count: the fastest of a short probe over {8, 16, 32, 64} (torch's CPU
-    index/scatter ops slow down badly when oversubscribed across a 256-thread host); reported as `cores`."""
+    """The CPU oracle (op-for-op unfused PyG form) timed on this box's host cores on a BOUNDED sample, SURVEY 8(d) protocol:
+    one warm-up pass AT SIZE, then the median of 3 timed passes.  `value` uses the thread count a short probe over
+    {8, 16, 32, 64} found fastest (torch's CPU index / scatter ops slow down badly when oversubscribed across a
+    256-thread host) - reported as `cores`; `all_cores` is the same protocol with torch.set_num_threads(os.cpu_count())
+    (warm-up + median of up to 3, cut short when a pass exceeds its budget).  The sample is sized so that one pass takes
+    ~5 s at the probe-best thread count: the whole leg stays within about a minute."""
+    import statistics
     from oracle import stin_oracle
     from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
     torch.manual_seed(49)
@@ -135,29 +139,52 @@ def cpu_baseline(n0_target, levels, seed):
 
     probe = make_synthetic_mesh(10_000, levels, seed=seed)
     ncpu = os.cpu_count() or 1
-    best_t, best_threads = None, None
+    best_t, best_threads, probe_log = None, None, {}
     for th in [t for t in (8, 16, 32, 64) if t <= ncpu] or [ncpu]:
         torch.set_num_threads(th)
         run(probe)                               # warm-up (allocator, thread pool)
         t = run(probe)
+        probe_log[th] = probe.x.shape[0] / t
         if best_t is None or t < best_t:
             best_t, best_threads = t, th
         if t > 8.0:                              # keep the probe itself bounded
             break
-    torch.set_num_threads(best_threads)
     per_vertex = best_t / probe.x.shape[0]
-    n0 = n0_target if per_vertex * n0_target <= 30.0 else max(10_000, int(20.0 / per_vertex))
-    if n0 <= probe.x.shape[0]:
-        sample, t = probe, run(probe)
-    else:
-        sample = make_synthetic_mesh(n0, levels, seed=seed)
-        t = run(sample)
+    # sample size: one pass ~4 s.  The per-vertex cost grows with the mesh (caches: 34 k vertices/s at 10 k vertices, 10 k at
+    # 200 k on the EPYC 9575F boxes), hence the factor 3 on the probe's rate.
+    n0 = int(min(n0_target, max(10_000, 4.0 / (3.0 * per_vertex))))
+    sample = probe if n0 <= probe.x.shape[0] else make_synthetic_mesh(n0, levels, seed=seed)
     nv = sample.x.shape[0]
-    return {'value': nv / t, 'unit': 'vertices/s', 'cores': best_threads, 'kind': 'port',
-            'cpu_model': _cpu_model(),
-            'sample': 'one fwd+loss+bwd of the CPU oracle (unfused PyG-form restatement, torch %s CPU, fp32, %d of %d '
-                      'host threads of %s) on a synthetic %d-vertex %d-level mesh, %.1f s'
-                      % (torch.__version__, best_threads, ncpu, _cpu_model(), nv, levels, t)}
+
+    def protocol(smp, threads, budget_s):
+        """-> (warm-up seconds, [timed passes]): up to 3 passes, none started once the budget would be exceeded."""
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        warm = run(smp)
+        ts = []
+        while len(ts) < 3 and time.perf_counter() - t0 + max([warm] + ts) <= budget_s:
+            ts.append(run(smp))
+        return warm, ts
+
+    warm, ts = protocol(sample, best_threads, 30.0)
+    med = statistics.median(ts) if ts else warm
+    out = {'value': nv / med, 'unit': 'vertices/s', 'cores': best_threads, 'kind': 'port', 'cpu_model': _cpu_model(),
+           'host_threads': ncpu, 'sample_vertices': nv, 'passes_s': [round(t, 3) for t in ts], 'warmup_s': round(warm, 3),
+           'thread_probe_vertices_per_s': {str(k): round(v, 1) for k, v in probe_log.items()}}
+    if ncpu != best_threads:
+        # SURVEY 8(d) names torch.set_num_threads(os.cpu_count()): on the 256-thread hosts that is ~10x SLOWER than the
+        # probe-best count (oversubscribed scatter / index kernels), so this leg runs on the small probe mesh only
+        warm_a, ts_a = protocol(probe, ncpu, 15.0)
+        med_a = statistics.median(ts_a) if ts_a else warm_a
+        out['all_cores'] = {'cores': ncpu, 'value': probe.x.shape[0] / med_a, 'unit': 'vertices/s', 'sample_vertices': probe.x.shape[0],
+                            'passes_s': [round(t, 3) for t in ts_a], 'warmup_s': round(warm_a, 3),
+                            'same_mesh_at_probe_best_threads_vertices_per_s': round(probe_log[best_threads], 1)}
+    torch.set_num_threads(best_threads)
+    out['sample'] = ('fwd+loss+bwd of the CPU oracle (unfused PyG-form restatement, torch %s CPU, fp32) on a synthetic %d-vertex '
+                     '%d-level mesh: 1 warm-up at size + median of %d passes (%.2f s) with %d of %d host threads of %s (probe-best); '
+                     'all_cores = the same protocol with all %d threads on the 10 k-vertex probe mesh'
+                     % (torch.__version__, nv, levels, len(ts), med, best_threads, ncpu, _cpu_model(), ncpu))
+    return out
 
 
 def _cpu_model():
@@ -312,13 +339,15 @@ def main():
 
     pending_plan = [None]
 
-    def one_step():
+    def one_step(prefetch=True):
         if not args.cache_plan:
             # a fresh CSR plan per step (part of the step).  As a loader with one batch of look-ahead does
             # (TrainStep.prefetch), the plan of step k+1 is built on the plan side streams while step k runs; the
             # first step builds its own at first use.  --no-prefetch-plan: every step builds its plan on the compute stream.
+            # prefetch=False (the HIP-event-bracketed step): nothing runs on the side streams while kernels are being timed -
+            # the step after it then builds its plan at first use on the compute stream.
             sample._plan_cache = pending_plan[0]
-            pending_plan[0] = None if (args.no_prefetch_plan or args.graph) else net.build_plan(sample)
+            pending_plan[0] = None if (args.no_prefetch_plan or args.graph or not prefetch) else net.build_plan(sample)
         return step(sample)
 
     def fence():
@@ -341,11 +370,13 @@ def main():
     timed = edge_names + (gemm_names if args.time_gemms else [])
     # HIP-event brackets need the per-kernel host path (the whole-block C calls enqueue their kernels natively) and event
     # pairs are not free: bracket the edge launches of the FIRST timed step, the rest runs un-instrumented.
-    def eager_step():
-        """one_step() through the per-launch host path even with --graph (HIP-event brackets cannot sit inside a replay)."""
+    def eager_step(prefetch=False):
+        """one_step() through the per-launch host path even with --graph (HIP-event brackets cannot sit inside a replay).
+        prefetch=False: no next-step plan build on the side streams beside the bracketed kernels (round 2's config-5 brackets
+        timed that contention instead of the kernel: 997 us bracketed vs 390 us in the rocprof trace)."""
         g, step.graph = step.graph, False
         try:
-            return one_step()
+            return one_step(prefetch=prefetch)
         finally:
             step.graph = g
 
@@ -359,8 +390,9 @@ def main():
         # (ONE bracketed step per run: a bracketed step takes the per-kernel host path and costs ~1.5 ms more than a plain one)
         SF.KernelTimer.start(timed, max_records=1_000_000 if args.time_gemms else per_step)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
+    for it in range(args.steps):
+        # the bracketed step (the first timed one) leaves the plan side streams idle: its HIP events time kernels, not contention
+        loss = one_step(prefetch=not (SF.KernelTimer.enabled and it == 0))
     dt_enqueue = time.perf_counter() - t0                   # host side done (everything enqueued); the GPU may still be running
     fence()
     dt = time.perf_counter() - t0
@@ -370,6 +402,15 @@ def main():
             eager_step()
         fence()
     ktimes = SF.KernelTimer.stop()
+    # the same brackets WITH the next step's plan build co-running on the side streams (what un-bracketed steps experience):
+    # reported as `contention`, never as the roofline figure
+    ctimes = {}
+    if not (args.no_secondary or args.cache_plan or args.no_prefetch_plan or args.graph):
+        fence()
+        SF.KernelTimer.start(edge_names, max_records=1_000_000)
+        eager_step(prefetch=True)
+        ctimes = SF.KernelTimer.stop()
+        fence()
     step.finish()                                           # deferred index checks of the timed steps (all clean)
     allreduce_us = None
     if world > 1 and step.bucket.allreduce_log:
@@ -456,6 +497,15 @@ def main():
                                  'level-0 forward kernel (chosen by the workload, not by measured time); every edge kernel/shape '
                                  'incl. the backward ones is in edge_kernels, the GEMMs (MFMA side, a larger share of the step) '
                                  'are in roofline_gemm'}
+        contention = None
+        ck = [(k, v) for k, v in ctimes.items() if k[0] == dom['kernel'] and k[1] == (dom['N'], dom['E'], dom['H'])]
+        if ck:
+            cavg = sum(ck[0][1]) / len(ck[0][1])
+            contention = {'kernel': roofline['kernel'], 'avg_us': cavg * 1e6, 'frac': dom['algorithmic_MB'] * 1e6 / cavg / 1e9 / HBM_PEAK_GBS,
+                          'slowdown_vs_roofline_bracket': cavg * 1e6 / dom['avg_us'],
+                          'note': 'the roofline kernel bracketed in a step whose NEXT plan is being built on the side streams at the '
+                                  'same time (prefetch on, as in the un-bracketed timed steps); the `roofline` bracket runs with the '
+                                  'side streams idle'}
         out = {
             'metric': 'vertices/sec forward+backward on 200k-vert ScanNet mesh; scatter-add GB/s vs HBM roofline',
             'value': total_vertices * args.steps / dt, 'unit': 'vertices/s', 'n_gpus': ranks_counted, 'steps': args.steps,
@@ -485,6 +535,7 @@ def main():
                 'ms_per_step': dt_fb / args.steps * 1e3, 'vertices_per_s_per_gpu': n0 * args.steps / dt_fb,
                 'note': 'same scene, CSR plan reused, no gradient all-reduce, no optimizer step (rank 0)'},
             'roofline': roofline,
+            'contention': contention,
             'edge_stage_ms_per_step': edge_total_ms,
             'edge_kernels': table[:6],
         }

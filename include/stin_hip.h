@@ -481,6 +481,22 @@ int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, const void*
                             size_t workspace_bytes, stin_stream_t stream, stin_stream_t wgrad_stream, stin_event_t ev_dagg,
                             stin_event_t ev_dy, stin_event_t ev_done, int join);
 
+/* All weight gradients of one fused block in two launches (round 3): BOTH transposed products
+ *   dW2 | db2 = dagg^T [hE[:, :H] | hE[:, H]]        (second Linear; db2 weighted by the [deg > 0] column of hE)
+ *   [dW1 ; dWs | db1 ; dbs] = dY^T [x | 1]           (first Linear + shortcut in the packed operand layout)
+ * as ONE grid of the producer / consumer TN kernel (csrc/stin_wgrad.hip) where both have 128 x 128 tiles and 16-byte rows
+ * (otherwise one TN launch each), then ONE kernel that sums the partial slabs in the fixed order of the stand-alone
+ * stin_gemm_tn_* reduction and writes the reference-layout gradients directly - bit-identical to
+ * stin_gemm_tn_f32 x 2 + stin_edgeconv_unpack_grads_f32, which it replaces inside stin_edgeconv_block_bwd.
+ * Replaces the autograd backward of the two nn.Linear modules of edge_conv_filter.py:46-57 and of the shortcut Linear
+ * (models/surfacetextureinpaintingnet.py:489-492) for the gradients w.r.t. their parameters.
+ * storage: 0 = fp32 rows, 1 = bf16 rows (dagg, hE, dY, x); hE has at least H + 1 columns; precision as stin_gemm_tn_f32. */
+size_t stin_edgeconv_wgrad_workspace_bytes(int64_t N, int Cp, int H, int Cout, int has_shortcut);
+int stin_edgeconv_wgrad(int storage, const void* dagg, int64_t ld_dagg, const void* hE, int64_t ldh, const void* dY,
+                        int64_t ldy, const void* x, int64_t ldx, int64_t N, int Cin, int Cp, int H, int Cout,
+                        int has_shortcut, int trans_inv, int precision, float* dW1, float* db1, float* dW2, float* db2,
+                        float* dWs, float* dbs, void* workspace, size_t workspace_bytes, stin_stream_t stream);
+
 /* ------------------------------------------------- offline preprocessing on the GPU --
  * The dilated-edge walk of preprocessing/graph_dilation.py:85-137 (`compute_dilated_edges`), one thread per
  * directed adjacency entry (centre c = row_of[e], one-hop h = col[e]) of the COALESCED adjacency CSR

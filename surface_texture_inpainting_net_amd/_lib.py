@@ -106,6 +106,9 @@ SIGNATURES['stin_edgeconv_block_bwd_workspace_bytes'] = (c_size, [c_i64, c_int, 
 SIGNATURES['stin_edgeconv_block_bwd'] = (c_int, [c_int, c_ptr, c_i64, c_ptr, c_i64, c_i64] + [c_int] * 6 + [c_ptr, c_i64, c_ptr, c_i64,
                                                  c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr] + [c_ptr] * 6 + [c_int, c_ptr, c_ptr, c_ptr, c_int,
                                                  c_int, c_ptr, c_i64] + [c_ptr] * 6 + [c_ptr, c_size, c_ptr] + [c_ptr] * 4 + [c_int])
+SIGNATURES['stin_edgeconv_wgrad_workspace_bytes'] = (c_size, [c_i64, c_int, c_int, c_int, c_int])
+SIGNATURES['stin_edgeconv_wgrad'] = (c_int, [c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64] + [c_int] * 7 + [c_ptr] * 6 +
+                                     [c_ptr, c_size, c_ptr])
 SIGNATURES['stin_norm_bwd_coef_m_quirk_f32'] = (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr])
 SIGNATURES['stin_gather_add_rows_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_bn_mean_bwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64] + [c_ptr] * 7 + [c_f32, c_i64, c_int, c_ptr, c_i64, c_ptr])

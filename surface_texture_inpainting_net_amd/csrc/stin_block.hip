@@ -148,13 +148,10 @@ extern "C" size_t stin_edgeconv_block_bwd_workspace_bytes(int64_t N, int Cp, int
     if (N < 0 || Cp <= 0 || H <= 0 || Cout <= 0 || B <= 0) return 0;
     const size_t Yw = 2 * (size_t)H + (has_shortcut ? Cout : 0);
     const size_t es = storage ? 2 : 4;
-    size_t tn = stin_gemm_tn_workspace_bytes(N, Cout, H, 1);
-    const size_t tn2 = stin_gemm_tn_workspace_bytes(N, (int)Yw, Cp, 1);
-    if (tn2 > tn) tn = tn2;
+    const size_t tn = stin_edgeconv_wgrad_workspace_bytes(N, Cp, H, Cout, has_shortcut);   // the slabs of both products
     return up256((size_t)N * Cout * es)      /* dagg */
            + up256((size_t)N * H * es)       /* dhE  */
            + up256((size_t)N * Yw * es)      /* dY   */
-           + up256((size_t)Cout * (H + 1) * 4) + up256(Yw * (size_t)(Cp + 1) * 4) /* dw2b, dwb */
            + 5 * up256((size_t)B * Cout * 4) /* k, m (+ T1, S0, U with the linspace-slice quirk) */
            + up256(stin_colreduce_workspace_bytes(Cout, B)) + up256(tn) + 256;
 }
@@ -187,8 +184,6 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
     void* dagg = carve(p, (size_t)N * Cout * es);
     void* dhE = carve(p, (size_t)N * H * es);
     void* dY = carve(p, (size_t)N * Yw * es);
-    float* dw2b = reinterpret_cast<float*>(carve(p, (size_t)Cout * (H + 1) * 4));
-    float* dwb = reinterpret_cast<float*>(carve(p, (size_t)Yw * (Cp + 1) * 4));
     float* kk = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
     float* mm = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
     float* t1 = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
@@ -204,7 +199,8 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
     // weight-gradient GEMMs are off the critical path dx <- g: with a wgrad_stream they run beside the edge-stage /
     // dx kernels of this block (and the head of the next one), ordered by the caller's events
     const bool side = wgrad_stream != nullptr && wgrad_stream != stream;
-    if (side) STIN_REQUIRE(ev_dagg && ev_dy && ev_done, STIN_E_NULL);
+    if (side) STIN_REQUIRE(ev_dy && ev_done, STIN_E_NULL);
+    (void)ev_dagg;                             // (round 2 forked the dW2 product here; both products now start behind ev_dy)
     stin_stream_t ws_ = side ? wgrad_stream : stream;
     auto fork = [&](stin_event_t ev) -> int {
         if (!side) return STIN_OK;
@@ -235,9 +231,6 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         STIN_TRY(stin_norm_act_bwd_f32(static_cast<const float*>(agg), Cout, gf, ldg, mean, rstd, rstd, kk, mm, gid, sid_n, N,
                                        Cout, 1, static_cast<float*>(dagg), Cout, stream));
         // second Linear: weight gradient (+ masked bias gradient) and input gradient
-        STIN_TRY(fork(ev_dagg));
-        STIN_TRY(stin_gemm_tn_f32(static_cast<const float*>(dagg), Cout, hf, ldh, N, Cout, H, 1, hf + H, ldh, dw2b, H + 1,
-                                  prec_bwd, tn_ws, tn_bytes, ws_));
         STIN_TRY(stin_gemm_nt_f32(static_cast<const float*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H, Cout,
                                   static_cast<float*>(dhE), H, pb, stream));
         // edge stage backward from the saved ReLU mask -> dY = [dA | dB | g]
@@ -253,9 +246,11 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
             if (e != hipSuccess) return (int)e;
         }
         // first Linear (+ shortcut): packed weight gradient and the block-input gradient (+ identity residual)
+        // all weight gradients: both transposed products in one grid + one finalize launch (stin_wgrad.hip), off the
+        // critical path dx <- g on the caller's weight-gradient stream
         STIN_TRY(fork(ev_dy));
-        STIN_TRY(stin_gemm_tn_f32(dYf, Yw, static_cast<const float*>(x), ldx, N, Yw, Cp, 1, nullptr, 0, dwb, Cp + 1, prec_bwd,
-                                  tn_ws, tn_bytes, ws_));
+        STIN_TRY(stin_edgeconv_wgrad(0, dagg, Cout, hf, ldh, dYf, Yw, x, ldx, N, Cin, Cp, H, Cout, has_shortcut, trans_inv, prec_bwd,
+                                     dW1, db1, dW2, db2, dWs, dbs, tn_ws, tn_bytes, ws_));
         if (dx != nullptr)
             STIN_TRY(stin_gemm_nt_f32(dYf, Yw, wcatT, Yw, nullptr, nullptr, 0, has_shortcut ? nullptr : gf, ldg, N, Cp, Yw,
                                       static_cast<float*>(dx), lddx, pb, stream));
@@ -279,9 +274,6 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         }
         STIN_TRY(stin_norm_act_bwd_bf16(static_cast<const stin_bf16_t*>(agg), Cout, gh, ldg, mean, rstd, rstd, kk, mm, gid, sid_n, N,
                                         Cout, 1, static_cast<stin_bf16_t*>(dagg), Cout, stream));
-        STIN_TRY(fork(ev_dagg));
-        STIN_TRY(stin_gemm_tn_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, hh, ldh, N, Cout, H, 1, hh + H, ldh, dw2b, H + 1,
-                                   tn_ws, tn_bytes, ws_));
         const int wbb = (Cp % 8 == 0 && Cout % 8 == 0) ? STIN_GEMM_W_BF16 : 0;   // as written by the forward call's pack
         STIN_TRY(stin_gemm_nt_bf16(static_cast<const stin_bf16_t*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H,
                                    Cout, dhE, H, wbb, stream));
@@ -296,14 +288,12 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
             if (e != hipSuccess) return (int)e;
         }
         STIN_TRY(fork(ev_dy));
-        STIN_TRY(stin_gemm_tn_bf16(dYh, Yw, static_cast<const stin_bf16_t*>(x), ldx, N, Yw, Cp, 1, nullptr, 0, dwb, Cp + 1, tn_ws,
-                                   tn_bytes, ws_));
+        STIN_TRY(stin_edgeconv_wgrad(1, dagg, Cout, hh, ldh, dYh, Yw, x, ldx, N, Cin, Cp, H, Cout, has_shortcut, trans_inv, prec_bwd,
+                                     dW1, db1, dW2, db2, dWs, dbs, tn_ws, tn_bytes, ws_));
         if (dx != nullptr)
             STIN_TRY(stin_gemm_nt_bf16(dYh, Yw, wcatT, Yw, nullptr, nullptr, 0, has_shortcut ? nullptr : gh, ldg, N, Cp, Yw, dx,
                                        lddx, wbb, stream));
     }
-    STIN_TRY(stin_edgeconv_unpack_grads_f32(dwb, dw2b, Cin, Cp, H, Cout, has_shortcut, trans_inv, dW1, db1, dWs, dbs, dW2, db2,
-                                            ws_));
     if (side) {
         hipError_t e = hipEventRecord((hipEvent_t)ev_done, (hipStream_t)wgrad_stream);
         if (e == hipSuccess && join) e = hipStreamWaitEvent(hs, (hipEvent_t)ev_done, 0);

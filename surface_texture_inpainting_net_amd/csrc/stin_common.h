@@ -67,3 +67,27 @@ __device__ __forceinline__ void st1(stin_bf16* p, float v) { *p = (stin_bf16)v; 
 template <typename T> static inline bool stin_aligned_vec4(const void* p) {
     return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0;
 }
+
+// ---- weight-gradient (TN) products shared between stin_gemm.hip and stin_wgrad.hip ------------------------------------
+// One dW[Nc, K (+1)] = G[M, Nc]^T [X[M, K] | w] product split over row chunks: its geometry and operands as the TN kernels
+// take them.  Pointers are typed float* also for bf16 storage (only the fp32 kernels read them through this struct).
+struct stin_tn_problem {
+    const float *G, *X, *row_w;
+    float* slab;                       // [chunks][Nc * Kq + roundup4(Nc)] partial results
+    int64_t ldg, ldx, ld_w, M, chunks;
+    int Nc, K, Kq, has_bias, rows_per_chunk, tiles_i, tiles_j, TI, TJ, vec;
+    unsigned block0;                   // first block of the problem in a merged grid (set by stin_tn_ws_launch)
+};
+struct stin_tn_batch {
+    stin_tn_problem p[2];
+    int n;
+};
+// stin_gemm.hip: geometry of one product (*ws_eligible = 1: the producer / consumer kernel of stin_wgrad.hip takes it);
+// stin_tn_slabs launches the product's TN kernel only (partial slabs, no reduction)
+int stin_tn_problem_init(stin_tn_problem* p, int storage, const void* G, int64_t ldg, const void* X, int64_t ldx, int64_t M,
+                         int Nc, int K, int ones_column, const void* row_w, int64_t ld_w, int precision, float* slab,
+                         int* ws_eligible);
+int stin_tn_slabs(const stin_tn_problem* p, int storage, int precision, stin_stream_t stream);
+// stin_wgrad.hip
+bool stin_tn_ws_enabled();
+int stin_tn_ws_launch(stin_tn_batch batch, stin_stream_t stream);

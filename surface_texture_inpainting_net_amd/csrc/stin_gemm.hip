@@ -1683,18 +1683,26 @@ inline int stin_cu_count() {
     return n;
 }
 
-inline int tn_rows_per_chunk(int64_t M, int tiles) {
+inline int tn_rows_per_chunk(int64_t M, int tiles, bool one_per_cu = false) {
     // ~384 blocks (up to 2 resident per CU, one round), chunks a multiple of the LDS slab.  Round 1 measured 512 best of
     // 256..1536; with loads two slabs ahead a block hides more latency by itself and fewer chunks mean fewer partial slabs to
     // store and reduce: 384 is 0.3-0.5 % faster on the step than 512 (256: 0.4 % slower)
-    static const int target = getenv("STIN_TN_BLOCKS") ? atoi(getenv("STIN_TN_BLOCKS")) : 384;   // tuning aid
-    int64_t chunks = (target + tiles - 1) / tiles;
+    // one_per_cu (round 3: fp32 bf16x3 products on 128 x 128 tiles with M <= 32 k rows, the shapes of the bottleneck level):
+    // 256 blocks - the producer / consumer kernel's fixed cost per block (first-load latency ~5 k cycles, slab store ~9 k) is
+    // a sixth of a 750-row chunk; measured 18 063 x 1024 x 256 49.7 -> 45.7 us, block weight gradients 69 -> 62 us, while the
+    // 60 k-row products lose 10 % with 256 blocks and keep 384
+    static const int target = getenv("STIN_TN_BLOCKS") ? atoi(getenv("STIN_TN_BLOCKS")) : 0;   // tuning aid
+    const int want = target > 0 ? target : (one_per_cu ? 256 : 384);
+    int64_t chunks = (want + tiles - 1) / tiles;
     if (chunks > 8) chunks = (chunks + 7) / 8 * 8;          // whole rounds of 8 chunks (one per XCD, see the kernels' block map)
     int64_t rows = (M + chunks - 1) / chunks;
     if (rows < 4 * TN_R) rows = 4 * TN_R;
     if (rows > 128 * TN_R) rows = 128 * TN_R;
     rows = (rows + TN_R - 1) / TN_R * TN_R;
     return (int)rows;
+}
+inline bool tn_one_per_cu(int storage, int precision, int TI, int TJ, int64_t M) {
+    return storage == 0 && precision == STIN_GEMM_BF16X3 && TI == 128 && TJ == 128 && M <= 32768;
 }
 
 }  // namespace
@@ -1839,33 +1847,83 @@ extern "C" size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int one
     (void)ones_column;
     const int TI = tn_tile(Nc), TJ = tn_tile(K);
     const int tiles = ((Nc + TI - 1) / TI) * ((K + TJ - 1) / TJ);
-    const int rows = tn_rows_per_chunk(M, tiles);
-    const int64_t chunks = (M + rows - 1) / rows;
-    return (size_t)(chunks > 0 ? chunks : 1) * (size_t)tn_chunk_stride(Nc, (K + 3) & ~3) * sizeof(float) + 256;
+    int64_t chunks = 1;
+    for (int rule = 0; rule < 2; ++rule) {                       // (the chunk rule depends on storage / precision: take the larger)
+        const int rows = tn_rows_per_chunk(M, tiles, rule == 1);
+        const int64_t c = (M + rows - 1) / rows;
+        if (c > chunks) chunks = c;
+    }
+    return (size_t)chunks * (size_t)tn_chunk_stride(Nc, (K + 3) & ~3) * sizeof(float) + 256;
 }
 
-extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
-                                int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
-                                int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
-    stin_clear_stale_error();
+// Geometry of one TN product (shared with stin_wgrad.hip).  ws_eligible: fp32 storage, 2-piece bf16 split, 128 x 128 tiles,
+// 16-byte rows - what k_gemm_tn_ws is written for (STIN_TN_WS=0 keeps the four-wave kernel, A/B aid).
+int stin_tn_problem_init(stin_tn_problem* p, int storage, const void* G, int64_t ldg, const void* X, int64_t ldx, int64_t M,
+                         int Nc, int K, int ones_column, const void* row_w, int64_t ld_w, int precision, float* slab,
+                         int* ws_eligible) {
+    STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && ldg >= Nc && ldx >= K, STIN_E_SIZE);
+    STIN_REQUIRE(slab && (M == 0 || (G && X)), STIN_E_NULL);
+    p->G = static_cast<const float*>(G);
+    p->X = static_cast<const float*>(X);
+    p->row_w = static_cast<const float*>(row_w);
+    p->slab = slab;
+    p->ldg = ldg;
+    p->ldx = ldx;
+    p->ld_w = ld_w;
+    p->M = M;
+    p->Nc = Nc;
+    p->K = K;
+    p->TI = tn_tile(Nc);
+    p->TJ = tn_tile(K);
+    p->tiles_i = (Nc + p->TI - 1) / p->TI;
+    p->tiles_j = (K + p->TJ - 1) / p->TJ;
+    p->rows_per_chunk = tn_rows_per_chunk(M, p->tiles_i * p->tiles_j, tn_one_per_cu(storage, precision, p->TI, p->TJ, M));
+    p->chunks = M > 0 ? (M + p->rows_per_chunk - 1) / p->rows_per_chunk : 0;
+    p->Kq = (K + 3) & ~3;
+    p->has_bias = ones_column ? 1 : 0;
+    p->block0 = 0;
+    const int a = storage ? 8 : 4;                                 // elements per 16-byte vector
+    p->vec = (Nc % a == 0) && (K % a == 0) && (ldg % a == 0) && (ldx % a == 0) && stin_aligned16(G) && stin_aligned16(X);
+    if (ws_eligible)
+        *ws_eligible = (storage == 0 && precision == STIN_GEMM_BF16X3 && p->TI == 128 && p->TJ == 128 && p->vec && M > 0 &&
+                        stin_tn_ws_enabled()) ? 1 : 0;
+    return STIN_OK;
+}
+
+// The TN kernel of one product: partial slabs only (k_reduce_slabs / k_wgrad_finalize add them).
+int stin_tn_slabs(const stin_tn_problem* p, int storage, int precision, stin_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    const int Kp = K + (ones_column ? 1 : 0);
-    STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && ldg >= Nc && ldx >= K && lddw >= Kp, STIN_E_SIZE);
-    STIN_REQUIRE(dW && workspace && (M == 0 || (G && X)), STIN_E_NULL);
-    STIN_REQUIRE(workspace_bytes >= stin_gemm_tn_workspace_bytes(M, Nc, K, ones_column), STIN_E_WORKSPACE);
-    STIN_REQUIRE(precision == STIN_GEMM_F32 || precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6,
-                 STIN_E_UNSUPPORTED);
-    float* slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    const int TI = tn_tile(Nc), TJ = tn_tile(K);
-    const int tiles_i = (Nc + TI - 1) / TI, tiles_j = (K + TJ - 1) / TJ;
-    const int rows = tn_rows_per_chunk(M, tiles_i * tiles_j);
-    const int64_t chunks = M > 0 ? (M + rows - 1) / rows : 0;
-    const int Kq = (K + 3) & ~3, has_bias = ones_column ? 1 : 0;
-    const int64_t n4 = (int64_t)Nc * Kq / 4 + (has_bias ? (Nc + 3) / 4 : 0);
-    if (chunks > 0) {
-        const bool vec = (Nc % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldx % 4 == 0) && stin_aligned16(G) &&
-                         stin_aligned16(X);
-        const int64_t blocks = (chunks >= 8 ? ((chunks + 7) / 8) * 8 : chunks) * (int64_t)tiles_i * tiles_j;   // 8 chunks (one per XCD) per round
+    if (p->chunks <= 0) return STIN_OK;
+    const int64_t M = p->M, ldg = p->ldg, ldx = p->ldx, ld_weight = p->ld_w, chunks = p->chunks;
+    const int Nc = p->Nc, K = p->K, Kq = p->Kq, has_bias = p->has_bias, rows = p->rows_per_chunk, tiles_i = p->tiles_i,
+              tiles_j = p->tiles_j, TI = p->TI, TJ = p->TJ;
+    const bool vec = p->vec != 0;
+    float* slab = p->slab;
+    const int64_t blocks = (chunks >= 8 ? ((chunks + 7) / 8) * 8 : chunks) * (int64_t)tiles_i * tiles_j;   // 8 chunks (one per XCD) per round
+    if (storage == 1) {
+        const stin_bf16* G = reinterpret_cast<const stin_bf16*>(p->G);
+        const stin_bf16* X = reinterpret_cast<const stin_bf16*>(p->X);
+        const stin_bf16* row_weight = reinterpret_cast<const stin_bf16*>(p->row_w);
+#define STIN_TNK(TI_, TJ_)                                                                                            \
+    do {                                                                                                              \
+        if (vec) hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
+        else hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
+    } while (0)
+        if (TI == 128 && TJ == 128) STIN_TNK(128, 128);
+        else if (TI == 128) STIN_TNK(128, 64);
+        else if (TJ == 128) STIN_TNK(64, 128);
+        else STIN_TNK(64, 64);
+#undef STIN_TNK
+        return stin_launch_status();
+    }
+    const float *G = p->G, *X = p->X, *row_weight = p->row_w;
+    if (precision == STIN_GEMM_BF16X3 && TI == 128 && TJ == 128 && vec && stin_tn_ws_enabled()) {
+        stin_tn_batch batch;
+        batch.p[0] = *p;
+        batch.p[1] = *p;
+        batch.n = 1;
+        return stin_tn_ws_launch(batch, stream_);
+    }
 #define STIN_TN(TI_, TJ_)                                                                                            \
     do {                                                                                                             \
         if (vec) hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
@@ -1883,15 +1941,35 @@ extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int
         else if (TJ == 128) LAUNCH(64, 128, ##__VA_ARGS__);          \
         else LAUNCH(64, 64, ##__VA_ARGS__);                          \
     } while (0)
-        if (precision == STIN_GEMM_BF16X3) STIN_TN_PICK(STIN_TNB, 2);
-        else if (precision == STIN_GEMM_BF16X6) STIN_TN_PICK(STIN_TNB, 3);
-        else STIN_TN_PICK(STIN_TN);
+    if (precision == STIN_GEMM_BF16X3) STIN_TN_PICK(STIN_TNB, 2);
+    else if (precision == STIN_GEMM_BF16X6) STIN_TN_PICK(STIN_TNB, 3);
+    else STIN_TN_PICK(STIN_TN);
 #undef STIN_TN_PICK
 #undef STIN_TNB
 #undef STIN_TN
-    }
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n4 + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, chunks, Nc, K,
-                       Kq, has_bias, dW, lddw);
+    return stin_launch_status();
+}
+
+extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
+                                int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
+                                int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    const int Kp = K + (ones_column ? 1 : 0);
+    STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && ldg >= Nc && ldx >= K && lddw >= Kp, STIN_E_SIZE);
+    STIN_REQUIRE(dW && workspace && (M == 0 || (G && X)), STIN_E_NULL);
+    STIN_REQUIRE(workspace_bytes >= stin_gemm_tn_workspace_bytes(M, Nc, K, ones_column), STIN_E_WORKSPACE);
+    STIN_REQUIRE(precision == STIN_GEMM_F32 || precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6,
+                 STIN_E_UNSUPPORTED);
+    float* slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    stin_tn_problem p;
+    int rc = stin_tn_problem_init(&p, 0, G, ldg, X, ldx, M, Nc, K, ones_column, row_weight, ld_weight, precision, slab, nullptr);
+    if (rc != STIN_OK) return rc;
+    rc = stin_tn_slabs(&p, 0, precision, stream_);
+    if (rc != STIN_OK) return rc;
+    const int64_t n4 = (int64_t)Nc * p.Kq / 4 + (p.has_bias ? (Nc + 3) / 4 : 0);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n4 + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, p.chunks, Nc, K,
+                       p.Kq, p.has_bias, dW, lddw);
     return stin_launch_status();
 }
 
@@ -1944,36 +2022,18 @@ extern "C" int stin_gemm_tn_bf16(const stin_bf16_t* G_, int64_t ldg, const stin_
                                  int64_t lddw, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
-    const stin_bf16* G = reinterpret_cast<const stin_bf16*>(G_);
-    const stin_bf16* X = reinterpret_cast<const stin_bf16*>(X_);
-    const stin_bf16* row_weight = reinterpret_cast<const stin_bf16*>(row_weight_);
     const int Kp = K + (ones_column ? 1 : 0);
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && ldg >= Nc && ldx >= K && lddw >= Kp, STIN_E_SIZE);
-    STIN_REQUIRE(dW && workspace && (M == 0 || (G && X)), STIN_E_NULL);
+    STIN_REQUIRE(dW && workspace && (M == 0 || (G_ && X_)), STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_gemm_tn_workspace_bytes(M, Nc, K, ones_column), STIN_E_WORKSPACE);
     float* slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    const int TI = tn_tile(Nc), TJ = tn_tile(K);
-    const int tiles_i = (Nc + TI - 1) / TI, tiles_j = (K + TJ - 1) / TJ;
-    const int rows = tn_rows_per_chunk(M, tiles_i * tiles_j);
-    const int64_t chunks = M > 0 ? (M + rows - 1) / rows : 0;
-    const int Kq = (K + 3) & ~3, has_bias = ones_column ? 1 : 0;
-    const int64_t n4 = (int64_t)Nc * Kq / 4 + (has_bias ? (Nc + 3) / 4 : 0);
-    if (chunks > 0) {
-        const bool vec = (Nc % 8 == 0) && (K % 8 == 0) && (ldg % 8 == 0) && (ldx % 8 == 0) && stin_aligned16(G) &&
-                         stin_aligned16(X);
-        const int64_t blocks = (chunks >= 8 ? ((chunks + 7) / 8) * 8 : chunks) * (int64_t)tiles_i * tiles_j;
-#define STIN_TNK(TI_, TJ_)                                                                                            \
-    do {                                                                                                              \
-        if (vec) hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
-        else hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
-    } while (0)
-        if (TI == 128 && TJ == 128) STIN_TNK(128, 128);
-        else if (TI == 128) STIN_TNK(128, 64);
-        else if (TJ == 128) STIN_TNK(64, 128);
-        else STIN_TNK(64, 64);
-#undef STIN_TNK
-    }
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n4 + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, chunks, Nc, K,
-                       Kq, has_bias, dW, lddw);
+    stin_tn_problem p;
+    int rc = stin_tn_problem_init(&p, 1, G_, ldg, X_, ldx, M, Nc, K, ones_column, row_weight_, ld_weight, STIN_GEMM_BF16X3, slab, nullptr);
+    if (rc != STIN_OK) return rc;
+    rc = stin_tn_slabs(&p, 1, STIN_GEMM_BF16X3, stream_);
+    if (rc != STIN_OK) return rc;
+    const int64_t n4 = (int64_t)Nc * p.Kq / 4 + (p.has_bias ? (Nc + 3) / 4 : 0);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n4 + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, p.chunks, Nc, K,
+                       p.Kq, p.has_bias, dW, lddw);
     return stin_launch_status();
 }

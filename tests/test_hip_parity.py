@@ -281,6 +281,69 @@ def test_gemm_nt_strip_kernel_equals_tiled_kernel(M, Nc, K):
         assert float((SF.gemm_nt(A, Wf, b, row_mask=mask, precision=prec | SF.GEMM_W_PRESPLIT | FR).double() - ref).abs().max()) <= tol * scale
 
 
+@pytest.mark.parametrize('M,Nc,K', [(18063, 256, 512), (18063, 1024, 256), (5000, 320, 128), (777, 128, 260), (65, 132, 128),
+                                    (31, 256, 128), (4097, 1280, 128), (60211, 128, 256), (1, 128, 128)])
+def test_gemm_tn_ws_kernel_equals_four_wave_kernel(M, Nc, K, monkeypatch):
+    """The producer / consumer TN kernel (csrc/stin_wgrad.hip: 8 waves, fixed roles, double-buffered LDS) against the
+    four-wave kernel it replaces for 128 x 128-tiled bf16x3 products: same chunking, k order and MFMA order -> the summed
+    slabs are bit-identical, with and without the bias column / row weights, ragged row counts and partial edge tiles."""
+    g = torch.Generator().manual_seed(M + Nc + K)
+    G = torch.randn(M + 2, Nc + 4, generator=g).to(DEV)[1:M + 1, :Nc]              # strided views: ld != width
+    X = torch.randn(M, K + 8, generator=g).to(DEV)[:, 4:K + 4]
+    w = torch.rand(M, 3, generator=g).to(DEV)[:, 1]
+    want64 = torch.cat([G.double().t() @ X.double(), (G.double() * w.double()[:, None]).sum(0)[:, None]], 1)
+    res = {}
+    for ws in ('0', '1'):
+        monkeypatch.setenv('STIN_TN_WS', ws)
+        res[ws] = [SF.gemm_tn(G, X, ones_column=True, row_weight=w, precision=SF.GEMM_BF16X3),
+                   SF.gemm_tn(G, X, ones_column=True, precision=SF.GEMM_BF16X3),
+                   SF.gemm_tn(G, X, precision=SF.GEMM_BF16X3)]
+        assert torch.equal(res[ws][0], SF.gemm_tn(G, X, ones_column=True, row_weight=w, precision=SF.GEMM_BF16X3))   # deterministic
+    for a, b in zip(res['0'], res['1']):
+        assert torch.equal(a, b)
+    assert float((res['1'][0].double() - want64).abs().max()) <= 3e-5 * float(want64.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize('N,Cin,Cout,shortcut,trans_inv', [(18063, 256, 256, False, False), (5000, 128, 256, True, False),
+                                                          (3001, 10, 64, True, True), (2000, 64, 128, True, False),
+                                                          (257, 512, 512, False, False), (40, 128, 128, False, True)])
+def test_edgeconv_wgrad_equals_two_tn_gemms_plus_unpack(N, Cin, Cout, shortcut, trans_inv):
+    """stin_edgeconv_wgrad (both transposed products in one grid where both are 128 x 128-tiled + ONE finalize launch that
+    sums the slabs and writes the reference-layout gradients) against what it replaces: stin_gemm_tn_f32 twice +
+    stin_edgeconv_unpack_grads_f32 - bit-identical, also where only one / none of the products takes the new kernel."""
+    lib = _lib_load()
+    g = torch.Generator().manual_seed(N + Cin + Cout)
+    H = 2 * Cout
+    Cp = (Cin + 3) // 4 * 4
+    Yw = 2 * H + (Cout if shortcut else 0)
+    dagg = torch.randn(N, Cout, generator=g).to(DEV)
+    hE = torch.randn(N, H + 4, generator=g).to(DEV)
+    hE[:, H] = (torch.rand(N, generator=g) < 0.8).float().to(DEV)
+    dY = torch.randn(N, Yw, generator=g).to(DEV)
+    x = torch.zeros(N, Cp, device=DEV)
+    x[:, :Cin] = torch.randn(N, Cin, generator=g).to(DEV)
+    ld1 = Cin if trans_inv else 2 * Cin
+    # reference: the two stand-alone products + the unpack kernel
+    dw2b = SF.gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H], precision=SF.GEMM_BF16X3)
+    dwb = SF.gemm_tn(dY, x, ones_column=True, precision=SF.GEMM_BF16X3)
+    want = [torch.empty(H, ld1, device=DEV), torch.empty(H, device=DEV), torch.empty(Cout, H, device=DEV), torch.empty(Cout, device=DEV),
+            torch.empty(Cout, Cin, device=DEV) if shortcut else None, torch.empty(Cout, device=DEV) if shortcut else None]
+    SF._call('stin_edgeconv_unpack_grads_f32', SF._ptr(dwb), SF._ptr(dw2b), Cin, Cp, H, Cout, int(shortcut), int(trans_inv),
+             SF._ptr(want[0]), SF._ptr(want[1]), SF._ptr(want[4]), SF._ptr(want[5]), SF._ptr(want[2]), SF._ptr(want[3]), SF._stream(x))
+    got = [torch.full_like(t, 7.0) if t is not None else None for t in want]
+    ws_bytes = lib.stin_edgeconv_wgrad_workspace_bytes(N, Cp, H, Cout, int(shortcut))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    SF._call('stin_edgeconv_wgrad', 0, SF._ptr(dagg), Cout, SF._ptr(hE), hE.stride(0), SF._ptr(dY), Yw, SF._ptr(x), Cp, N, Cin, Cp, H,
+             Cout, int(shortcut), int(trans_inv), SF.GEMM_BF16X3, SF._ptr(got[0]), SF._ptr(got[1]), SF._ptr(got[2]), SF._ptr(got[3]),
+             SF._ptr(got[4]), SF._ptr(got[5]), SF._ptr(ws), ws_bytes, SF._stream(x))
+    for i, (a, b) in enumerate(zip(got, want)):
+        if b is not None:
+            assert torch.equal(a, b), i
+    # and against fp64
+    ref = dagg.double().t() @ hE[:, :H].double()
+    assert float((got[2].double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize('M,Nc,K', [(18063, 256, 512), (60211, 128, 256), (130, 256, 512), (64, 128, 256), (4097, 256, 1024),
                                     (129, 128, 256), (190, 128, 512)])
 def test_gemm_nt_with_fused_column_statistics(M, Nc, K):
