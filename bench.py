@@ -225,6 +225,48 @@ def hbm_honest_edge_kernel(device, n=1_000_000, e=6_000_000, h=128, iters=10):
             'note': 'gathered operand 512 MB > 256 MB Infinity Cache: served by HBM (random graph, fp32 rows)'}
 
 
+def irregular_edge_kernel(device, n0=200_000, h=128, iters=20):
+    """The level-0 forward edge kernel on an IRREGULAR 200 k-vertex mesh (Delaunay triangulation of random points: vertex
+    degrees 3 ... ~18, mean 6, sigma 1.3 - the valence spread of a QEM-decimated scan) beside the 6-regular jittered grid
+    of the headline: what the degree spread alone costs the one-lane-group-per-row kernels."""
+    from surface_texture_inpainting_net_amd import functional as SF
+    from surface_texture_inpainting_net_amd.plan import EdgeSet
+    from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
+    s = make_synthetic_mesh(n0, 1, seed=0, dilations=(), irregular=True)
+    ei = s.edge_index.to(device)
+    n, e = s.x.shape[0], ei.shape[1]
+    deg = torch.bincount(s.edge_index[1], minlength=n)
+    bad = torch.zeros(1, dtype=torch.int32, device=device)
+    edges = EdgeSet(ei, n, bad)
+    Y = torch.randn(n, 2 * h, device=device)
+    out = torch.empty(n, h + 4, device=device)
+    mask = torch.empty(e * (h // 32), dtype=torch.int32, device=device)
+    g = torch.randn(n, h, device=device)
+    dY = torch.empty(n, 2 * h, device=device)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / iters
+
+    tf = timed(lambda: SF.edge_relu_mean_fwd(Y[:, :h], Y[:, h:], edges.by_dst, out, indicator=True, mask=mask))
+    tb = timed(lambda: SF.edge_relu_mean_bwd_mask(g, mask, edges, dY[:, :h], dY[:, h:]))
+    bf, bb = edge_bytes('stin_edge_relu_mean_fwd_f32', n, e, h), edge_bytes('stin_edge_relu_mean_bwd_mask_f32', n, e, h)
+    return {'kernel': 'stin_edge_relu_mean_fwd_f32[N=%d,E=%d,H=%d]' % (n, e, h), 'bound': 'hbm', 'avg_us': tf * 1e6,
+            'algorithmic_bytes': bf, 'achieved': bf / tf / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': bf / tf / 1e9 / HBM_PEAK_GBS,
+            'backward': {'kernel': 'stin_edge_relu_mean_bwd_mask_f32', 'avg_us': tb * 1e6, 'GBps': bb / tb / 1e9,
+                         'frac': bb / tb / 1e9 / HBM_PEAK_GBS},
+            'in_degree': {'min': int(deg.min()), 'max': int(deg.max()), 'mean': float(deg.float().mean()),
+                          'std': float(deg.float().std())},
+            'note': 'stand-alone, fp32 rows, Delaunay mesh (synthetic.make_synthetic_mesh(irregular=True)); the headline mesh is 6-regular'}
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -287,6 +329,8 @@ def main():
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the passes after the timed region (fwd+loss+bwd-only loop, GEMM table, standalone kernels, CPU '
                          'baseline) - profiling runs: keeps the kernel mix = the step')
+    ap.add_argument('--irregular', action='store_true', help='the whole step on an irregular (Delaunay) mesh of the same size '
+                    'instead of the 6-regular jittered grid (NOT the headline)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="activation storage: f32 = the headline (reference numerics); bf16 = the build's "
                          "mixed-precision mode of BASELINE configs 3/5 (NOT the headline, stated tolerance)")
@@ -333,7 +377,7 @@ def main():
         sizes = [12_000 + (16_000 * i) // max(args.crops - 1, 1) for i in range(args.crops)]
         sample = collate([make_synthetic_mesh(n, args.levels, seed=100 * rank + i) for i, n in enumerate(sizes)]).to(device)
     else:
-        sample = make_synthetic_mesh(args.vertices, args.levels, seed=rank).to(device)   # one scene per rank
+        sample = make_synthetic_mesh(args.vertices, args.levels, seed=rank, irregular=args.irregular).to(device)   # one scene per rank
     n0 = sample.x.shape[0]
     e0 = sample.edge_index.shape[1]
 
@@ -521,7 +565,7 @@ def main():
                        'parallelism': 'dp%d' % world, 'plan_build_in_step': not args.cache_plan,
                        'plan_prefetched_one_step_ahead': not (args.cache_plan or args.no_prefetch_plan or args.graph),
                        'hip_graph': bool(args.graph),
-                       'crops_per_step': args.crops or None},
+                       'crops_per_step': args.crops or None, 'irregular_mesh': bool(args.irregular)},
             'gemm_precision': ({'fwd': SF.PREC_NAMES[SF.PREC_FWD], 'bwd': SF.PREC_NAMES[SF.PREC_BWD],
                                 'note': 'fp32 storage, operands split into 16-bit pieces on the MFMA path (fp16x3: 22-bit '
                                         'products; bf16x3: 16-bit products), fp32 accumulate'} if args.dtype == 'f32' else
@@ -564,6 +608,7 @@ def main():
         if world == 1 and not args.no_secondary:
             out['scatter_add'] = scatter_add_standalone(device)
             out['hbm_honest'] = hbm_honest_edge_kernel(device)
+            out['roofline_irregular'] = irregular_edge_kernel(device)
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(args.vertices, args.levels, seed=0)
         print(json.dumps(out), flush=True)

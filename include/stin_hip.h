@@ -89,6 +89,27 @@ int stin_csr_pair_from_edges_i64(const int64_t* src, const int64_t* dst, int64_t
                                  int32_t* rowptr_dst, int32_t* col_dst, float* inv_deg_dst,
                                  int32_t* rowptr_src, int32_t* col_src, int32_t* xslot, float* w_src,
                                  int32_t* bad, void* workspace, size_t workspace_bytes, stin_stream_t stream);
+/* Every CSR structure of a sample in ONE batch of 7 launches (round 3; the two entry points above are batches of one job).
+ * A job = one CSR grouped by a[] with the value b[] (b == NULL: the pair id itself, e.g. the children of every coarse vertex
+ * of hierarchy_trace_index_l) or, with pair != 0, both CSRs of one directed edge set (a = edge_index[1] = targets,
+ * b = edge_index[0] = sources; outputs as stin_csr_pair_from_edges_i64).  narrow_out (may be NULL): the int32 copy of a[]
+ * (0 where out of range) - the `trace` the pool / unpool kernels gather with, written by the counting pass.
+ * jobs: HOST array (copied into the kernel arguments); out-of-range pairs set *bad and are left out, as above.
+ * workspace >= stin_plan_build_workspace_bytes(sum of E, sum over jobs of (pair ? 2 : 1) * N + 1). */
+#define STIN_PLAN_MAX_JOBS 16
+typedef struct stin_plan_job {
+    const int64_t *a, *b;
+    int64_t E, N, b_limit;
+    int32_t *rowptr0, *col0, *perm0;
+    float* inv_deg0;
+    int32_t *rowptr1, *col1, *xslot;
+    float* w_src;
+    int32_t* narrow_out;
+    int32_t pair, reserved;
+} stin_plan_job_t;                                    /* 11 pointers + 3 int64 + 2 int32 = 120 bytes */
+size_t stin_plan_build_workspace_bytes(int64_t total_E, int64_t total_counters);
+int stin_plan_build_many(const stin_plan_job_t* jobs, int n_jobs, int32_t* bad, void* workspace, size_t workspace_bytes,
+                         stin_stream_t stream);
 /* dst[i] = (int32) src[i]; *bad set when a value is outside [0, limit). */
 int stin_narrow_i64_to_i32(const int64_t* src, int64_t n, int64_t limit, int32_t* dst, int32_t* bad,
                            stin_stream_t stream);

@@ -1,11 +1,17 @@
-// COO -> CSR graph-plan construction on the GPU (once per sample): a counting sort.
-//   1. count    : integer atomicAdd histogram of the keys (result independent of arrival order)
-//   2. scan     : one rocPRIM inclusive scan -> row pointers
-//   3. fill     : atomic cursor per row drops each pair id into its row (arrival order arbitrary)
-//   4. rank     : every slot finds its rank among the pair ids of its row and moves there
-//                 => within a row entries are in ORIGINAL pair order, exactly a stable sort,
-//                 deterministic although steps 1 and 3 use atomics.
-// Both CSRs of an edge set (by destination and by source) are built by the same launches.
+// COO -> CSR graph-plan construction on the GPU (once per sample): a counting sort, for ALL structures of a sample at once.
+//   1. count : one returning integer atomicAdd per (edge, side): the arrival index of the edge in its row + the histogram
+//   2. scan  : one rocPRIM inclusive scan over the concatenated histograms of every job -> row pointers
+//   3. rows  : row pointers / 1 / max(1, degree) of every job
+//   4. fill  : every edge drops its id at rowptr[row] + arrival index (plain stores, no second pass of atomics)
+//   5. rank  : every edge finds the rank of its id among the ids of its row and writes the final entry there
+//              => within a row entries are in ORIGINAL pair order, exactly a stable sort, deterministic although step 1
+//              uses atomics; for an edge set the same thread places the edge in BOTH CSRs, so the cross map
+//              xslot[source-CSR slot] = destination-CSR slot and w_src come out of the same kernel.
+// A JOB is one CSR (pool map: children of each coarse vertex, optionally with the int64 -> int32 narrowing of the trace) or
+// both CSRs of one directed edge set.  Round 3: the 7 edge sets and 2 pool maps of a 3-level sample are ONE batch = 7
+// launches (memset, count, scan x 2, rows, fill, rank) where rounds 1-2 ran ~8 launches per structure (72 per sample),
+// the atomic passes are halved (one returning atomic per edge and side instead of a histogram pass plus a cursor pass),
+// and the small coarse-level builds fill the chip together instead of one after the other.
 // Contract: include/stin_hip.h.
 #include <cstring>
 #include <cstdlib>
@@ -16,128 +22,114 @@ namespace {
 
 constexpr int T = 256;
 
-// sides: 0 = group by a[e] with value b[e]; 1 (pair mode only) = group by b[e] with value a[e].
-__global__ void k_count(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t E, int64_t N,
-                        int64_t b_limit, int pair, int32_t* __restrict__ cnt, int32_t* __restrict__ bad) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    int64_t ka = a[e];
-    bool oob = (ka < 0) | (ka >= N);
+struct Batch {
+    stin_plan_job_t j[STIN_PLAN_MAX_JOBS];
+    int64_t e_off[STIN_PLAN_MAX_JOBS + 1];        // first global edge index of job i (prefix sums of E): index into the scratch arrays
+    int64_t c_off[STIN_PLAN_MAX_JOBS + 1];        // first counter of job i: the job owns sides * N + 1 counters, [0] stays 0
+    unsigned e_blk[STIN_PLAN_MAX_JOBS + 1];       // first BLOCK of job i in the per-edge launches (every block serves one job:
+    unsigned c_blk[STIN_PLAN_MAX_JOBS + 1];       //   the job lookup is wave-uniform = scalar loads), and in the per-counter launch
+    int n;
+};
+
+// block -> job (n <= 16: a scan over kernel-argument scalars, uniform for the whole block)
+__device__ __forceinline__ int job_of(const unsigned* blk, int n) {
+    int i = 0;
+#pragma unroll 1
+    while (i + 1 < n && blockIdx.x >= blk[i + 1]) ++i;
+    return i;
+}
+
+__global__ __launch_bounds__(T) void k_count(const Batch b, int32_t* __restrict__ cnt, int32_t* __restrict__ pos0,
+                                             int32_t* __restrict__ pos1, int32_t* __restrict__ bad) {
+    const int ji = job_of(b.e_blk, b.n);
+    const stin_plan_job_t& J = b.j[ji];
+    const int64_t e = (int64_t)(blockIdx.x - b.e_blk[ji]) * T + threadIdx.x;
+    if (e >= J.E) return;
+    const int64_t g = b.e_off[ji] + e;
+    const int64_t ka = J.a[e];
+    bool oob = (ka < 0) | (ka >= J.N);
     int64_t kb = 0;
-    if (b != nullptr) {
-        kb = b[e];
-        oob |= (kb < 0) | (kb >= b_limit);
+    if (J.b != nullptr) {
+        kb = J.b[e];
+        oob |= (kb < 0) | (kb >= J.b_limit);
     }
+    if (J.narrow_out != nullptr) J.narrow_out[e] = oob ? 0 : (int32_t)ka;
     if (oob) {
         if (bad != nullptr) atomicOr(bad, 1);
-        return;                      // dropped from the plan; the host raises IndexError before using it
+        pos0[g] = -1;                 // dropped from the plan; the host raises IndexError before using it
+        return;
     }
-    atomicAdd(&cnt[1 + ka], 1);
-    if (pair) atomicAdd(&cnt[1 + N + kb], 1);
+    int32_t* c = cnt + b.c_off[ji];
+    pos0[g] = atomicAdd(&c[1 + ka], 1);
+    if (J.pair) pos1[g] = atomicAdd(&c[1 + J.N + kb], 1);
 }
 
-// cnt (inclusive-scanned, cnt[0] = 0) -> rowptr(s), cursors, inv_deg
-__global__ void k_rows(const int32_t* __restrict__ scanned, int64_t N, int pair, int32_t* __restrict__ rowptr0,
-                       int32_t* __restrict__ rowptr1, int32_t* __restrict__ cursor, float* __restrict__ inv_deg0,
-                       float* __restrict__ inv_deg1) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n > N) return;
-    const int32_t p0 = scanned[n];
-    rowptr0[n] = p0;
-    if (n < N) {
-        cursor[n] = p0;
-        if (inv_deg0 != nullptr) {
-            const int32_t d = scanned[n + 1] - p0;
-            inv_deg0[n] = 1.0f / (float)(d > 0 ? d : 1);
+// scanned histograms -> rowptr(s), inv_deg
+__global__ __launch_bounds__(T) void k_rows(const Batch b, const int32_t* __restrict__ scanned) {
+    const int ji = job_of(b.c_blk, b.n);
+    const stin_plan_job_t& J = b.j[ji];
+    int64_t n = (int64_t)(blockIdx.x - b.c_blk[ji]) * T + threadIdx.x;      // 0 .. sides * N
+    if (n > (J.pair ? 2 : 1) * J.N) return;
+    const int32_t* s = scanned + b.c_off[ji];
+    const int32_t base = s[0];                         // everything counted by earlier jobs
+    if (n <= J.N) {
+        const int32_t p0 = s[n] - base;
+        J.rowptr0[n] = p0;
+        if (n < J.N && J.inv_deg0 != nullptr) {
+            const int32_t d = s[n + 1] - base - p0;
+            J.inv_deg0[n] = 1.0f / (float)(d > 0 ? d : 1);
         }
     }
-    if (pair) {
-        const int32_t total0 = scanned[N];
-        const int32_t p1 = scanned[N + n] - total0;
-        rowptr1[n] = p1;
-        if (n < N) {
-            cursor[N + n] = p1;
-            if (inv_deg1 != nullptr) {
-                const int32_t d = scanned[N + n + 1] - total0 - p1;
-                inv_deg1[n] = 1.0f / (float)(d > 0 ? d : 1);
-            }
-        }
+    if (J.pair && n >= J.N) {                          // side 1 shares counter N (= total of side 0) as its zero
+        n -= J.N;
+        J.rowptr1[n] = s[J.N + n] - s[J.N];
     }
 }
 
-__global__ void k_fill(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t E, int64_t N,
-                       int64_t b_limit, int pair, int32_t* __restrict__ cursor, int32_t* __restrict__ tmp_id0,
-                       int32_t* __restrict__ tmp_key0, int32_t* __restrict__ tmp_id1, int32_t* __restrict__ tmp_key1) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    const int64_t ka = a[e];
-    const int64_t kb = b != nullptr ? b[e] : 0;
-    if (ka < 0 || ka >= N || (b != nullptr && (kb < 0 || kb >= b_limit))) return;
-    const int32_t s0 = atomicAdd(&cursor[ka], 1);
-    tmp_id0[s0] = (int32_t)e;
-    tmp_key0[s0] = (int32_t)ka;
-    if (pair) {
-        const int32_t s1 = atomicAdd(&cursor[N + kb], 1);
-        tmp_id1[s1] = (int32_t)e;
-        tmp_key1[s1] = (int32_t)kb;
-    }
+__global__ __launch_bounds__(T) void k_fill(const Batch b, const int32_t* __restrict__ pos0, const int32_t* __restrict__ pos1,
+                                            int32_t* __restrict__ id0, int32_t* __restrict__ id1) {
+    const int ji = job_of(b.e_blk, b.n);
+    const stin_plan_job_t& J = b.j[ji];
+    const int64_t e = (int64_t)(blockIdx.x - b.e_blk[ji]) * T + threadIdx.x;
+    if (e >= J.E) return;
+    const int64_t eo = b.e_off[ji], g = eo + e;
+    const int32_t p0 = pos0[g];
+    if (p0 < 0) return;
+    id0[eo + J.rowptr0[J.a[e]] + p0] = (int32_t)e;
+    if (J.pair) id1[eo + J.rowptr1[J.b[e]] + pos1[g]] = (int32_t)e;
 }
 
-// slot t of side `side`: rank of its pair id within its row -> final position
-__global__ void k_rank(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t N, int64_t n_slots0,
-                       int64_t n_slots1, const int32_t* __restrict__ rowptr0, const int32_t* __restrict__ rowptr1,
-                       const int32_t* __restrict__ tmp_id0, const int32_t* __restrict__ tmp_key0,
-                       const int32_t* __restrict__ tmp_id1, const int32_t* __restrict__ tmp_key1,
-                       int32_t* __restrict__ col0, int32_t* __restrict__ perm0, int32_t* __restrict__ col1,
-                       int32_t* __restrict__ perm1, int32_t* __restrict__ slot_of_edge) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int side = 0;
-    if (t >= n_slots0) {
-        t -= n_slots0;
-        side = 1;
-        if (t >= n_slots1) return;
-    }
-    const int32_t* ids = side ? tmp_id1 : tmp_id0;
-    const int32_t* keys = side ? tmp_key1 : tmp_key0;
-    const int32_t* rowptr = side ? rowptr1 : rowptr0;
-    if (t >= rowptr[N]) return;      // fewer slots than pairs when out-of-range pairs were dropped
-    const int32_t row = keys[t];
-    const int32_t beg = rowptr[row], end = rowptr[row + 1];
-    const int32_t mine = ids[t];
+__device__ __forceinline__ int32_t rank_in_row(const int32_t* __restrict__ ids, int32_t beg, int32_t end, int32_t mine) {
     int32_t rank = 0;
     for (int32_t u = beg; u < end; ++u) rank += (ids[u] < mine) ? 1 : 0;
-    const int32_t pos = beg + rank;
-    int32_t* col = side ? col1 : col0;
-    int32_t* perm = side ? perm1 : perm0;
+    return rank;
+}
+
+__global__ __launch_bounds__(T) void k_rank(const Batch b, const int32_t* __restrict__ pos0, const int32_t* __restrict__ id0,
+                                            const int32_t* __restrict__ id1) {
+    const int ji = job_of(b.e_blk, b.n);
+    const stin_plan_job_t& J = b.j[ji];
+    const int64_t e64 = (int64_t)(blockIdx.x - b.e_blk[ji]) * T + threadIdx.x;
+    if (e64 >= J.E) return;
+    const int64_t eo = b.e_off[ji];
+    if (pos0[eo + e64] < 0) return;
+    const int32_t e = (int32_t)e64;
+    const int64_t ka = J.a[e];
+    const int32_t beg0 = J.rowptr0[ka];
+    const int32_t slot0 = beg0 + rank_in_row(id0 + eo, beg0, J.rowptr0[ka + 1], e);
     // value stored with the entry: the OTHER endpoint (or the pair id itself when there is no value array)
-    const int64_t* other = side ? a : b;
-    col[pos] = other != nullptr ? (int32_t)other[mine] : mine;
-    if (perm != nullptr) perm[pos] = mine;
-    if (side == 0 && slot_of_edge != nullptr) slot_of_edge[mine] = pos;
-}
-
-// xslot[src-CSR slot] = dst-CSR slot of the same edge (slot_of_edge is the inverse of the dst-side perm)
-// and w_src[src-CSR slot] = 1 / max(1, in-degree of that edge's target): sequential weights for the dB pass
-__global__ void k_xslot(const int32_t* __restrict__ perm_src, const int32_t* __restrict__ slot_of_edge, int64_t E,
-                        const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ col_src,
-                        const float* __restrict__ inv_deg_dst, int64_t N, int32_t* __restrict__ xslot,
-                        float* __restrict__ w_src) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= E || t >= rowptr_src[N]) return;
-    xslot[t] = slot_of_edge[perm_src[t]];
-    if (w_src != nullptr) w_src[t] = inv_deg_dst[col_src[t]];
-}
-
-__global__ void k_narrow(const int64_t* __restrict__ src, int64_t n, int64_t limit, int32_t* __restrict__ dst,
-                         int32_t* __restrict__ bad) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int64_t v = src[i];
-    if (v < 0 || v >= limit) {
-        if (bad != nullptr) atomicOr(bad, 1);
-        v = 0;
+    const int64_t kb = J.b != nullptr ? J.b[e] : 0;
+    J.col0[slot0] = J.b != nullptr ? (int32_t)kb : e;
+    if (J.perm0 != nullptr) J.perm0[slot0] = e;
+    if (J.pair) {
+        const int32_t beg1 = J.rowptr1[kb];
+        const int32_t slot1 = beg1 + rank_in_row(id1 + eo, beg1, J.rowptr1[kb + 1], e);
+        J.col1[slot1] = (int32_t)ka;
+        // cross map for the masked backward: the destination-CSR slot of the edge at this source-CSR slot, and the mean
+        // weight of the edge's target laid out sequentially for the dB pass
+        if (J.xslot != nullptr) J.xslot[slot1] = slot0;
+        if (J.w_src != nullptr) J.w_src[slot1] = J.inv_deg0[ka];
     }
-    dst[i] = (int32_t)v;
 }
 
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -151,92 +143,118 @@ size_t scan_temp_bytes(int64_t n) {
 }
 
 struct Layout {
-    size_t cnt, cursor, id0, key0, id1, key1, x0, x1, scan, total;
+    size_t cnt, pos0, pos1, id0, id1, scan, total;
 };
-
-Layout layout(int64_t E, int64_t N, int pair) {
+Layout layout(int64_t total_E, int64_t total_cnt) {
     Layout L;
-    const size_t sides = pair ? 2 : 1;
-    const size_t e = (size_t)(E > 0 ? E : 1);
+    const size_t e = (size_t)(total_E > 0 ? total_E : 1), c = (size_t)(total_cnt > 0 ? total_cnt : 1);
     size_t off = 0;
-    L.cnt = off;    off += align_up((sides * N + 2) * sizeof(int32_t));
-    L.cursor = off; off += align_up((sides * N + 2) * sizeof(int32_t));
-    L.id0 = off;    off += align_up(e * sizeof(int32_t));
-    L.key0 = off;   off += align_up(e * sizeof(int32_t));
-    L.id1 = off;    off += pair ? align_up(e * sizeof(int32_t)) : 0;
-    L.key1 = off;   off += pair ? align_up(e * sizeof(int32_t)) : 0;
-    L.x0 = off;     off += pair ? align_up(e * sizeof(int32_t)) : 0;
-    L.x1 = off;     off += pair ? align_up(e * sizeof(int32_t)) : 0;
-    L.scan = off;   off += align_up(scan_temp_bytes((int64_t)(sides * N + 1)));
+    L.cnt = off;  off += align_up(c * sizeof(int32_t));
+    L.pos0 = off; off += align_up(e * sizeof(int32_t));
+    L.pos1 = off; off += align_up(e * sizeof(int32_t));
+    L.id0 = off;  off += align_up(e * sizeof(int32_t));
+    L.id1 = off;  off += align_up(e * sizeof(int32_t));
+    L.scan = off; off += align_up(scan_temp_bytes((int64_t)c));
     L.total = off + 256;
     return L;
 }
 
-int build(const int64_t* a, const int64_t* b, int64_t E, int64_t N, int64_t b_limit, int pair, int32_t* rowptr0,
-          int32_t* col0, int32_t* perm0, float* inv_deg0, int32_t* rowptr1, int32_t* col1, int32_t* perm1,
-          float* inv_deg1, int32_t* xslot, float* w_src, int32_t* bad, void* workspace, size_t workspace_bytes,
-          hipStream_t stream) {
-    const Layout L = layout(E, N, pair);
+int check_job(const stin_plan_job_t& J) {
+    STIN_REQUIRE(J.E >= 0 && J.N >= 0 && J.N < ((int64_t)1 << 30) && J.E < ((int64_t)1 << 30), STIN_E_SIZE);
+    STIN_REQUIRE(J.rowptr0 != nullptr && (J.E == 0 || (J.a != nullptr && J.col0 != nullptr)), STIN_E_NULL);
+    if (J.b != nullptr) STIN_REQUIRE(J.b_limit >= 0 && J.b_limit < ((int64_t)1 << 31), STIN_E_SIZE);
+    if (J.pair) {
+        STIN_REQUIRE(J.rowptr1 != nullptr && (J.E == 0 || (J.b != nullptr && J.col1 != nullptr)), STIN_E_NULL);
+        STIN_REQUIRE(J.w_src == nullptr || (J.xslot != nullptr && J.inv_deg0 != nullptr), STIN_E_NULL);
+    }
+    return STIN_OK;
+}
+
+int build(const stin_plan_job_t* jobs, int n_jobs, int32_t* bad, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    STIN_REQUIRE(n_jobs >= 0 && n_jobs <= STIN_PLAN_MAX_JOBS, STIN_E_SIZE);
+    if (n_jobs == 0) return STIN_OK;
+    STIN_REQUIRE(jobs != nullptr && workspace != nullptr, STIN_E_NULL);
+    Batch b;
+    b.n = n_jobs;
+    b.e_off[0] = b.c_off[0] = 0;
+    b.e_blk[0] = b.c_blk[0] = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const int rc = check_job(jobs[i]);
+        if (rc != STIN_OK) return rc;
+        b.j[i] = jobs[i];
+        const int64_t counters = (jobs[i].pair ? 2 : 1) * jobs[i].N + 1;
+        b.e_off[i + 1] = b.e_off[i] + jobs[i].E;
+        b.c_off[i + 1] = b.c_off[i] + counters;
+        b.e_blk[i + 1] = b.e_blk[i] + grid_for(jobs[i].E);
+        b.c_blk[i + 1] = b.c_blk[i] + grid_for(counters);
+    }
+    for (int i = n_jobs; i < STIN_PLAN_MAX_JOBS; ++i) {
+        memset(&b.j[i], 0, sizeof(stin_plan_job_t));
+        b.e_off[i + 1] = b.e_off[n_jobs];
+        b.c_off[i + 1] = b.c_off[n_jobs];
+        b.e_blk[i + 1] = b.e_blk[n_jobs];
+        b.c_blk[i + 1] = b.c_blk[n_jobs];
+    }
+    const int64_t total_E = b.e_off[n_jobs], total_cnt = b.c_off[n_jobs];
+    STIN_REQUIRE(total_E < ((int64_t)1 << 31) && total_cnt < ((int64_t)1 << 31), STIN_E_SIZE);
+    const Layout L = layout(total_E, total_cnt);
     STIN_REQUIRE(workspace_bytes >= L.total, STIN_E_WORKSPACE);
     char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     int32_t* cnt = reinterpret_cast<int32_t*>(ws + L.cnt);
-    int32_t* cursor = reinterpret_cast<int32_t*>(ws + L.cursor);
+    int32_t* pos0 = reinterpret_cast<int32_t*>(ws + L.pos0);
+    int32_t* pos1 = reinterpret_cast<int32_t*>(ws + L.pos1);
     int32_t* id0 = reinterpret_cast<int32_t*>(ws + L.id0);
-    int32_t* key0 = reinterpret_cast<int32_t*>(ws + L.key0);
     int32_t* id1 = reinterpret_cast<int32_t*>(ws + L.id1);
-    int32_t* key1 = reinterpret_cast<int32_t*>(ws + L.key1);
-    const int64_t sides = pair ? 2 : 1;
-    const int64_t n_cnt = sides * N + 1;
 
-    hipError_t err = hipMemsetAsync(cnt, 0, (size_t)n_cnt * sizeof(int32_t), stream);
+    hipError_t err = hipMemsetAsync(cnt, 0, (size_t)total_cnt * sizeof(int32_t), stream);
     if (err != hipSuccess) return (int)err;
-    if (E > 0) hipLaunchKernelGGL(k_count, dim3(grid_for(E)), dim3(T), 0, stream, a, b, E, N, b_limit, pair, cnt, bad);
-    size_t scan_bytes = scan_temp_bytes(n_cnt);
-    err = rocprim::inclusive_scan(ws + L.scan, scan_bytes, cnt, cnt, (size_t)n_cnt, rocprim::plus<int32_t>(), stream);
+    const unsigned e_blocks = b.e_blk[n_jobs], c_blocks = b.c_blk[n_jobs];
+    if (e_blocks > 0) hipLaunchKernelGGL(k_count, dim3(e_blocks), dim3(T), 0, stream, b, cnt, pos0, pos1, bad);
+    size_t scan_bytes = scan_temp_bytes(total_cnt);
+    err = rocprim::inclusive_scan(ws + L.scan, scan_bytes, cnt, cnt, (size_t)total_cnt, rocprim::plus<int32_t>(), stream);
     if (err != hipSuccess) return (int)err;
-    hipLaunchKernelGGL(k_rows, dim3(grid_for(N + 1)), dim3(T), 0, stream, cnt, N, pair, rowptr0, rowptr1, cursor,
-                       inv_deg0, inv_deg1);
-    if (E > 0) {
-        hipLaunchKernelGGL(k_fill, dim3(grid_for(E)), dim3(T), 0, stream, a, b, E, N, b_limit, pair, cursor, id0, key0, id1,
-                           key1);
-        // out-of-range pairs were dropped, so the slot counts are the scanned totals; over-launch with E per side and
-        // let the kernel stop at the true totals (read from rowptr[N] would need a sync): slots beyond the total
-        // hold stale ids, so bound the grid by E and guard by row ranges instead.
-        // cross-slot map for the masked backward: reuse the (now dead) fill buffers key0 / key1 as
-        // slot_of_edge / perm_src
-        int32_t* slot_of_edge = xslot != nullptr ? key0 + 0 : nullptr;
-        int32_t* perm_src = xslot != nullptr ? key1 : perm1;
-        if (xslot != nullptr) {
-            // key0/key1 are still read by k_rank: use id-free scratch instead -> the cursor array (2N+2 ints) is too
-            // small, so take dedicated space appended to the workspace layout
-            slot_of_edge = reinterpret_cast<int32_t*>(ws + L.x0);
-            perm_src = reinterpret_cast<int32_t*>(ws + L.x1);
-        }
-        hipLaunchKernelGGL(k_rank, dim3(grid_for(sides * E)), dim3(T), 0, stream, a, b, N, E, pair ? E : 0, rowptr0, rowptr1,
-                           id0, key0, id1, key1, col0, perm0, col1, perm_src, slot_of_edge);
-        if (xslot != nullptr)
-            hipLaunchKernelGGL(k_xslot, dim3(grid_for(E)), dim3(T), 0, stream, perm_src, slot_of_edge, E, rowptr1, col1, inv_deg0, N,
-                               xslot, w_src);
+    hipLaunchKernelGGL(k_rows, dim3(c_blocks), dim3(T), 0, stream, b, cnt);
+    if (e_blocks > 0) {
+        hipLaunchKernelGGL(k_fill, dim3(e_blocks), dim3(T), 0, stream, b, pos0, pos1, id0, id1);
+        hipLaunchKernelGGL(k_rank, dim3(e_blocks), dim3(T), 0, stream, b, pos0, id0, id1);
     }
     return stin_launch_status();
 }
 
 }  // namespace
 
+extern "C" size_t stin_plan_build_workspace_bytes(int64_t total_E, int64_t total_counters) {
+    if (total_E < 0 || total_counters < 0) return 0;
+    return layout(total_E, total_counters).total;
+}
+
+extern "C" int stin_plan_build_many(const stin_plan_job_t* jobs, int n_jobs, int32_t* bad, void* workspace, size_t workspace_bytes,
+                                    stin_stream_t stream) {
+    stin_clear_stale_error();
+    return build(jobs, n_jobs, bad, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 extern "C" size_t stin_csr_workspace_bytes(int64_t E, int64_t N) {
     if (E < 0 || N < 0) return 0;
-    return layout(E, N, 1).total;   // sized for the pair build (covers the single build)
+    return layout(E, 2 * N + 1).total;   // sized for the pair build (covers the single build)
 }
 
 extern "C" int stin_csr_from_coo_i64(const int64_t* key, const int64_t* val, int64_t E, int64_t N, int64_t val_limit,
                                      int32_t* rowptr, int32_t* col, int32_t* perm, float* inv_deg, int32_t* bad,
                                      void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
     stin_clear_stale_error();
-    STIN_REQUIRE(E >= 0 && N >= 0 && N < ((int64_t)1 << 30) && E < ((int64_t)1 << 30), STIN_E_SIZE);
-    STIN_REQUIRE(rowptr != nullptr && workspace != nullptr && (E == 0 || (key != nullptr && col != nullptr)), STIN_E_NULL);
-    if (val != nullptr) STIN_REQUIRE(val_limit >= 0 && val_limit < ((int64_t)1 << 31), STIN_E_SIZE);
-    return build(key, val, E, N, val_limit, 0, rowptr, col, perm, inv_deg, nullptr, nullptr, nullptr, nullptr, nullptr,
-                 nullptr, bad, workspace, workspace_bytes, (hipStream_t)stream_);
+    stin_plan_job_t J;
+    memset(&J, 0, sizeof(J));
+    J.a = key;
+    J.b = val;
+    J.E = E;
+    J.N = N;
+    J.b_limit = val_limit;
+    J.rowptr0 = rowptr;
+    J.col0 = col;
+    J.perm0 = perm;
+    J.inv_deg0 = inv_deg;
+    return build(&J, 1, bad, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 extern "C" int stin_csr_pair_from_edges_i64(const int64_t* src, const int64_t* dst, int64_t E, int64_t N,
@@ -245,13 +263,38 @@ extern "C" int stin_csr_pair_from_edges_i64(const int64_t* src, const int64_t* d
                                             int32_t* bad, void* workspace, size_t workspace_bytes,
                                             stin_stream_t stream_) {
     stin_clear_stale_error();
-    STIN_REQUIRE(E >= 0 && N >= 0 && N < ((int64_t)1 << 30) && E < ((int64_t)1 << 30), STIN_E_SIZE);
-    STIN_REQUIRE(rowptr_dst && rowptr_src && workspace && (E == 0 || (src && dst && col_dst && col_src)), STIN_E_NULL);
-    STIN_REQUIRE(w_src == nullptr || (xslot != nullptr && inv_deg_dst != nullptr), STIN_E_NULL);
     // side 0 groups by dst (value = src), side 1 groups by src (value = dst)
-    return build(dst, src, E, N, N, 1, rowptr_dst, col_dst, nullptr, inv_deg_dst, rowptr_src, col_src, nullptr, nullptr,
-                 xslot, w_src, bad, workspace, workspace_bytes, (hipStream_t)stream_);
+    stin_plan_job_t J;
+    memset(&J, 0, sizeof(J));
+    J.a = dst;
+    J.b = src;
+    J.E = E;
+    J.N = N;
+    J.b_limit = N;
+    J.pair = 1;
+    J.rowptr0 = rowptr_dst;
+    J.col0 = col_dst;
+    J.inv_deg0 = inv_deg_dst;
+    J.rowptr1 = rowptr_src;
+    J.col1 = col_src;
+    J.xslot = xslot;
+    J.w_src = w_src;
+    return build(&J, 1, bad, workspace, workspace_bytes, (hipStream_t)stream_);
 }
+
+namespace {
+__global__ void k_narrow(const int64_t* __restrict__ src, int64_t n, int64_t limit, int32_t* __restrict__ dst,
+                         int32_t* __restrict__ bad) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t v = src[i];
+    if (v < 0 || v >= limit) {
+        if (bad != nullptr) atomicOr(bad, 1);
+        v = 0;
+    }
+    dst[i] = (int32_t)v;
+}
+}  // namespace
 
 extern "C" int stin_narrow_i64_to_i32(const int64_t* src, int64_t n, int64_t limit, int32_t* dst, int32_t* bad,
                                       stin_stream_t stream_) {

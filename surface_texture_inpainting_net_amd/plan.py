@@ -11,6 +11,8 @@ object, shared by all blocks of a level:
 Indices are int64 at the Python boundary (as in the reference) and int32 inside.
 """
 import collections
+import ctypes
+import struct
 
 import torch
 
@@ -90,9 +92,41 @@ class CSR:
         self.n_rows, self.n_entries = n_rows, n_entries
 
 
-def build_csr(key, val, n_rows, val_limit, bad, want_perm=False):
-    """key/val: int64 device tensors [E] (val may be None) -> CSR grouped by key."""
-    lib = _lib.load()
+_JOB = struct.Struct('<2Q3q3QQ3QQQ2i')     # stin_plan_job_t (include/stin_hip.h): 120 bytes
+JOBS_MAX = 16                              # STIN_PLAN_MAX_JOBS
+
+
+class PlanJobs:
+    """CSR builds collected for ONE batched launch sequence (stin_plan_build_many: 7 launches for all of them)."""
+
+    def __init__(self):
+        self.blobs, self.total_e, self.total_cnt, self.keep = [], 0, 0, []
+
+    def add(self, a, b, E, N, b_limit, pair, rowptr0, col0, perm0, inv_deg0, rowptr1=None, col1=None, xslot=None, w_src=None,
+            narrow_out=None):
+        self.blobs.append(_JOB.pack(_ptr(a), _ptr(b), E, N, b_limit, _ptr(rowptr0), _ptr(col0), _ptr(perm0), _ptr(inv_deg0),
+                                    _ptr(rowptr1), _ptr(col1), _ptr(xslot), _ptr(w_src), _ptr(narrow_out), int(pair), 0))
+        self.total_e += E
+        self.total_cnt += (2 if pair else 1) * N + 1
+        self.keep.append((a, b))                 # contiguous copies of the index rows must outlive the launches
+
+    def run(self, bad, device):
+        """Enqueue the builds on torch's current stream of `device`."""
+        if not self.blobs:
+            return
+        lib = _lib.load()
+        for i in range(0, len(self.blobs), JOBS_MAX):
+            chunk = self.blobs[i:i + JOBS_MAX]
+            ws_bytes = lib.stin_plan_build_workspace_bytes(self.total_e, self.total_cnt)     # (upper bound for a chunk)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+            buf = ctypes.create_string_buffer(b''.join(chunk), len(chunk) * _JOB.size)
+            _lib.check(lib.stin_plan_build_many(buf, len(chunk), _ptr(bad), _ptr(ws), ws_bytes, _stream(ws)), 'stin_plan_build_many')
+        self.blobs, self.keep = [], []
+
+
+def build_csr(key, val, n_rows, val_limit, bad, want_perm=False, jobs=None):
+    """key/val: int64 device tensors [E] (val may be None) -> CSR grouped by key.  jobs: a PlanJobs to add the build to
+    (the caller runs it); None = build now."""
     assert key.dtype == torch.int64 and key.is_cuda and key.is_contiguous()
     E = key.numel()
     dev = key.device
@@ -100,22 +134,22 @@ def build_csr(key, val, n_rows, val_limit, bad, want_perm=False):
     col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev) if want_perm else None
     inv_deg = torch.empty(max(n_rows, 1), dtype=torch.float32, device=dev)
-    ws_bytes = lib.stin_csr_workspace_bytes(E, n_rows)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     if val is not None:
         assert val.dtype == torch.int64 and val.is_contiguous() and val.numel() == E
-    _lib.check(lib.stin_csr_from_coo_i64(_ptr(key), _ptr(val), E, n_rows, val_limit, _ptr(rowptr), _ptr(col),
-                                         _ptr(perm), _ptr(inv_deg), _ptr(bad), _ptr(ws), ws_bytes, _stream(key)),
-               'stin_csr_from_coo_i64')
+    own = jobs is None
+    if own:
+        jobs = PlanJobs()
+    jobs.add(key, val, E, n_rows, val_limit, 0, rowptr, col, perm, inv_deg)
+    if own:
+        jobs.run(bad, dev)
     return CSR(rowptr, col[:E], None if perm is None else perm[:E], inv_deg[:n_rows], n_rows, E)
 
 
 class EdgeSet:
     """One directed edge set of one level (edge_index[0] = source j, [1] = target i)."""
 
-    def __init__(self, edge_index, n, bad):
+    def __init__(self, edge_index, n, bad, jobs=None):
         assert edge_index.dim() == 2 and edge_index.shape[0] == 2, 'edge_index must be [2, E]'
-        lib = _lib.load()
         self.n = n
         src = edge_index[0].contiguous()
         dst = edge_index[1].contiguous()
@@ -130,12 +164,13 @@ class EdgeSet:
         xslot = idx[2 * (n + 1) + 2 * e1:]
         inv_deg = torch.empty(max(n, 1) + e1, dtype=torch.float32, device=dev)
         w_src = inv_deg[max(n, 1):]
-        ws_bytes = lib.stin_csr_workspace_bytes(E, n)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        _lib.check(lib.stin_csr_pair_from_edges_i64(_ptr(src), _ptr(dst), E, n, _ptr(rp_d), _ptr(col_d), _ptr(inv_deg),
-                                                    _ptr(rp_s), _ptr(col_s), _ptr(xslot), _ptr(w_src), _ptr(bad), _ptr(ws), ws_bytes,
-                                                    _stream(src)),
-                   'stin_csr_pair_from_edges_i64')
+        own = jobs is None
+        if own:
+            jobs = PlanJobs()
+        # side 0 groups by dst (value = src), side 1 groups by src (value = dst)
+        jobs.add(dst, src, E, n, n, 1, rp_d, col_d, None, inv_deg, rp_s, col_s, xslot, w_src)
+        if own:
+            jobs.run(bad, dev)
         self.by_dst = CSR(rp_d, col_d[:E], None, inv_deg[:n], n, E)     # rows = targets, col = sources
         self.by_src = CSR(rp_s, col_s[:E], None, None, n, E)            # rows = sources, col = targets
         self.inv_deg = self.by_dst.inv_deg                               # 1 / max(1, in-degree)
@@ -152,16 +187,25 @@ class EdgeSet:
 class PoolMap:
     """trace: fine vertex -> coarse vertex (hierarchy_trace_index_l)."""
 
-    def __init__(self, trace, n_fine, n_coarse, bad):
-        lib = _lib.load()
+    def __init__(self, trace, n_fine, n_coarse, bad, jobs=None):
         assert trace.numel() == n_fine
         trace = trace.contiguous()
+        assert trace.dtype == torch.int64 and trace.is_cuda
+        dev = trace.device
         self.n_fine, self.n_coarse = n_fine, n_coarse
-        self.children = build_csr(trace, None, n_coarse, n_fine, bad)   # col = fine ids, ascending
+        rowptr = torch.empty(n_coarse + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(max(n_fine, 1), dtype=torch.int32, device=dev)
+        inv_deg = torch.empty(max(n_coarse, 1), dtype=torch.float32, device=dev)
+        self.trace = torch.empty(max(n_fine, 1), dtype=torch.int32, device=dev)[:n_fine]
+        own = jobs is None
+        if own:
+            jobs = PlanJobs()
+        # children CSR (col = fine ids, ascending) and the int32 trace in the same counting pass
+        jobs.add(trace, None, n_fine, n_coarse, 0, 0, rowptr, col, None, inv_deg, narrow_out=self.trace)
+        if own:
+            jobs.run(bad, dev)
+        self.children = CSR(rowptr, col[:n_fine], None, inv_deg[:n_coarse], n_coarse, n_fine)
         self.inv_count = self.children.inv_deg
-        self.trace = torch.empty(max(n_fine, 1), dtype=torch.int32, device=trace.device)[:n_fine]
-        _lib.check(lib.stin_narrow_i64_to_i32(_ptr(trace), n_fine, n_coarse, _ptr(self.trace), _ptr(bad),
-                                              _stream(trace)), 'stin_narrow_i64_to_i32')
 
     def tensors(self):
         c = self.children
@@ -249,50 +293,64 @@ class GraphPlan:
         self._validated = False
         self._flag_host = None
 
+    def _todo(self, edge_items, pool_levels):
+        return ([('e', k, l) for (k, l) in edge_items if k not in self._edges] +
+                [('p', l, l) for l in pool_levels if l not in self._pools])
+
+    def _build_batch(self, todo):
+        """All listed structures as ONE batch of launches (PlanJobs) on torch's current stream -> the new objects."""
+        jobs, made = PlanJobs(), []
+        for kind, key, level in todo:
+            if kind == 'e':
+                ei = self._sample.edge_index if key == 'edge_index' else self._sample[key]
+                obj = self._edges[key] = EdgeSet(ei, self.level_sizes[level], self._bad, jobs)
+            else:
+                trace = self._sample['hierarchy_trace_index_%d' % level]
+                obj = self._pools[level] = PoolMap(trace, self.level_sizes[level - 1], self.level_sizes[level], self._bad, jobs)
+            made.append(obj)
+        jobs.run(self._bad, self.device)
+        self._validated = False
+        return made
+
+    def ensure(self, edge_items=(), pool_levels=()):
+        """Build whatever of the listed structures is still missing, as one batch on the current stream (forward() calls
+        this once instead of building each piece at its first use: 7 launches for a whole sample)."""
+        if self._pending:
+            self.join()
+        todo = self._todo(edge_items, pool_levels)
+        if todo:
+            self._build_batch(todo)
+        return self
+
     def prefetch(self, edge_items=(), pool_levels=(), inputs_ready=False, join=True, after=None):
-        """Build the listed edge sets [(key, level), ...] and pool maps [level, ...] NOW, side by side on a pool of HIP
-        streams, instead of one after the other at first use on the compute stream.  The compute stream then waits
-        for them once.  inputs_ready=True asserts that the sample's index tensors are already complete in memory (a
-        loader handed over resident tensors): the builds then do not wait for work still queued on the compute stream
-        and overlap with it (the previous step's tail); otherwise they start after everything queued so far.
-        after = an event the index tensors are complete at (a loader's upload stream): the builds wait for it instead.
-        join=False leaves the compute stream alone: it waits for the builds when the plan is first USED (a plan built
-        for the NEXT step while the current one is still being enqueued - TrainStep.prefetch)."""
-        todo = [('e', k, l) for (k, l) in edge_items if k not in self._edges]
-        todo += [('p', l, l) for l in pool_levels if l not in self._pools]
+        """Build the listed edge sets [(key, level), ...] and pool maps [level, ...] NOW as one batch on a side stream
+        instead of at first use on the compute stream.  inputs_ready=True asserts that the sample's index tensors are
+        already complete in memory (a loader handed over resident tensors): the build then does not wait for work still
+        queued on the compute stream and overlaps with it (the previous step's tail); otherwise it starts after
+        everything queued so far.  after = an event the index tensors are complete at (a loader's upload stream): the
+        build waits for it instead.  join=False leaves the compute stream alone: it waits for the build when the plan is
+        first USED (a plan built for the NEXT step while the current one is still being enqueued - TrainStep.prefetch).
+        (Rounds 1-2 spread ~72 small launches over four side streams; the batched build is 7 launches on one.)"""
+        todo = self._todo(edge_items, pool_levels)
         if not todo:
             return self
         if _capturing():                                  # captured step: built at first use on the captured stream
             return self
         main = torch.cuda.current_stream(self.device)
-        streams = _side_streams(self.device)
-        used = []
-        for i, (kind, key, level) in enumerate(todo):
-            s = streams[i % len(streams)]
-            if s not in used:
-                used.append(s)
-                if after is not None:
-                    s.wait_event(after)
-                    s.wait_event(self._bad_ready)
-                elif inputs_ready:
-                    s.wait_event(self._bad_ready)
-                else:
-                    s.wait_stream(main)
-            with torch.cuda.stream(s):
-                if kind == 'e':
-                    ei = self._sample.edge_index if key == 'edge_index' else self._sample[key]
-                    obj = self._edges[key] = EdgeSet(ei, self.level_sizes[level], self._bad)
-                else:
-                    trace = self._sample['hierarchy_trace_index_%d' % level]
-                    obj = self._pools[level] = PoolMap(trace, self.level_sizes[level - 1], self.level_sizes[level], self._bad)
+        s = _side_streams(self.device)[0]                 # (the stream the out-of-range flag was zeroed on)
+        if after is not None:
+            s.wait_event(after)
+        elif not inputs_ready:
+            s.wait_stream(main)
+        with torch.cuda.stream(s):
+            made = self._build_batch(todo)
+        for obj in made:
             for t in obj.tensors():
                 t.record_stream(main)            # allocated on s, consumed on the compute stream: defer reuse accordingly
         if join:
-            for s in used:
-                main.wait_stream(s)
+            main.wait_stream(s)
         else:
-            self._pending += [s.record_event() for s in used]
-        self._validated = False
+            self._pending.append(s.record_event())
         return self
 
     def join(self):

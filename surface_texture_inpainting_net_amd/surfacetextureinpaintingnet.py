@@ -292,6 +292,7 @@ class SurfaceTextureInpaintingNet(nn.Module):
         check_deferred()                                                      # deferred index checks of earlier calls
         plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm,      # pieces not prefetched are built at first use
                         validation=self.plan_validation)
+        plan.ensure(*self._plan_items())                                      # ONE batched build of whatever is missing
         num_levels = len(self.decoder_blocks) + 1
         out = sample.x
         if self.activation_dtype != out.dtype:

@@ -37,6 +37,26 @@ def _grid_mesh(rows, cols, rng):
     return n, src, dst, pos, nrm
 
 
+def _delaunay_mesh(n, rng):
+    """Irregular 2-manifold-like triangulation: the Delaunay triangulation of n uniformly random points of a square
+    (vertex degrees 3 ... ~14, mean ~6, standard deviation ~1.3 - the valence spread of a QEM-decimated scan, where the
+    jittered grid is 6-regular).  Same height field / normals as the grid mesh."""
+    from scipy.spatial import Delaunay
+    side = float(np.sqrt(n))
+    xy = rng.uniform(0.0, side, size=(n, 2))
+    tri = Delaunay(xy).simplices.astype(np.int64)
+    a = np.concatenate([tri[:, 0], tri[:, 1], tri[:, 2]])
+    b = np.concatenate([tri[:, 1], tri[:, 2], tri[:, 0]])
+    key = np.unique(np.concatenate([a * n + b, b * n + a]))          # symmetric, duplicates (shared triangle edges) removed
+    src, dst = key // n, key % n
+    pos = np.zeros((n, 3))
+    pos[:, :2] = xy
+    pos[:, 2] = 0.5 * np.sin(pos[:, 0] / 17.0) * np.cos(pos[:, 1] / 23.0) + rng.normal(0, 0.05, n)
+    nrm = np.stack([rng.normal(0, 0.1, n), rng.normal(0, 0.1, n), np.ones(n)], 1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return n, src, dst, pos, nrm
+
+
 def _group_by_source(src, dst):
     order = np.lexsort((dst, src))
     return src[order], dst[order]
@@ -121,14 +141,18 @@ def _dilated_edges(n, src, dst, pos, nrm, dilations):
 
 
 def make_synthetic_mesh(n0=200_000, levels=3, seed=0, dilations=(2, 4, 8, 16), permute=True,
-                        keep_ratio=0.3, masked_fraction=0.25, dtype=torch.float32):
+                        keep_ratio=0.3, masked_fraction=0.25, dtype=torch.float32, irregular=False):
     """-> HierarchicalBatch (CPU tensors) for ONE graph with ``levels`` graph levels.
 
     ``n0`` is rounded UP to a square grid (200 000 -> 448 x 448 = 200 704
-    vertices, 1 200 642 directed edges)."""
+    vertices, 1 200 642 directed edges).  irregular=True: the same vertex count on a Delaunay
+    triangulation of random points instead of the 6-regular jittered grid (degrees 3 ... ~14)."""
     rng = np.random.default_rng(seed)
     side = max(2, int(np.ceil(np.sqrt(n0))))
-    n, src, dst, pos, nrm = _grid_mesh(side, side, rng)
+    if irregular:
+        n, src, dst, pos, nrm = _delaunay_mesh(side * side, rng)
+    else:
+        n, src, dst, pos, nrm = _grid_mesh(side, side, rng)
     if permute:
         perm = rng.permutation(n)                 # new id of old vertex v = perm[v]
         inv = np.empty(n, dtype=np.int64)
