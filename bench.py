@@ -267,6 +267,72 @@ def irregular_edge_kernel(device, n0=200_000, h=128, iters=20):
             'note': 'stand-alone, fp32 rows, Delaunay mesh (synthetic.make_synthetic_mesh(irregular=True)); the headline mesh is 6-regular'}
 
 
+def rccl_debug_setup(rank):
+    """Before the process group exists: have RCCL log its setup (INFO: init, graph, tuning) into a per-process file, so that
+    the line can say which algorithm / protocol / channel count the gradient all-reduce ran with.
+    Nothing goes to stdout (ONE JSON line).  -> the log path of this process."""
+    import tempfile
+    os.environ.setdefault('NCCL_DEBUG', 'INFO')
+    os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,TUNING,ENV')
+    path = os.environ.get('NCCL_DEBUG_FILE')
+    if path is None:
+        path = os.path.join(tempfile.gettempdir(), 'stin_rccl_%d_rank%d.log' % (os.getppid(), rank))
+        os.environ['NCCL_DEBUG_FILE'] = path
+    return path
+
+
+def rccl_debug_parse(path, nbytes):
+    """What RCCL said about itself: version, channels, rings / trees, and the (algorithm, protocol) its tuner picked for the
+    gradient bucket's size.  Tolerant by design (the wording differs between RCCL releases): every figure is optional and
+    the matched lines ride along verbatim."""
+    import re
+    out = {'log': path, 'NCCL_ALGO': os.environ.get('NCCL_ALGO'), 'NCCL_PROTO': os.environ.get('NCCL_PROTO'),
+           'NCCL_MIN_NCHANNELS': os.environ.get('NCCL_MIN_NCHANNELS'), 'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS')}
+    try:
+        text = open(path, errors='replace').read()
+    except OSError:
+        out['note'] = 'no RCCL debug log found'
+        return out
+    lines = text.splitlines()
+    keep = []
+
+    def first(pattern, flags=re.I):
+        for ln in lines:
+            m = re.search(pattern, ln, flags)
+            if m:
+                keep.append(ln.strip()[:240])
+                return m
+        return None
+
+    m = first(r'(?:RCCL|NCCL) version ([^\s]+)')
+    out['version'] = m.group(1) if m else None
+    m = first(r'(\d+) coll channels')
+    out['coll_channels'] = int(m.group(1)) if m else None
+    chans = [ln for ln in lines if re.search(r'Channel \d+/\d+', ln)]
+    if chans:
+        m = re.search(r'Channel \d+/(\d+)', chans[0])
+        out['ring_channels'] = int(m.group(1))
+        keep.append(chans[0].strip()[:240])
+    out['rings_connected'] = first(r'Connected all rings') is not None
+    out['trees_connected'] = first(r'Connected all trees') is not None
+    # tuner decisions: "<bytes> Bytes -> Algo <a> proto <p> time <t>"; report the one closest to the bucket size
+    algo_names = {0: 'Tree', 1: 'Ring', 2: 'CollNetDirect', 3: 'CollNetChain', 4: 'NVLS', 5: 'NVLSTree'}
+    proto_names = {0: 'LL', 1: 'LL128', 2: 'Simple'}
+    best = None
+    for ln in lines:
+        m = re.search(r'(\d+) Bytes -> Algo (\d+) proto (\d+)', ln)
+        if m:
+            b = int(m.group(1))
+            if best is None or abs(b - nbytes) < abs(best[0] - nbytes):
+                best = (b, int(m.group(2)), int(m.group(3)), ln.strip()[:240])
+    if best is not None:
+        out['allreduce_tuning'] = {'bytes': best[0], 'algo': algo_names.get(best[1], best[1]), 'proto': proto_names.get(best[2], best[2])}
+        keep.append(best[3])
+    out['lines'] = keep[:12]
+    out['log_lines_total'] = len(lines)
+    return out
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -350,9 +416,11 @@ def main():
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
+    rccl_log = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.backend == 'nccl':
+            rccl_log = rccl_debug_setup(rank)
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
@@ -572,7 +640,9 @@ def main():
                                {'fwd': 'bf16', 'bwd': 'bf16', 'note': 'bf16 storage, one bf16 MFMA per k-step, fp32 accumulate'}),
             'distributed': {'world_size': world, 'backend': (dist.get_backend() if world > 1 else None),
                             'ranks_counted_by_allreduce': ranks_counted, 'ms_per_step_per_rank': rank_ms,
-                            'allreduce_us': allreduce_us, 'replicas_bit_identical': identical, 'cores_per_rank': cores_per_rank},
+                            'allreduce_us': allreduce_us, 'replicas_bit_identical': identical, 'cores_per_rank': cores_per_rank,
+                            'rccl': (rccl_debug_parse(rccl_log, step.bucket.flat.numel() * 4) if rccl_log else None),
+                            'allreduce_overlap_validated_on_hardware': False},
             'loss': float(loss),
             'host_enqueue_ms_per_step': dt_enqueue / args.steps * 1e3,   # < ms_per_step: the GPU, not the host, bounds the step
             'fwd_loss_bwd_only': None if args.no_secondary else {

@@ -442,8 +442,16 @@ class TrainStep:
     (least recently used dropped), all in one memory pool."""
 
     def __init__(self, model, lr=7e-5, weight_decay=0.0, amsgrad=True, use_mask_weighted_loss=True, group=None,
-                 accumulate=1, overlap_allreduce_min_bytes=32 << 20, time_allreduce=False, graph=False, graph_cache=8):
+                 accumulate=1, overlap_allreduce_min_bytes=None, time_allreduce=False, graph=False, graph_cache=8,
+                 loss_fn=None):
         self.model = model
+        # loss_fn(model, sample) -> scalar loss: any other objective on the same flat-bucket / all-reduce / Adam step, e.g. the
+        # segmentation trainer's cross entropy around SingleConvMeshNet (trainers/segmentation_trainer.py:139-148 - the
+        # reference's only multi-GPU user).  None = the inpainting trainer's masked weighted L1 (the fused HIP loss kernel).
+        self.loss_fn = loss_fn
+        # overlap_allreduce_min_bytes (e.g. 32 << 20): reduce the bucket in segments of at least that size while backward is
+        # still running (FlatGradBucket.enable_overlap).  OPT-IN since round 3: the path is tested bit-for-bit against the
+        # single tail all-reduce with two gloo ranks on one GPU, but has never run over RCCL on more than one GPU.
         self.group = group
         self.use_mask_weighted_loss = use_mask_weighted_loss
         self.accumulate = max(1, int(accumulate))
@@ -496,7 +504,9 @@ class TrainStep:
         """One forward + loss + backward; the bucket then holds d(loss * grad_scale)/dw of THIS sample."""
         self.bucket.detach_grads()
         try:
-            if self.on_gpu:
+            if self.loss_fn is not None:
+                loss = self.loss_fn(self.model, sample)
+            elif self.on_gpu:
                 from . import functional as SF
                 loss = SF.masked_l1_loss(self.model(sample), sample.color, sample.mask, self.use_mask_weighted_loss)
             else:

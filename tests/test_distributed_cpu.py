@@ -77,3 +77,58 @@ def test_flat_bucket_views_survive_zero_grad():
     lin.zero_grad(set_to_none=True)
     b.zero()
     assert lin.weight.grad is not None and float(b.flat.abs().sum()) == 0.0
+
+
+SCMN = dict(feature_number=10, num_propagation_steps=1, filter_sizes=[8, 12], num_classes=4)
+
+
+def _xent(model, sample):
+    """The segmentation trainer's objective (trainers/segmentation_trainer.py:139-148): cross entropy of the per-vertex
+    class scores against data.labels."""
+    return torch.nn.functional.cross_entropy(model(sample), sample.labels)
+
+
+def _scmn_sample(rank):
+    from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
+    s = make_synthetic_mesh(260 + 90 * rank, 2, seed=10 + rank, dilations=())
+    g = torch.Generator().manual_seed(rank)
+    s['labels'] = torch.randint(0, SCMN['num_classes'], (s.x.shape[0],), generator=g)
+    return s
+
+
+def _scmn_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import scmn_oracle
+    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    torch.manual_seed(7 + rank)
+    net = scmn_oracle.SingleConvMeshNet(pooling_method='mean', **SCMN)
+    step = TrainStep(net, lr=1e-3, amsgrad=True, loss_fn=_xent)
+    p0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+    loss = step(_scmn_sample(rank))
+    torch.save({'p0': p0, 'p1': torch.cat([p.detach().reshape(-1) for p in net.parameters()]), 'grad': step.bucket.flat.clone(),
+                'loss': loss}, os.path.join(out_dir, 's%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_with_a_loss_hook_for_singleconvmeshnet(tmp_path):
+    """TrainStep(loss_fn=...): the flat-bucket data-parallel step around SingleConvMeshNet with the segmentation trainer's
+    cross entropy - the reference's only multi-GPU user (torch_geometric.nn.DataParallel, segmentation_trainer.py:34-35)."""
+    mp.spawn(_scmn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 's0.pt'), torch.load(tmp_path / 's1.pt')
+    assert torch.equal(r0['p0'], r1['p0']) and torch.equal(r0['grad'], r1['grad']) and torch.equal(r0['p1'], r1['p1'])
+    assert not torch.equal(r0['p0'], r0['p1'])
+    from oracle import scmn_oracle
+    torch.manual_seed(7)
+    net = scmn_oracle.SingleConvMeshNet(pooling_method='mean', **SCMN)
+    torch.nn.utils.vector_to_parameters(r0['p0'], net.parameters())
+    grads = []
+    for rank in range(2):
+        net.zero_grad(set_to_none=True)
+        net.train()
+        _xent(net, _scmn_sample(rank)).backward()
+        grads.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in net.parameters()]))
+    want = (grads[0] + grads[1]) / 2
+    assert float((r0['grad'] - want).abs().max()) <= 5e-6 * float(want.abs().max()) + 1e-9      # (BatchNorm: 1 vs 8 host threads)

@@ -148,6 +148,64 @@ def test_bench_self_launches_two_ranks_from_a_plain_python_invocation():
     assert out['value'] > 0 and abs(out['ms_per_step'] - max(out['distributed']['ms_per_step_per_rank'])) < 1e-6
 
 
+@pytest.mark.gpu
+def test_bench_eight_rank_self_launch_dry_run_on_one_gpu():
+    """The 8-rank path the driver's scaling run takes (`python bench.py --gpus 8`), dry-run on ONE device with gloo: the
+    self-launch (free port, 127.0.0.1 rendezvous), the core-affinity shares (cores // 8 per rank), OMP_NUM_THREADS, the
+    all-reduced rank count, per-rank times and bit-identical replicas - everything but RCCL itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--steps', '2',
+                        '--warmup', '1', '--vertices', '3000', '--no-cpu-baseline'], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, 'rank 0 prints ONE json line'
+    out = json.loads(lines[0])
+    d = out['distributed']
+    assert out['n_gpus'] == 8 and d['world_size'] == 8 and d['ranks_counted_by_allreduce'] == 8
+    assert len(d['ms_per_step_per_rank']) == 8 and d['replicas_bit_identical'] is True
+    ncpu = len(os.sched_getaffinity(0))
+    assert d['cores_per_rank'] == max(1, ncpu // 8)
+    assert out['scaling'] == 'weak' and out['config']['parallelism'] == 'dp8'
+    assert abs(out['ms_per_step'] - max(d['ms_per_step_per_rank'])) < 1e-6
+    assert abs(out['value'] - 8 * out['config']['vertices_per_gpu'] * out['steps'] / (out['ms_per_step'] * 1e-3 * out['steps'])) < 1e-3 * out['value']
+
+
+def _scmn_xent(model, sample):
+    return torch.nn.functional.cross_entropy(model(sample), sample.labels)
+
+
+def _scmn_gpu_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from surface_texture_inpainting_net_amd.singleconvmeshnet import SingleConvMeshNet
+    torch.manual_seed(3 + rank)                      # different init per rank: the flat broadcast must make the replicas equal
+    net = SingleConvMeshNet(10, 1, [16, 32], num_classes=5).to(DEV)
+    step = TrainStep(net, lr=1e-3, loss_fn=_scmn_xent)
+    s = make_synthetic_mesh(2500 + 700 * rank, 2, seed=rank, dilations=()).to(DEV)
+    s['labels'] = torch.randint(0, 5, (s.x.shape[0],), generator=torch.Generator().manual_seed(rank)).to(DEV)
+    losses = [float(step(s)) for _ in range(3)]
+    step.finish()
+    torch.save({'loss': losses, 'grad': step.bucket.flat.cpu(), 'p': torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()},
+               os.path.join(out_dir, 'scmn%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_singleconvmeshnet_data_parallel_step_with_a_loss_hook(tmp_path):
+    """TrainStep(loss_fn=cross entropy) around the HIP SingleConvMeshNet on two ranks (gloo, both on cuda:0): the reference's
+    only multi-GPU model (trainers/segmentation_trainer.py:34-35, :139-148) on the flat-bucket all-reduce + FlatAdam step."""
+    import torch.multiprocessing as mp
+    mp.spawn(_scmn_gpu_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / ('scmn%d.pt' % i)) for i in range(2)]
+    assert torch.equal(r[0]['p'], r[1]['p']) and torch.equal(r[0]['grad'], r[1]['grad'])
+    assert all(torch.isfinite(torch.tensor(x['loss'])).all() for x in r)
+    assert r[0]['loss'][2] < r[0]['loss'][0]          # (three Adam steps on the same scene reduce its loss)
+
+
 def _overlap_worker(rank, world, port, out_dir, min_bytes, mix=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
