@@ -121,6 +121,9 @@ int stin_narrow_i64_to_i32(const int64_t* src, int64_t n, int64_t limit, int32_t
  * models/modules/sage_conv_filter.py:122; backward of `x[traces]`, :391; PyG
  * aggr='add' in utils/metrics/graph_metrics.py:6-16).
  */
+#define STIN_SEG_NONTEMPORAL 2   /* OR-ed into `mean`: the gathered source is read once and is larger than the 256 MB Infinity Cache
+                                   (the standalone scatter-add of BASELINE: 307 MB) -> non-temporal loads, +5 %; on a
+                                   cache-resident source they cost 25-40 %, so the caller decides by the source's size */
 int stin_segment_sum_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col,
                          int64_t N, int C, int mean, float* out, int64_t ld_out, stin_stream_t stream);
 

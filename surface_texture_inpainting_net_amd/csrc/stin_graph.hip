@@ -13,6 +13,9 @@ constexpr int BLOCK = 256;
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+template <typename T> struct is_f32_type { static constexpr bool value = false; };
+template <> struct is_f32_type<float> { static constexpr bool value = true; };
+
 template <int G, int VPL>
 struct Lane {
     int lg;        // lane within the group
@@ -26,13 +29,14 @@ struct Lane {
 };
 
 // ------------------------------------------------------------------ edge stage, forward
-template <typename T, int G, int VPL, int U>
-__global__ __launch_bounds__(BLOCK) void k_edge_fwd(const T* __restrict__ A, int64_t lda,
-                                                    const T* __restrict__ B, int64_t ldb,
-                                                    const int32_t* __restrict__ rowptr,
-                                                    const int32_t* __restrict__ col, int64_t N, int H,
-                                                    T* __restrict__ out, int64_t ldo, int indicator,
-                                                    uint32_t* __restrict__ mask) {
+// EXACT: H == 4 * G * VPL (every width the saved-mask path supports): no per-chunk predicates on the gathers
+template <typename T, int G, int VPL, int U, bool EXACT>
+__device__ __forceinline__ void edge_fwd_body(const T* __restrict__ A, int64_t lda,
+                                              const T* __restrict__ B, int64_t ldb,
+                                              const int32_t* __restrict__ rowptr,
+                                              const int32_t* __restrict__ col, int64_t N, int H,
+                                              T* __restrict__ out, int64_t ldo, int indicator,
+                                              uint32_t* __restrict__ mask) {
     Lane<G, VPL> L;
     const bool row_ok = L.row < N;
     if (!row_ok) return;
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd(const T* __restrict__ A, int
     bool on[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
-        on[k] = row_ok && L.chan(k) < H;
+        on[k] = EXACT || L.chan(k) < H;
         a[k] = on[k] ? ld4(A + L.row * lda + L.chan(k)) : f4zero();
         acc[k] = f4zero();
     }
@@ -102,6 +106,20 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd(const T* __restrict__ A, int
     for (int k = 0; k < VPL; ++k)
         if (on[k]) st4(out + L.row * ldo + L.chan(k), make_float4(acc[k].x / s, acc[k].y / s, acc[k].z / s, acc[k].w / s));
     if (indicator && L.lg == 0) st4(out + L.row * ldo + H, make_float4(deg > 0 ? 1.f : 0.f, 0.f, 0.f, 0.f));
+}
+template <typename T, int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_fwd(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
+                                                    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                    int64_t N, int H, T* __restrict__ out, int64_t ldo, int indicator,
+                                                    uint32_t* __restrict__ mask) {
+    edge_fwd_body<T, G, VPL, U, false>(A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+}
+template <typename T, int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_fwd_exact(const T* __restrict__ A, int64_t lda, const T* __restrict__ B, int64_t ldb,
+                                                          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                          int64_t N, int H, T* __restrict__ out, int64_t ldo, int indicator,
+                                                          uint32_t* __restrict__ mask) {
+    edge_fwd_body<T, G, VPL, U, true>(A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
 }
 
 // ------------------------------------------ edge stage, backward w.r.t. A (destination CSR)
@@ -221,7 +239,7 @@ __device__ __forceinline__ void edge_bwd_dst_mask_body(unsigned vblock, const T*
     bool on[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
-        on[k] = L.chan(k) < H;
+        on[k] = true;                                    // the mask path exists for H == 4 * G * VPL only
         cnt[k][0] = cnt[k][1] = cnt[k][2] = cnt[k][3] = 0;
     }
     constexpr int WPC = G / 32;                          // 32-bit words per component
@@ -291,7 +309,7 @@ __device__ __forceinline__ void edge_bwd_src_mask_body(unsigned vblock, const T*
     bool on[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
-        on[k] = L.chan(k) < H;
+        on[k] = true;                                    // the mask path exists for H == 4 * G * VPL only
         acc[k] = f4zero();
     }
     constexpr int WPC = G / 32;
@@ -721,6 +739,68 @@ __global__ __launch_bounds__(BLOCK) void k_segment_sum(const T* __restrict__ src
         if (on[k]) st4(out + L.row * ldo + L.chan(k), make_float4(acc[k].x / s, acc[k].y / s, acc[k].z / s, acc[k].w / s));
 }
 
+// Round 3 form for rows whose chunks divide evenly over the lanes (C / 4 = G * VPL): no per-chunk predicates, and FEWER
+// lanes per row than chunks - each lane owns VPL = 2 chunks 16 G bytes apart, so a wave covers twice the rows and every
+// load instruction touches twice as many independent rows (memory-level parallelism at the same register cost).  Measured on
+// MI355X (profiles/_seg_tune.py): the standalone scatter-add (E = 1.2 M random 256-byte rows -> N = 200 k) 90.1 us with
+// G = 16 / U = 4 -> 72.6 us with G = 8 / VPL = 2 / U = 2 -> 68.9 us with non-temporal loads on top (0.50 -> 0.66 of the HBM
+// peak); the unpool backward of the step 28.5 -> 23.3 us (C = 128), 17.6 -> 15.5 us (C = 256).  NT (non-temporal loads of the
+// gathered rows) only pays when the gathered source cannot stay in the 256 MB Infinity Cache anyway: cache-resident sources
+// LOSE 25-40 % with it, so the host sets it by the source's size.  Same summation order per row as k_segment_sum
+// (sequential over the row's entries): bit-identical results.
+template <typename T, int G, int VPL, int U, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_segment_sum_x(const T* __restrict__ src, int64_t lds_,
+                                                         const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col, int64_t N, int C,
+                                                         int mean, T* __restrict__ out, int64_t ldo) {
+    Lane<G, VPL> L;
+    if (L.row >= N) return;
+    const int beg = rowptr[L.row], end = rowptr[L.row + 1];
+    float4 acc[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) acc[k] = f4zero();
+    for (int e = beg; e < end; e += U) {
+        float4 v[U][VPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ee = min(e + u, end - 1);
+            const int64_t j = col != nullptr ? (int64_t)col[ee] : (int64_t)ee;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                const T* p = src + j * lds_ + L.chan(k);
+                if constexpr (NT && is_f32_type<T>::value) {
+                    const float* q = reinterpret_cast<const float*>(p);
+                    v[u][k].x = __builtin_nontemporal_load(q);
+                    v[u][k].y = __builtin_nontemporal_load(q + 1);
+                    v[u][k].z = __builtin_nontemporal_load(q + 2);
+                    v[u][k].w = __builtin_nontemporal_load(q + 3);
+                } else {
+                    v[u][k] = ld4(p);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float w = (e + u < end) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                acc[k].x += w * v[u][k].x;
+                acc[k].y += w * v[u][k].y;
+                acc[k].z += w * v[u][k].z;
+                acc[k].w += w * v[u][k].w;
+            }
+        }
+    }
+    float s = 1.f;
+    if (mean) {
+        const int deg = end - beg;
+        s = (float)(deg > 0 ? deg : 1);
+    }
+#pragma unroll
+    for (int k = 0; k < VPL; ++k)
+        st4(out + L.row * ldo + L.chan(k), make_float4(acc[k].x / s, acc[k].y / s, acc[k].z / s, acc[k].w / s));
+}
+
 // ------------------------------------------------------------------------- max pool
 template <typename T, int G, int VPL, int U>
 __global__ __launch_bounds__(BLOCK) void k_pool_max_fwd(const T* __restrict__ x, int64_t ldx,
@@ -1004,7 +1084,9 @@ int edge_fwd_impl(const T* A, int64_t lda, const T* B, int64_t ldb, const int32_
             return stin_launch_status();
         }
     }
-    if (vec) {
+    if (vec && mask != nullptr) {                    // mask shapes are exact multiples of the lane geometry
+        STIN_DISPATCH(H, k_edge_fwd_exact, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+    } else if (vec) {
         STIN_DISPATCH(H, k_edge_fwd, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
     } else if constexpr (is_f32((const T*)nullptr)) {
         hipLaunchKernelGGL((k_scalar<OP_EDGE_FWD>), dim3(grid_elems(N * H)), dim3(BLOCK), 0, stream, A, lda, B, ldb,
@@ -1110,9 +1192,36 @@ int edge_bwd_mask_pair8_impl(const stin_bf16* G, int64_t ldg, const uint32_t* ma
 template <typename T>
 int segment_sum_impl(const T* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col, int64_t N, int C, int mean,
                      T* out, int64_t ld_out, hipStream_t stream) {
+    const bool want_nt = (mean & STIN_SEG_NONTEMPORAL) != 0;
+    mean &= 1;
     STIN_REQUIRE(N >= 0 && C > 0 && ld_src >= C && ld_out >= C, STIN_E_SIZE);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(src && rowptr && out, STIN_E_NULL);
+    {
+        // even split of the row over G = C / 8 lanes with 2 chunks each (C / 4 a power of two, 16 <= C <= 512), wider rows on a
+        // full wave; anything else (ragged channel counts) keeps the predicated kernel below
+        const int c4 = C / 4;
+        static const bool force_old = getenv("STIN_SEG_OLD") != nullptr && atoi(getenv("STIN_SEG_OLD")) != 0;   // A/B aid
+        if (!force_old && C % 4 == 0 && c4 >= 4 && (c4 & (c4 - 1)) == 0 && c4 <= 512 && vec_ok<T>(C, {src, out}, {ld_src, ld_out})) {
+            // non-temporal loads only for a source that cannot be Infinity-Cache resident (see the kernel comment)
+            const bool nt = is_f32((const T*)nullptr) && want_nt;
+#define SEGX(G_, V_, U_)                                                                                                  \
+    do {                                                                                                                  \
+        if (nt) hipLaunchKernelGGL((k_segment_sum_x<T, G_, V_, U_, true>), dim3(grid_rows(N, G_)), dim3(BLOCK), 0, stream, src, ld_src, rowptr, col, N, C, mean, out, ld_out); \
+        else hipLaunchKernelGGL((k_segment_sum_x<T, G_, V_, U_, false>), dim3(grid_rows(N, G_)), dim3(BLOCK), 0, stream, src, ld_src, rowptr, col, N, C, mean, out, ld_out);   \
+    } while (0)
+            if (c4 == 4) SEGX(2, 2, 2);
+            else if (c4 == 8) SEGX(4, 2, 2);
+            else if (c4 == 16) SEGX(8, 2, 2);
+            else if (c4 == 32) SEGX(16, 2, 2);
+            else if (c4 == 64) SEGX(32, 2, 2);
+            else if (c4 == 128) SEGX(64, 2, 2);
+            else if (c4 == 256) SEGX(64, 4, 2);
+            else SEGX(64, 8, 1);
+#undef SEGX
+            return stin_launch_status();
+        }
+    }
     if (vec_ok<T>(C, {src, out}, {ld_src, ld_out})) {
         STIN_DISPATCH(C, k_segment_sum, 1, src, ld_src, rowptr, col, N, C, mean, out, ld_out);
     } else if constexpr (is_f32((const T*)nullptr)) {

@@ -151,7 +151,9 @@ def edge_relu_mean_bwd_src(A, B, G, inv_deg, csr_src, dB):
 def segment_sum(src, rowptr, col, n_rows, mean=False):
     src, ld = _mat(src)
     out = torch.empty(n_rows, src.shape[1], dtype=src.dtype, device=src.device)
-    _call('stin_segment_sum' + _sfx(src), _ptr(src), ld, _ptr(rowptr), _ptr(col), n_rows, src.shape[1], int(mean), _ptr(out),
+    # (STIN_SEG_NONTEMPORAL = 2: a source that cannot be Infinity-Cache resident is read with non-temporal loads)
+    flags = int(mean) | (2 if (src.dtype == torch.float32 and src.shape[0] * ld * 4 > (256 << 20)) else 0)
+    _call('stin_segment_sum' + _sfx(src), _ptr(src), ld, _ptr(rowptr), _ptr(col), n_rows, src.shape[1], flags, _ptr(out),
           out.stride(0) if n_rows > 1 else src.shape[1], _stream(src))
     return out
 
