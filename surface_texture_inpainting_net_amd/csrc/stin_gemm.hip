@@ -655,21 +655,46 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
 // dropped: a second group of 4 waves per block splitting K (two waves per SIMD; the block-wide barrier keeps the groups in
 // lock-step: 59 us), rotating the K order per block (L2 channel hot spots: no change), padding the 4 KB row pitch (no change);
 // SQ counters of the first version: profiles/r02_pmc_nt_wide.md.
-constexpr int WD_KC = 64, WD_STEPS = WD_KC / 16, WD_THREADS = 256;
+constexpr int WD_KC = 64, WD_STEPS = WD_KC / 16;
+// profiling build only (profiles/nt_stamps.hip compiles this file with -DSTIN_NT_STAMPS): s_memtime stamps per wave
+#ifdef STIN_NT_STAMPS
+__device__ unsigned long long* stin_nt_stamp_buf = nullptr;
+#define NT_STAMP(i)                                                                                                    \
+    do {                                                                                                               \
+        if ((threadIdx.x & 63) == 0 && stin_nt_stamp_buf != nullptr && (i) < 32)                                        \
+            stin_nt_stamp_buf[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define NT_STAMP(i)
+#endif
 
-template <typename PT, int NW>
-__global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __restrict__ A, int64_t lda,
+// WAVES_M = waves along the rows of the block (each wave owns 64 rows x 64 columns): the block has NW * WAVES_M waves and
+// BM = 64 * WAVES_M rows.  Round 3, from in-kernel stamps (profiles/nt_stamps.hip, 18 063 x 256 x 1024, BM = 64): a block alone
+// on its CU needs 62 k cycles - 5.5 k of first-load latency, 8 x 5.9 k for the K loop and 10 k for an epilogue of 64 dword
+// stores per wave - and the K loop runs at 60 cycles per MFMA where a register-fed loop runs 32 and an LDS-fed one 43
+// (profiles/micro/mfma_rate.hip).  A block with HALF the rows per wave (32 x 64 tiles) needs the SAME 5.5 k cycles per two
+// chunks: the loop is bound by what the CU can pull out of L2 - every block streams the whole fragment-order weight operand
+// (1 MB at 256 x 1024) plus its A rows, ~27 bytes per cycle and CU, the rate the guide gives for L2-resident gathers - not
+// by the matrix pipe.  So (1) blocks of 128 rows on 8 waves (2 per SIMD): the weight bytes per output row halve, and the
+// 283-blocks-on-256-CUs second round disappears (142 blocks, one per CU, the idle CUs cost less than a second round did);
+// (2) the epilogue restages the tile through the (then idle) LDS and stores whole 256-byte row segments with 16 bytes per
+// lane: 8 store instructions per 32 x 64 tile instead of 32.
+template <typename PT, int NW, int WAVES_M>
+__global__ __launch_bounds__(64 * NW * WAVES_M) void k_gemm_nt_wide(const float* __restrict__ A, int64_t lda,
                                                              const float* __restrict__ Wf,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ row_mask, int64_t ld_mask,
                                                              const float* __restrict__ res, int64_t ld_res, int64_t M,
                                                              int K, float* __restrict__ C, int64_t ldc,
-                                                             double* __restrict__ colstats) {
+                                                             double* __restrict__ colstats, int vec_out) {
     typedef typename PieceTraits<PT>::vec8 vec8;
     constexpr float ASCALE = PieceTraits<PT>::ascale, WSCALE = PieceTraits<PT>::wscale;
-    constexpr int WAVES_M = 4 / NW, BM = 64 * WAVES_M, PASSES = BM / 32;       // staging: 32 rows per pass
+    constexpr int MT = 2, WROWS = 32 * MT, BM = WROWS * WAVES_M, THREADS = 64 * NW * WAVES_M;
+    constexpr int RPP = THREADS / 8, PASSES = BM / RPP;                         // staging: THREADS / 8 rows per pass, 8 lanes per row
     constexpr int STEP_BYTES = BM * 32, PLANE = WD_STEPS * STEP_BYTES, BUF = 2 * PLANE;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+    constexpr int SMEM = 2 * BUF > NW * WAVES_M * 8192 ? 2 * BUF : NW * WAVES_M * 8192;   // (the epilogue restages 8 KB per wave)
+    static_assert(PASSES >= 2 && PASSES % 2 == 0, "staging is spread as PASSES / 2 pieces per k-step");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
     __shared__ float mask_s[BM];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -680,6 +705,7 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
     const int64_t row0 = (int64_t)blockIdx.x * BM;
     const int nchunk = K / WD_KC, KS_total = K / 16;
 
+    NT_STAMP(0);
     if (row_mask != nullptr && tid < BM) {
         const int64_t row = row0 + tid;
         mask_s[tid] = row_mask[(row < M ? row : M - 1) * ld_mask];
@@ -696,7 +722,7 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int t = 0; t < PASSES; ++t) {
-                const int64_t row = row0 + r0 + t * 32;
+                const int64_t row = row0 + r0 + t * RPP;
                 // rows past M read row M - 1 (valid memory): their accumulators are never stored, so no zeroing - a select
                 // here would make the compiler wait for the load right where it is issued
                 r[h][t] = ld4(A + (row < M ? row : M - 1) * lda + c * WD_KC + h * 32 + kq * 4);
@@ -704,7 +730,7 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
     };
     auto sstore_piece = [&](const float4 (&r)[2][PASSES], int buf, int h, int t) {
         const int ks = h * 2 + (kq >> 2), kh_ = (kq >> 1) & 1;
-        const int row = r0 + t * 32;
+        const int row = r0 + t * RPP;
         PT* dst = reinterpret_cast<PT*>(smem + buf * BUF + ks * STEP_BYTES + row * 32 + ((kh_ ^ ((row >> 3) & 1)) << 4) + (kq & 1) * 8);
         split_store<2, PT>(r[h][t], dst, PLANE / 2, ASCALE);
     };
@@ -726,22 +752,22 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
         for (int t = 0; t < PASSES; ++t) sstore_piece(ra[0], 0, h, t);
     gload(ra[1], nchunk > 1 ? 1 : 0);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const unsigned char* a_frag = smem + (wm * 64 + li) * 32 + ((kh ^ ((li >> 3) & 1)) << 4);
+    const unsigned char* a_frag = smem + (wm * WROWS + li) * 32 + ((kh ^ ((li >> 3) & 1)) << 4);
     struct AFrag {
-        vec8 a0[2], a1[2];
+        vec8 a0[MT], a1[MT];
     };
     auto aread = [&](const unsigned char* ab, int j) {
         AFrag f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MT; ++i) {
             f.a0[i] = *reinterpret_cast<const vec8*>(ab + j * STEP_BYTES + i * 1024);
             f.a1[i] = *reinterpret_cast<const vec8*>(ab + PLANE + j * STEP_BYTES + i * 1024);
         }
@@ -766,20 +792,24 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
             acc[0][0] = mfma_k16(cur.a1[0], b00, acc[0][0]);
             acc[0][0] = mfma_k16(cur.a0[0], b00, acc[0][0]);
             __builtin_amdgcn_sched_barrier(0);
+            // this k-step's share of the staging: 2 * PASSES pieces per chunk over the WD_STEPS = 4 k-steps
 #pragma unroll
-            for (int q = 0; q < PASSES / 2; ++q)                               // this k-step's share of the staging
-                sstore_piece(stage, (c + 1) & 1, j >> 1, (j & 1) * (PASSES / 2) + q);
+            for (int q = 0; q < PASSES / 2; ++q) sstore_piece(stage, (c + 1) & 1, j >> 1, (j & 1) * (PASSES / 2) + q);
             __builtin_amdgcn_sched_barrier(0);
-            acc[1][0] = mfma_k16(cur.a0[1], b01, acc[1][0]);
-            acc[1][0] = mfma_k16(cur.a1[1], b00, acc[1][0]);
-            acc[1][0] = mfma_k16(cur.a0[1], b00, acc[1][0]);
+            if (MT == 2) {
+                acc[MT - 1][0] = mfma_k16(cur.a0[MT - 1], b01, acc[MT - 1][0]);
+                acc[MT - 1][0] = mfma_k16(cur.a1[MT - 1], b00, acc[MT - 1][0]);
+                acc[MT - 1][0] = mfma_k16(cur.a0[MT - 1], b00, acc[MT - 1][0]);
+            }
             wf[j][0] = st_wload(wb0 + (int64_t)(nxt + j) * 2048, lane_off);
             acc[0][1] = mfma_k16(cur.a0[0], b11, acc[0][1]);
             acc[0][1] = mfma_k16(cur.a1[0], b10, acc[0][1]);
             acc[0][1] = mfma_k16(cur.a0[0], b10, acc[0][1]);
-            acc[1][1] = mfma_k16(cur.a0[1], b11, acc[1][1]);
-            acc[1][1] = mfma_k16(cur.a1[1], b10, acc[1][1]);
-            acc[1][1] = mfma_k16(cur.a0[1], b10, acc[1][1]);
+            if (MT == 2) {
+                acc[MT - 1][1] = mfma_k16(cur.a0[MT - 1], b11, acc[MT - 1][1]);
+                acc[MT - 1][1] = mfma_k16(cur.a1[MT - 1], b10, acc[MT - 1][1]);
+                acc[MT - 1][1] = mfma_k16(cur.a0[MT - 1], b10, acc[MT - 1][1]);
+            }
             wf[j][1] = st_wload(wb1 + (int64_t)(nxt + j) * 2048, lane_off);
             __builtin_amdgcn_sched_barrier(0);
             cur = nx;
@@ -787,18 +817,80 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
         __syncthreads();
     };
     __syncthreads();
+    NT_STAMP(1);
     int c = 0;
     for (; c + 1 < nchunk; c += 2) {
         chunk(c, ra[1], ra[0]);
         chunk(c + 1, ra[0], ra[1]);
+        NT_STAMP(2 + (c >> 1));
     }
     if (c < nchunk) chunk(c, ra[1], ra[0]);
+    NT_STAMP(30);
 
     // ---- epilogue: v = acc / (ascale wscale) + bias [* row mask] + residual
-    // colstats (optional): per 64-row group (blockIdx * WAVES_M + wm) the column sums of the STORED values and of their
+    // colstats (optional): per WROWS-row group (blockIdx * WAVES_M + wm) the column sums of the STORED values and of their
     // squares in fp64, [group][2][Nc] - the first stage of the instance-norm statistics (stin_moments_final_f32 is the second),
     // fixed summation order: rows of the lane in storage order, then the two 32-lane halves.
     const float sc = 1.f / (ASCALE * WSCALE);
+    if (vec_out) {
+        // (every wave has passed the barrier that ends the last chunk: the staging buffers are free)  Per 32-row tile the wave
+        // writes its 32 x 64 values into its own 8 KB of LDS (one dword per lane and instruction: conflict-free) and reads
+        // them back as whole 256-byte row segments, 16 lanes per row: 4 rows per 16-byte store instruction.  The residual is
+        // loaded in the same shape and added after the bias term, as before: bit-identical values.
+        float* stage_f = reinterpret_cast<float*>(smem + wave * 8192);
+        double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+        float bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bv[t] = bias != nullptr ? bias[wn * 64 + t * 32 + li] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int lrow0 = wm * WROWS + i * 32;                             // first block-local row of this tile
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tr = (r & 3) + 8 * (r >> 2) + 4 * kh;            // row inside the tile
+                    const float v = acc[i][t][r] * sc + (row_mask != nullptr ? bv[t] * mask_s[lrow0 + tr] : bv[t]);
+                    stage_f[tr * 64 + t * 32 + li] = v;
+                    if (colstats != nullptr && row0 + lrow0 + tr < M) {        // (colstats launches carry no residual)
+                        const double d = (double)v;
+                        s1[t] += d;
+                        s2[t] += d * d;
+                    }
+                }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int tr = q * 4 + (lane >> 4), c16 = lane & 15;
+                const int64_t grow = row0 + lrow0 + tr;
+                float4 v = *reinterpret_cast<const float4*>(stage_f + tr * 64 + c16 * 4);
+                if (grow < M) {
+                    const int col = wn * 64 + c16 * 4;
+                    if (res != nullptr) {
+                        const float4 rv = ld4(res + grow * ld_res + col);
+                        v.x += rv.x;
+                        v.y += rv.y;
+                        v.z += rv.z;
+                        v.w += rv.w;
+                    }
+                    st4(C + grow * ldc + col, v);
+                }
+            }
+        }
+        if (colstats != nullptr) {                                             // block-uniform
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                s1[t] += __shfl_xor(s1[t], 32);
+                s2[t] += __shfl_xor(s2[t], 32);
+                if (kh == 0 && row0 + wm * WROWS < M) {                        // (a group wholly past M does not exist)
+                    double* dst = colstats + ((int64_t)blockIdx.x * WAVES_M + wm) * 2 * (NW * 64) + wn * 64 + t * 32 + li;
+                    dst[0] = s1[t];
+                    dst[NW * 64] = s2[t];
+                }
+            }
+        }
+        NT_STAMP(31);
+        return;
+    }
     const bool full_rows = row0 + BM <= M;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -806,8 +898,8 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
         const float bv = bias != nullptr ? bias[col] : 0.f;
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int lr0 = wm * 64 + i * 32 + 4 * kh;
+        for (int i = 0; i < MT; ++i) {
+            const int lr0 = wm * WROWS + i * 32 + 4 * kh;
             if (full_rows) {
                 float ld[16];
 #pragma unroll
@@ -845,13 +937,14 @@ __global__ __launch_bounds__(WD_THREADS) void k_gemm_nt_wide(const float* __rest
         if (colstats != nullptr) {                                             // block-uniform
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
-            if (kh == 0 && row0 + wm * 64 < M) {                               // (a 64-row group wholly past M does not exist)
+            if (kh == 0 && row0 + wm * WROWS < M) {                            // (a group wholly past M does not exist)
                 double* dst = colstats + ((int64_t)blockIdx.x * WAVES_M + wm) * 2 * (NW * 64) + col;
                 dst[0] = s1;
                 dst[NW * 64] = s2;
             }
         }
     }
+    NT_STAMP(31);
 }
 
 // ----------------------------------------------------------------------------- TN
@@ -1701,6 +1794,15 @@ inline int tn_rows_per_chunk(int64_t M, int tiles, bool one_per_cu = false) {
     rows = (rows + TN_R - 1) / TN_R * TN_R;
     return (int)rows;
 }
+// all-columns NT kernel: waves along the rows of a block (see k_gemm_nt_wide).  8 waves per block (128 rows) for Nc = 256
+// while the 128-row blocks fit the chip in one round: 18 063 x 256 x 1024 41.6 -> 36.7 us, x 512 29.3 -> 27.7; slower for 60 k
+// rows (471 blocks: 59 -> 64 us) and for Nc = 128 (256-row blocks: 71 of them at 18 k rows, 34 -> 52 us), which keep 4 waves.
+inline int wide_waves_m(int64_t M, int Nc) {
+    static const int force = getenv("STIN_WIDE_WAVES") ? atoi(getenv("STIN_WIDE_WAVES")) : 0;      // tuning aid: 4 | 8 waves per block
+    const int nw = Nc / 64;
+    if (force == 4 || force == 8) return force / nw;
+    return (Nc == 256 && (M + 127) / 128 <= (int64_t)stin_cu_count()) ? 2 : 4 / nw;
+}
 inline bool tn_one_per_cu(int storage, int precision, int TI, int TJ, int64_t M) {
     return storage == 0 && precision == STIN_GEMM_BF16X3 && TI == 128 && TJ == 128 && M <= 32768;
 }
@@ -1751,9 +1853,18 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
     if (wfrag && Nc <= 256) {
         // all-columns kernel (k_gemm_nt_wide): Nc = 128 / 256, the fragment-order weight operand cannot be read by any other kernel
         STIN_REQUIRE(vec, STIN_E_ALIGN);
+        const int wm = wide_waves_m(M, Nc);
+        // the LDS-restaged epilogue stores 16 bytes per lane: C (and the residual) rows must allow it
+        const int vec_out = (ldc % 4 == 0 && stin_aligned16(C) && (residual == nullptr || (ld_res % 4 == 0 && stin_aligned16(residual))) &&
+                             !(colstats != nullptr && residual != nullptr)) ? 1 : 0;
+#define STIN_WIDE_L(PT_, NW_, WM_)                                                                                        \
+    hipLaunchKernelGGL((k_gemm_nt_wide<PT_, NW_, WM_>), dim3((unsigned)((M + 64 * WM_ - 1) / (64 * WM_))), dim3(64 * NW_ * WM_), 0, stream, \
+                       A, lda, W, bias, row_mask, ld_mask, residual, ld_res, M, K, C, ldc, colstats, vec_out)
 #define STIN_WIDE(PT_, NW_)                                                                                               \
-    hipLaunchKernelGGL((k_gemm_nt_wide<PT_, NW_>), dim3((unsigned)((M + 64 * (4 / NW_) - 1) / (64 * (4 / NW_)))), dim3(WD_THREADS), 0, \
-                       stream, A, lda, W, bias, row_mask, ld_mask, residual, ld_res, M, K, C, ldc, colstats)
+    do {                                                                                                                  \
+        if (wm == 8 / NW_) STIN_WIDE_L(PT_, NW_, 8 / NW_);                                                                \
+        else STIN_WIDE_L(PT_, NW_, 4 / NW_);                                                                              \
+    } while (0)
         if (precision == STIN_GEMM_BF16X3) {
             if (Nc == 256) STIN_WIDE(__bf16, 4);
             else STIN_WIDE(__bf16, 2);
@@ -1761,6 +1872,7 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
             if (Nc == 256) STIN_WIDE(_Float16, 4);
             else STIN_WIDE(_Float16, 2);
         }
+#undef STIN_WIDE_L
 #undef STIN_WIDE
     } else if (wfrag) {
         // resident-strip kernel (k_gemm_nt_strip): the fragment-order weight operand cannot be read by any other kernel
@@ -1829,7 +1941,7 @@ extern "C" int64_t stin_gemm_nt_colstats_groups(int64_t M, int Nc, int K, int pr
     const bool ok = (precision & STIN_GEMM_W_PRESPLIT) && (precision & STIN_GEMM_W_FRAG) && Nc <= 256 && stin_w_frag_shape(Nc, K);
     const int p = precision & ~(STIN_GEMM_W_PRESPLIT | STIN_GEMM_W_FRAG);
     if (!ok || M <= 0 || (p != STIN_GEMM_BF16X3 && p != STIN_GEMM_F16X3)) return 0;
-    return (M + 63) / 64;
+    return (M + 63) / 64;                                   // one statistics group per wave row group (64 rows)
 }
 extern "C" int stin_gemm_nt_colstats_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                                          const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res,
