@@ -427,7 +427,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
                                                               const float* __restrict__ row_mask, int64_t ld_mask,
                                                               const float* __restrict__ res, int64_t ld_res, int64_t M,
                                                               int Nc, int K, float* __restrict__ C, int64_t ldc, int KC,
-                                                              int64_t units, int P) {
+                                                              int64_t units, int P, int restage) {
     typedef typename PieceTraits<PT>::vec8 vec8;
     constexpr float ASCALE = PieceTraits<PT>::ascale, WSCALE = PieceTraits<PT>::wscale;
     constexpr int BM = ST_BM, MT = ST_MT;
@@ -435,6 +435,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
     const int plane_bytes = (KC / 16) * ST_STEP_BYTES;                    // one piece of the resident chunk
     float* bias_s = reinterpret_cast<float*>(strip_smem + 2 * plane_bytes);   // [Nc rounded up to 128]
     float* mask_s = bias_s + P * ST_PANEL;                                // [BM]
+    float* stage_s = mask_s + BM;                                         // [4 waves][16 rows][32 columns]: the epilogue's restage
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform: the sequence logic stays scalar
@@ -574,35 +575,48 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
         const bool tile_ok = col0 < Nc;                                   // Nc is a multiple of 32: a whole tile is in or out
         const bool full_rows = (run.s + 1) * BM <= M;
         const float sc = 1.f / (ASCALE * WSCALE);
-        if (run.c == 0 && res == nullptr && tile_ok && full_rows) {
-            // the common case loads nothing: 32 stores, row base pointers wave-uniform (scalar), the lane's offset one register
+        if (restage && run.c == 0 && res == nullptr && tile_ok && full_rows) {
+            // the common case loads nothing.  Round 3: the 64 x 32 wave tile is restaged through 2 KB of LDS per wave (16 rows x
+            // 32 columns at a time: one dword per lane and ds_write, conflict-free) and leaves as 16-byte stores, 8 rows x 128
+            // contiguous bytes per instruction - 8 store instructions per tile instead of 32 dword stores (in the all-columns
+            // kernel the dword-store epilogue was 10 k of a block's 62 k cycles, profiles/nt_stamps.hip).  Same values.
+            const float bv = bias_s[col0 + li];
+            float* stage_f = stage_s + wave * 512;
+            const int r16 = lane >> 3, c8 = lane & 7;
+            float* cbase = C + (run.s * BM + r16) * ldc + col0 + c8 * 4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = p * 8 + r8;
+                        const int tr = (r & 3) + 8 * ((r >> 2) & 1) + 4 * kh;             // row inside this 16-row pass
+                        const float m = row_mask != nullptr ? mask_s[i * 32 + p * 16 + tr] : 1.f;
+                        stage_f[tr * 32 + li] = row_mask != nullptr ? acc[i][r] * sc + bv * m + 0.f : acc[i][r] * sc + bv + 0.f;
+                        acc[i][r] = 0.f;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(stage_f + (q * 8 + r16) * 32 + c8 * 4);
+                        st4(cbase + (int64_t)(i * 32 + p * 16 + q * 8) * ldc, v);
+                    }
+                }
+        } else if (run.c == 0 && res == nullptr && tile_ok && full_rows) {
+            // (no LDS to spare for the restage without losing a block of occupancy: K chunks of 128) 32 dword stores, row base
+            // pointers wave-uniform (scalar), the lane's offset one register
             const float bv = bias_s[col0 + li];
             float* cbase = C + run.s * BM * ldc + col0;
             const unsigned coff = (unsigned)(4 * kh) * (unsigned)ldc + (unsigned)li;
-            if (row_mask != nullptr) {
-                float mk[MT][16];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mk[i][r] = mask_s[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float* rp = cbase + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc;
-                        rp[coff] = acc[i][r] * sc + bv * mk[i][r] + 0.f;
-                        acc[i][r] = 0.f;
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float* rp = cbase + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc;
-                        rp[coff] = acc[i][r] * sc + bv + 0.f;
-                        acc[i][r] = 0.f;
-                    }
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = i * 32 + (r & 3) + 8 * (r >> 2);
+                    float* rp = cbase + (int64_t)lr * ldc;
+                    rp[coff] = row_mask != nullptr ? acc[i][r] * sc + bv * mask_s[lr + 4 * kh] + 0.f : acc[i][r] * sc + bv + 0.f;
+                    acc[i][r] = 0.f;
+                }
         } else {
             // partial strip / tile past Nc / residual / later K chunk: every load first (clamped addresses), then the stores
             const int col = col0 + li;
@@ -1880,7 +1894,12 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
                      STIN_E_ALIGN);
         const int KC = K < 256 ? K : 256;                             // resident K chunk: 64 rows x 256 k x 4 B = 64 KB -> 2 blocks per CU
         const int P = (Nc + ST_PANEL - 1) / ST_PANEL;
-        const size_t lds = (size_t)2 * (KC / 32) * ST_BM * 64 + (size_t)P * ST_PANEL * 4 + ST_BM * 4;
+        size_t lds = (size_t)2 * (KC / 32) * ST_BM * 64 + (size_t)P * ST_PANEL * 4 + ST_BM * 4;
+        // the epilogue's restage area (2 KB per wave) only where it does not cost a resident block (K chunks of 256: 2 blocks
+        // per CU either way; chunks of 128 would drop from 4 to 3 and lose more than the wide stores gain: 130 -> 155 us at
+        // 200 704 x 320 x 128)
+        const int restage = (160 * 1024 / (lds + 4 * 2048) == 160 * 1024 / lds) ? 1 : 0;
+        if (restage) lds += 4 * 2048;
         const int64_t units = ((M + ST_BM - 1) / ST_BM) * P;
         int occ = (int)(160 * 1024 / lds);
         if (occ > 8) occ = 8;
@@ -1897,7 +1916,7 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
             attr_set = true;                                                                                              \
         }                                                                                                                 \
         hipLaunchKernelGGL((k_gemm_nt_strip<PT_>), dim3((unsigned)grid), dim3(ST_THREADS), lds, stream, A, lda, W, bias, row_mask, \
-                           ld_mask, residual, ld_res, M, Nc, K, C, ldc, KC, units, P);                                   \
+                           ld_mask, residual, ld_res, M, Nc, K, C, ldc, KC, units, P, restage);                          \
     } while (0)
         if (precision == STIN_GEMM_BF16X3) STIN_STRIP(__bf16);
         else STIN_STRIP(_Float16);
