@@ -502,10 +502,13 @@ def main():
         # (ONE bracketed step per run: a bracketed step takes the per-kernel host path and costs ~1.5 ms more than a plain one)
         SF.KernelTimer.start(timed, max_records=1_000_000 if args.time_gemms else per_step)
     t0 = time.perf_counter()
+    cpu0 = time.thread_time()
     for it in range(args.steps):
         # the bracketed step (the first timed one) leaves the plan side streams idle: its HIP events time kernels, not contention
         loss = one_step(prefetch=not (SF.KernelTimer.enabled and it == 0))
     dt_enqueue = time.perf_counter() - t0                   # host side done (everything enqueued); the GPU may still be running
+    dt_cpu = time.thread_time() - cpu0                      # CPU time of the enqueuing thread (the wall figure above also contains
+                                                            # waits and, on the shared pool hosts, other tenants' interference)
     fence()
     dt = time.perf_counter() - t0
     if args.graph:                                          # kernel brackets from two eager steps AFTER the timed replays
@@ -645,6 +648,7 @@ def main():
                             'allreduce_overlap_validated_on_hardware': False},
             'loss': float(loss),
             'host_enqueue_ms_per_step': dt_enqueue / args.steps * 1e3,   # < ms_per_step: the GPU, not the host, bounds the step
+            'host_thread_cpu_ms_per_step': dt_cpu / args.steps * 1e3,    # CPU time of the main thread only (backward's Python runs in autograd's device thread)
             'fwd_loss_bwd_only': None if args.no_secondary else {
                 'ms_per_step': dt_fb / args.steps * 1e3, 'vertices_per_s_per_gpu': n0 * args.steps / dt_fb,
                 'note': 'same scene, CSR plan reused, no gradient all-reduce, no optimizer step (rank 0)'},

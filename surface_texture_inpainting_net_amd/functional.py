@@ -620,7 +620,8 @@ class PackSet:
             blob += struct.pack('<10Q8i', _ptr(W1), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2), wcat, bcat, _ptr(wts),
                                 _ptr(wts) + 4 * Yw * Cp, w2s if fsp else 0, Cin, Cp, H, Cout, int(has_sc), int(trans_inv), fsp, bsp)
             self.max_elems = max(self.max_elems, Yw * Cp + H * Cout)
-            self.buffers.append((ws, wts, fsp, bsp))
+            # (the two backward operands as ready-made views: no tensor views are created inside autograd.Function.forward)
+            self.buffers.append((ws, wts, fsp, bsp, wts[:Yw * Cp].view(Cp, Yw), wts[Yw * Cp:].view(H, Cout)))
         self.jobs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
         self.n = len(specs)
 
@@ -677,16 +678,17 @@ class EdgeConvBlockFn(torch.autograd.Function):
             B = groups.B
             packed = 0
             if prepacked is not None and not b16 and prepacked[2] == fsp and prepacked[3] == bsp:
-                ws, wts, packed = prepacked[0], prepacked[1], BLOCK_PACKED       # operands already packed (PackSet.run)
-            else:
-                wts = torch.empty(Yw * Cp + H * Cout, dtype=torch.float32, device=dev)   # backward weight operands
-            wcatT, w2T = wts[:Yw * Cp].view(Cp, Yw), wts[Yw * Cp:].view(H, Cout)
+                ws, packed = prepacked[0], BLOCK_PACKED                           # operands already packed (PackSet.run)
+                wcatT, w2T = prepacked[4], prepacked[5]
+            else:                                                                 # backward weight operands (no views in here)
+                wcatT = torch.empty(Cp, Yw, dtype=torch.float32, device=dev)
+                w2T = torch.empty(H, Cout, dtype=torch.float32, device=dev)
             Y = torch.empty(N, Yw, dtype=x.dtype, device=dev)
             hE = torch.empty(N, H + pad, dtype=x.dtype, device=dev)
             mask = torch.empty(max(edges.n_edges, 1) * (H // 32), dtype=torch.int32, device=dev)
             agg = torch.empty(N, Cout, dtype=x.dtype, device=dev)
-            stats = torch.empty(2, B, Cout, dtype=torch.float32, device=dev)
-            mean, rstd = stats[0], stats[1]
+            mean = torch.empty(B, Cout, dtype=torch.float32, device=dev)
+            rstd = torch.empty(B, Cout, dtype=torch.float32, device=dev)
             out = torch.empty(N, Cout, dtype=x.dtype, device=dev)
             ws_bytes = lib.stin_edgeconv_block_fwd_workspace_bytes(Cin, Cp, H, Cout, int(has_shortcut), B)
             if not packed:
