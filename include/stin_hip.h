@@ -505,6 +505,39 @@ int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, const void*
                             size_t workspace_bytes, stin_stream_t stream, stin_stream_t wgrad_stream, stin_event_t ev_dagg,
                             stin_event_t ev_dy, stin_event_t ev_done, int join);
 
+/* A CHAIN of fused blocks of one level in one call per direction (round 3): the n consecutive identity-residual blocks of
+ * the bottleneck (models/surfacetextureinpaintingnet.py:437-443: `for i in range(n_blocks): x = bottleneck_blocks[i](x, ...)`)
+ * share N, the width (Cin = Cout, no shortcut) and the norm groups; block i reads block i - 1's output, the edge set may
+ * differ per block (dilations).  The calls only loop over stin_edgeconv_block_fwd / _bwd with the per-block pointers of the
+ * HOST job array - identical kernels in identical order, one foreign call and one autograd node instead of n.
+ *   fwd: x [N, Cp] feeds job 0; job i writes the tensors backward needs (Y, hE, mask, agg, mean, rstd, wcatT, w2T) and `out`.
+ *   bwd: g = dL/d(out of the last job); job i's input gradient goes to scratch[i & 1] ([N, Cp] each) and is job i - 1's g;
+ *        job 0's goes to dx (may be NULL).  Every job needs its OWN bwd workspace while a weight-gradient stream is in use
+ *        (its kernels read dagg / dY from it after the call has returned).  ev_dy / ev_done per job as in block_bwd. */
+typedef struct stin_chain_job {
+    const float *W1, *b1, *W2, *b2;
+    float *wcatT, *w2T;
+    void* fwd_ws;
+    const int32_t *rowptr_dst, *col_dst, *rowptr_src, *col_src, *xslot;
+    const float* w_src;
+    void *Y, *hE;
+    uint32_t* mask;
+    void* agg;
+    float *mean, *rstd;
+    void* out;
+    float *dW1, *db1, *dW2, *db2;
+    void* bwd_ws;
+    stin_event_t ev_dy, ev_done;
+    int32_t trans_inv, fwd_split, bwd_split, prec_fwd;
+} stin_chain_job_t;                                   /* 27 pointers + 4 int32 = 232 bytes */
+int stin_edgeconv_chain_fwd(int storage, const stin_chain_job_t* jobs, int n_jobs, const void* x, int64_t ldx, int64_t N,
+                            int C, int Cp, int H, const int32_t* ptr_sum, int B, const int32_t* gid, const float* inv_cnt,
+                            int slice_quirk, float eps, size_t fwd_ws_bytes, stin_stream_t stream);
+int stin_edgeconv_chain_bwd(int storage, const stin_chain_job_t* jobs, int n_jobs, const void* g, int64_t ldg, const void* x,
+                            int64_t ldx, int64_t N, int C, int Cp, int H, const int32_t* ptr_true, int B, const int32_t* gid,
+                            const int32_t* sid, const float* inv_cnt, int prec_bwd, void* dx, int64_t lddx, void* scratch0,
+                            void* scratch1, size_t bwd_ws_bytes, stin_stream_t stream, stin_stream_t wgrad_stream);
+
 /* All weight gradients of one fused block in two launches (round 3): BOTH transposed products
  *   dW2 | db2 = dagg^T [hE[:, :H] | hE[:, H]]        (second Linear; db2 weighted by the [deg > 0] column of hE)
  *   [dW1 ; dWs | db1 ; dbs] = dY^T [x | 1]           (first Linear + shortcut in the packed operand layout)

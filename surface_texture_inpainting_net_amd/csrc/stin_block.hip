@@ -301,3 +301,53 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
     }
     return STIN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ chains of blocks
+extern "C" int stin_edgeconv_chain_fwd(int storage, const stin_chain_job_t* jobs, int n_jobs, const void* x, int64_t ldx, int64_t N,
+                                       int C, int Cp, int H, const int32_t* ptr_sum, int B, const int32_t* gid, const float* inv_cnt,
+                                       int slice_quirk, float eps, size_t fwd_ws_bytes, stin_stream_t stream) {
+    STIN_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || jobs != nullptr), STIN_E_NULL);
+    STIN_REQUIRE(Cp == C || n_jobs <= 1, STIN_E_SIZE);                  // (a chain feeds [N, C] outputs back in as [N, Cp] inputs)
+    const int Yw = 2 * H;
+    const int pad = storage ? 8 : 4;
+    const void* xi = x;
+    int64_t ldi = ldx;
+    for (int i = 0; i < n_jobs; ++i) {
+        const stin_chain_job_t& J = jobs[i];
+        STIN_TRY(stin_edgeconv_block_fwd(storage, xi, ldi, N, C, Cp, H, C, 0, J.trans_inv, J.W1, J.b1, J.W2, J.b2, nullptr, nullptr,
+                                         J.rowptr_dst, J.col_dst, ptr_sum, B, gid, inv_cnt, slice_quirk, eps, J.prec_fwd, J.fwd_split,
+                                         J.bwd_split, J.wcatT, J.w2T, J.Y, Yw, J.hE, H + pad, J.mask, J.agg, J.mean, J.rstd, J.out, C,
+                                         J.fwd_ws, fwd_ws_bytes, stream));
+        xi = J.out;
+        ldi = C;
+    }
+    return STIN_OK;
+}
+
+extern "C" int stin_edgeconv_chain_bwd(int storage, const stin_chain_job_t* jobs, int n_jobs, const void* g, int64_t ldg,
+                                       const void* x, int64_t ldx, int64_t N, int C, int Cp, int H, const int32_t* ptr_true, int B,
+                                       const int32_t* gid, const int32_t* sid, const float* inv_cnt, int prec_bwd, void* dx,
+                                       int64_t lddx, void* scratch0, void* scratch1, size_t bwd_ws_bytes, stin_stream_t stream,
+                                       stin_stream_t wgrad_stream) {
+    STIN_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || jobs != nullptr), STIN_E_NULL);
+    STIN_REQUIRE(n_jobs <= 1 || (scratch0 != nullptr && scratch1 != nullptr && Cp == C), STIN_E_NULL);
+    const int Yw = 2 * H;
+    const int pad = storage ? 8 : 4;
+    const void* gi = g;
+    int64_t ldgi = ldg;
+    for (int i = n_jobs - 1; i >= 0; --i) {
+        const stin_chain_job_t& J = jobs[i];
+        const void* xi = i == 0 ? x : jobs[i - 1].out;                  // the block's input = its predecessor's output
+        const int64_t ldxi = i == 0 ? ldx : C;
+        void* dxi = i == 0 ? dx : ((i & 1) ? scratch1 : scratch0);
+        const int64_t lddxi = i == 0 ? lddx : Cp;
+        STIN_TRY(stin_edgeconv_block_bwd(storage, gi, ldgi, xi, ldxi, N, C, Cp, H, C, 0, J.trans_inv, J.Y, Yw, J.hE, H + pad, J.mask,
+                                         J.agg, J.mean, J.rstd, J.wcatT, J.w2T, J.rowptr_dst, J.rowptr_src, J.col_src, J.xslot,
+                                         J.w_src, ptr_true, B, gid, sid, inv_cnt, prec_bwd, J.bwd_split, dxi, lddxi, J.dW1, J.db1,
+                                         J.dW2, J.db2, nullptr, nullptr, J.bwd_ws, bwd_ws_bytes, stream, wgrad_stream, J.ev_dy,
+                                         J.ev_dy, J.ev_done, 0));
+        gi = dxi;
+        ldgi = Cp;
+    }
+    return STIN_OK;
+}

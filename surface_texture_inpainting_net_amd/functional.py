@@ -842,6 +842,222 @@ class EdgeConvBlockFn(torch.autograd.Function):
         return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None, None, None, None
 
 
+# ---- a chain of fused blocks of one level in ONE autograd node ------------------------------------------------------------
+USE_CHAIN = os.environ.get('STIN_CHAIN', '1') != '0'
+_CHAIN_JOB = None
+
+
+def _chain_struct():
+    global _CHAIN_JOB
+    if _CHAIN_JOB is None:
+        import struct
+        _CHAIN_JOB = struct.Struct('<27Q4i')             # stin_chain_job_t (include/stin_hip.h): 232 bytes
+    return _CHAIN_JOB
+
+
+def chain_eligible(blocks, x, edges_list, groups):
+    """The n blocks can run as one EdgeConvChainFn: all fused EdgeConv + instance-norm blocks of the same width without
+    shortcut (the bottleneck of the network), operands packed by the network's PackSet, saved-mask path available."""
+    if not (USE_CHAIN and USE_BLOCK_CALL and USE_EDGE_MASK and not KernelTimer.enabled and len(blocks) >= 2 and x.is_cuda):
+        return False
+    if x.dim() != 2 or x.shape[0] <= 1 or x.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    C = x.shape[1]
+    pad = 8 if x.dtype == torch.bfloat16 else 4
+    if C % pad != 0:
+        return False
+    if not edge_mask_supported(2 * C):
+        return False
+    b16 = x.dtype == torch.bfloat16
+    fsp, bsp = block_split_modes(PREC_FWD, b16, C)
+    packed = [b._prepacked is not None for b in blocks]
+    if any(packed) != all(packed) or (b16 and any(packed)):      # all operands packed by the network's PackSet, or none
+        return False
+    for b in blocks:
+        pp = b._prepacked
+        if pp is not None and (len(pp) < 6 or pp[2] != fsp or pp[3] != bsp):
+            return False
+        if (b.dim_in != C or b.dim_out != C or b.unbounded_input or hasattr(b, 'shortcut')
+                or b.first_norm.eps != blocks[0].first_norm.eps):
+            return False
+    return True
+
+
+class EdgeConvChainFn(torch.autograd.Function):
+    """n consecutive GraphResnetBlocks (EdgeConv(mean) + instance norm + ELU + identity residual) of one level as ONE
+    autograd node and one C call per direction (stin_edgeconv_chain_fwd / _bwd: a loop over the whole-block launch
+    sequences, same kernels in the same order -> bit-identical to n EdgeConvBlockFn nodes).  What it removes is host time:
+    n - 1 autograd nodes, 2 (n - 1) foreign calls and ~12 (n - 1) tensor allocations per step (the 9 bottleneck blocks of
+    the 3-D config).  args: x, meta = (edges_list, groups, eps, prec_fwd, prepacked_list, trans_inv_list), then the flat
+    parameters W1, b1, W2, b2 of every block."""
+
+    calls = 0                    # (tests check that the chain path was actually taken)
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        EdgeConvChainFn.calls += 1
+        edges_list, groups, eps, prec_fwd, prepacked, trans_inv = meta
+        n = len(edges_list)
+        lib = _lib.load()
+        x, _ = _mat(x)
+        N, C = x.shape
+        H = 2 * C
+        dev, dt = x.device, x.dtype
+        b16 = dt == torch.bfloat16
+        pad = 8 if b16 else 4
+        B = groups.B
+        Yw = 2 * H
+        fsp, bsp = block_split_modes(prec_fwd, b16, C)
+        # one arena per tensor kind (no views of them are created in here: block i's slices are addressed by pointer)
+        Y = torch.empty(n, N, Yw, dtype=dt, device=dev)
+        hE = torch.empty(n, N, H + pad, dtype=dt, device=dev)
+        agg = torch.empty(n, N, C, dtype=dt, device=dev)
+        outs = torch.empty(max(n - 1, 1), N, C, dtype=dt, device=dev)         # outputs of blocks 0 .. n - 2
+        out = torch.empty(N, C, dtype=dt, device=dev)                         # the chain's output (block n - 1)
+        stats = torch.empty(n, 2, B, C, dtype=torch.float32, device=dev)
+        words = [max(e.n_edges, 1) * (H // 32) for e in edges_list]
+        mask = torch.empty(sum(words), dtype=torch.int32, device=dev)
+        es = x.element_size()
+        ws_bytes = lib.stin_edgeconv_block_fwd_workspace_bytes(C, C, H, C, 0, B)
+        packed = prepacked[0] is not None
+        wts_n = Yw * C + H * C                                                # backward weight operands wcatT | w2T per block
+        wts = ws = None
+        if not packed:                                                        # the block calls run their own pack: own buffers
+            wts = torch.empty(n, wts_n, dtype=torch.float32, device=dev)
+            ws = torch.empty(n, ws_bytes, dtype=torch.uint8, device=dev)
+        st = _chain_struct()
+        blob, moff = [], 0
+        pY, pH, pA, pO, pS, pM = _ptr(Y), _ptr(hE), _ptr(agg), _ptr(outs), _ptr(stats), _ptr(mask)
+        for i in range(n):
+            W1, b1, W2, b2 = params[4 * i:4 * i + 4]
+            pp = prepacked[i]
+            if packed:
+                if pp[2] != fsp or pp[3] != bsp or pp[0].numel() < ws_bytes:
+                    raise RuntimeError('EdgeConvChainFn: prepacked operands do not match this call (stale PackSet)')
+                p_wcatT, p_w2T, p_ws, flag = _ptr(pp[4]), _ptr(pp[5]), _ptr(pp[0]), fsp | BLOCK_PACKED
+            else:
+                p_wcatT = _ptr(wts) + i * wts_n * 4
+                p_w2T, p_ws, flag = p_wcatT + Yw * C * 4, _ptr(ws) + i * ws_bytes, fsp
+            cd = edges_list[i].by_dst
+            o_i = _ptr(out) if i == n - 1 else pO + i * N * C * es
+            blob.append(st.pack(_ptr(W1.contiguous()), _ptr(b1), _ptr(W2.contiguous()), _ptr(b2), p_wcatT, p_w2T, p_ws,
+                                _ptr(cd.rowptr), _ptr(cd.col), 0, 0, 0, 0,
+                                pY + i * N * Yw * es, pH + i * N * (H + pad) * es, pM + moff * 4, pA + i * N * C * es,
+                                pS + (2 * i) * B * C * 4, pS + (2 * i + 1) * B * C * 4, o_i, 0, 0, 0, 0, 0, 0, 0,
+                                int(trans_inv[i]), flag, bsp, int(prec_fwd)))
+            moff += words[i]
+        import ctypes
+        buf = ctypes.create_string_buffer(b''.join(blob), n * st.size)
+        _call('stin_edgeconv_chain_fwd', int(b16), buf, n, _ptr(x), x.stride(0), N, C, C, H, _ptr(groups.ptr_sum), B, _ptr(groups.gid),
+              _ptr(groups.inv_cnt), int(groups.quirk), float(eps), ws_bytes, _stream(x))
+        ctx.save_for_backward(x, Y, hE, agg, outs, stats, mask)
+        ctx.meta = (edges_list, groups, prepacked, trans_inv, words, bsp, wts)
+        ctx.params = params
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Y, hE, agg, outs, stats, mask = ctx.saved_tensors
+        edges_list, groups, prepacked, trans_inv, words, bsp, wts = ctx.meta
+        params = ctx.params
+        n = len(edges_list)
+        lib = _lib.load()
+        N, C = x.shape
+        b16 = x.dtype == torch.bfloat16
+        H, Yw, pad, B = 2 * C, 4 * C, (8 if b16 else 4), groups.B
+        wts_n = Yw * C + H * C
+        dev, dt, es = x.device, x.dtype, x.element_size()
+        g, ldg = _mat(g)
+        _same(x, g)
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty(N, C, dtype=dt, device=dev) if need_dx else None
+        scratch = torch.empty(2, N, C, dtype=dt, device=dev)
+        # gradients: straight into an accepting TrainStep bucket (all blocks or none), else fresh tensors handed to autograd
+        direct = []
+        for i in range(n):
+            W1, b1, W2, b2 = params[4 * i:4 * i + 4]
+            d = _direct_grad_views((W1, b1, W2, b2, None, None))
+            if d is None:
+                break
+            direct.append(d)
+        if len(direct) != n:
+            if direct:
+                raise RuntimeError('EdgeConvChainFn: only some blocks of the chain could write their gradients into the bucket')
+            grads = []
+            for i in range(n):
+                W1, b1, W2, b2 = params[4 * i:4 * i + 4]
+                grads += [torch.empty(W1.shape, dtype=torch.float32, device=dev),
+                          torch.empty(H, dtype=torch.float32, device=dev) if b1 is not None else None,
+                          torch.empty(C, H, dtype=torch.float32, device=dev),
+                          torch.empty(C, dtype=torch.float32, device=dev) if b2 is not None else None]
+        ws_bytes = lib.stin_edgeconv_block_bwd_workspace_bytes(N, C, H, C, 0, B, int(b16))
+        ws = torch.empty(n, ws_bytes, dtype=torch.uint8, device=dev)          # every block its own: the side stream reads it later
+        work = float(N) * Yw * C
+        all_params = [p for p in params]
+        use_side = (USE_WGRAD_STREAM and WGRAD_MIN_WORK <= work <= WGRAD_MAX_WORK and WGRAD_DEFER_JOIN and
+                    (bool(direct) or (_plain_autograd_may_defer() and all(
+                        p is None or (p.is_leaf and p.grad is None and not p._backward_hooks and
+                                      not getattr(p, '_post_accumulate_grad_hooks', None)) for p in all_params))))
+        side_stream, evs = 0, [(0, 0)] * n
+        if use_side:
+            side = _wgrad_side(dev)
+            side.hold.append((ws, x, hE, outs, Y, agg, mask, scratch, wts))
+            side_stream = side.stream.cuda_stream
+            evs = []
+            for _ in range(n):
+                tri = side.next_events()
+                evs.append((tri[1].cuda_event, tri[2].cuda_event))
+            if not direct:
+                for t in grads:
+                    if t is not None:
+                        t.record_stream(side.stream)
+        st = _chain_struct()
+        blob, moff = [], 0
+        pY, pH, pA, pO, pS, pM, pW = _ptr(Y), _ptr(hE), _ptr(agg), _ptr(outs), _ptr(stats), _ptr(mask), _ptr(ws)
+        for i in range(n):
+            pp = prepacked[i]
+            e = edges_list[i]
+            cs = e.by_src
+            if direct:
+                dW1, db1, dW2, db2 = direct[i][:4]
+            else:
+                dW1, db1, dW2, db2 = grads[4 * i:4 * i + 4]
+            if pp is not None:
+                p_wcatT, p_w2T = _ptr(pp[4]), _ptr(pp[5])
+            else:
+                p_wcatT = _ptr(wts) + i * wts_n * 4
+                p_w2T = p_wcatT + Yw * C * 4
+            blob.append(st.pack(0, 0, 0, 0, p_wcatT, p_w2T, 0,
+                                _ptr(e.by_dst.rowptr), 0, _ptr(cs.rowptr), _ptr(cs.col), _ptr(e.xslot), _ptr(e.w_src),
+                                pY + i * N * Yw * es, pH + i * N * (H + pad) * es, pM + moff * 4, pA + i * N * C * es,
+                                pS + (2 * i) * B * C * 4, pS + (2 * i + 1) * B * C * 4, (pO + i * N * C * es) if i < n - 1 else 0,
+                                _ptr(dW1), _ptr(db1), _ptr(dW2), _ptr(db2), pW + i * ws_bytes, evs[i][0], evs[i][1],
+                                int(trans_inv[i]), 0, bsp, 0))
+            moff += words[i]
+        import ctypes
+        buf = ctypes.create_string_buffer(b''.join(blob), n * st.size)
+        _call('stin_edgeconv_chain_bwd', int(b16), buf, n, _ptr(g), ldg, _ptr(x), x.stride(0), N, C, C, H, _ptr(groups.ptr_true), B,
+              _ptr(groups.gid), _ptr(groups.sid if groups.quirk else None), _ptr(groups.inv_cnt), int(PREC_BWD), _ptr(dx), C,
+              _ptr(scratch[0]), _ptr(scratch[1]), ws_bytes, _stream(x), side_stream)
+        if use_side:
+            _wgrad_deferred_join(dev, all_params if not direct else (), () if direct else grads)
+        if direct:
+            sd = _WGRAD_SIDE.get(dev.index if dev.index is not None else torch.cuda.current_device())
+            params[0]._stin_slot[0].block_done(sd.last_done if (sd is not None and sd.hold) else None)
+            return (dx, None) + (None,) * len(params)
+        return (dx, None) + tuple(grads)
+
+
+def edgeconv_chain(x, blocks, edges_list, groups, eps, prec_fwd):
+    params = []
+    for b in blocks:
+        lin1, lin2 = b.first_filter.nn[0], b.first_filter.nn[2]
+        params += [lin1.weight, lin1.bias, lin2.weight, lin2.bias]
+    meta = (list(edges_list), groups, float(eps), int(prec_fwd), [b._prepacked for b in blocks],
+            [bool(b.first_filter.trans_inv) for b in blocks])
+    return EdgeConvChainFn.apply(x, meta, *params)
+
+
 class EdgeReluMeanFn(torch.autograd.Function):
     """h = mean_j ReLU(A_i + B_j) as a standalone differentiable op."""
 

@@ -306,13 +306,21 @@ class SurfaceTextureInpaintingNet(nn.Module):
             out = self._pooling(out, plan.pool(level))
             out = blk(out, plan.edges('hierarchy_edge_index_%d' % level, level), self._norm_arg(plan, level))
         last = num_levels - 1
+        bn_edges = []
         for i, blk in enumerate(self.bottleneck_blocks):
             if self.dilations[i] > 1:
                 key = 'hierarchy_dil_{}_edge_index_{}'.format(self.dilations[i], last)
             else:
                 key = 'hierarchy_edge_index_{}'.format(last)
-            edges = e0 if last == 0 and self.dilations[i] <= 1 else plan.edges(key, last)
-            out = blk(out, edges, self._norm_arg(plan, last))
+            bn_edges.append(e0 if last == 0 and self.dilations[i] <= 1 else plan.edges(key, last))
+        bn = list(self.bottleneck_blocks)
+        if (self.norm is M.FastInstanceNorm and bn and all(isinstance(b.first_filter, M.EdgeConv) for b in bn)
+                and SF.chain_eligible(bn, out, bn_edges, None)):
+            # the whole bottleneck as ONE autograd node / one foreign call per direction (functional.EdgeConvChainFn)
+            out = SF.edgeconv_chain(out, bn, bn_edges, self._norm_arg(plan, last), bn[0].first_norm.eps, SF.PREC_FWD)
+        else:
+            for blk, edges in zip(bn, bn_edges):
+                out = blk(out, edges, self._norm_arg(plan, last))
         for i, blk in enumerate(self.decoder_blocks):
             level = i + 1
             out = self._unpooling(out, plan.pool(num_levels - level))

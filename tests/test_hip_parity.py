@@ -995,6 +995,52 @@ def test_block_call_equals_per_kernel_path_bitwise(batched, dtype):
     assert all(torch.equal(a, b) for a, b in zip(got, want))
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('batched', [False, True])
+def test_bottleneck_chain_equals_per_block_nodes_bitwise(batched, dtype):
+    """functional.EdgeConvChainFn (the bottleneck blocks as ONE autograd node, stin_edgeconv_chain_fwd / _bwd) only loops
+    over the whole-block launch sequences: outputs, input gradient and every parameter gradient equal the per-block
+    autograd nodes bit for bit - plain autograd and the TrainStep bucket route, single graph and a batch of unequal crops."""
+    from surface_texture_inpainting_net_amd.data import collate
+    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=4, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 4, 1])
+    if batched:
+        s = collate([make_synthetic_mesh(n, 3, seed=80 + i, dilations=(2, 4)) for i, n in enumerate((900, 1500, 700))]).to(DEV)
+    else:
+        s = make_synthetic_mesh(5000, 3, seed=80, dilations=(2, 4)).to(DEV)
+
+    def run(chain):
+        old = SF.USE_CHAIN
+        SF.USE_CHAIN = chain
+        try:
+            torch.manual_seed(9)
+            net = S.define_G(**cfg).to(DEV)
+            if dtype == 'bf16':
+                net.set_activation_dtype(torch.bfloat16)
+            x = s.x.clone().requires_grad_(True)
+            s2 = type(s)(**{k: (x if k == 'x' else s[k]) for k in s.keys()})
+            s2._nv_host = s._nv_host
+            out = net(s2)
+            out.float().square().mean().backward()
+            res = [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+            # and three optimizer steps through the bucket route
+            step = TrainStep(net, lr=1e-3)
+            losses = [float(step(s)) for _ in range(3)]
+            step.finish()
+            return res + [torch.tensor(losses)] + [p.detach().clone() for p in net.parameters()]
+        finally:
+            SF.USE_CHAIN = old
+
+    want = run(False)
+    before = SF.EdgeConvChainFn.calls
+    got = run(True)
+    assert SF.EdgeConvChainFn.calls == before + 4, 'the chain path must have been taken (1 plain + 3 TrainStep forwards)'
+    assert len(want) == len(got)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), i
+
+
 def test_batch_of_unequal_crops_full_width_vs_oracle():
     """The linspace-slice quirk through the whole-block calls (ngf = 64: saved-mask widths) against the CPU oracle."""
     from surface_texture_inpainting_net_amd.data import collate
