@@ -451,7 +451,7 @@ def main():
 
     pending_plan = [None]
 
-    def one_step(prefetch=True):
+    def one_step(prefetch=True, behind_compute=False):
         if not args.cache_plan:
             # a fresh CSR plan per step (part of the step).  As a loader with one batch of look-ahead does
             # (TrainStep.prefetch), the plan of step k+1 is built on the plan side streams while step k runs; the
@@ -459,7 +459,12 @@ def main():
             # prefetch=False (the HIP-event-bracketed step): nothing runs on the side streams while kernels are being timed -
             # the step after it then builds its plan at first use on the compute stream.
             sample._plan_cache = pending_plan[0]
-            pending_plan[0] = None if (args.no_prefetch_plan or args.graph or not prefetch) else net.build_plan(sample)
+            # behind_compute=True (the step AFTER the bracketed one): its look-ahead build starts only when everything enqueued so
+            # far has finished on the GPU - at 1 M vertices the host runs a whole step ahead of the GPU, so a build enqueued
+            # here would otherwise run beside the bracketed step's kernels (k_count, 1.1 ms at 1 M, beside a level-0 edge
+            # launch: 1 290 us instead of 530 in the rocprofv3 trace; which launch it hit changed from run to run)
+            pending_plan[0] = None if (args.no_prefetch_plan or args.graph or not prefetch) else \
+                net.build_plan(sample, inputs_ready=not behind_compute)
         return step(sample)
 
     def fence():
@@ -501,11 +506,12 @@ def main():
     if not args.graph:
         # (ONE bracketed step per run: a bracketed step takes the per-kernel host path and costs ~1.5 ms more than a plain one)
         SF.KernelTimer.start(timed, max_records=1_000_000 if args.time_gemms else per_step)
+    bracketed = SF.KernelTimer.enabled
     t0 = time.perf_counter()
     cpu0 = time.thread_time()
     for it in range(args.steps):
         # the bracketed step (the first timed one) leaves the plan side streams idle: its HIP events time kernels, not contention
-        loss = one_step(prefetch=not (SF.KernelTimer.enabled and it == 0))
+        loss = one_step(prefetch=not (SF.KernelTimer.enabled and it == 0), behind_compute=(bracketed and it == 1))
     dt_enqueue = time.perf_counter() - t0                   # host side done (everything enqueued); the GPU may still be running
     dt_cpu = time.thread_time() - cpu0                      # CPU time of the enqueuing thread (the wall figure above also contains
                                                             # waits and, on the shared pool hosts, other tenants' interference)
@@ -580,7 +586,7 @@ def main():
             nbytes = edge_bytes(name, n, e, h)
             avg = sum(ts) / len(ts)
             table.append({'kernel': name, 'N': n, 'E': e, 'H': h, 'launches': len(ts), 'avg_us': avg * 1e6,
-                          'total_ms': sum(ts) * 1e3, 'algorithmic_MB': nbytes / 1e6, 'GBps': nbytes / avg / 1e9})
+                          'each_us': [round(t * 1e6, 1) for t in ts[:8]], 'total_ms': sum(ts) * 1e3, 'algorithmic_MB': nbytes / 1e6, 'GBps': nbytes / avg / 1e9})
         esz = 2.0 if args.dtype == 'bf16' else 4.0
         for (name, tag), ts in gtimes.items():
             m, nc, k = tag
@@ -605,7 +611,7 @@ def main():
                     'traffic': pmc_traffic_bytes(dom['kernel'], dom['N'], dom['E'], dom['H']),
                     'traffic_unit': 'FABRIC bytes per launch incl. Infinity-Cache hits ((2*FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 '
                                     'PMC), REPLAYED from the committed profiles/r*_pmc_traffic.json - not measured in this run',
-                    'avg_us': dom['avg_us'], 'algorithmic_bytes': dom['algorithmic_MB'] * 1e6,
+                    'avg_us': dom['avg_us'], 'each_us': dom['each_us'], 'algorithmic_bytes': dom['algorithmic_MB'] * 1e6,
                     'convention': 'algorithmic bytes (SURVEY 8d): every gathered row charged once per edge; at 200k vertices the '
                                   'gathered operand (102 MB) is Infinity-Cache resident - see hbm_honest for the HBM-served size',
                     'selection': 'the forward edge-stage (aggregation, HBM-bound) launch with the most algorithmic bytes = the '

@@ -404,9 +404,14 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
 // Same arithmetic, same k order and same epilogue expression as k_gemm_nt_bf16s<.., NS = 2, .., WPRE = true>: bit-identical
 // results while K fits one chunk (tests/test_hip_parity.py::test_gemm_nt_strip_kernel_equals_tiled_kernel).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int ST_MT = 2;                            // 32-row MFMA tiles per wave: strips of 64 rows
-constexpr int ST_BM = 32 * ST_MT, ST_PANEL = 128, ST_THREADS = 256, ST_RING = 4;
-constexpr int ST_STEP_BYTES = ST_BM * 32;           // LDS bytes of one piece of one k-step (64 rows x 32 B)
+// MT = 32-row MFMA tiles per wave, QM = wave quads stacked along the rows: strips of BM = 32 MT QM rows, 256 QM threads.
+// (2, 1) is the kernel described above.  Round 3: every wave pulls its W fragments (2 KB per 16-wide k-step) from L2 and
+// spends 3 MT MFMAs on them; at MT = 2 with eight waves on the CU the MFMA rate asks for ~31 B/clk of fragment traffic and
+// the L2 -> CU path delivers ~27 (profiles/nt_stamps.hip, profiles/micro/load_pattern.hip): the kernel was bound by that
+// path.  (2, 2) = two quads on the two 64-row halves of a 128-row strip walking the same panels (the second quad's
+// fragment loads hit the CU's vector L1 when the quads stay close), (4, 1) = 128-row strips on one quad (half the
+// fragment bytes per MFMA outright, one wave per SIMD).  Selection: strip_config().
+constexpr int ST_PANEL = 128, ST_RING = 4;
 
 // fragment of one k-step: 2 x 16 bytes per lane at base + lane * 32 (base wave-uniform -> scalar registers)
 struct StFrag {
@@ -420,8 +425,8 @@ __device__ __forceinline__ StFrag st_wload(const unsigned char* base, unsigned l
     return f;
 }
 
-template <typename PT>
-__global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __restrict__ A, int64_t lda,
+template <typename PT, int MT, int QM>
+__global__ __launch_bounds__(256 * QM) void k_gemm_nt_strip(const float* __restrict__ A, int64_t lda,
                                                               const float* __restrict__ Wf,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ row_mask, int64_t ld_mask,
@@ -430,15 +435,19 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
                                                               int64_t units, int P, int restage) {
     typedef typename PieceTraits<PT>::vec8 vec8;
     constexpr float ASCALE = PieceTraits<PT>::ascale, WSCALE = PieceTraits<PT>::wscale;
-    constexpr int BM = ST_BM, MT = ST_MT;
+    constexpr int BM = 32 * MT * QM, ST_THREADS = 256 * QM;
+    constexpr int ST_STEP_BYTES = BM * 32;          // LDS bytes of one piece of one k-step (BM rows x 32 B)
+    constexpr int RPP = 32 * QM;                    // rows per staging pass (8 threads along k per row)
     extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
     const int plane_bytes = (KC / 16) * ST_STEP_BYTES;                    // one piece of the resident chunk
     float* bias_s = reinterpret_cast<float*>(strip_smem + 2 * plane_bytes);   // [Nc rounded up to 128]
     float* mask_s = bias_s + P * ST_PANEL;                                // [BM]
-    float* stage_s = mask_s + BM;                                         // [4 waves][16 rows][32 columns]: the epilogue's restage
+    float* stage_s = mask_s + BM;                                         // [waves][16 rows][32 columns]: the epilogue's restage
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform: the sequence logic stays scalar
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);       // provably wave-uniform: the sequence logic stays scalar
+    const int wave = wave_all & 3, quad = wave_all >> 2;                  // column tile of the panel, row quad of the strip
+    const int qrow = quad * MT * 32;                                      // first strip row of this quad
     const int kh = lane >> 5, li = lane & 31;
     const int kq = tid & 7, r0 = tid >> 3;                                // staging: float4 index along k, first row (32 rows per pass)
     const int KS_total = K / 16;                                          // k-steps of the whole K (K is a multiple of 64)
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     // A fragment of (row tile i, k-step ks, piece p): a_frag + p * plane_bytes + ks * ST_STEP_BYTES + i * 1024
-    const unsigned char* a_frag = strip_smem + li * 32 + ((kh ^ ((li >> 3) & 1)) << 4);
+    const unsigned char* a_frag = strip_smem + qrow * 32 + li * 32 + ((kh ^ ((li >> 3) & 1)) << 4);
     int staged_c = -1;
     int64_t staged_s = -1;
     while (run.live) {
@@ -506,26 +515,27 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
         if (run.s != staged_s || run.c != staged_c) {
             __syncthreads();
             const int KTc = ks_of(run.c) / 2;
-            for (int kt0 = 0; kt0 < KTc; kt0 += 4) {    // four k-tiles (4 x MT float4 per thread) in flight
-                float4 ra[4][MT];
+            constexpr int SH = MT >= 4 ? 2 : 4;         // k-tiles in flight (SH x MT float4 per thread)
+            for (int kt0 = 0; kt0 < KTc; kt0 += SH) {
+                float4 ra[SH][MT];
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
+                for (int h = 0; h < SH; ++h) {
                     const int ktc = kt0 + h < KTc ? kt0 + h : KTc - 1;
                     const int k = run.c * KC + ktc * 32 + kq * 4;
 #pragma unroll
                     for (int t = 0; t < MT; ++t) {
-                        const int64_t row = run.s * BM + r0 + t * 32;
+                        const int64_t row = run.s * BM + r0 + t * RPP;
                         const float4 v = ld4(A + (row < M ? row : M - 1) * lda + k);
                         ra[h][t] = row < M ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
+                for (int h = 0; h < SH; ++h) {
                     if (kt0 + h >= KTc) break;
                     const int ks = (kt0 + h) * 2 + (kq >> 2), kh_ = (kq >> 1) & 1;
 #pragma unroll
                     for (int t = 0; t < MT; ++t) {
-                        const int row = r0 + t * 32;
+                        const int row = r0 + t * RPP;
                         PT* dst = reinterpret_cast<PT*>(strip_smem + ks * ST_STEP_BYTES + row * 32 + ((kh_ ^ ((row >> 3) & 1)) << 4) + (kq & 1) * 8);
                         split_store<2, PT>(ra[h][t], dst, plane_bytes / 2, ASCALE);
                     }
@@ -581,9 +591,9 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
             // contiguous bytes per instruction - 8 store instructions per tile instead of 32 dword stores (in the all-columns
             // kernel the dword-store epilogue was 10 k of a block's 62 k cycles, profiles/nt_stamps.hip).  Same values.
             const float bv = bias_s[col0 + li];
-            float* stage_f = stage_s + wave * 512;
+            float* stage_f = stage_s + wave_all * 512;
             const int r16 = lane >> 3, c8 = lane & 7;
-            float* cbase = C + (run.s * BM + r16) * ldc + col0 + c8 * 4;
+            float* cbase = C + (run.s * BM + qrow + r16) * ldc + col0 + c8 * 4;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
                     for (int r8 = 0; r8 < 8; ++r8) {
                         const int r = p * 8 + r8;
                         const int tr = (r & 3) + 8 * ((r >> 2) & 1) + 4 * kh;             // row inside this 16-row pass
-                        const float m = row_mask != nullptr ? mask_s[i * 32 + p * 16 + tr] : 1.f;
+                        const float m = row_mask != nullptr ? mask_s[qrow + i * 32 + p * 16 + tr] : 1.f;
                         stage_f[tr * 32 + li] = row_mask != nullptr ? acc[i][r] * sc + bv * m + 0.f : acc[i][r] * sc + bv + 0.f;
                         acc[i][r] = 0.f;
                     }
@@ -606,7 +616,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
             // (no LDS to spare for the restage without losing a block of occupancy: K chunks of 128) 32 dword stores, row base
             // pointers wave-uniform (scalar), the lane's offset one register
             const float bv = bias_s[col0 + li];
-            float* cbase = C + run.s * BM * ldc + col0;
+            float* cbase = C + (run.s * BM + qrow) * ldc + col0;
             const unsigned coff = (unsigned)(4 * kh) * (unsigned)ldc + (unsigned)li;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -614,7 +624,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
                 for (int r = 0; r < 16; ++r) {
                     const int lr = i * 32 + (r & 3) + 8 * (r >> 2);
                     float* rp = cbase + (int64_t)lr * ldc;
-                    rp[coff] = row_mask != nullptr ? acc[i][r] * sc + bv * mask_s[lr + 4 * kh] + 0.f : acc[i][r] * sc + bv + 0.f;
+                    rp[coff] = row_mask != nullptr ? acc[i][r] * sc + bv * mask_s[qrow + lr + 4 * kh] + 0.f : acc[i][r] * sc + bv + 0.f;
                     acc[i][r] = 0.f;
                 }
         } else {
@@ -627,7 +637,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t row = run.s * BM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int64_t row = run.s * BM + qrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                     const int64_t rc = row < M ? row : M - 1;
                     ld[i][r] = run.c > 0 ? C[rc * ldc + cc] : (res != nullptr ? res[rc * ld_res + cc] : 0.f);
                 }
@@ -635,7 +645,7 @@ __global__ __launch_bounds__(ST_THREADS) void k_gemm_nt_strip(const float* __res
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int lr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int lr = qrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                     const int64_t row = run.s * BM + lr;
                     float v;
                     if (run.c == 0) v = acc[i][r] * sc + (row_mask != nullptr ? bv * mask_s[lr] : bv) + ld[i][r];
@@ -1808,6 +1818,17 @@ inline int tn_rows_per_chunk(int64_t M, int tiles, bool one_per_cu = false) {
     rows = (rows + TN_R - 1) / TN_R * TN_R;
     return (int)rows;
 }
+// Strip-kernel configuration (see k_gemm_nt_strip): 21 / 22 / 41.  STIN_STRIP_CFG overrides (tuning aid).
+inline int strip_config(int64_t M, int Nc, int KC) {
+    const char* e = getenv("STIN_STRIP_CFG");                         // re-read per call: profiles/gemm_shapes.py flips it
+    const int forced = e ? atoi(e) : 0;
+    if (forced == 21 || forced == 22 || forced == 41) return forced;
+    // measured (profiles/r03_strip_cfg.md): two quads gain 2-5 % where a strip has many panels (18 063 x 1024 x 256: 46.6 -> 44.4 us,
+    // x 1280 x 128 43.3 -> 42.1, 60 211 x 640 x 256 79.7 -> 77.8, 200 704 x 320 x 128 135.5 -> 133.2) and lose 3 % at Nc = 512
+    // (30.2 -> 31.2); MT = 4 on one quad (one wave per SIMD) is 25-40 % slower everywhere and stays a tested tuning variant
+    (void)M; (void)KC;
+    return Nc >= 640 ? 22 : 21;
+}
 // all-columns NT kernel: waves along the rows of a block (see k_gemm_nt_wide).  8 waves per block (128 rows) for Nc = 256
 // while the 128-row blocks fit the chip in one round: 18 063 x 256 x 1024 41.6 -> 36.7 us, x 512 29.3 -> 27.7; slower for 60 k
 // rows (471 blocks: 59 -> 64 us) and for Nc = 128 (256-row blocks: 71 of them at 18 k rows, 34 -> 52 us), which keep 4 waves.
@@ -1894,13 +1915,15 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
                      STIN_E_ALIGN);
         const int KC = K < 256 ? K : 256;                             // resident K chunk: 64 rows x 256 k x 4 B = 64 KB -> 2 blocks per CU
         const int P = (Nc + ST_PANEL - 1) / ST_PANEL;
-        size_t lds = (size_t)2 * (KC / 32) * ST_BM * 64 + (size_t)P * ST_PANEL * 4 + ST_BM * 4;
+        const int cfg = strip_config(M, Nc, KC);                      // 21 = (MT 2, one quad), 22 = two quads, 41 = MT 4
+        const int bm = cfg == 21 ? 64 : 128, waves = cfg == 22 ? 8 : 4;
+        size_t lds = (size_t)2 * (KC / 32) * bm * 64 + (size_t)P * ST_PANEL * 4 + bm * 4;
         // the epilogue's restage area (2 KB per wave) only where it does not cost a resident block (K chunks of 256: 2 blocks
         // per CU either way; chunks of 128 would drop from 4 to 3 and lose more than the wide stores gain: 130 -> 155 us at
         // 200 704 x 320 x 128)
-        const int restage = (160 * 1024 / (lds + 4 * 2048) == 160 * 1024 / lds) ? 1 : 0;
-        if (restage) lds += 4 * 2048;
-        const int64_t units = ((M + ST_BM - 1) / ST_BM) * P;
+        const int restage = (160 * 1024 / (lds + waves * 2048) == 160 * 1024 / lds) ? 1 : 0;
+        if (restage) lds += waves * 2048;
+        const int64_t units = ((M + bm - 1) / bm) * P;
         int occ = (int)(160 * 1024 / lds);
         if (occ > 8) occ = 8;
         if (occ < 1) occ = 1;
@@ -1908,18 +1931,25 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
         if (e_occ && atoi(e_occ) > 0) occ = atoi(e_occ);
         int64_t grid = (int64_t)stin_cu_count() * occ;
         if (grid > units) grid = units;
-#define STIN_STRIP(PT_)                                                                                                   \
+#define STIN_STRIP_L(PT_, MT_, QM_)                                                                                       \
     do {                                                                                                                  \
         static bool attr_set = false;                                                                                     \
         if (!attr_set) {                                                                                                  \
-            (void)hipFuncSetAttribute((const void*)k_gemm_nt_strip<PT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_strip<PT_, MT_, QM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                              \
         }                                                                                                                 \
-        hipLaunchKernelGGL((k_gemm_nt_strip<PT_>), dim3((unsigned)grid), dim3(ST_THREADS), lds, stream, A, lda, W, bias, row_mask, \
+        hipLaunchKernelGGL((k_gemm_nt_strip<PT_, MT_, QM_>), dim3((unsigned)grid), dim3(256 * QM_), lds, stream, A, lda, W, bias, row_mask, \
                            ld_mask, residual, ld_res, M, Nc, K, C, ldc, KC, units, P, restage);                          \
+    } while (0)
+#define STIN_STRIP(PT_)                                                                                                   \
+    do {                                                                                                                  \
+        if (cfg == 22) STIN_STRIP_L(PT_, 2, 2);                                                                           \
+        else if (cfg == 41) STIN_STRIP_L(PT_, 4, 1);                                                                      \
+        else STIN_STRIP_L(PT_, 2, 1);                                                                                     \
     } while (0)
         if (precision == STIN_GEMM_BF16X3) STIN_STRIP(__bf16);
         else STIN_STRIP(_Float16);
+#undef STIN_STRIP_L
 #undef STIN_STRIP
     } else if (wpre) {
         // pre-split W: the 16-byte vector path only (K % 4 == 0, aligned rows) - one tile shape, the data is per-network

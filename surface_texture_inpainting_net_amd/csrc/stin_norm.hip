@@ -156,6 +156,15 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce_final(const double* __restr
         const double* p = partial + ((int64_t)b * nch * nout + o) * C + c;
         const int64_t stride = (int64_t)nout * C;
         int k = ty;
+        // 16 loads in flight per lane before the first add (round 3: with 4 the 564-chunk list of the bottleneck level was nine
+        // dependent memory round trips = 9.4 us for 2 MB); the adds keep the order of the 4-wide loop below: bit-identical
+        for (; k + 15 * FIN_KL < nch; k += 16 * FIN_KL) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(k + u * FIN_KL) * stride];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+        }
         for (; k + 3 * FIN_KL < nch; k += 4 * FIN_KL) {
             s0 += p[(int64_t)k * stride];
             s1 += p[(int64_t)(k + FIN_KL) * stride];
@@ -195,6 +204,13 @@ __global__ void k_moments_final(const double* __restrict__ partial, int nch, int
         const int64_t st = (int64_t)2 * C;
         double t1 = 0.0, t2 = 0.0;
         int k = ty;
+        for (; k + 7 * FIN_KL < nch; k += 8 * FIN_KL) {   // 16 loads in flight, adds in the order of the 2-wide loop below
+            double a[8], q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = p[(k + u * FIN_KL) * st]; q[u] = p[(k + u * FIN_KL) * st + C]; }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { s1 += a[u]; s2 += q[u]; t1 += a[u + 1]; t2 += q[u + 1]; }
+        }
         for (; k + FIN_KL < nch; k += 2 * FIN_KL) {       // two independent loads in flight
             s1 += p[k * st];
             s2 += p[k * st + C];

@@ -281,6 +281,38 @@ def test_gemm_nt_strip_kernel_equals_tiled_kernel(M, Nc, K):
         assert float((SF.gemm_nt(A, Wf, b, row_mask=mask, precision=prec | SF.GEMM_W_PRESPLIT | FR).double() - ref).abs().max()) <= tol * scale
 
 
+@pytest.mark.parametrize('cfg', ['22', '41'])
+@pytest.mark.parametrize('M,Nc,K', [(1, 320, 128), (37, 320, 192), (300, 352, 128), (5000, 1024, 256), (18063, 640, 256), (129, 1024, 128),
+                                    (777, 1280, 256), (64, 384, 256), (18063, 512, 256), (127, 320, 256), (128, 320, 256), (200, 320, 128)])
+def test_gemm_nt_strip_configurations_are_bit_identical(M, Nc, K, cfg, monkeypatch):
+    """k_gemm_nt_strip<PT, MT, QM>: 128-row strips on two wave quads (STIN_STRIP_CFG=22) or on one quad with four row tiles
+    per wave (41) against the 64-row configuration (21): the same MFMA sequence per output element -> bit-identical, with
+    every epilogue (bias, masked bias, residual, strided output), ragged last strips and unit ranges that cross strips."""
+    g = torch.Generator().manual_seed(M + Nc + K)
+    A = torch.randn(M + 3, K + 4, generator=g).to(DEV)[1:M + 1, :K]
+    W = (torch.randn(Nc, K, generator=g) * 0.1).to(DEV)
+    b = torch.randn(Nc, generator=g).to(DEV)
+    mask = (torch.rand(M, 3, generator=g) < 0.7).float().to(DEV)[:, 1]
+    res = torch.randn(M, Nc, generator=g).to(DEV)
+    FR = 0x400
+    assert _lib_load().stin_gemm_w_is_frag(Nc, K)
+    for prec in (SF.GEMM_F16X3, SF.GEMM_BF16X3):
+        Wf = SF.split_weights(W, prec | FR)
+        for kw in (dict(), dict(bias=b), dict(bias=b, row_mask=mask), dict(residual=res), dict(bias=b, residual=res)):
+            monkeypatch.setenv('STIN_STRIP_CFG', '21')
+            base = SF.gemm_nt(A, Wf, precision=prec | SF.GEMM_W_PRESPLIT | FR, **kw)
+            monkeypatch.setenv('STIN_STRIP_CFG', cfg)
+            for _ in range(2):
+                got = SF.gemm_nt(A, Wf, precision=prec | SF.GEMM_W_PRESPLIT | FR, **kw)
+                assert torch.equal(got, base), (prec, sorted(kw))
+        wide = torch.full((M + 2, Nc + 8), 3.0, device=DEV)
+        SF.gemm_nt(A, Wf, b, out=wide[1:M + 1, 4:Nc + 4], precision=prec | SF.GEMM_W_PRESPLIT | FR)
+        monkeypatch.setenv('STIN_STRIP_CFG', '21')
+        assert torch.equal(wide[1:M + 1, 4:Nc + 4], SF.gemm_nt(A, Wf, b, precision=prec | SF.GEMM_W_PRESPLIT | FR))
+        wide[1:M + 1, 4:Nc + 4] = 3.0
+        assert float((wide - 3.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('M,Nc,K', [(18063, 256, 512), (18063, 1024, 256), (5000, 320, 128), (777, 128, 260), (65, 132, 128),
                                     (31, 256, 128), (4097, 1280, 128), (60211, 128, 256), (1, 128, 128)])
 def test_gemm_tn_ws_kernel_equals_four_wave_kernel(M, Nc, K, monkeypatch):
