@@ -538,6 +538,55 @@ int stin_edgeconv_chain_bwd(int storage, const stin_chain_job_t* jobs, int n_job
                             const int32_t* sid, const float* inv_cnt, int prec_bwd, void* dx, int64_t lddx, void* scratch0,
                             void* scratch1, size_t bwd_ws_bytes, stin_stream_t stream, stin_stream_t wgrad_stream);
 
+/* The WHOLE graph part of the network in one call per direction (round 3): every fused EdgeConv + instance-norm block and the
+ * pool / unpool steps between them, in network order (models/surfacetextureinpaintingnet.py:404-455: input blocks, `for`
+ * over the encoder levels - `_pooling` :384-386 then a block -, the bottleneck blocks, `for` over the decoder levels -
+ * `_unpooling` :390-391 then a block -, the output blocks).  The calls loop over stin_edgeconv_block_fwd / _bwd,
+ * stin_pool_max_{fwd,bwd}_*, stin_gather_rows_* and stin_segment_sum_* with the per-op pointers of a HOST op array: identical
+ * kernels in identical order (bit-identical to the per-op calls), ONE foreign call and one autograd node per direction
+ * instead of ~20 - what it removes is host time (the launch-bound sizes: 20 k-vertex crops, the 8-crop batches).
+ *   op i reads `x` (ops[0]: the network input padded to Cp channels; else ops[i - 1].out) and writes `out`;
+ *   bwd walks the ops in reverse: the gradient of op i's output is ops[i + 1].dx (the call's `g` for the last op), op i writes
+ *   its input gradient to `dx` (NULL for ops[0] when the network input needs none).
+ *   STIN_OP_BLOCK: the arguments of stin_edgeconv_block_fwd / _bwd (n_out = n_in = N rows); use_side != 0 puts the block's
+ *     weight-gradient work on `wgrad_stream` behind ev_dy and records ev_done there (as stin_edgeconv_block_bwd).
+ *   STIN_OP_POOL_MAX: x [n_in, Cout] -> out [n_out, Cout], arg [n_out, Cout]; rowptr_dst / col_dst = the children CSR, trace = the
+ *     fine -> coarse map (backward).  STIN_OP_UNPOOL: out[v] = x[trace[v]] (n_out fine rows); backward = the segment sum
+ *     over the children CSR. */
+#define STIN_OP_BLOCK 0
+#define STIN_OP_POOL_MAX 1
+#define STIN_OP_UNPOOL 2
+typedef struct stin_net_op {
+    int32_t kind, Cin, Cp, H, Cout, has_shortcut, trans_inv, prec_fwd, fwd_split, bwd_split, B, slice_quirk, use_side, reserved0,
+        reserved1, reserved2;
+    float eps;
+    int32_t reserved3;
+    int64_t n_out, n_in, ldx, ldo, lddx, ldy, ldh;
+    uint64_t fwd_ws_bytes, bwd_ws_bytes;
+    const void* x;
+    void* out;
+    void* dx;
+    const float *W1, *b1, *W2, *b2, *Ws, *bs;
+    float *wcatT, *w2T;
+    void* fwd_ws;
+    const int32_t *rowptr_dst, *col_dst, *rowptr_src, *col_src, *xslot;
+    const float* w_src;
+    const int32_t *ptr_sum, *ptr_true, *gid, *sid;
+    const float* inv_cnt;
+    void *Y, *hE;
+    uint32_t* mask;
+    void* agg;
+    float *mean, *rstd;
+    int32_t* arg;
+    const int32_t* trace;
+    float *dW1, *db1, *dW2, *db2, *dWs, *dbs;
+    void* bwd_ws;
+    stin_event_t ev_dy, ev_done;
+} stin_net_op_t;                      /* 16 int32 + float + int32 + 7 int64 + 2 uint64 + 40 pointers = 464 bytes */
+int stin_net_fwd(int storage, const stin_net_op_t* ops, int n_ops, stin_stream_t stream);
+int stin_net_bwd(int storage, const stin_net_op_t* ops, int n_ops, const void* g, int64_t ldg, int prec_bwd, stin_stream_t stream,
+                 stin_stream_t wgrad_stream);
+
 /* All weight gradients of one fused block in two launches (round 3): BOTH transposed products
  *   dW2 | db2 = dagg^T [hE[:, :H] | hE[:, H]]        (second Linear; db2 weighted by the [deg > 0] column of hE)
  *   [dW1 ; dWs | db1 ; dbs] = dY^T [x | 1]           (first Linear + shortcut in the packed operand layout)

@@ -351,3 +351,84 @@ extern "C" int stin_edgeconv_chain_bwd(int storage, const stin_chain_job_t* jobs
     }
     return STIN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The graph part of the network as one op list per direction (include/stin_hip.h: stin_net_op_t).  Only loops: every op is
+// one of the existing entry points with the pointers of the host array.
+static_assert(sizeof(stin_net_op_t) == 16 * 4 + 8 + 7 * 8 + 2 * 8 + 40 * 8, "stin_net_op_t layout (functional._net_struct packs it)");
+
+extern "C" int stin_net_fwd(int storage, const stin_net_op_t* ops, int n_ops, stin_stream_t stream) {
+    STIN_REQUIRE(n_ops >= 0 && (n_ops == 0 || ops != nullptr), STIN_E_NULL);
+    STIN_REQUIRE(storage == 0 || storage == 1, STIN_E_UNSUPPORTED);
+    for (int i = 0; i < n_ops; ++i) {
+        const stin_net_op_t& J = ops[i];
+        if (J.kind == STIN_OP_BLOCK) {
+            STIN_TRY(stin_edgeconv_block_fwd(storage, J.x, J.ldx, J.n_out, J.Cin, J.Cp, J.H, J.Cout, J.has_shortcut, J.trans_inv, J.W1,
+                                             J.b1, J.W2, J.b2, J.Ws, J.bs, J.rowptr_dst, J.col_dst, J.ptr_sum, J.B, J.gid, J.inv_cnt,
+                                             J.slice_quirk, J.eps, J.prec_fwd, J.fwd_split, J.bwd_split, J.wcatT, J.w2T, J.Y, J.ldy,
+                                             J.hE, J.ldh, J.mask, J.agg, J.mean, J.rstd, J.out, J.ldo, J.fwd_ws, (size_t)J.fwd_ws_bytes,
+                                             stream));
+        } else if (J.kind == STIN_OP_POOL_MAX) {
+            if (storage)
+                STIN_TRY(stin_pool_max_fwd_bf16(static_cast<const stin_bf16_t*>(J.x), J.ldx, J.rowptr_dst, J.col_dst, J.n_out, J.Cout,
+                                                static_cast<stin_bf16_t*>(J.out), J.ldo, J.arg, stream));
+            else
+                STIN_TRY(stin_pool_max_fwd_f32(static_cast<const float*>(J.x), J.ldx, J.rowptr_dst, J.col_dst, J.n_out, J.Cout,
+                                               static_cast<float*>(J.out), J.ldo, J.arg, stream));
+        } else if (J.kind == STIN_OP_UNPOOL) {
+            if (storage)
+                STIN_TRY(stin_gather_rows_bf16(static_cast<const stin_bf16_t*>(J.x), J.ldx, J.trace, nullptr, J.n_out, J.Cout,
+                                               static_cast<stin_bf16_t*>(J.out), J.ldo, stream));
+            else
+                STIN_TRY(stin_gather_rows_f32(static_cast<const float*>(J.x), J.ldx, J.trace, nullptr, J.n_out, J.Cout,
+                                              static_cast<float*>(J.out), J.ldo, stream));
+        } else {
+            return STIN_E_UNSUPPORTED;
+        }
+    }
+    return STIN_OK;
+}
+
+extern "C" int stin_net_bwd(int storage, const stin_net_op_t* ops, int n_ops, const void* g, int64_t ldg, int prec_bwd,
+                            stin_stream_t stream, stin_stream_t wgrad_stream) {
+    STIN_REQUIRE(n_ops >= 0 && (n_ops == 0 || ops != nullptr), STIN_E_NULL);
+    STIN_REQUIRE(storage == 0 || storage == 1, STIN_E_UNSUPPORTED);
+    const void* gi = g;
+    int64_t ldgi = ldg;
+    for (int i = n_ops - 1; i >= 0; --i) {
+        const stin_net_op_t& J = ops[i];
+        STIN_REQUIRE(J.dx != nullptr || i == 0, STIN_E_NULL);
+        if (J.kind == STIN_OP_BLOCK) {
+            STIN_TRY(stin_edgeconv_block_bwd(storage, gi, ldgi, J.x, J.ldx, J.n_out, J.Cin, J.Cp, J.H, J.Cout, J.has_shortcut, J.trans_inv,
+                                             J.Y, J.ldy, J.hE, J.ldh, J.mask, J.agg, J.mean, J.rstd, J.wcatT, J.w2T, J.rowptr_dst,
+                                             J.rowptr_src, J.col_src, J.xslot, J.w_src, J.ptr_true, J.B, J.gid, J.sid, J.inv_cnt, prec_bwd,
+                                             J.bwd_split, J.dx, J.lddx, J.dW1, J.db1, J.dW2, J.db2, J.dWs, J.dbs, J.bwd_ws,
+                                             (size_t)J.bwd_ws_bytes, stream, J.use_side ? wgrad_stream : nullptr, J.ev_dy, J.ev_dy,
+                                             J.ev_done, 0));
+        } else if (J.kind == STIN_OP_POOL_MAX) {
+            if (J.dx != nullptr) {
+                if (storage)
+                    STIN_TRY(stin_pool_max_bwd_bf16(static_cast<const stin_bf16_t*>(gi), ldgi, J.arg, J.trace, J.n_in, J.Cout,
+                                                    static_cast<stin_bf16_t*>(J.dx), J.lddx, stream));
+                else
+                    STIN_TRY(stin_pool_max_bwd_f32(static_cast<const float*>(gi), ldgi, J.arg, J.trace, J.n_in, J.Cout,
+                                                   static_cast<float*>(J.dx), J.lddx, stream));
+            }
+        } else if (J.kind == STIN_OP_UNPOOL) {
+            if (J.dx != nullptr) {
+                if (storage)
+                    STIN_TRY(stin_segment_sum_bf16(static_cast<const stin_bf16_t*>(gi), ldgi, J.rowptr_dst, J.col_dst, J.n_in, J.Cout, 0,
+                                                   static_cast<stin_bf16_t*>(J.dx), J.lddx, stream));
+                else   // (non-temporal loads on a once-read source beyond the Infinity Cache, as functional.segment_sum asks for)
+                    STIN_TRY(stin_segment_sum_f32(static_cast<const float*>(gi), ldgi, J.rowptr_dst, J.col_dst, J.n_in, J.Cout,
+                                                  (J.n_out * (int64_t)J.Cout * 4 > ((int64_t)256 << 20)) ? STIN_SEG_NONTEMPORAL : 0,
+                                                  static_cast<float*>(J.dx), J.lddx, stream));
+            }
+        } else {
+            return STIN_E_UNSUPPORTED;
+        }
+        gi = J.dx;
+        ldgi = J.lddx;
+    }
+    return STIN_OK;
+}

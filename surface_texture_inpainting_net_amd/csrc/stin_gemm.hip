@@ -1375,6 +1375,78 @@ __device__ __forceinline__ uint4 f8_to_bf16x8(float4 a, float4 b) {
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
+// Epilogue shared by the bf16-storage NT kernels: + bias * row_mask + residual in fp32, one rounding; bf16 tiles leave through
+// LDS (smem: the operand tiles, free once every wave has passed the caller's last barrier) as 16-byte row-contiguous stores.
+template <int BM, int BN, int WM, int WN, typename OUT>
+__device__ __forceinline__ void nt_b16_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], unsigned char* smem, int64_t m0, int n0,
+                                                const float* __restrict__ bias, const stin_bf16* __restrict__ row_mask,
+                                                int64_t ld_mask, const stin_bf16* __restrict__ res, int64_t ld_res, int64_t M,
+                                                int Nc, OUT* __restrict__ C, int64_t ldc, int vec_out) {
+    constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
+    constexpr int CPITCH = BN + 32;                               // output staging pitch (bf16): rows r, r+1 on disjoint banks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kh = lane >> 5, li = lane & 31;
+    // ---- epilogue: + bias * row_mask + residual in fp32, one rounding
+    constexpr bool OUT_BF16 = sizeof(OUT) == 2;
+    const bool staged = OUT_BF16 && vec_out;
+    if (staged) __syncthreads();                                  // every wave is done with the operand tiles
+    stin_bf16(*Cs)[CPITCH] = reinterpret_cast<stin_bf16(*)[CPITCH]>(smem);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int lcol = wn * TN + j * 32 + li;
+        const int col = n0 + lcol;
+        const bool col_ok = col < Nc;
+        const float bv = (bias != nullptr && col_ok) ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int64_t row = m0 + lrow;
+                float t = acc[i][j][r];
+                if (row < M && col_ok) {
+                    if (bias != nullptr) t += row_mask != nullptr ? bv * (float)row_mask[row * ld_mask] : bv;
+                    if (res != nullptr) t += (float)res[row * ld_res + col];
+                }
+                v[r] = t;
+            }
+            if (staged) {
+                // lanes (li, li^1) trade one value per register pair so that each writes two adjacent columns of ONE row
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool odd = li & 1;
+                    const float got = __shfl_xor(odd ? v[2 * q] : v[2 * q + 1], 1);
+                    const int lrow = wm * TM + i * 32 + ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * kh + (odd ? 1 : 0);
+                    const uint32_t pr = odd ? pack_bf16x2(got, v[2 * q + 1]) : pack_bf16x2(v[2 * q], got);
+                    *reinterpret_cast<uint32_t*>(&Cs[lrow][lcol & ~1]) = pr;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (row < M && col_ok) st1(C + row * ldc + col, v[r]);
+                }
+            }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        constexpr int CHUNKS = BM * BN / 8;                       // 16-byte chunks of the output tile
+#pragma unroll
+        for (int s = 0; s < CHUNKS / BLOCK; ++s) {
+            const int c = tid + s * BLOCK;
+            const int lrow = c / (BN / 8), lc = (c % (BN / 8)) * 8;
+            const int64_t row = m0 + lrow;
+            const int col = n0 + lc;
+            if (row < M && col < Nc)
+                *reinterpret_cast<uint4*>(reinterpret_cast<stin_bf16*>(C) + row * ldc + col) =
+                    *reinterpret_cast<const uint4*>(&Cs[lrow][lc]);
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, typename OUT, bool VEC, bool WB = false>   // WB: W already holds bf16 (ldw in bf16 elements)
 __global__ __launch_bounds__(BLOCK) void k_gemm_nt_b16(const stin_bf16* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ W, int64_t ldw,
@@ -1498,64 +1570,114 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_b16(const stin_bf16* __restri
         }
     }
 
-    // ---- epilogue: + bias * row_mask + residual in fp32, one rounding
-    constexpr bool OUT_BF16 = sizeof(OUT) == 2;
-    const bool staged = OUT_BF16 && vec_out;
-    if (staged) __syncthreads();                                  // every wave is done with the operand tiles
-    stin_bf16(*Cs)[CPITCH] = reinterpret_cast<stin_bf16(*)[CPITCH]>(smem);
+    nt_b16_epilogue<BM, BN, WM, WN, OUT>(acc, smem, m0, n0, bias, row_mask, ld_mask, res, ld_res, M, Nc, C, ldc, vec_out);
+}
+
+// Fat shapes of the deep hierarchies (BASELINE config 5: 8 100 rows x 1024..4096 channels, 27 k x 512..2048): both operands
+// bf16, K a multiple of 64, where the register-staged 64 x 64 / 128 x 64 tiles above ran at 0.11-0.18 of the MFMA peak (one
+// LDS buffer: load -> wait -> write -> barrier per k-tile).  128 x 128 tile, 4 waves of 64 x 64, the two operand tiles of a
+// k-step (2 x 16 KB) staged by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction = 8 rows x 128 B, no VGPRs, no
+// ds_write) into one of TWO buffers while the MFMAs of the previous k-tile run; one barrier per k-tile.  An LDS-DMA writes
+// wave-linear (base + lane * 16), so the bank swizzle of the image - the 16-byte chunk c of row r sits at position
+// c ^ ((r >> 1) & 7), the image k_gemm_nt_b16 reads conflict-free - is applied to the per-lane SOURCE address.  Rows past M
+// / Nc are clamped to the last valid row (their products are never stored).  Same MFMA sequence per output element as
+// k_gemm_nt_b16 (k ascending in steps of 16): bit-identical results.
+// Block -> tile: with a multiple of 8 column tiles every XCD owns Nc / 8 columns (its W panel, 1 MB at K = 1024 and Nc = 4096,
+// stays in that XCD's L2 while the A row tiles stream through, each read by the XCD's consecutive blocks); otherwise the
+// row-tile-per-XCD order of nt_block_tile.
+template <typename OUT>
+__global__ __launch_bounds__(BLOCK, 2) void k_gemm_nt_b16_glds(const stin_bf16* __restrict__ A, int64_t lda,
+                                                            const stin_bf16* __restrict__ W, int64_t ldw,
+                                                            const float* __restrict__ bias,
+                                                            const stin_bf16* __restrict__ row_mask, int64_t ld_mask,
+                                                            const stin_bf16* __restrict__ res, int64_t ld_res, int64_t M,
+                                                            int Nc, int K, OUT* __restrict__ C, int64_t ldc, int vec_out) {
+    constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TM = 64, TN = 64, MT = 2, NT = 2;
+    constexpr int BUF = (BM + BN) * BKB * 2;                      // one k-tile of both operands: 32 KB
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int64_t m0;
+    int n0;
+    const int ncol = (Nc + BN - 1) / BN;
+    if (ncol % 8 == 0) {
+        const int cpx = ncol / 8;
+        const int64_t j = blockIdx.x >> 3;
+        m0 = (j / cpx) * BM;
+        n0 = (int)((blockIdx.x & 7) * cpx + j % cpx) * BN;
+    } else if (!nt_block_tile(M, Nc, BM, BN, m0, n0)) {
+        return;                                                   // block-uniform
+    }
+    // staging: lane -> LDS position (row tid >> 3 of a 32-row pass, 16-byte slot tid & 7), source chunk = slot ^ swizzle(row)
+    const int slot = tid & 7, r0 = tid >> 3;
+    const stin_bf16* asrc[4];
+    const stin_bf16* wsrc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int row = r0 + 32 * s;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int64_t ar = m0 + row < M ? m0 + row : M - 1;
+        const int wr = n0 + row < Nc ? n0 + row : Nc - 1;
+        asrc[s] = A + ar * lda + chunk * 8;
+        wsrc[s] = W + (int64_t)wr * ldw + chunk * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+        unsigned char* base = smem + buf * BUF + wave * 1024;     // this wave's 8 rows of every 32-row pass
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[s] + k0),
+                                             (__attribute__((address_space(3))) void*)(base + s * 4096), 16, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[s] + k0),
+                                             (__attribute__((address_space(3))) void*)(base + BM * 128 + s * 4096), 16, 0, 0);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kh = lane >> 5, li = lane & 31;
+    // fragment byte offsets inside a tile: row * 128 + ((2 ks + kh) ^ ((row >> 1) & 7)) * 16; row & 1 does not enter the swizzle
+    int aoff[MT], boff[NT], asw[MT], bsw[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = wm * TM + i * 32 + li;
+        aoff[i] = row * 128;
+        asw[i] = (row >> 1) & 7;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int lcol = wn * TN + j * 32 + li;
-        const int col = n0 + lcol;
-        const bool col_ok = col < Nc;
-        const float bv = (bias != nullptr && col_ok) ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lrow = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int64_t row = m0 + lrow;
-                float t = acc[i][j][r];
-                if (row < M && col_ok) {
-                    if (bias != nullptr) t += row_mask != nullptr ? bv * (float)row_mask[row * ld_mask] : bv;
-                    if (res != nullptr) t += (float)res[row * ld_res + col];
-                }
-                v[r] = t;
-            }
-            if (staged) {
-                // lanes (li, li^1) trade one value per register pair so that each writes two adjacent columns of ONE row
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const bool odd = li & 1;
-                    const float got = __shfl_xor(odd ? v[2 * q] : v[2 * q + 1], 1);
-                    const int lrow = wm * TM + i * 32 + ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * kh + (odd ? 1 : 0);
-                    const uint32_t pr = odd ? pack_bf16x2(got, v[2 * q + 1]) : pack_bf16x2(v[2 * q], got);
-                    *reinterpret_cast<uint32_t*>(&Cs[lrow][lcol & ~1]) = pr;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    if (row < M && col_ok) st1(C + row * ldc + col, v[r]);
-                }
-            }
-        }
+        const int row = wn * TN + j * 32 + li;
+        boff[j] = BM * 128 + row * 128;
+        bsw[j] = (row >> 1) & 7;
     }
-    if (staged) {
-        __syncthreads();
-        constexpr int CHUNKS = BM * BN / 8;                       // 16-byte chunks of the output tile
+    const int nt = K / BKB;
+    stage(0, 0);
+    __syncthreads();                                              // (hipcc drains the LDS-DMAs before the barrier)
+    for (int t = 0; t < nt; ++t) {
+        const unsigned char* tile = smem + (t & 1) * BUF;
+        if (t + 1 < nt) stage((t + 1) & 1, (t + 1) * BKB);        // the buffer every wave finished reading before the last barrier
 #pragma unroll
-        for (int s = 0; s < CHUNKS / BLOCK; ++s) {
-            const int c = tid + s * BLOCK;
-            const int lrow = c / (BN / 8), lc = (c % (BN / 8)) * 8;
-            const int64_t row = m0 + lrow;
-            const int col = n0 + lc;
-            if (row < M && col < Nc)
-                *reinterpret_cast<uint4*>(reinterpret_cast<stin_bf16*>(C) + row * ldc + col) =
-                    *reinterpret_cast<const uint4*>(&Cs[lrow][lc]);
+        for (int ks = 0; ks < BKB / 16; ++ks) {
+            bf16x8 a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(tile + aoff[i] + (((2 * ks + kh) ^ asw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(tile + boff[j] + (((2 * ks + kh) ^ bsw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();                                          // next tile landed (vmcnt(0) of the DMAs) and this one is free
     }
+    nt_b16_epilogue<BM, BN, WM, WN, OUT>(acc, smem, m0, n0, bias, row_mask, ld_mask, res, ld_res, M, Nc, C, ldc, vec_out);
 }
 
 // dW[Nc, K(+1)] = G^T [X | w] with G, X (and the optional row weight w) stored as bf16; fp32 slabs as k_gemm_tn.
@@ -1817,6 +1939,16 @@ inline int tn_rows_per_chunk(int64_t M, int tiles, bool one_per_cu = false) {
     if (rows > 128 * TN_R) rows = 128 * TN_R;
     rows = (rows + TN_R - 1) / TN_R * TN_R;
     return (int)rows;
+}
+// bf16-storage NT: when the 128 x 128 LDS-DMA kernel (k_gemm_nt_b16_glds) replaces the register-staged tiles.  It needs enough
+// k-tiles to amortise its prologue and enough 128 x 128 tiles to fill the chip; the tall-skinny level-0 / level-1 shapes
+// (K <= 128, bound by their output bytes) stay on the small tiles.  STIN_NT_GLDS = 0 | 1 forces (re-read per call).
+inline bool nt_b16_glds_pays(int64_t M, int Nc, int K) {
+    const char* e = getenv("STIN_NT_GLDS");
+    if (e) return atoi(e) != 0;
+    // measured (profiles/r03_nt_bf16_fat.md): +10..25 % from K = 1024 up (8 100 x 4096 x 1024: 124 -> 110 us, x 1024 x 4096: 104 -> 82),
+    // a loss at K <= 512 where four to eight k-tiles do not amortise the two-buffer prologue and the output bytes dominate
+    return K >= 1024 && Nc >= 256 && ((M + 127) / 128) * ((Nc + 127) / 128) >= 128;
 }
 // Strip-kernel configuration (see k_gemm_nt_strip): 21 / 22 / 41.  STIN_STRIP_CFG overrides (tuning aid).
 inline int strip_config(int64_t M, int Nc, int KC) {
@@ -2171,6 +2303,15 @@ extern "C" int stin_gemm_nt_bf16(const stin_bf16_t* A_, int64_t lda, const float
         else if (force_tile == 2 || (force_tile == 0 && tall_tile)) STIN_NTB(128, 64, 2, 2, OUT_);   \
         else STIN_NTB(64, 64, 2, 2, OUT_);                                                           \
     } while (0)
+    // fat shapes with bf16 weights: the LDS-DMA kernel (STIN_NT_GLDS=0 keeps the register-staged tiles: tuning aid / A-B)
+    if (wb && K % BKB == 0 && nt_b16_glds_pays(M, Nc, K)) {
+        const int64_t nrow = (M + 127) / 128, ncol = (Nc + 127) / 128;
+        dim3 grid(ncol % 8 == 0 ? (unsigned)(nrow * ncol) : nt_grid(M, Nc, 128, 128));
+        const stin_bf16* Wb = reinterpret_cast<const stin_bf16*>(W);
+        if (c_is_f32) hipLaunchKernelGGL((k_gemm_nt_b16_glds<float>), grid, dim3(BLOCK), 0, stream, A, lda, Wb, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (float*)C, ldc, vec_out);
+        else hipLaunchKernelGGL((k_gemm_nt_b16_glds<stin_bf16>), grid, dim3(BLOCK), 0, stream, A, lda, Wb, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (stin_bf16*)C, ldc, vec_out);
+        return stin_launch_status();
+    }
     if (c_is_f32) STIN_NTB_PICK(float);
     else STIN_NTB_PICK(stin_bf16);
 #undef STIN_NTB_PICK

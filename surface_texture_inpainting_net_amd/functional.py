@@ -276,6 +276,7 @@ PREC_NAMES = {GEMM_F32: 'fp32', GEMM_BF16X3: 'bf16x3', GEMM_BF16X6: 'bf16x6', GE
 PREC_FWD = int(os.environ.get('STIN_GEMM_FWD', GEMM_F16X3))
 PREC_BWD = int(os.environ.get('STIN_GEMM_BWD', GEMM_BF16X3))
 GEMM_W_PRESPLIT = 0x100            # nt: the weight operand already holds its two 16-bit pieces (stin_hip.h)
+GEMM_W_BF16 = 0x200                # stin_gemm_nt_bf16: the weight operand holds bf16 [Nc][K] (stin_hip.h)
 # pre-split operands in MFMA fragment order where the shape allows (stin_hip.h STIN_GEMM_W_FRAG): what the resident-strip NT
 # kernel reads.  STIN_NT_STRIP=0 keeps the k-group layout and with it the tiled kernel (A/B aid).
 GEMM_W_FRAG = 0x400 if os.environ.get('STIN_NT_STRIP', '1') != '0' else 0
@@ -336,8 +337,8 @@ def gemm_nt(A, W, bias=None, out=None, row_mask=None, precision=GEMM_F32, residu
 def _gemm_nt_bf16(A, W, bias, out, row_mask, residual, out_dtype):
     A, lda = _mat(A)
     W, ldw = _mat(W)
-    if W.dtype != torch.float32:
-        raise TypeError('gemm_nt on bf16 activations takes the fp32 master weights')
+    if W.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError('gemm_nt on bf16 activations takes the fp32 master weights or their bf16 rounding')
     _same(A, row_mask, residual)
     M, K = A.shape
     Nc = W.shape[0]
@@ -349,7 +350,8 @@ def _gemm_nt_bf16(A, W, bias, out, row_mask, residual, out_dtype):
         residual, ld_res = _mat(residual)
     _call('stin_gemm_nt_bf16', _ptr(A), lda, _ptr(W), ldw, _ptr(bias), _ptr(row_mask),
           row_mask.stride(0) if row_mask is not None else 0, _ptr(residual), ld_res, M, Nc, K, _ptr(out),
-          out.stride(0) if M > 1 else max(Nc, out.stride(0)), int(out.dtype == torch.float32), _stream(A), tag=(M, Nc, K))
+          out.stride(0) if M > 1 else max(Nc, out.stride(0)),
+          int(out.dtype == torch.float32) | (GEMM_W_BF16 if W.dtype == torch.bfloat16 else 0), _stream(A), tag=(M, Nc, K))
     return out
 
 
@@ -1003,10 +1005,10 @@ class EdgeConvChainFn(torch.autograd.Function):
             side = _wgrad_side(dev)
             side.hold.append((ws, x, hE, outs, Y, agg, mask, scratch, wts))
             side_stream = side.stream.cuda_stream
-            evs = []
-            for _ in range(n):
+            evs = [None] * n
+            for i in reversed(range(n)):          # in BACKWARD order: side.last_done must be the event recorded last (block 0's)
                 tri = side.next_events()
-                evs.append((tri[1].cuda_event, tri[2].cuda_event))
+                evs[i] = (tri[1].cuda_event, tri[2].cuda_event)
             if not direct:
                 for t in grads:
                     if t is not None:
@@ -1056,6 +1058,325 @@ def edgeconv_chain(x, blocks, edges_list, groups, eps, prec_fwd):
     meta = (list(edges_list), groups, float(eps), int(prec_fwd), [b._prepacked for b in blocks],
             [bool(b.first_filter.trans_inv) for b in blocks])
     return EdgeConvChainFn.apply(x, meta, *params)
+
+
+# ---- the graph part of the network in ONE autograd node ----------------------------------------------------------------------
+USE_NET_CALL = os.environ.get('STIN_NET_CALL', '1') != '0'
+_NET_OP = None
+OP_BLOCK, OP_POOL_MAX, OP_UNPOOL = 0, 1, 2
+
+
+def _net_struct():
+    global _NET_OP
+    if _NET_OP is None:
+        import struct
+        _NET_OP = struct.Struct('<16ifi7q2Q40Q')             # stin_net_op_t (include/stin_hip.h): 464 bytes
+        assert _NET_OP.size == 464
+    return _NET_OP
+
+
+def _align256(n):
+    return (n + 255) & ~255
+
+
+def net_eligible(steps, x):
+    """steps = [('block', GraphResnetBlock, EdgeSet, NormGroups) | ('pool', PoolMap) | ('unpool', PoolMap)] can run as one
+    NetFn: fused EdgeConv + instance-norm blocks on the whole-block path (saved ReLU mask available), max pooling, fp32 or
+    bf16 storage; operands of every block packed by the network's PackSet or of none."""
+    if not (USE_NET_CALL and USE_BLOCK_CALL and USE_EDGE_MASK and not KernelTimer.enabled and x.is_cuda and x.dim() == 2):
+        return False
+    if x.dtype not in (torch.float32, torch.bfloat16) or x.shape[0] <= 1:
+        return False
+    b16 = x.dtype == torch.bfloat16
+    packed = []
+    for st in steps:
+        if st[0] != 'block':
+            continue
+        b = st[1]
+        H = b.first_filter.nn[0].weight.shape[0]
+        if not edge_mask_supported(H) or st[2].n <= 1:
+            return False
+        pp = b._prepacked
+        if pp is not None:
+            fsp, bsp = block_split_modes(forward_precision(b.unbounded_input), b16, b.dim_out)
+            if b16 or len(pp) < 6 or pp[2] != fsp or pp[3] != bsp:
+                return False
+        packed.append(pp is not None)
+    return bool(packed) and any(packed) == all(packed)
+
+
+class NetFn(torch.autograd.Function):
+    """Every fused block and pool / unpool step of the network's graph part as ONE autograd node and one C call per direction
+    (stin_net_fwd / _bwd: loops over the per-op entry points, same kernels in the same order -> bit-identical to the per-op
+    nodes).  All tensors backward needs live in one arena allocation, the op table is packed on the host (464 bytes per op).
+    args: x, meta = (steps, prec list), then the flat parameters (W1, b1, W2, b2, Ws, bs) of every block in step order."""
+
+    calls = 0
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        NetFn.calls += 1
+        steps = meta
+        lib = _lib.load()
+        x, _ = _mat(x)
+        dev, dt = x.device, x.dtype
+        b16 = dt == torch.bfloat16
+        es = x.element_size()
+        pad = 8 if b16 else 4
+        N0, Cin0 = x.shape
+        Cp0 = (Cin0 + pad - 1) // pad * pad
+        if Cp0 != Cin0:                                          # (the 10-channel network input -> 12; bf16: 16)
+            xp = x.new_zeros(N0, Cp0)
+            xp[:, :Cin0] = x
+        else:
+            xp = x
+        # ---- pass 1: shapes and arena layout
+        plan, off, pi = [], 0, 0
+        n_rows, width = N0, Cin0
+
+        def take(nbytes):
+            nonlocal off
+            o = off
+            off = _align256(off + nbytes)
+            return o
+        for si, stp in enumerate(steps):
+            last = si == len(steps) - 1
+            if stp[0] == 'block':
+                blk, edges, groups = stp[1], stp[2], stp[3]
+                W1, b1, W2, b2, Ws, bs = params[pi:pi + 6]
+                pi += 6
+                H, Cout = W1.shape[0], W2.shape[0]
+                Cin = width
+                Cp = (Cin + pad - 1) // pad * pad
+                sc = Ws is not None
+                Yw = 2 * H + (Cout if sc else 0)
+                B = groups.B
+                prec = forward_precision(blk.unbounded_input)
+                fsp, bsp = block_split_modes(prec, b16, Cout)
+                pp = blk._prepacked
+                ws_bytes = lib.stin_edgeconv_block_fwd_workspace_bytes(Cin, Cp, H, Cout, int(sc), B)
+                d = dict(kind=OP_BLOCK, N=n_rows, Cin=Cin, Cp=Cp, H=H, Cout=Cout, sc=sc, Yw=Yw, B=B, prec=prec, fsp=fsp, bsp=bsp, pp=pp,
+                         ws_bytes=ws_bytes, edges=edges, groups=groups, ti=bool(blk.first_filter.trans_inv), eps=float(blk.first_norm.eps),
+                         params=(W1, b1, W2, b2, Ws, bs))
+                d['oY'] = take(n_rows * Yw * es)
+                d['oH'] = take(n_rows * (H + pad) * es)
+                d['oM'] = take(max(edges.n_edges, 1) * (H // 32) * 4)
+                d['oA'] = take(n_rows * Cout * es)
+                d['oS'] = take(2 * B * Cout * 4)
+                if pp is None:
+                    d['oW'] = take((Yw * Cp + H * Cout) * 4)
+                    d['oWS'] = take(ws_bytes)
+                elif pp[0].numel() < ws_bytes:
+                    raise RuntimeError('NetFn: prepacked workspace too small for this batch (PackSet built for another batch size)')
+                d['oO'] = None if last else take(n_rows * Cout * es)
+                width = Cout
+            else:
+                pool = stp[1]
+                if stp[0] == 'pool':
+                    d = dict(kind=OP_POOL_MAX, pool=pool, n_in=pool.n_fine, n_out=pool.n_coarse, C=width)
+                    d['oArg'] = take(pool.n_coarse * width * 4)
+                else:
+                    d = dict(kind=OP_UNPOOL, pool=pool, n_in=pool.n_coarse, n_out=pool.n_fine, C=width)
+                n_rows = d['n_out']
+                d['oO'] = None if last else take(n_rows * width * es)
+            plan.append(d)
+        arena = torch.empty(off, dtype=torch.uint8, device=dev)
+        out = torch.empty(n_rows, width, dtype=dt, device=dev)
+        base, p_out = _ptr(arena), _ptr(out)
+        assert base % 256 == 0
+        # ---- pass 2: the op table
+        stc = _net_struct()
+        blob = []
+        xin, ldx = _ptr(xp), xp.stride(0)
+        for d in plan:
+            o = p_out if d['oO'] is None else base + d['oO']
+            if d['kind'] == OP_BLOCK:
+                W1, b1, W2, b2, Ws, bs = d['params']
+                pp = d['pp']
+                if pp is not None:
+                    p_wcatT, p_w2T, p_ws, flag = _ptr(pp[4]), _ptr(pp[5]), _ptr(pp[0]), d['fsp'] | BLOCK_PACKED
+                else:
+                    p_wcatT = base + d['oW']
+                    p_w2T, p_ws, flag = p_wcatT + d['Yw'] * d['Cp'] * 4, base + d['oWS'], d['fsp']
+                d['p_wcatT'], d['p_w2T'] = p_wcatT, p_w2T
+                g, cd = d['groups'], d['edges'].by_dst
+                H, Cout, B = d['H'], d['Cout'], d['B']
+                d['x'], d['ldx'], d['out'] = xin, ldx, o
+                blob.append(stc.pack(OP_BLOCK, d['Cin'], d['Cp'], H, Cout, int(d['sc']), int(d['ti']), int(d['prec']), flag, d['bsp'], B,
+                                     int(g.quirk), 0, 0, 0, 0, d['eps'], 0,
+                                     d['N'], d['N'], ldx, Cout, 0, d['Yw'], H + pad, d['ws_bytes'], 0,
+                                     xin, o, 0,
+                                     _ptr(W1.contiguous()), _ptr(b1), _ptr(W2.contiguous()), _ptr(b2), _ptr(Ws), _ptr(bs), p_wcatT, p_w2T, p_ws,
+                                     _ptr(cd.rowptr), _ptr(cd.col), 0, 0, 0, 0,
+                                     _ptr(g.ptr_sum), 0, _ptr(g.gid), 0, _ptr(g.inv_cnt),
+                                     base + d['oY'], base + d['oH'], base + d['oM'], base + d['oA'], base + d['oS'],
+                                     base + d['oS'] + B * Cout * 4, 0, 0,
+                                     0, 0, 0, 0, 0, 0, 0, 0, 0))
+                xin, ldx = o, Cout
+            else:
+                pool, C = d['pool'], d['C']
+                d['x'], d['ldx'], d['out'] = xin, ldx, o
+                ch = pool.children
+                blob.append(stc.pack(d['kind'], C, C, 0, C, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0,
+                                     d['n_out'], d['n_in'], ldx, C, 0, 0, 0, 0, 0,
+                                     xin, o, 0,
+                                     0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                     _ptr(ch.rowptr), _ptr(ch.col), 0, 0, 0, 0,
+                                     0, 0, 0, 0, 0,
+                                     0, 0, 0, 0, 0, 0,
+                                     (base + d['oArg']) if d['kind'] == OP_POOL_MAX else 0, _ptr(pool.trace),
+                                     0, 0, 0, 0, 0, 0, 0, 0, 0))
+                xin, ldx = o, C
+        import ctypes
+        buf = ctypes.create_string_buffer(b''.join(blob), len(plan) * stc.size)
+        _call('stin_net_fwd', int(b16), buf, len(plan), _stream(x))
+        ctx.save_for_backward(xp, arena)
+        ctx.plan = plan
+        ctx.cin0 = Cin0
+        ctx.params = params
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, arena = ctx.saved_tensors
+        plan, params = ctx.plan, ctx.params
+        lib = _lib.load()
+        dev, dt = xp.device, xp.dtype
+        b16 = dt == torch.bfloat16
+        es = xp.element_size()
+        pad = 8 if b16 else 4
+        g, ldg = _mat(g)
+        _same(xp, g)
+        base = _ptr(arena)
+        need_dx = ctx.needs_input_grad[0]
+        blocks = [d for d in plan if d['kind'] == OP_BLOCK]
+        # gradients: straight into an accepting TrainStep bucket (all blocks or none), else fresh tensors handed to autograd
+        direct = []
+        for d in blocks:
+            dv = _direct_grad_views(d['params'])
+            if dv is None:
+                break
+            direct.append(dv)
+        grads = None
+        if len(direct) != len(blocks):
+            if direct:
+                raise RuntimeError('NetFn: only some blocks could write their gradients into the bucket')
+            grads = []
+            for d in blocks:
+                W1, b1, W2, b2, Ws, bs = d['params']
+                H, Cout = d['H'], d['Cout']
+                grads += [torch.empty(W1.shape, dtype=torch.float32, device=dev),
+                          torch.empty(H, dtype=torch.float32, device=dev) if b1 is not None else None,
+                          torch.empty(Cout, H, dtype=torch.float32, device=dev),
+                          torch.empty(Cout, dtype=torch.float32, device=dev) if b2 is not None else None,
+                          torch.empty(Ws.shape, dtype=torch.float32, device=dev) if Ws is not None else None,
+                          torch.empty(Cout, dtype=torch.float32, device=dev) if bs is not None else None]
+        # scratch: input gradients ping-pong between two buffers of the largest size; every block its own backward workspace
+        # (the side stream reads it after this call has returned)
+        dx_bytes, ws_off, off = 0, [], 0
+        for i, d in enumerate(plan):
+            if d['kind'] == OP_BLOCK:
+                if i > 0 or need_dx:
+                    dx_bytes = max(dx_bytes, d['N'] * d['Cp'] * es)
+                d['bwd_ws_bytes'] = lib.stin_edgeconv_block_bwd_workspace_bytes(d['N'], d['Cp'], d['H'], d['Cout'], int(d['sc']), d['B'], int(b16))
+                ws_off.append(off)
+                off = _align256(off + d['bwd_ws_bytes'])
+            else:
+                dx_bytes = max(dx_bytes, d['n_in'] * d['C'] * es)
+        dx_bytes = _align256(dx_bytes)
+        scratch = torch.empty(2 * dx_bytes + off, dtype=torch.uint8, device=dev)
+        p_scr = _ptr(scratch)
+        p_ws = p_scr + 2 * dx_bytes
+        dx0 = None
+        d0 = plan[0]
+        if need_dx:
+            dx0 = torch.empty(d0['N'] if d0['kind'] == OP_BLOCK else d0['n_in'], d0['Cp'] if d0['kind'] == OP_BLOCK else d0['C'],
+                              dtype=dt, device=dev)
+        all_params = [p for d in blocks for p in d['params']]
+        side_ok = (USE_WGRAD_STREAM and WGRAD_DEFER_JOIN and
+                   (bool(direct) or (_plain_autograd_may_defer() and all(
+                       p is None or (p.is_leaf and p.grad is None and not p._backward_hooks and
+                                     not getattr(p, '_post_accumulate_grad_hooks', None)) for p in all_params))))
+        use = [side_ok and WGRAD_MIN_WORK <= float(d['N']) * d['Yw'] * d['Cp'] <= WGRAD_MAX_WORK for d in blocks]
+        side_stream, any_side = 0, any(use)
+        evs = [(0, 0)] * len(blocks)
+        if any_side:
+            side = _wgrad_side(dev)
+            side.hold.append((scratch, xp, arena, g))
+            side_stream = side.stream.cuda_stream
+            for bi in reversed(range(len(blocks))):      # in BACKWARD order: side.last_done = the event recorded last
+                if use[bi]:
+                    tri = side.next_events()
+                    evs[bi] = (tri[1].cuda_event, tri[2].cuda_event)
+            if grads is not None:
+                for t in grads:
+                    if t is not None:
+                        t.record_stream(side.stream)
+        stc = _net_struct()
+        blob, bi = [], 0
+        for i, d in enumerate(plan):
+            p_dx = (_ptr(dx0) if i == 0 else p_scr + (i & 1) * dx_bytes)
+            if i == 0 and not need_dx:
+                p_dx = 0
+            if d['kind'] == OP_BLOCK:
+                e, gr = d['edges'], d['groups']
+                cs = e.by_src
+                H, Cout, B = d['H'], d['Cout'], d['B']
+                gs = direct[bi] if direct else grads[6 * bi:6 * bi + 6]
+                ev_dy, ev_done = evs[bi]
+                blob.append(stc.pack(OP_BLOCK, d['Cin'], d['Cp'], H, Cout, int(d['sc']), int(d['ti']), 0, 0, d['bsp'], B,
+                                     int(gr.quirk), int(use[bi]), 0, 0, 0, d['eps'], 0,
+                                     d['N'], d['N'], d['ldx'], Cout, d['Cp'], d['Yw'], H + pad, 0, d['bwd_ws_bytes'],
+                                     d['x'], d['out'], p_dx,
+                                     0, 0, 0, 0, 0, 0, d['p_wcatT'], d['p_w2T'], 0,
+                                     _ptr(e.by_dst.rowptr), 0, _ptr(cs.rowptr), _ptr(cs.col), _ptr(e.xslot), _ptr(e.w_src),
+                                     0, _ptr(gr.ptr_true), _ptr(gr.gid), _ptr(gr.sid if gr.quirk else None), _ptr(gr.inv_cnt),
+                                     base + d['oY'], base + d['oH'], base + d['oM'], base + d['oA'], base + d['oS'],
+                                     base + d['oS'] + B * Cout * 4, 0, 0,
+                                     _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gs[3]), _ptr(gs[4]), _ptr(gs[5]),
+                                     p_ws + ws_off[bi], ev_dy, ev_done))
+                bi += 1
+            else:
+                pool, C = d['pool'], d['C']
+                ch = pool.children
+                blob.append(stc.pack(d['kind'], C, C, 0, C, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0,
+                                     d['n_out'], d['n_in'], d['ldx'], C, C, 0, 0, 0, 0,
+                                     d['x'], d['out'], p_dx,
+                                     0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                     _ptr(ch.rowptr), _ptr(ch.col), 0, 0, 0, 0,
+                                     0, 0, 0, 0, 0,
+                                     0, 0, 0, 0, 0, 0,
+                                     (base + d['oArg']) if d['kind'] == OP_POOL_MAX else 0, _ptr(pool.trace),
+                                     0, 0, 0, 0, 0, 0, 0, 0, 0))
+        import ctypes
+        buf = ctypes.create_string_buffer(b''.join(blob), len(plan) * stc.size)
+        _call('stin_net_bwd', int(b16), buf, len(plan), _ptr(g), ldg, int(PREC_BWD), _stream(xp), side_stream)
+        if any_side:
+            _wgrad_deferred_join(dev, all_params if not direct else (), () if direct else grads)
+        if dx0 is not None and dx0.shape[1] != ctx.cin0:
+            dx0 = dx0[:, :ctx.cin0]
+        if direct:
+            sd = _WGRAD_SIDE.get(dev.index if dev.index is not None else torch.cuda.current_device())
+            slot = None
+            for p in all_params:
+                if p is not None:
+                    slot = p._stin_slot[0]
+                    break
+            slot.block_done(sd.last_done if (sd is not None and sd.hold) else None)      # (completed segments go to RCCL now)
+            return (dx0, None) + (None,) * len(params)
+        return (dx0, None) + tuple(grads)
+
+
+def run_net(x, steps):
+    """x through `steps` (see net_eligible) as one NetFn node."""
+    params = []
+    for st in steps:
+        if st[0] == 'block':
+            b = st[1]
+            lin1, lin2 = b.first_filter.nn[0], b.first_filter.nn[2]
+            sc = b.shortcut if b.dim_in != b.dim_out else None
+            params += [lin1.weight, lin1.bias, lin2.weight, lin2.bias, None if sc is None else sc.weight, None if sc is None else sc.bias]
+    return NetFn.apply(x, steps, *params)
 
 
 class EdgeReluMeanFn(torch.autograd.Function):

@@ -288,17 +288,31 @@ class SurfaceTextureInpaintingNet(nn.Module):
         edges, pools = self._plan_items()
         return plan.prefetch(edges, pools, inputs_ready=inputs_ready, join=False, after=after)
 
-    def forward(self, sample):
-        check_deferred()                                                      # deferred index checks of earlier calls
-        plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm,      # pieces not prefetched are built at first use
-                        validation=self.plan_validation)
-        plan.ensure(*self._plan_items())                                      # ONE batched build of whatever is missing
-        num_levels = len(self.decoder_blocks) + 1
-        out = sample.x
-        if self.activation_dtype != out.dtype:
-            out = out.to(self.activation_dtype)
-        e0 = plan.edges('edge_index', 0)
-        self._pack_weights(out, plan.num_graphs)
+    def _net_steps(self, plan, e0, bn_edges, num_levels):
+        """The graph part as the op list of functional.NetFn (reference order, :404-455), or None when a block is not the
+        fused kind (EdgeConv + instance norm) or the pooling is not max."""
+        if self.norm is not M.FastInstanceNorm or self._pooling_type != 'max':
+            return None
+        groups = (list(self.input_blocks), list(self.encoder_blocks), list(self.bottleneck_blocks), list(self.decoder_blocks),
+                  list(self.output_blocks))
+        if not all(isinstance(b.first_filter, M.EdgeConv) and isinstance(b.first_norm, M.FastInstanceNorm) for grp in groups for b in grp):
+            return None
+        last = num_levels - 1
+        steps = [('block', blk, e0, self._norm_arg(plan, 0, whole_batch=True)) for blk in groups[0]]
+        for i, blk in enumerate(groups[1]):
+            level = i + 1
+            steps.append(('pool', plan.pool(level)))
+            steps.append(('block', blk, plan.edges('hierarchy_edge_index_%d' % level, level), self._norm_arg(plan, level)))
+        steps += [('block', blk, edges, self._norm_arg(plan, last)) for blk, edges in zip(groups[2], bn_edges)]
+        for i, blk in enumerate(groups[3]):
+            level = i + 1
+            tgt = num_levels - level - 1
+            steps.append(('unpool', plan.pool(num_levels - level)))
+            steps.append(('block', blk, e0 if tgt == 0 else plan.edges('hierarchy_edge_index_%d' % tgt, tgt), self._norm_arg(plan, tgt)))
+        steps += [('block', blk, e0, self._norm_arg(plan, 0, whole_batch=True)) for blk in groups[4]]
+        return steps
+
+    def _forward_per_block(self, out, plan, e0, bn_edges, num_levels):
         for blk in self.input_blocks:                               # norm over the WHOLE batch (reference :406-407)
             out = blk(out, e0, self._norm_arg(plan, 0, whole_batch=True))
         for i, blk in enumerate(self.encoder_blocks):
@@ -306,13 +320,6 @@ class SurfaceTextureInpaintingNet(nn.Module):
             out = self._pooling(out, plan.pool(level))
             out = blk(out, plan.edges('hierarchy_edge_index_%d' % level, level), self._norm_arg(plan, level))
         last = num_levels - 1
-        bn_edges = []
-        for i, blk in enumerate(self.bottleneck_blocks):
-            if self.dilations[i] > 1:
-                key = 'hierarchy_dil_{}_edge_index_{}'.format(self.dilations[i], last)
-            else:
-                key = 'hierarchy_edge_index_{}'.format(last)
-            bn_edges.append(e0 if last == 0 and self.dilations[i] <= 1 else plan.edges(key, last))
         bn = list(self.bottleneck_blocks)
         if (self.norm is M.FastInstanceNorm and bn and all(isinstance(b.first_filter, M.EdgeConv) for b in bn)
                 and SF.chain_eligible(bn, out, bn_edges, None)):
@@ -329,6 +336,33 @@ class SurfaceTextureInpaintingNet(nn.Module):
             out = blk(out, edges, self._norm_arg(plan, tgt))
         for blk in self.output_blocks:
             out = blk(out, e0, self._norm_arg(plan, 0, whole_batch=True))
+        return out
+
+    def forward(self, sample):
+        check_deferred()                                                      # deferred index checks of earlier calls
+        plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm,      # pieces not prefetched are built at first use
+                        validation=self.plan_validation)
+        plan.ensure(*self._plan_items())                                      # ONE batched build of whatever is missing
+        num_levels = len(self.decoder_blocks) + 1
+        out = sample.x
+        if self.activation_dtype != out.dtype:
+            out = out.to(self.activation_dtype)
+        e0 = plan.edges('edge_index', 0)
+        self._pack_weights(out, plan.num_graphs)
+        last = num_levels - 1
+        bn_edges = []
+        for i, blk in enumerate(self.bottleneck_blocks):
+            if self.dilations[i] > 1:
+                key = 'hierarchy_dil_{}_edge_index_{}'.format(self.dilations[i], last)
+            else:
+                key = 'hierarchy_edge_index_{}'.format(last)
+            bn_edges.append(e0 if last == 0 and self.dilations[i] <= 1 else plan.edges(key, last))
+        steps = self._net_steps(plan, e0, bn_edges, num_levels)
+        if steps is not None and SF.net_eligible(steps, out):
+            # the whole graph part as ONE autograd node / one foreign call per direction (functional.NetFn)
+            out = SF.run_net(out, steps)
+        else:
+            out = self._forward_per_block(out, plan, e0, bn_edges, num_levels)
         tail_prec = SF.forward_precision(not self.using_norm)
         out = SF.linear(out, self.final_linear1.weight, self.final_linear1.bias, precision=tail_prec)
         if self.norm is M.FastInstanceNorm:                         # per-graph branch even for B = 1 (:465, Q3)

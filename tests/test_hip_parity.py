@@ -281,6 +281,37 @@ def test_gemm_nt_strip_kernel_equals_tiled_kernel(M, Nc, K):
         assert float((SF.gemm_nt(A, Wf, b, row_mask=mask, precision=prec | SF.GEMM_W_PRESPLIT | FR).double() - ref).abs().max()) <= tol * scale
 
 
+@pytest.mark.parametrize('M,Nc,K', [(8100, 4096, 1024), (8100, 1024, 2048), (2700, 512, 1024), (1000, 384, 256), (300, 1024, 320), (129, 256, 64),
+                                    (1, 128, 64), (127, 1152, 128), (4097, 2048, 512)])
+def test_gemm_nt_bf16_lds_dma_kernel_equals_register_staged_kernel(M, Nc, K, monkeypatch):
+    """k_gemm_nt_b16_glds (128 x 128 tile, operand tiles staged by LDS-DMA into two buffers, source-side swizzle; the fat
+    shapes of the 5-level hierarchy) against the register-staged bf16 kernel: same MFMA sequence per output element ->
+    bit-identical, bf16 and fp32 outputs, bias / masked bias / residual, ragged row and column tiles (rows past M / Nc are
+    clamped sources), both block -> tile orders (column tiles a multiple of 8 or not).  And against fp64."""
+    g = torch.Generator().manual_seed(M + Nc + K)
+    A = torch.randn(M + 2, K + 8, generator=g).to(DEV).bfloat16()[1:M + 1, :K]            # lda != K
+    W = (torch.randn(Nc, K, generator=g) * 0.1).to(DEV).bfloat16()
+    b = torch.randn(Nc, generator=g).to(DEV)
+    mask = (torch.rand(M, 3, generator=g) < 0.7).to(DEV).bfloat16()[:, 1]
+    res = torch.randn(M, Nc, generator=g).to(DEV).bfloat16()
+    for kw in (dict(), dict(bias=b), dict(bias=b, row_mask=mask), dict(residual=res), dict(bias=b, residual=res),
+               dict(bias=b, out_dtype=torch.float32)):
+        monkeypatch.setenv('STIN_NT_GLDS', '0')
+        base = SF.gemm_nt(A, W, **kw)
+        monkeypatch.setenv('STIN_NT_GLDS', '1')
+        for _ in range(2):
+            got = SF.gemm_nt(A, W, **kw)
+            assert got.dtype == base.dtype and torch.equal(got, base), sorted(kw)
+    wide = torch.full((M + 2, Nc + 16), 3.0, device=DEV).bfloat16()                     # output as a view into a wider matrix
+    SF.gemm_nt(A, W, b, out=wide[1:M + 1, 8:Nc + 8])
+    assert torch.equal(wide[1:M + 1, 8:Nc + 8], base.bfloat16() if base.dtype != torch.bfloat16 else SF.gemm_nt(A, W, b))
+    wide[1:M + 1, 8:Nc + 8] = 3.0
+    assert float((wide.float() - 3.0).abs().max()) == 0.0
+    want = A.double() @ W.double().t() + b.double()
+    got = SF.gemm_nt(A, W, b, out_dtype=torch.float32).double()
+    assert float((got - want).abs().max()) <= 2e-5 * (float(want.abs().max()) + 1.0) * max(1.0, (K / 256) ** 0.5)
+
+
 @pytest.mark.parametrize('cfg', ['22', '41'])
 @pytest.mark.parametrize('M,Nc,K', [(1, 320, 128), (37, 320, 192), (300, 352, 128), (5000, 1024, 256), (18063, 640, 256), (129, 1024, 128),
                                     (777, 1280, 256), (64, 384, 256), (18063, 512, 256), (127, 320, 256), (128, 320, 256), (200, 320, 128)])
@@ -1043,8 +1074,8 @@ def test_bottleneck_chain_equals_per_block_nodes_bitwise(batched, dtype):
         s = make_synthetic_mesh(5000, 3, seed=80, dilations=(2, 4)).to(DEV)
 
     def run(chain):
-        old = SF.USE_CHAIN
-        SF.USE_CHAIN = chain
+        old, old_net = SF.USE_CHAIN, SF.USE_NET_CALL
+        SF.USE_CHAIN, SF.USE_NET_CALL = chain, False          # (the whole-network node would take the bottleneck with it)
         try:
             torch.manual_seed(9)
             net = S.define_G(**cfg).to(DEV)
@@ -1062,12 +1093,62 @@ def test_bottleneck_chain_equals_per_block_nodes_bitwise(batched, dtype):
             step.finish()
             return res + [torch.tensor(losses)] + [p.detach().clone() for p in net.parameters()]
         finally:
-            SF.USE_CHAIN = old
+            SF.USE_CHAIN, SF.USE_NET_CALL = old, old_net
 
     want = run(False)
     before = SF.EdgeConvChainFn.calls
     got = run(True)
     assert SF.EdgeConvChainFn.calls == before + 4, 'the chain path must have been taken (1 plain + 3 TrainStep forwards)'
+    assert len(want) == len(got)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('batched', [False, True])
+def test_network_graph_part_as_one_node_equals_per_op_nodes_bitwise(batched, dtype):
+    """functional.NetFn (every fused block and pool / unpool step of the network as ONE autograd node, stin_net_fwd / _bwd)
+    only loops over the per-op entry points: output, input gradient and every parameter gradient equal the per-op autograd
+    nodes bit for bit - plain autograd (fresh gradient tensors, weight-gradient side stream with the deferred join) and the
+    TrainStep bucket route, single graph and a batch of unequal crops (linspace-slice statistics), 3 levels."""
+    from surface_texture_inpainting_net_amd.data import collate
+    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 4])
+    if batched:
+        s = collate([make_synthetic_mesh(n, 3, seed=90 + i, dilations=(2, 4)) for i, n in enumerate((900, 1500, 700))]).to(DEV)
+    else:
+        s = make_synthetic_mesh(6000, 3, seed=90, dilations=(2, 4)).to(DEV)
+
+    def run(net_call):
+        old = SF.USE_NET_CALL
+        SF.USE_NET_CALL = net_call
+        try:
+            torch.manual_seed(11)
+            net = S.define_G(**cfg).to(DEV)
+            if dtype == 'bf16':
+                net.set_activation_dtype(torch.bfloat16)
+            x = s.x.clone().requires_grad_(True)
+            s2 = type(s)(**{k: (x if k == 'x' else s[k]) for k in s.keys()})
+            s2._nv_host = s._nv_host
+            out = net(s2)
+            out.float().square().mean().backward()
+            res = [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+            net.zero_grad(set_to_none=True)
+            out = net(s)                                       # the network input needs no gradient: op 0 writes none
+            out.float().abs().mean().backward()
+            res += [p.grad.clone() for p in net.parameters()]
+            step = TrainStep(net, lr=1e-3)
+            losses = [float(step(s)) for _ in range(3)]
+            step.finish()
+            return res + [torch.tensor(losses)] + [p.detach().clone() for p in net.parameters()]
+        finally:
+            SF.USE_NET_CALL = old
+
+    want = run(False)
+    before = SF.NetFn.calls
+    got = run(True)
+    assert SF.NetFn.calls == before + 5, 'the whole-network path must have been taken (2 plain + 3 TrainStep forwards)'
     assert len(want) == len(got)
     for i, (a, b) in enumerate(zip(got, want)):
         assert torch.equal(a, b), i
