@@ -155,23 +155,33 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce_final(const double* __restr
     if (c < C) {
         const double* p = partial + ((int64_t)b * nch * nout + o) * C + c;
         const int64_t stride = (int64_t)nout * C;
-        int k = ty;
-        // 16 loads in flight per lane before the first add (round 3: with 4 the 564-chunk list of the bottleneck level was nine
-        // dependent memory round trips = 9.4 us for 2 MB); the adds keep the order of the 4-wide loop below: bit-identical
-        for (; k + 15 * FIN_KL < nch; k += 16 * FIN_KL) {
-            double v[16];
+        // Every load of a lane's chunk list in flight before the first add, 32 at a time (round 3).  The partials were written by
+        // the previous kernel on other XCDs, so each dependent batch of loads is a trip to the fabric (~2 us under load): with
+        // 4 in flight the 564-chunk list of the bottleneck level took nine trips (9.4 us for 2 MB), now two.  The adds keep the
+        // order of the original loop - groups of four strides round-robin into s0..s3 while a whole group is in range, the
+        // ragged tail into s0 - so the sums are bit-identical; out-of-range slots load a clamped address and add nothing.
+        for (int k = ty; k < nch; k += 32 * FIN_KL) {
+            double v[32];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(k + u * FIN_KL) * stride];
+            for (int u = 0; u < 32; ++u) {
+                const int ku = k + u * FIN_KL;
+                v[u] = p[(int64_t)(ku < nch ? ku : ty) * stride];
+            }
 #pragma unroll
-            for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+            for (int q = 0; q < 8; ++q) {
+                const int k0 = k + 4 * q * FIN_KL;
+                if (k0 + 3 * FIN_KL < nch) {
+                    s0 += v[4 * q];
+                    s1 += v[4 * q + 1];
+                    s2 += v[4 * q + 2];
+                    s3 += v[4 * q + 3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k0 + j * FIN_KL < nch) s0 += v[4 * q + j];
+                }
+            }
         }
-        for (; k + 3 * FIN_KL < nch; k += 4 * FIN_KL) {
-            s0 += p[(int64_t)k * stride];
-            s1 += p[(int64_t)(k + FIN_KL) * stride];
-            s2 += p[(int64_t)(k + 2 * FIN_KL) * stride];
-            s3 += p[(int64_t)(k + 3 * FIN_KL) * stride];
-        }
-        for (; k < nch; k += FIN_KL) s0 += p[(int64_t)k * stride];
     }
     sm[ty][tx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -203,23 +213,30 @@ __global__ void k_moments_final(const double* __restrict__ partial, int nch, int
         const double* p = partial + (int64_t)b * nch * 2 * C + c;
         const int64_t st = (int64_t)2 * C;
         double t1 = 0.0, t2 = 0.0;
-        int k = ty;
-        for (; k + 7 * FIN_KL < nch; k += 8 * FIN_KL) {   // 16 loads in flight, adds in the order of the 2-wide loop below
-            double a[8], q[8];
+        // (all loads of the lane's list in flight, 16 groups at a time; adds in the order of the original two-accumulator loop:
+        // pairs of strides alternate (s1, s2) / (t1, t2) while a whole pair is in range, a ragged last stride goes to (s1, s2))
+        for (int k = ty; k < nch; k += 16 * FIN_KL) {
+            double a[16], q[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a[u] = p[(k + u * FIN_KL) * st]; q[u] = p[(k + u * FIN_KL) * st + C]; }
+            for (int u = 0; u < 16; ++u) {
+                const int ku = k + u * FIN_KL;
+                const int kc = ku < nch ? ku : ty;
+                a[u] = p[kc * st];
+                q[u] = p[kc * st + C];
+            }
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) { s1 += a[u]; s2 += q[u]; t1 += a[u + 1]; t2 += q[u + 1]; }
-        }
-        for (; k + FIN_KL < nch; k += 2 * FIN_KL) {       // two independent loads in flight
-            s1 += p[k * st];
-            s2 += p[k * st + C];
-            t1 += p[(k + FIN_KL) * st];
-            t2 += p[(k + FIN_KL) * st + C];
-        }
-        for (; k < nch; k += FIN_KL) {
-            s1 += p[k * st];
-            s2 += p[k * st + C];
+            for (int h = 0; h < 8; ++h) {
+                const int k0 = k + 2 * h * FIN_KL;
+                if (k0 + FIN_KL < nch) {
+                    s1 += a[2 * h];
+                    s2 += q[2 * h];
+                    t1 += a[2 * h + 1];
+                    t2 += q[2 * h + 1];
+                } else if (k0 < nch) {
+                    s1 += a[2 * h];
+                    s2 += q[2 * h];
+                }
+            }
         }
         s1 += t1;
         s2 += t2;
