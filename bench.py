@@ -395,6 +395,10 @@ def main():
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the passes after the timed region (fwd+loss+bwd-only loop, GEMM table, standalone kernels, CPU '
                          'baseline) - profiling runs: keeps the kernel mix = the step')
+    ap.add_argument('--coherent-order', action='store_true', help='experiment: keep the grid (row-major) vertex order instead of the '
+                    'random permutation the synthetic meshes get by default (an upper bound on what vertex locality is worth)')
+    ap.add_argument('--morton-order', action='store_true', help='experiment: renumber the vertices of every level by locality on the host '
+                    'before the run (synthetic.renumber_by_locality)')
     ap.add_argument('--irregular', action='store_true', help='the whole step on an irregular (Delaunay) mesh of the same size '
                     'instead of the 6-regular jittered grid (NOT the headline)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
@@ -445,7 +449,12 @@ def main():
         sizes = [12_000 + (16_000 * i) // max(args.crops - 1, 1) for i in range(args.crops)]
         sample = collate([make_synthetic_mesh(n, args.levels, seed=100 * rank + i) for i, n in enumerate(sizes)]).to(device)
     else:
-        sample = make_synthetic_mesh(args.vertices, args.levels, seed=rank, irregular=args.irregular).to(device)   # one scene per rank
+        sample = make_synthetic_mesh(args.vertices, args.levels, seed=rank, irregular=args.irregular,
+                                     permute=not args.coherent_order)               # one scene per rank
+        if args.morton_order:
+            from surface_texture_inpainting_net_amd.synthetic import renumber_by_locality
+            sample = renumber_by_locality(sample)[0]
+        sample = sample.to(device)
     n0 = sample.x.shape[0]
     e0 = sample.edge_index.shape[1]
 

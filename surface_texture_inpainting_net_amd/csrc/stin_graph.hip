@@ -16,11 +16,27 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 template <typename T> struct is_f32_type { static constexpr bool value = false; };
 template <> struct is_f32_type<float> { static constexpr bool value = true; };
 
+// Block -> logical block.  Row kernels are launched as a plain 1-D grid (logical = blockIdx.x) or, as an experiment switch
+// (xcd_rows_on below), as an (8, q) grid: workgroups are dealt round-robin to the 8 XCDs in linear order (x fastest), so
+// blockIdx.x is the XCD and the logical block x * q + y gives every XCD one CONTIGUOUS range of rows.  One formula serves
+// both launch shapes.
+__device__ __forceinline__ unsigned vblock_id() { return blockIdx.x * gridDim.y + blockIdx.y; }
+// two-role launches (role 0 first): plain = 2 nb blocks in x; XCD order = (8, 2 q) with the roles split along y
+__device__ __forceinline__ unsigned vblock_role(unsigned nb, unsigned& role) {
+    if (gridDim.y == 1) {
+        role = blockIdx.x >= nb ? 1u : 0u;
+        return blockIdx.x - role * nb;
+    }
+    const unsigned q = gridDim.y >> 1;
+    role = blockIdx.y >= q ? 1u : 0u;
+    return blockIdx.x * q + (blockIdx.y - role * q);
+}
+
 template <int G, int VPL>
 struct Lane {
     int lg;        // lane within the group
     int64_t row;   // row owned by the group
-    __device__ __forceinline__ Lane() : Lane(blockIdx.x) {}
+    __device__ __forceinline__ Lane() : Lane(vblock_id()) {}
     __device__ __forceinline__ explicit Lane(unsigned vblock) {          // vblock: the block index the kernel body should see
         lg = threadIdx.x % G;
         row = (int64_t)vblock * (BLOCK / G) + threadIdx.x / G;
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask(const T* __restrict
                                                              const uint32_t* __restrict__ mask,
                                                              const int32_t* __restrict__ rowptr, int64_t N, int H,
                                                              T* __restrict__ dA, int64_t ldda) {
-    edge_bwd_dst_mask_body<T, G, VPL, U>(blockIdx.x, Gr, ldg, mask, rowptr, N, H, dA, ldda);
+    edge_bwd_dst_mask_body<T, G, VPL, U>(vblock_id(), Gr, ldg, mask, rowptr, N, H, dA, ldda);
 }
 
 // dB[j,c] = sum over out-edges (j -> i) of inv_deg[i] * G[i,c] * mask[xslot][c]: gathers G rows and 32-bit mask
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask(const T* __restrict
                                                              const int32_t* __restrict__ col,
                                                              const int32_t* __restrict__ xslot, int64_t N, int H,
                                                              T* __restrict__ dB, int64_t lddb) {
-    edge_bwd_src_mask_body<T, G, VPL, U>(blockIdx.x, Gr, ldg, w_slot, mask, rowptr, col, xslot, N, H, dB, lddb);
+    edge_bwd_src_mask_body<T, G, VPL, U>(vblock_id(), Gr, ldg, w_slot, mask, rowptr, col, xslot, N, H, dB, lddb);
 }
 
 // Both halves of the mask backward in ONE launch: blocks [0, nb) compute dB rows (the longer, gather-bound half first),
@@ -379,20 +395,22 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_pair(const T* __restric
                                                               T* __restrict__ dA, int64_t ldda, T* __restrict__ dB,
                                                               int64_t lddb, unsigned nb, const T* __restrict__ cp_src,
                                                               int64_t ld_cps, T* __restrict__ cp_dst, int64_t ld_cpd, int Ccp) {
-    if (blockIdx.x < nb) {
-        edge_bwd_src_mask_body<T, G, VPL, US>(blockIdx.x, Gr, ldg, w_slot, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
+    unsigned role;
+    const unsigned vb = vblock_role(nb, role);
+    if (role == 0) {
+        edge_bwd_src_mask_body<T, G, VPL, US>(vb, Gr, ldg, w_slot, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
     } else {
         // optional row copy riding on the streaming role (the block backward's dY[:, 2H:] = g of a shortcut block: one
         // 2-D memcpy launch less); Ccp <= H channels, 4 per lane
         if (cp_src != nullptr) {
-            Lane<G, VPL> L(blockIdx.x - nb);
+            Lane<G, VPL> L(vb);
             if (L.row < N) {
 #pragma unroll
                 for (int k = 0; k < VPL; ++k)
                     if (L.chan(k) < Ccp) st4(cp_dst + L.row * ld_cpd + L.chan(k), ld4(cp_src + L.row * ld_cps + L.chan(k)));
             }
         }
-        edge_bwd_dst_mask_body<T, G, VPL, UD>(blockIdx.x - nb, Gr, ldg, mask, rowptr_dst, N, H, dA, ldda);
+        edge_bwd_dst_mask_body<T, G, VPL, UD>(vb, Gr, ldg, mask, rowptr_dst, N, H, dA, ldda);
     }
 }
 
@@ -432,7 +450,7 @@ template <int G>
 struct Lane8 {
     int lg;
     int64_t row;
-    __device__ __forceinline__ Lane8() : Lane8(blockIdx.x) {}
+    __device__ __forceinline__ Lane8() : Lane8(vblock_id()) {}
     __device__ __forceinline__ explicit Lane8(unsigned vblock) {
         lg = threadIdx.x % G;
         row = (int64_t)vblock * (BLOCK / G) + threadIdx.x / G;
@@ -587,7 +605,7 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask8(const stin_bf16* _
                                                               const uint32_t* __restrict__ mask,
                                                               const int32_t* __restrict__ rowptr, int64_t N, int H,
                                                               stin_bf16* __restrict__ dA, int64_t ldda) {
-    edge_bwd_dst_mask8_body<G, VPL, U>(blockIdx.x, Gr, ldg, mask, rowptr, N, H, dA, ldda);
+    edge_bwd_dst_mask8_body<G, VPL, U>(vblock_id(), Gr, ldg, mask, rowptr, N, H, dA, ldda);
 }
 
 template <int G, int VPL, int U>
@@ -645,7 +663,7 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask8(const stin_bf16* _
                                                               const int32_t* __restrict__ col,
                                                               const int32_t* __restrict__ xslot, int64_t N, int H,
                                                               stin_bf16* __restrict__ dB, int64_t lddb) {
-    edge_bwd_src_mask8_body<G, VPL, U>(blockIdx.x, Gr, ldg, w_slot, mask, rowptr, col, xslot, N, H, dB, lddb);
+    edge_bwd_src_mask8_body<G, VPL, U>(vblock_id(), Gr, ldg, w_slot, mask, rowptr, col, xslot, N, H, dB, lddb);
 }
 // dB blocks then dA blocks in one launch, as k_edge_bwd_mask_pair does for fp32 rows
 template <int G, int VPL, int UD, int US>
@@ -660,11 +678,13 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_pair8(const stin_bf16* 
                                                                stin_bf16* __restrict__ dB, int64_t lddb, unsigned nb,
                                                                const stin_bf16* __restrict__ cp_src, int64_t ld_cps,
                                                                stin_bf16* __restrict__ cp_dst, int64_t ld_cpd, int Ccp) {
-    if (blockIdx.x < nb) {
-        edge_bwd_src_mask8_body<G, VPL, US>(blockIdx.x, Gr, ldg, w_slot, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
+    unsigned role;
+    const unsigned vb = vblock_role(nb, role);
+    if (role == 0) {
+        edge_bwd_src_mask8_body<G, VPL, US>(vb, Gr, ldg, w_slot, mask, rowptr_src, col_src, xslot, N, H, dB, lddb);
     } else {
         if (cp_src != nullptr) {                           // optional row copy, 8 channels (16 bytes) per lane
-            Lane8<G> L(blockIdx.x - nb);
+            Lane8<G> L(vb);
             if (L.row < N) {
 #pragma unroll
                 for (int k = 0; k < VPL; ++k)
@@ -673,7 +693,7 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_pair8(const stin_bf16* 
                             *reinterpret_cast<const uint4*>(cp_src + L.row * ld_cps + L.chan(k));
             }
         }
-        edge_bwd_dst_mask8_body<G, VPL, UD>(blockIdx.x - nb, Gr, ldg, mask, rowptr_dst, N, H, dA, ldda);
+        edge_bwd_dst_mask8_body<G, VPL, UD>(vb, Gr, ldg, mask, rowptr_dst, N, H, dA, ldda);
     }
 }
 
@@ -682,7 +702,7 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_pair8(const stin_bf16* 
 // 8 waves per SIMD resident (<= 64 VGPRs) rather than deep per-wave unrolling - U = 2 (71 vs 98 us at U = 4 for the
 // level-0 forward, 48 vs 104 us at U = 6 for the level-1 backward), U = 1 once a lane holds 2 or 4 chunks; the
 // streaming dA kernel keeps U = 6 / 3 / 3 / 2 / 1.
-#define STIN_L8(KERNEL_, G_, V_, U_, grid_, ...) hipLaunchKernelGGL((KERNEL_<G_, V_, U_>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__)
+#define STIN_L8(KERNEL_, G_, V_, U_, grid_, ...) hipLaunchKernelGGL((KERNEL_<G_, V_, U_>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__)
 #define STIN_DISPATCH8(H_, KERNEL, U16_, U32_, U64_, U64X2_, U64X4_, ...)                                            \
     do {                                                                                                             \
         if ((H_) == 128) STIN_L8(KERNEL, 16, 1, U16_, grid_rows(N, 16), __VA_ARGS__);                                \
@@ -1006,6 +1026,18 @@ inline bool vec_ok(int C, std::initializer_list<const void*> ptrs, std::initiali
 inline bool mask_shape_ok(int H) { return H == 128 || H == 256 || H == 512 || H == 1024 || H == 2048; }
 
 inline unsigned grid_rows(int64_t N, int G) { return (unsigned)((N + (BLOCK / G) - 1) / (BLOCK / G)); }
+// Launch shape of a row kernel (see vblock_id): plain 1-D order by default; STIN_XCD_ROWS=1 (re-read per call) selects (8, q) =
+// one contiguous row range per XCD.  Measured in round 3 and left OFF: no gain on the randomly numbered benchmark meshes
+// (nothing to reuse), and on coherently numbered ones the plain order is the better one (level-0 forward at 200 704 vertices,
+// grid order: 82 us plain vs 96 us chunked; 1 M bf16: 344 vs 353) - with round-robin dealing the 8 XCDs sweep the SAME
+// neighbourhood together and share its lines in the Infinity Cache, chunked they stream eight distant regions at once.
+inline bool xcd_rows_on(unsigned nwg) {
+    const char* e = getenv("STIN_XCD_ROWS");
+    if (!e || atoi(e) == 0) return false;
+    return nwg >= 64 && (nwg + 7) / 8 <= 32767;
+}
+inline dim3 rows_grid(unsigned nwg) { return xcd_rows_on(nwg) ? dim3(8, (nwg + 7) / 8) : dim3(nwg); }
+inline dim3 pair_grid(unsigned nb) { return xcd_rows_on(nb) ? dim3(8, 2 * ((nb + 7) / 8)) : dim3(2 * nb); }
 inline unsigned grid_elems(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
 inline bool wide8_ok(int H, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> lds) {
@@ -1029,16 +1061,16 @@ inline bool wide8_ok(int H, std::initializer_list<const void*> ptrs, std::initia
         const int g_ = stin_group_lanes(c4_);                                                                \
         const int vpl_ = (c4_ + g_ - 1) / g_;                                                                \
         const unsigned grid_ = grid_rows(N, g_);                                                             \
-        if (g_ == 1) hipLaunchKernelGGL((KERNEL<T, 1, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);        \
-        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<T, 2, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<T, 4, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<T, 8, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<T, 16, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<T, 32, 1, STIN_U(6, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<T, 64, 1, STIN_U(4, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<T, 64, 2, STIN_U(2, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<T, 64, 4, STIN_U(2, DIV)>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<T, 64, 8, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);       \
+        if (g_ == 1) hipLaunchKernelGGL((KERNEL<T, 1, 1, STIN_U(4, DIV)>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);        \
+        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<T, 2, 1, STIN_U(4, DIV)>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<T, 4, 1, STIN_U(4, DIV)>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<T, 8, 1, STIN_U(4, DIV)>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<T, 16, 1, STIN_U(4, DIV)>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<T, 32, 1, STIN_U(6, DIV)>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<T, 64, 1, STIN_U(4, DIV)>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<T, 64, 2, STIN_U(2, DIV)>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<T, 64, 4, STIN_U(2, DIV)>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<T, 64, 8, 1>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);       \
     } while (0)
 
 #define STIN_DISPATCH_NOU(C_, KERNEL, ...)                                                                   \
@@ -1047,16 +1079,16 @@ inline bool wide8_ok(int H, std::initializer_list<const void*> ptrs, std::initia
         const int g_ = stin_group_lanes(c4_);                                                                \
         const int vpl_ = (c4_ + g_ - 1) / g_;                                                                \
         const unsigned grid_ = grid_rows(N, g_);                                                             \
-        if (g_ == 1) hipLaunchKernelGGL((KERNEL<T, 1, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<T, 2, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<T, 4, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<T, 8, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<T, 16, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<T, 32, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<T, 64, 1>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<T, 64, 2>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<T, 64, 4>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<T, 64, 8>), dim3(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);          \
+        if (g_ == 1) hipLaunchKernelGGL((KERNEL<T, 1, 1>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 2) hipLaunchKernelGGL((KERNEL<T, 2, 1>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 4) hipLaunchKernelGGL((KERNEL<T, 4, 1>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 8) hipLaunchKernelGGL((KERNEL<T, 8, 1>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+        else if (g_ == 16) hipLaunchKernelGGL((KERNEL<T, 16, 1>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (g_ == 32) hipLaunchKernelGGL((KERNEL<T, 32, 1>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 1) hipLaunchKernelGGL((KERNEL<T, 64, 1>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ == 2) hipLaunchKernelGGL((KERNEL<T, 64, 2>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else if (vpl_ <= 4) hipLaunchKernelGGL((KERNEL<T, 64, 4>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<T, 64, 8>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__);          \
     } while (0)
 
 constexpr bool is_f32(const float*) { return true; }
@@ -1148,7 +1180,7 @@ int edge_bwd_mask_pair_impl(const float* G, int64_t ldg, const uint32_t* mask, c
     const int c4 = H / 4, g = stin_group_lanes(c4), vpl = (c4 + g - 1) / g;
     const unsigned nb = grid_rows(N, g);
 #define STIN_PAIR(G_, VPL_, BASE_)                                                                                       \
-    hipLaunchKernelGGL((k_edge_bwd_mask_pair<T, G_, VPL_, STIN_U(BASE_, 1), STIN_U(BASE_, 2)>), dim3(2 * nb), dim3(BLOCK), 0,  \
+    hipLaunchKernelGGL((k_edge_bwd_mask_pair<T, G_, VPL_, STIN_U(BASE_, 1), STIN_U(BASE_, 2)>), pair_grid(nb), dim3(BLOCK), 0,  \
                        stream, G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src,       \
                        ld_cps, cp_dst, ld_cpd, Ccp)
     if (g == 32) STIN_PAIR(32, 1, 6);                 // H = 128
@@ -1176,7 +1208,7 @@ int edge_bwd_mask_pair8_impl(const stin_bf16* G, int64_t ldg, const uint32_t* ma
 #define STIN_PAIR8(G_, V_, UD_, US_)                                                                                          \
     do {                                                                                                                      \
         const unsigned nb = grid_rows(N, G_);                                                                                 \
-        hipLaunchKernelGGL((k_edge_bwd_mask_pair8<G_, V_, UD_, US_>), dim3(2 * nb), dim3(BLOCK), 0, stream, G, ldg, mask,     \
+        hipLaunchKernelGGL((k_edge_bwd_mask_pair8<G_, V_, UD_, US_>), pair_grid(nb), dim3(BLOCK), 0, stream, G, ldg, mask,     \
                            rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src, ld_cps,        \
                            cp_dst, ld_cpd, Ccp);                                                                               \
     } while (0)
@@ -1207,8 +1239,8 @@ int segment_sum_impl(const T* src, int64_t ld_src, const int32_t* rowptr, const 
             const bool nt = is_f32((const T*)nullptr) && want_nt;
 #define SEGX(G_, V_, U_)                                                                                                  \
     do {                                                                                                                  \
-        if (nt) hipLaunchKernelGGL((k_segment_sum_x<T, G_, V_, U_, true>), dim3(grid_rows(N, G_)), dim3(BLOCK), 0, stream, src, ld_src, rowptr, col, N, C, mean, out, ld_out); \
-        else hipLaunchKernelGGL((k_segment_sum_x<T, G_, V_, U_, false>), dim3(grid_rows(N, G_)), dim3(BLOCK), 0, stream, src, ld_src, rowptr, col, N, C, mean, out, ld_out);   \
+        if (nt) hipLaunchKernelGGL((k_segment_sum_x<T, G_, V_, U_, true>), rows_grid(grid_rows(N, G_)), dim3(BLOCK), 0, stream, src, ld_src, rowptr, col, N, C, mean, out, ld_out); \
+        else hipLaunchKernelGGL((k_segment_sum_x<T, G_, V_, U_, false>), rows_grid(grid_rows(N, G_)), dim3(BLOCK), 0, stream, src, ld_src, rowptr, col, N, C, mean, out, ld_out);   \
     } while (0)
             if (c4 == 4) SEGX(2, 2, 2);
             else if (c4 == 8) SEGX(4, 2, 2);

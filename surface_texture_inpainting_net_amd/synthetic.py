@@ -194,3 +194,52 @@ def make_synthetic_mesh(n0=200_000, levels=3, seed=0, dilations=(2, 4, 8, 16), p
     sample['num_vertices'] = torch.tensor([nv], dtype=torch.int32)
     sample['batch'] = torch.zeros(n, dtype=torch.long)
     return sample
+
+
+def _morton3(p, bits=10):
+    """30-bit Morton code of positions p [n, 3] (quantised on the bounding box)."""
+    lo, hi = p.min(0, keepdims=True), p.max(0, keepdims=True)
+    q = np.minimum(((p - lo) / np.maximum(hi - lo, 1e-12) * (1 << bits)).astype(np.int64), (1 << bits) - 1)
+    code = np.zeros(p.shape[0], dtype=np.int64)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return code
+
+
+def renumber_by_locality(sample, position_channels=(6, 9)):
+    """HOST-side experiment / reader-side preprocessing: renumber the vertices of every level of a single-graph sample so that
+    memory order follows space - level 0 by the Morton code of its positions (x[:, 6:9] in the reference's feature layout),
+    every coarser level by the smallest new id among its children.  Edge lists keep their order (so every CSR row keeps its
+    neighbour order), index values are relabelled.  Returns (new sample, perm0) with new_x = x[perm0]."""
+    x = sample.x.numpy()
+    n_levels = int(sample.num_vertices.shape[-1])
+    order = np.argsort(_morton3(x[:, position_channels[0]:position_channels[1]].astype(np.float64)), kind='stable')
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    out = HierarchicalBatch()
+    out['x'] = sample.x[torch.from_numpy(order)]
+    out['color'] = sample.color[torch.from_numpy(order)]
+    out['mask'] = sample.mask[torch.from_numpy(order)]
+    out['batch'] = sample.batch.clone()
+    out['num_vertices'] = sample.num_vertices.clone()
+    out['edge_index'] = torch.from_numpy(rank[sample.edge_index.numpy()])
+    ranks = [rank]
+    for lvl in range(1, n_levels):
+        tr = sample['hierarchy_trace_index_%d' % lvl].numpy()
+        nc = int(tr.max()) + 1
+        first = np.full(nc, np.iinfo(np.int64).max, dtype=np.int64)
+        np.minimum.at(first, tr, ranks[-1])
+        c_order = np.argsort(first, kind='stable')
+        c_rank = np.empty_like(c_order)
+        c_rank[c_order] = np.arange(nc)
+        new_tr = np.empty_like(tr)
+        new_tr[ranks[-1]] = c_rank[tr]
+        out['hierarchy_trace_index_%d' % lvl] = torch.from_numpy(new_tr)
+        out['hierarchy_edge_index_%d' % lvl] = torch.from_numpy(c_rank[sample['hierarchy_edge_index_%d' % lvl].numpy()])
+        ranks.append(c_rank)
+    for k in sample.keys():
+        if k.startswith('hierarchy_dil_'):
+            lvl = int(k.rsplit('_', 1)[1])
+            out[k] = torch.from_numpy(ranks[lvl][sample[k].numpy()])
+    return out, torch.from_numpy(order)
