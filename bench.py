@@ -698,6 +698,25 @@ def main():
             out['scatter_add'] = scatter_add_standalone(device)
             out['hbm_honest'] = hbm_honest_edge_kernel(device)
             out['roofline_irregular'] = irregular_edge_kernel(device)
+            if world == 1 and not (args.crops or args.morton_order or args.coherent_order or args.graph):
+                # what vertex LOCALITY is worth: the same scene renumbered once on the host (synthetic.renumber_by_locality: level 0
+                # by the Morton code of its positions, coarser levels by their first child - what a reader can do at load time),
+                # a few plain steps.  The benchmark meshes are randomly numbered on purpose (ScanNet-like order), the
+                # headline value stays on that order.
+                from surface_texture_inpainting_net_amd.synthetic import renumber_by_locality
+                loc = renumber_by_locality(sample.to('cpu'))[0].to(device)
+                for _ in range(3):
+                    loc._plan_cache = None
+                    step(loc)
+                fence()
+                t2 = time.perf_counter()
+                for _ in range(10):
+                    loc._plan_cache = None
+                    step(loc)
+                fence()
+                out['vertex_locality'] = {'ms_per_step': (time.perf_counter() - t2) / 10 * 1e3,
+                                          'note': 'same scene, vertices of every level renumbered by locality on the host before the run '
+                                                  '(Morton order of the positions; not part of the timed step, not the headline)'}
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(args.vertices, args.levels, seed=0)
         print(json.dumps(out), flush=True)
