@@ -90,7 +90,7 @@ def pmc_traffic_bytes(kernel, n, e, h):
     if not files:
         return None
     table = json.load(open(files[-1]))
-    hits = [v for k, v in table.items() if k.startswith(prefix)]
+    hits = [v for k, v in table.items() if k.startswith(prefix) or k.startswith(prefix.replace('k_edge_fwd<', 'k_edge_fwd_exact<'))]
     return hits[0]['hbm_MB_per_launch'] * 1e6 if hits else None
 
 
