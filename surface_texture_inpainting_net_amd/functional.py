@@ -1479,6 +1479,20 @@ class UnpoolFn(torch.autograd.Function):
         return segment_sum(g, p.children.rowptr, p.children.col, p.n_coarse, mean=False), None
 
 
+class PermuteRowsFn(torch.autograd.Function):
+    """y = x[idx] for a PERMUTATION idx (inv = its inverse): the two gathers at the model's boundary when the plan has
+    renumbered the vertices (plan.GraphPlan._ensure_order); backward = the gather with the inverse."""
+
+    @staticmethod
+    def forward(ctx, x, idx, inv):
+        ctx.inv = inv
+        return gather_rows(x, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        return gather_rows(g.contiguous(), ctx.inv), None, None
+
+
 class InstanceNormActResFn(torch.autograd.Function):
     """y = res + act(InstanceNorm(x)) (res optional, act = ELU or identity)."""
 

@@ -187,7 +187,11 @@ class EdgeSet:
 class PoolMap:
     """trace: fine vertex -> coarse vertex (hierarchy_trace_index_l)."""
 
-    def __init__(self, trace, n_fine, n_coarse, bad, jobs=None):
+    def __init__(self, trace, n_fine, n_coarse, bad, jobs=None, renumbered=None):
+        """renumbered = (coarse_new, fine_new, trace_new): the map after a vertex renumbering (GraphPlan._ensure_order) -
+        coarse_new[v] / fine_new[v] = the NEW ids of trace[v] / v for v in ORIGINAL order (so every children list keeps the
+        original order of its members: the arg-first rule of max pooling picks the same child as before the renumbering),
+        trace_new int32 [n_fine] = new fine id -> new coarse id."""
         assert trace.numel() == n_fine
         trace = trace.contiguous()
         assert trace.dtype == torch.int64 and trace.is_cuda
@@ -196,10 +200,18 @@ class PoolMap:
         rowptr = torch.empty(n_coarse + 1, dtype=torch.int32, device=dev)
         col = torch.empty(max(n_fine, 1), dtype=torch.int32, device=dev)
         inv_deg = torch.empty(max(n_coarse, 1), dtype=torch.float32, device=dev)
-        self.trace = torch.empty(max(n_fine, 1), dtype=torch.int32, device=dev)[:n_fine]
         own = jobs is None
         if own:
             jobs = PlanJobs()
+        if renumbered is not None:
+            coarse_new, fine_new, self.trace = renumbered
+            jobs.add(coarse_new, fine_new, n_fine, n_coarse, n_fine, 0, rowptr, col, None, inv_deg)
+            if own:
+                jobs.run(bad, dev)
+            self.children = CSR(rowptr, col[:n_fine], None, inv_deg[:n_coarse], n_coarse, n_fine)
+            self.inv_count = self.children.inv_deg
+            return
+        self.trace = torch.empty(max(n_fine, 1), dtype=torch.int32, device=dev)[:n_fine]
         # children CSR (col = fine ids, ascending) and the int32 trace in the same counting pass
         jobs.add(trace, None, n_fine, n_coarse, 0, 0, rowptr, col, None, inv_deg, narrow_out=self.trace)
         if own:
@@ -255,7 +267,7 @@ class NormGroups:
 class GraphPlan:
     """All CSR structures of one (possibly batched) hierarchical sample."""
 
-    def __init__(self, sample, linspace_quirk=True, validate=True, validation=None):
+    def __init__(self, sample, linspace_quirk=True, validate=True, validation=None, positions=None):
         x = sample.x
         assert x.is_cuda, 'the HIP path needs the sample on the GPU (sample.to("cuda"))'
         self.device = x.device
@@ -292,6 +304,93 @@ class GraphPlan:
         self._validation = validation or VALIDATION          # 'sync' | 'deferred', see validate()
         self._validated = False
         self._flag_host = None
+        # vertex renumbering by locality ("optional vertex reordering, inverted at the boundary"): see _ensure_order
+        self._pos_cols = positions
+        self._ranks = None                 # per level: int64 [n_l + 1], old id -> new id (last entry = n_l: the out-of-range sentinel)
+        self.order0 = self.rank0 = None    # int32: new -> old / old -> new at level 0, for the gathers at the model's boundary
+        self._reorder = bool(positions is not None and REORDER and self.num_graphs == 1 and self.level_sizes[0] >= REORDER_MIN
+                             and x.dim() == 2 and x.shape[1] >= positions[1] and not _capturing())
+
+    # ---- vertex renumbering -------------------------------------------------------------
+    def _ensure_order(self):
+        """Renumber the vertices of every level so that memory order follows space (round 3).  The gathers of the edge
+        kernels read neighbour rows; on a mesh whose vertex numbering has no locality (ScanNet order, the benchmark's random
+        permutation) every gathered row comes over the fabric, with a coherent numbering most are L2 hits (level-2 forward
+        45 -> 36 us, level 0 118 -> 103 at the headline size).  Level 0: stable sort by the 30-bit Morton code of the vertex
+        positions (columns `positions` of x - [6, 9) in the reference's feature layout,
+        datasets/scannetcolorgraph_dataloader.py:113-121); level l + 1: by the smallest new id among a vertex's children.
+        Only index VALUES change: every edge list and trace keeps its order, so each CSR row keeps the neighbour order of the
+        reference's sequential scatter and each children list the order the arg-first max rule needs - per-row results are
+        bit-identical, only the row order of the column reductions (instance-norm statistics, fp64 partial sums) differs.
+        Single graphs only (the linspace-slice statistics of a batch depend on the row order).  Runs on torch's current stream
+        (the plan side stream when prefetched)."""
+        if not self._reorder or self._ranks is not None:
+            return
+        s, dev = self._sample, self.device
+        a, b = self._pos_cols
+        pos = s.x[:, a:b].to(torch.float32)
+        lo, hi = pos.amin(0, keepdim=True), pos.amax(0, keepdim=True)
+        q = ((pos - lo) / (hi - lo).clamp_min(1e-20) * 1024.0).to(torch.int64).clamp_(0, 1023)
+
+        def spread(v):                                    # 10 bits -> every third bit
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        order = torch.argsort(code, stable=True)
+        n = order.numel()
+        rank = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        rank[order] = torch.arange(n, device=dev)
+        rank[n] = n
+        ranks = [rank]
+        for lvl in range(1, len(self.level_sizes)):
+            nc = self.level_sizes[lvl]
+            tr = s['hierarchy_trace_index_%d' % lvl]
+            ok = (tr >= 0) & (tr < nc)
+            first = torch.full((nc,), n, dtype=torch.int64, device=dev)
+            first.scatter_reduce_(0, torch.where(ok, tr, 0), torch.where(ok, ranks[-1][:-1], n), 'amin', include_self=True)
+            c_order = torch.argsort(first, stable=True)
+            c_rank = torch.empty(nc + 1, dtype=torch.int64, device=dev)
+            c_rank[c_order] = torch.arange(nc, device=dev)
+            c_rank[nc] = nc
+            ranks.append(c_rank)
+            n = nc
+        self._ranks = ranks
+        self.order0 = order.to(torch.int32)
+        self.rank0 = ranks[0][:-1].to(torch.int32)
+
+    def _relabelled(self, idx, level):
+        """Index tensor of vertex ids of `level` in the new numbering; out-of-range ids map to n_level, which the CSR build
+        flags and leaves out exactly as it does an out-of-range original id."""
+        r = self._ranks[level]
+        n = r.numel() - 1
+        return r[idx.clamp(-1, n)]                        # (-1 wraps to the last entry = the sentinel n)
+
+    def _edge_tensor(self, key, level):
+        ei = self._sample.edge_index if key == 'edge_index' else self._sample[key]
+        if self._reorder:
+            self._ensure_order()
+            ei = self._relabelled(ei, level)
+        return ei
+
+    def _pool_map(self, level, jobs=None):
+        trace = self._sample['hierarchy_trace_index_%d' % level]
+        nf, nc = self.level_sizes[level - 1], self.level_sizes[level]
+        if not self._reorder:
+            return PoolMap(trace, nf, nc, self._bad, jobs)
+        self._ensure_order()
+        coarse_new = self._relabelled(trace.contiguous(), level)          # [nf], original fine order
+        fine_new = self._ranks[level - 1][:-1]
+        trace_new = torch.empty(max(nf, 1), dtype=torch.int32, device=self.device)[:nf]
+        trace_new[fine_new] = torch.where(coarse_new < nc, coarse_new, 0).to(torch.int32)
+        return PoolMap(trace, nf, nc, self._bad, jobs, renumbered=(coarse_new, fine_new.contiguous(), trace_new))
+
+    def order_tensors(self):
+        """The renumbering's tensors (record_stream when built on a side stream)."""
+        if self._ranks is None:
+            return ()
+        return tuple(self._ranks) + (self.order0, self.rank0)
 
     def _todo(self, edge_items, pool_levels):
         return ([('e', k, l) for (k, l) in edge_items if k not in self._edges] +
@@ -302,11 +401,9 @@ class GraphPlan:
         jobs, made = PlanJobs(), []
         for kind, key, level in todo:
             if kind == 'e':
-                ei = self._sample.edge_index if key == 'edge_index' else self._sample[key]
-                obj = self._edges[key] = EdgeSet(ei, self.level_sizes[level], self._bad, jobs)
+                obj = self._edges[key] = EdgeSet(self._edge_tensor(key, level), self.level_sizes[level], self._bad, jobs)
             else:
-                trace = self._sample['hierarchy_trace_index_%d' % level]
-                obj = self._pools[level] = PoolMap(trace, self.level_sizes[level - 1], self.level_sizes[level], self._bad, jobs)
+                obj = self._pools[level] = self._pool_map(level, jobs)
             made.append(obj)
         jobs.run(self._bad, self.device)
         self._validated = False
@@ -347,6 +444,8 @@ class GraphPlan:
         for obj in made:
             for t in obj.tensors():
                 t.record_stream(main)            # allocated on s, consumed on the compute stream: defer reuse accordingly
+        for t in self.order_tensors():
+            t.record_stream(main)
         if join:
             main.wait_stream(s)
         else:
@@ -366,8 +465,7 @@ class GraphPlan:
         if self._pending:
             self.join()
         if key not in self._edges:
-            ei = self._sample.edge_index if key == 'edge_index' else self._sample[key]
-            self._edges[key] = EdgeSet(ei, self.level_sizes[level], self._bad)
+            self._edges[key] = EdgeSet(self._edge_tensor(key, level), self.level_sizes[level], self._bad)
             self._validated = False
         return self._edges[key]
 
@@ -383,8 +481,7 @@ class GraphPlan:
         if self._pending:
             self.join()
         if level not in self._pools:
-            trace = self._sample['hierarchy_trace_index_%d' % level]
-            self._pools[level] = PoolMap(trace, self.level_sizes[level - 1], self.level_sizes[level], self._bad)
+            self._pools[level] = self._pool_map(level)
             self._validated = False
         return self._pools[level]
 
@@ -450,6 +547,15 @@ class GraphPlan:
 # 'sync' | 'deferred' (see GraphPlan.validate); STIN_PLAN_VALIDATION overrides the default
 import os as _os
 VALIDATION = _os.environ.get('STIN_PLAN_VALIDATION', 'sync')
+# vertex renumbering by locality inside the plan build (GraphPlan._ensure_order): OFF by default, STIN_REORDER=1 enables it for
+# level-0 sizes from STIN_REORDER_MIN up.  Measured (round 3, 200 704 vertices): the edge kernels gain 0.26 ms per step (level-0
+# forward 117 -> 96 us, level 1 73 -> 61, level 2 46 -> 41) but the renumbering itself - two stable sorts per level and the
+# relabelling gathers, ~45 framework kernels on the plan stream beside the step - costs more when it is redone for EVERY step
+# (7.53 -> 7.67 ms; 1 M vertices bf16 28.0 -> 29.7).  It pays where a plan is built once and reused (a scene cache); the data
+# pipeline's cheaper route is to renumber a scene ONCE when it is read (scene_io.load_scene(locality_order=True),
+# synthetic.renumber_by_locality) - the bench line's `vertex_locality` figure.
+REORDER = _os.environ.get('STIN_REORDER', '0') == '1'
+REORDER_MIN = int(_os.environ.get('STIN_REORDER_MIN', '65536'))
 _PENDING_CHECKS = []
 
 

@@ -118,6 +118,11 @@ class SurfaceTextureInpaintingNet(nn.Module):
         # 'sync': an out-of-range index raises IndexError in the forward call that used it (one host sync per new plan);
         # 'deferred': it raises at the next forward / TrainStep call instead and the host never stalls (plan.validate)
         self.plan_validation = 'sync'
+        # columns of sample.x that hold the vertex positions: the key of the plan's optional vertex renumbering by locality
+        # (plan.GraphPlan._ensure_order; inverted at the boundary of forward()).  The reference's 3-D inpainting features are
+        # x = [rgb * known, normal, pos, known] (datasets/scannetcolorgraph_dataloader.py:113-121): columns 6..8 when
+        # input_nc == 10.  None = no renumbering.
+        self.position_channels = (6, 9) if input_nc == 10 else None
         self._filter_type, self._norm_type = filter_type, norm_type
         inplace, use_bias = False, True
         if self._use_embedding:  # created but never used by forward, as in the reference (:277-278, :409-410)
@@ -273,7 +278,8 @@ class SurfaceTextureInpaintingNet(nn.Module):
         over GPU-resident index tensors can call this with inputs_ready=True as soon as the sample exists, so that the
         build overlaps with the step still running (measured on the 200k-vertex step: no net gain while the step is
         launch-bound on the host)."""
-        plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm, validation=self.plan_validation)
+        plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm, validation=self.plan_validation,
+                        positions=self.position_channels)
         edges, pools = self._plan_items()
         plan.prefetch(edges, pools, inputs_ready=inputs_ready)
         return plan
@@ -284,7 +290,8 @@ class SurfaceTextureInpaintingNet(nn.Module):
         prepare step k+1 while step k runs.  Hand it over with `sample._plan_cache = plan` (TrainStep.prefetch and
         loader.SceneLoader do).  after = event of the stream that uploads the sample's index tensors, if one does."""
         from .plan import GraphPlan
-        plan = GraphPlan(sample, linspace_quirk=self.compat_linspace_norm, validation=self.plan_validation)
+        plan = GraphPlan(sample, linspace_quirk=self.compat_linspace_norm, validation=self.plan_validation,
+                         positions=self.position_channels)
         edges, pools = self._plan_items()
         return plan.prefetch(edges, pools, inputs_ready=inputs_ready, join=False, after=after)
 
@@ -341,10 +348,12 @@ class SurfaceTextureInpaintingNet(nn.Module):
     def forward(self, sample):
         check_deferred()                                                      # deferred index checks of earlier calls
         plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm,      # pieces not prefetched are built at first use
-                        validation=self.plan_validation)
+                        validation=self.plan_validation, positions=self.position_channels)
         plan.ensure(*self._plan_items())                                      # ONE batched build of whatever is missing
         num_levels = len(self.decoder_blocks) + 1
         out = sample.x
+        if plan.order0 is not None:                                           # the plan renumbered the vertices: enter its order
+            out = SF.PermuteRowsFn.apply(out, plan.order0, plan.rank0)
         if self.activation_dtype != out.dtype:
             out = out.to(self.activation_dtype)
         e0 = plan.edges('edge_index', 0)
@@ -370,6 +379,8 @@ class SurfaceTextureInpaintingNet(nn.Module):
         else:
             out = F.elu(self.final_norm1(out, batch=sample.batch))
         out = torch.tanh(SF.linear(out, self.final_linear2.weight, self.final_linear2.bias, out_fp32=True, precision=tail_prec))
+        if plan.order0 is not None:                                           # ... and leave it: outputs in the sample's vertex order
+            out = SF.PermuteRowsFn.apply(out, plan.rank0, plan.order0)
         plan.validate()
         return out
 

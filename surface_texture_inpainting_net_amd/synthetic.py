@@ -221,7 +221,7 @@ def renumber_by_locality(sample, position_channels=(6, 9)):
     out['x'] = sample.x[torch.from_numpy(order)]
     out['color'] = sample.color[torch.from_numpy(order)]
     out['mask'] = sample.mask[torch.from_numpy(order)]
-    out['batch'] = sample.batch.clone()
+    out['batch'] = sample.batch.clone() if 'batch' in sample else torch.zeros(order.size, dtype=torch.long)
     out['num_vertices'] = sample.num_vertices.clone()
     out['edge_index'] = torch.from_numpy(rank[sample.edge_index.numpy()])
     ranks = [rank]
@@ -238,8 +238,11 @@ def renumber_by_locality(sample, position_channels=(6, 9)):
         out['hierarchy_trace_index_%d' % lvl] = torch.from_numpy(new_tr)
         out['hierarchy_edge_index_%d' % lvl] = torch.from_numpy(c_rank[sample['hierarchy_edge_index_%d' % lvl].numpy()])
         ranks.append(c_rank)
-    for k in sample.keys():
+    from .data import sample_keys
+    for k in sample_keys(sample):
         if k.startswith('hierarchy_dil_'):
             lvl = int(k.rsplit('_', 1)[1])
             out[k] = torch.from_numpy(ranks[lvl][sample[k].numpy()])
+        elif k not in out and k not in ('x', 'color', 'mask', 'batch', 'num_vertices', 'edge_index'):
+            out[k] = sample[k]                        # (name, labels of other levels, ...: carried over unchanged)
     return out, torch.from_numpy(order)

@@ -190,6 +190,36 @@ def test_scene_io_round_trip_in_reference_schema(tmp_path):
     assert t2.num_vertices.shape == (1, 2) and 'hierarchy_trace_index_2' not in t2
 
 
+def test_scene_reader_locality_order_is_a_consistent_renumbering(tmp_path):
+    """load_scene(locality_order=True): the same scene with the vertices of every level renumbered (Morton order of the
+    positions, first-child order above).  A relabelling must be invisible to the network: the CPU oracle on the renumbered
+    sample gives the rows of the original output in the new order (same weights), edge lists keep their order, and the
+    numbering is more local than the file's."""
+    from oracle import stin_oracle
+    from surface_texture_inpainting_net_amd.scene_io import load_scene, save_scene_like_reference
+    s = make_synthetic_mesh(900, 3, seed=12, dilations=(2,))
+    gp, mp = str(tmp_path / 'scene0001_00.pt'), str(tmp_path / '0.npz')
+    save_scene_like_reference(s, gp, mp, dilation_dists=(2,))
+    a = load_scene(gp, mp, end_level=3)
+    b = load_scene(gp, mp, end_level=3, locality_order=True)
+    order = b['vertex_order']
+    assert sorted(order.tolist()) == list(range(a.x.shape[0]))
+    assert torch.equal(b.x, a.x[order]) and torch.equal(b.color, a.color[order]) and torch.equal(b.mask, a.mask[order])
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(order.numel())
+    assert torch.equal(b.edge_index, rank[a.edge_index])                       # same edges, same order, new names
+    spread = lambda e: float((e[0] - e[1]).abs().float().mean())
+    assert spread(b.edge_index) < 0.5 * spread(a.edge_index)
+    assert spread(b['hierarchy_edge_index_1']) < 0.6 * spread(a['hierarchy_edge_index_1'])
+    cfg = dict(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconvtransinv', norm='instance', n_blocks=2, n_levels=2,
+               pooling_type='max', dilations=[1, 2])
+    torch.manual_seed(3)
+    net = stin_oracle.define_G(**cfg)
+    with torch.no_grad():
+        ya, yb = net(a), net(b)
+    assert float((yb - ya[order]).abs().max()) <= 2e-5
+
+
 def test_cpu_tensors_are_rejected_not_silently_computed():
     """No CPU / eager fallback: a CPU sample must fail loudly, never produce an answer."""
     s = make_synthetic_mesh(100, 2, seed=3, dilations=())

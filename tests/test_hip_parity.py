@@ -1330,3 +1330,63 @@ def test_model_with_an_empty_dilated_edge_set(dtype):
                 SF.USE_BLOCK_CALL = old
         assert all(torch.isfinite(t).all() for t in outs[0])
         assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_vertex_renumbering_by_locality_is_invisible_at_the_boundary(dtype, monkeypatch):
+    """plan.GraphPlan._ensure_order (Morton order of the position channels at level 0, first-child order above) relabels
+    index VALUES only: outputs come back in the sample's vertex order and equal the un-renumbered run up to the rounding of
+    the instance-norm column sums (other row order); every CSR row keeps its neighbour order and every children list its
+    original order - checked on a mesh with exact ties in the max pooling (duplicated feature rows), where the gradient
+    must reach the same child."""
+    from surface_texture_inpainting_net_amd import plan as P
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=2, n_levels=2,
+               pooling_type='max', dilations=[1, 2])
+    s = make_synthetic_mesh(4000, 3, seed=31, dilations=(2,))
+    m = s['x'][1::3].shape[0]
+    s['x'][0:3 * m:3] = s['x'][1::3]                                        # duplicated rows: ties at every level's max pooling
+    s = s.to(DEV)
+
+    def run(reorder):
+        monkeypatch.setattr(P, 'REORDER', reorder)
+        monkeypatch.setattr(P, 'REORDER_MIN', 0)
+        torch.manual_seed(5)
+        net = S.define_G(**cfg).to(DEV)
+        if dtype == 'bf16':
+            net.set_activation_dtype(torch.bfloat16)
+        s._plan_cache = None
+        x = s.x.clone().requires_grad_(True)
+        s2 = type(s)(**{k: (x if k == 'x' else s[k]) for k in s.keys()})
+        s2._nv_host = s._nv_host
+        out = net(s2)
+        assert (s2._plan_cache.order0 is not None) == reorder
+        (out.float() * torch.linspace(-1, 1, out.numel(), device=DEV).view_as(out)).sum().backward()
+        return [out.detach().float(), x.grad.float()] + [p.grad.clone() for p in net.parameters()]
+
+    want, got = run(False), run(True)
+    tol = 2e-5 if dtype == 'f32' else 6e-2
+    gscale = max(float(b.abs().max()) for b in want[2:])                   # (bias gradients in front of a norm are pure cancellation noise)
+    for i, (a, b) in enumerate(zip(got, want)):
+        scale = max(float(b.abs().max()), 5e-2 * gscale if i >= 2 else 0.0) + 1e-6
+        assert float((a - b).abs().max()) <= tol * scale, (i, float((a - b).abs().max()), scale)
+
+
+def test_vertex_renumbering_reports_out_of_range_indices():
+    """An out-of-range edge / trace id must still raise IndexError when the plan renumbers (the relabel maps it to the
+    out-of-range sentinel instead of indexing past the rank table)."""
+    from surface_texture_inpainting_net_amd import plan as P
+    cfg = dict(input_nc=10, output_nc=3, ngf=8, filter_type='edgeconvtransinv', norm='instance', n_blocks=1, n_levels=1,
+               pooling_type='max')
+    net = S.define_G(**cfg).to(DEV)
+    old = P.REORDER_MIN
+    P.REORDER_MIN = 0
+    try:
+        for key, val in (('edge_index', 10 ** 6), ('hierarchy_trace_index_1', -3), ('hierarchy_edge_index_1', 70000)):
+            s = make_synthetic_mesh(600, 2, seed=3, dilations=())
+            s[key] = s[key].clone()
+            s[key].view(-1)[5] = val
+            with pytest.raises(IndexError):
+                net(s.to(DEV))
+                torch.cuda.synchronize()
+    finally:
+        P.REORDER_MIN = old
