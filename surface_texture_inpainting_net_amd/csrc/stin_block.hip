@@ -73,7 +73,7 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
 
     // bf16 rows: the GEMM weight operands are written as bf16 once here (half the bytes every tile load, no conversion)
     // when every reduction length is a multiple of 8; fwd_split / bwd_split then carry STIN_GEMM_W_BF16
-    const bool packed = storage == 0 && (fwd_split & STIN_BLOCK_PACKED) != 0;      // the caller ran the pack (pack_many)
+    const bool packed = (fwd_split & STIN_BLOCK_PACKED) != 0;      // the caller ran the pack (pack_many; bf16 rows: with the modes below)
     fwd_split &= ~STIN_BLOCK_PACKED;
     if (storage == 1) fwd_split = bwd_split = (Cp % 8 == 0 && Cout % 8 == 0) ? STIN_GEMM_W_BF16 : 0;
     if (!packed)

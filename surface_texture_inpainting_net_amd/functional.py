@@ -596,20 +596,25 @@ class PackSet:
     and wcatT | w2T), a job table in device memory written once.  specs: [(W1, b1, W2, b2, Ws, bs, trans_inv, prec_fwd, B)]
     in block order, fp32 storage.  Valid while the parameters stay where they are (`matches`)."""
 
-    def __init__(self, specs, dev):
+    def __init__(self, specs, dev, b16=False):
         import ctypes
         import struct
         lib = _lib.load()
-        self.key = self.key_of(specs)
-        self.buffers = []                      # per block: (ws, wts, fwd_split, bwd_split)
+        self.key = self.key_of(specs) + (bool(b16),)
+        self.b16 = bool(b16)
+        self.buffers = []                      # per block: (ws, wts, fwd_split, bwd_split, wcatT view, w2T view, b16)
         blob, self.max_elems = b'', 0
+        pad = 8 if b16 else 4
         for (W1, b1, W2, b2, Ws, bs, trans_inv, prec_fwd, B) in specs:
             H, Cout = W1.shape[0], W2.shape[0]
             Cin = W1.shape[1] if trans_inv else W1.shape[1] // 2
-            Cp = (Cin + 3) // 4 * 4
+            Cp = (Cin + pad - 1) // pad * pad
             has_sc = Ws is not None
             Yw = 2 * H + (Cout if has_sc else 0)
-            fsp, bsp = block_split_modes(prec_fwd, False, Cout)
+            fsp, bsp = block_split_modes(prec_fwd, b16, Cout)       # what the block call is handed (bf16 rows: 0, 0)
+            # what the pack writes: bf16 rows -> plain bf16 operands where every reduction length is a multiple of 8
+            # (the rule of stin_edgeconv_block_fwd), else the fp32 / split form of the fp32-storage path
+            jf, jb = ((GEMM_W_BF16, GEMM_W_BF16) if (Cp % 8 == 0 and Cout % 8 == 0) else (0, 0)) if b16 else (fsp, bsp)
             ws = torch.empty(lib.stin_edgeconv_block_fwd_workspace_bytes(Cin, Cp, H, Cout, int(has_sc), B), dtype=torch.uint8, device=dev)
             wts = torch.empty(Yw * Cp + H * Cout, dtype=torch.float32, device=dev)
             off = [ctypes.c_size_t(0) for _ in range(3)]
@@ -620,10 +625,10 @@ class PackSet:
             W1c, W2c = W1.contiguous(), W2.contiguous()
             assert W1c.data_ptr() == W1.data_ptr() and W2c.data_ptr() == W2.data_ptr(), 'pack_many needs contiguous weights'
             blob += struct.pack('<10Q8i', _ptr(W1), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2), wcat, bcat, _ptr(wts),
-                                _ptr(wts) + 4 * Yw * Cp, w2s if fsp else 0, Cin, Cp, H, Cout, int(has_sc), int(trans_inv), fsp, bsp)
+                                _ptr(wts) + 4 * Yw * Cp, w2s if jf else 0, Cin, Cp, H, Cout, int(has_sc), int(trans_inv), jf, jb)
             self.max_elems = max(self.max_elems, Yw * Cp + H * Cout)
             # (the two backward operands as ready-made views: no tensor views are created inside autograd.Function.forward)
-            self.buffers.append((ws, wts, fsp, bsp, wts[:Yw * Cp].view(Cp, Yw), wts[Yw * Cp:].view(H, Cout)))
+            self.buffers.append((ws, wts, fsp, bsp, wts[:Yw * Cp].view(Cp, Yw), wts[Yw * Cp:].view(H, Cout), bool(b16)))
         self.jobs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
         self.n = len(specs)
 
@@ -632,8 +637,8 @@ class PackSet:
         return tuple((_ptr(W1), _ptr(b1), _ptr(W2), _ptr(Ws), _ptr(bs), tuple(W1.shape), tuple(W2.shape), bool(t), int(pf), int(B),
                       PREC_BWD, WEIGHT_PRESPLIT, GEMM_W_FRAG) for (W1, b1, W2, b2, Ws, bs, t, pf, B) in specs)
 
-    def matches(self, specs):
-        return self.key == self.key_of(specs)
+    def matches(self, specs, b16=False):
+        return self.key == self.key_of(specs) + (bool(b16),)
 
     def run(self):
         _call('stin_edgeconv_pack_many_f32', _ptr(self.jobs), self.n, self.max_elems, _stream(self.jobs))
@@ -679,7 +684,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
             lib = _lib.load()
             B = groups.B
             packed = 0
-            if prepacked is not None and not b16 and prepacked[2] == fsp and prepacked[3] == bsp:
+            if prepacked is not None and len(prepacked) > 6 and prepacked[6] == b16 and prepacked[2] == fsp and prepacked[3] == bsp:
                 ws, packed = prepacked[0], BLOCK_PACKED                           # operands already packed (PackSet.run)
                 wcatT, w2T = prepacked[4], prepacked[5]
             else:                                                                 # backward weight operands (no views in here)
@@ -873,11 +878,11 @@ def chain_eligible(blocks, x, edges_list, groups):
     b16 = x.dtype == torch.bfloat16
     fsp, bsp = block_split_modes(PREC_FWD, b16, C)
     packed = [b._prepacked is not None for b in blocks]
-    if any(packed) != all(packed) or (b16 and any(packed)):      # all operands packed by the network's PackSet, or none
+    if any(packed) != all(packed):                                # all operands packed by the network's PackSet, or none
         return False
     for b in blocks:
         pp = b._prepacked
-        if pp is not None and (len(pp) < 6 or pp[2] != fsp or pp[3] != bsp):
+        if pp is not None and (len(pp) < 7 or pp[6] != b16 or pp[2] != fsp or pp[3] != bsp):
             return False
         if (b.dim_in != C or b.dim_out != C or b.unbounded_input or hasattr(b, 'shortcut')
                 or b.first_norm.eps != blocks[0].first_norm.eps):
@@ -1099,7 +1104,7 @@ def net_eligible(steps, x):
         pp = b._prepacked
         if pp is not None:
             fsp, bsp = block_split_modes(forward_precision(b.unbounded_input), b16, b.dim_out)
-            if b16 or len(pp) < 6 or pp[2] != fsp or pp[3] != bsp:
+            if len(pp) < 7 or pp[6] != b16 or pp[2] != fsp or pp[3] != bsp:
                 return False
         packed.append(pp is not None)
     return bool(packed) and any(packed) == all(packed)

@@ -200,9 +200,10 @@ class SurfaceTextureInpaintingNet(nn.Module):
 
     def _pack_weights(self, x, num_graphs):
         """All fused blocks' weight operands in ONE launch (functional.PackSet) instead of one tiny launch at the head of
-        every block: 15 launches of ~8 us on the critical path become one.  fp32 storage on the whole-block path only."""
+        every block: 15 launches of ~8 us on the critical path become one.  fp32 and (round 3) bf16 storage, whole-block path only."""
         use = (SF.USE_PACK_MANY and SF.USE_BLOCK_CALL and SF.USE_EDGE_MASK and not SF.KernelTimer.enabled and x.is_cuda and
-               x.dtype == torch.float32 and self.norm is M.FastInstanceNorm)
+               x.dtype in (torch.float32, torch.bfloat16) and self.norm is M.FastInstanceNorm)
+        b16 = x.dtype == torch.bfloat16
         # per-step validity check of the cached set: the data pointers of EVERY packed tensor, read from the modules'
         # parameter tables each step (never from cached Parameter objects) - load_state_dict(assign=True), module surgery
         # (`lin.weight = nn.Parameter(...)`, a replaced filter / shortcut module) and `p.data = ...` on any one of them all
@@ -222,7 +223,7 @@ class SurfaceTextureInpaintingNet(nn.Module):
                     for t in lin._parameters.values():
                         if t is not None:
                             ptrs.append(t.data_ptr())
-        key = (use, tuple(ptrs), int(num_graphs), SF.PREC_FWD, SF.PREC_BWD, SF.GEMM_W_FRAG, SF.WEIGHT_PRESPLIT)
+        key = (use, tuple(ptrs), int(num_graphs), SF.PREC_FWD, SF.PREC_BWD, SF.GEMM_W_FRAG, SF.WEIGHT_PRESPLIT, b16)
         if key == self._pack_key:
             if use:
                 self._pack_set.run()
@@ -243,8 +244,8 @@ class SurfaceTextureInpaintingNet(nn.Module):
                 b._prepacked = None
             return
         ps = self._pack_set
-        if ps is None or not ps.matches(specs):
-            ps = self._pack_set = SF.PackSet(specs, x.device)
+        if ps is None or not ps.matches(specs, b16):
+            ps = self._pack_set = SF.PackSet(specs, x.device, b16)
         ps.run()
         for b, buf in zip(blocks, ps.buffers):
             b._prepacked = buf
