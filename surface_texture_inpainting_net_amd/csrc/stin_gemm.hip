@@ -1852,6 +1852,188 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_b16(const stin_bf16* __restri
     }
 }
 
+// ------------------------------------------------------------ TN, bf16 storage, hardware-transposed LDS reads (round 3)
+// dW tile [128 x 128] += G[m, i]^T X[m, j] over a chunk of rows m.  The reduction index is the ROW of both operands, so the
+// MFMA fragments (8 consecutive k per lane) run DOWN the columns of the row-major tiles.  k_gemm_tn_b16 transposes 4 x 8
+// patches in registers (v_perm) and scatters 8-byte runs into a k-major LDS image; gfx950 reads the transpose for free:
+// the tiles are staged as they lie in memory ([64 rows][128 cols] bf16 = 256-byte rows, one ds_write_b128 per 16-byte chunk,
+// no shuffles) and ds_read_b64_tr_b16 hands each lane of a 16-lane group one COLUMN of a 4-row x 16-column block - two of
+// them are the 32x32x16 operand of the transposed tile.  Image: chunk ch of row r at position ch ^ (((r & 3) << 2) |
+// ((r >> 2) & 3)) (conflict-free for the row writes and for the transposed reads; addressing checked on the device by
+// profiles/micro/tr_read_check.hip).  Two LDS buffers, ONE barrier per 64-row slab: the next slab's global loads are issued
+// before the MFMAs of the current one and written to the other buffer after them.  Same products in the same k order
+// as k_gemm_tn_b16 (bit-identical slabs); the bias column (sum_m w[m] G[m, i]) is accumulated from the A fragments in fp32
+// (other association than the staged form: equal to rounding).  128 x 128 tiles, 16-byte rows (Nc, K, ldg, ldx % 8 == 0).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lo, const unsigned char* hi) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi);
+    const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// Tile = (WI MT 32) x (WJ NT 32) on WI x WJ waves: 128 x 128 on 2 x 2 waves of 64 x 64 (two blocks per CU), or 256 x 256 on
+// 2 x 4 waves of 128 x 64 (one block per CU).  The big tile is what the fat shapes need: with 128 x 128 tiles every operand
+// element is re-read Nc / 128 (K / 128) times - 1.06 GB through the L2 -> CU paths for the 8 100 x 4096 x 1024 product, more
+// time than its MFMAs - the 256 x 256 tile halves that and reads 6 KB of LDS per 8 MFMAs instead of 4 KB per 4.
+template <int WI, int WJ, int MT, int NT>
+struct TrGeom {
+    static constexpr int TI = WI * MT * 32, TJ = WJ * NT * 32, THREADS = 64 * WI * WJ;
+    static constexpr int ROWB_G = TI * 2, ROWB_X = TJ * 2;                      // bytes of a tile row
+    static constexpr int TILE_G = 64 * ROWB_G, TILE_X = 64 * ROWB_X, BUF = TILE_G + TILE_X;
+    static constexpr int LDS = 2 * BUF + 2 * 64 * 4;                            // two buffers + two slabs of row weights
+    static_assert(TI == TJ, "the staging map assumes square tiles");
+    static_assert((64 * (TI / 8)) % THREADS == 0, "whole staging passes");
+};
+template <int ROWB>
+__device__ __forceinline__ int tr_offw(int row, int ch) { return ROWB * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+template <int WI, int WJ, int MT, int NT>
+__global__ __launch_bounds__(64 * WI * WJ) void k_gemm_tn_b16_tr(const stin_bf16* __restrict__ G, int64_t ldg,
+                                                                 const stin_bf16* __restrict__ X, int64_t ldx, int64_t M, int Nc,
+                                                                 int K, int Kq, int has_bias, const stin_bf16* __restrict__ row_w,
+                                                                 int64_t ld_w, int rows_per_chunk, int tiles_i, int tiles_j,
+                                                                 int64_t chunks, float* __restrict__ slab) {
+    typedef TrGeom<WI, WJ, MT, NT> Geo;
+    constexpr int TI = Geo::TI, TJ = Geo::TJ, THREADS = Geo::THREADS, CI = TI / 8;
+    constexpr int NS = 64 * CI / THREADS;                                      // staging passes (16 rows each)
+    constexpr int RPP = THREADS / CI;                                          // rows per pass
+    extern __shared__ __attribute__((aligned(16))) unsigned char tr_smem[];
+    float* wrow = reinterpret_cast<float*>(tr_smem + 2 * Geo::BUF);            // [2][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave / WJ, wj = wave % WJ;
+    const int tiles = tiles_i * tiles_j;
+    const int64_t b = blockIdx.x;
+    const int64_t xcd = b % 8, q8 = b / 8;                                     // (block -> chunk / tile as k_gemm_tn_b16)
+    const int64_t chunk = chunks >= 8 ? (q8 / tiles) * 8 + xcd : b / tiles;
+    const int tile = (int)(chunks >= 8 ? q8 % tiles : b % tiles);
+    if (chunk >= chunks) return;
+    const int tj = tile % tiles_j, ti = tile / tiles_j;
+    const int i0 = ti * TI, j0 = tj * TJ;
+    const int64_t mb = chunk * rows_per_chunk;
+    const int64_t me = (mb + rows_per_chunk < M) ? mb + rows_per_chunk : M;
+    const bool want_bias = has_bias && (tj == 0);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    float bias[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) bias[t] = 0.f;
+
+    // staging: chunk idx = tid + THREADS s of the 64 x CI chunk grid of a tile -> row idx / CI, chunk idx % CI (whole rows per wave)
+    const int sch = tid % CI, srow = tid / CI;                                 // rows srow + RPP s
+    const bool g_ok = i0 + sch * 8 < Nc, x_ok = j0 + sch * 8 < K;
+    const stin_bf16* gsrc = G + i0 + (g_ok ? sch * 8 : 0);
+    const stin_bf16* xsrc = X + j0 + (x_ok ? sch * 8 : 0);
+    int soff[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) soff[s] = tr_offw<Geo::ROWB_G>(srow + RPP * s, sch);
+    uint4 rg[NS], rx[NS];
+    float rw = 0.f;
+    auto load_slab = [&](int64_t m0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int64_t row = m0 + srow + RPP * s;
+            const int64_t rc = row < me ? row : me - 1;                         // clamped address, masked value
+            const uint4 vg = *reinterpret_cast<const uint4*>(gsrc + rc * ldg);
+            const uint4 vx = *reinterpret_cast<const uint4*>(xsrc + rc * ldx);
+            const bool live = row < me;
+            rg[s] = (live && g_ok) ? vg : make_uint4(0u, 0u, 0u, 0u);
+            rx[s] = (live && x_ok) ? vx : make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (want_bias && tid < 64) {
+            const int64_t row = m0 + tid;
+            rw = row < me ? (row_w != nullptr ? (float)row_w[row * ld_w] : 1.f) : 0.f;
+        }
+    };
+    auto store_slab = [&](int buf) {
+        unsigned char* base = tr_smem + buf * Geo::BUF;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            *reinterpret_cast<uint4*>(base + soff[s]) = rg[s];
+            *reinterpret_cast<uint4*>(base + Geo::TILE_G + soff[s]) = rx[s];
+        }
+        if (want_bias && tid < 64) wrow[buf * 64 + tid] = rw;
+    };
+
+    // transposed-read addresses of this lane for k-step 0 (a k-step further down = + 16 rows)
+    const int g16 = lane >> 4, tl = lane & 15, tq = tl >> 2, tp = tl & 3;
+    int aoff[MT][2], boff[NT][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 8 * (g16 >> 1) + 4 * h + tq;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            aoff[t][h] = tr_offw<Geo::ROWB_G>(row, (wi * (MT * 32) + t * 32 + 16 * (g16 & 1)) / 8 + (tp >> 1)) + 8 * (tp & 1);
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+            boff[u][h] = Geo::TILE_G + tr_offw<Geo::ROWB_X>(row, (wj * (NT * 32) + u * 32 + 16 * (g16 & 1)) / 8 + (tp >> 1)) + 8 * (tp & 1);
+    }
+    const int kh = lane >> 5, li = lane & 31;
+
+    load_slab(mb);
+    store_slab(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t m0 = mb; m0 < me; m0 += TNK_R) {
+        const bool more = m0 + TNK_R < me;
+        if (more) load_slab(m0 + TNK_R);                                       // in flight during the MFMAs below
+        const unsigned char* base = tr_smem + buf * Geo::BUF;
+#pragma unroll
+        for (int ks = 0; ks < TNK_R / 16; ++ks) {
+            bf16x8 a[MT], c[NT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                a[t] = tr_frag(base + ks * 16 * Geo::ROWB_G + aoff[t][0], base + ks * 16 * Geo::ROWB_G + aoff[t][1]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                c[u] = tr_frag(base + ks * 16 * Geo::ROWB_X + boff[u][0], base + ks * 16 * Geo::ROWB_X + boff[u][1]);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], c[u], acc[t][u], 0, 0, 0);
+            if (want_bias && wj == 0) {                                        // wave-uniform
+                const float* w = wrow + buf * 64 + ks * 16 + 8 * kh;
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bias[t] += w[e] * (float)a[t][e];
+            }
+        }
+        if (more) store_slab(buf ^ 1);                                         // the buffer nobody reads in this iteration
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    float* out = slab + chunk * tn_chunk_stride(Nc, Kq);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int col = j0 + wj * (NT * 32) + u * 32 + li;
+        if (col >= K) continue;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wi * (MT * 32) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < Nc) out[(int64_t)row * Kq + col] = acc[t][u][r];
+            }
+    }
+    if (want_bias && wj == 0) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const float tot = bias[t] + __shfl_xor(bias[t], 32);               // the two k-halves of the wave
+            const int row = i0 + wi * (MT * 32) + t * 32 + li;
+            if (kh == 0 && row < Nc) out[(int64_t)Nc * Kq + row] = tot;
+        }
+    }
+}
+
 // dW[row][col] = sum_c slab[c][row][col] (and the bias column from the chunk's bias block): 16 chunk-lanes x 16 float4
 // groups per block, each chunk-lane walks the chunk list with stride 16 (4 x 16-byte loads in flight), then a
 // fixed-order LDS reduction over the chunk-lanes -> deterministic.
@@ -1949,6 +2131,22 @@ inline bool nt_b16_glds_pays(int64_t M, int Nc, int K) {
     // measured (profiles/r03_nt_bf16_fat.md): +10..25 % from K = 1024 up (8 100 x 4096 x 1024: 124 -> 110 us, x 1024 x 4096: 104 -> 82),
     // a loss at K <= 512 where four to eight k-tiles do not amortise the two-buffer prologue and the output bytes dominate
     return K >= 1024 && Nc >= 256 && ((M + 127) / 128) * ((Nc + 127) / 128) >= 128;
+}
+// bf16-storage TN: 256 x 256 tiles (k_gemm_tn_b16_tr<2, 4, 4, 2>) for the fat products.  STIN_TN_BIG = 0 | 1 forces (re-read per call;
+// the workspace bound covers both choices).
+inline bool tn_b16_big_tile(int Nc, int K) {
+    const char* e = getenv("STIN_TN_BIG");
+    if (e) return atoi(e) != 0 && Nc >= 256 && K >= 256;
+    return Nc >= 512 && K >= 512;
+}
+// bf16-storage TN, 128 x 128 tiles: the transposed-read kernel (k_gemm_tn_b16_tr); STIN_TN_TR=0 keeps the register-transpose
+// kernel (A/B switch, re-read per call).
+inline bool tn_b16_tr_enabled(int Nc, int K) {
+    const char* e = getenv("STIN_TN_TR");
+    if (e) return atoi(e) != 0;
+    // whole tiles only: with a ragged third tile (161 362 x 320 x 128, the level-0 product of the crop batches) the 64 KB of LDS
+    // (two blocks per CU instead of four) cost more than the transposes: 54.6 -> 68.6 us; whole-tile shapes gain 5-17 %
+    return Nc % 128 == 0 && K % 128 == 0;
 }
 // Strip-kernel configuration (see k_gemm_nt_strip): 21 / 22 / 41.  STIN_STRIP_CFG overrides (tuning aid).
 inline int strip_config(int64_t M, int Nc, int KC) {
@@ -2146,6 +2344,11 @@ extern "C" size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int one
         const int64_t c = (M + rows - 1) / rows;
         if (c > chunks) chunks = c;
     }
+    if (Nc >= 256 && K >= 256) {                                 // the 256 x 256 tiles of the bf16-storage products: fewer tiles, more chunks
+        const int rows = tn_rows_per_chunk(M, ((Nc + 255) / 256) * ((K + 255) / 256), true);
+        const int64_t c = (M + rows - 1) / rows;
+        if (c > chunks) chunks = c;
+    }
     return (size_t)chunks * (size_t)tn_chunk_stride(Nc, (K + 3) & ~3) * sizeof(float) + 256;
 }
 
@@ -2166,11 +2369,14 @@ int stin_tn_problem_init(stin_tn_problem* p, int storage, const void* G, int64_t
     p->M = M;
     p->Nc = Nc;
     p->K = K;
-    p->TI = tn_tile(Nc);
-    p->TJ = tn_tile(K);
+    const int a16 = storage ? 8 : 4;                               // elements per 16-byte vector
+    const bool vec16 = (Nc % a16 == 0) && (K % a16 == 0) && (ldg % a16 == 0) && (ldx % a16 == 0) && stin_aligned16(G) && stin_aligned16(X);
+    const bool big = storage == 1 && vec16 && tn_b16_big_tile(Nc, K);
+    p->TI = big ? 256 : tn_tile(Nc);
+    p->TJ = big ? 256 : tn_tile(K);
     p->tiles_i = (Nc + p->TI - 1) / p->TI;
     p->tiles_j = (K + p->TJ - 1) / p->TJ;
-    p->rows_per_chunk = tn_rows_per_chunk(M, p->tiles_i * p->tiles_j, tn_one_per_cu(storage, precision, p->TI, p->TJ, M));
+    p->rows_per_chunk = tn_rows_per_chunk(M, p->tiles_i * p->tiles_j, big || tn_one_per_cu(storage, precision, p->TI, p->TJ, M));
     p->chunks = M > 0 ? (M + p->rows_per_chunk - 1) / p->rows_per_chunk : 0;
     p->Kq = (K + 3) & ~3;
     p->has_bias = ones_column ? 1 : 0;
@@ -2202,11 +2408,27 @@ int stin_tn_slabs(const stin_tn_problem* p, int storage, int precision, stin_str
         if (vec) hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
         else hipLaunchKernelGGL((k_gemm_tn_b16<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
     } while (0)
-        if (TI == 128 && TJ == 128) STIN_TNK(128, 128);
+#define STIN_TNTR(WI_, WJ_, MT_, NT_)                                                                                  \
+    do {                                                                                                              \
+        typedef TrGeom<WI_, WJ_, MT_, NT_> Geo_;                                                                      \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)k_gemm_tn_b16_tr<WI_, WJ_, MT_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo_::LDS); \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_gemm_tn_b16_tr<WI_, WJ_, MT_, NT_>), dim3((unsigned)blocks), dim3(Geo_::THREADS), Geo_::LDS, stream, G, ldg, X, \
+                           ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);  \
+    } while (0)
+        if (TI == 256 && TJ == 256) {
+            STIN_TNTR(2, 4, 4, 2);
+        } else if (TI == 128 && TJ == 128 && vec && Nc % 8 == 0 && K % 8 == 0 && tn_b16_tr_enabled(Nc, K)) {
+            STIN_TNTR(2, 2, 2, 2);
+        } else if (TI == 128 && TJ == 128) STIN_TNK(128, 128);
         else if (TI == 128) STIN_TNK(128, 64);
         else if (TJ == 128) STIN_TNK(64, 128);
         else STIN_TNK(64, 64);
 #undef STIN_TNK
+#undef STIN_TNTR
         return stin_launch_status();
     }
     const float *G = p->G, *X = p->X, *row_weight = p->row_w;

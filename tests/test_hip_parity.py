@@ -1390,3 +1390,38 @@ def test_vertex_renumbering_reports_out_of_range_indices():
                 torch.cuda.synchronize()
     finally:
         P.REORDER_MIN = old
+
+
+@pytest.mark.parametrize('M,Nc,K', [(8100, 1024, 512), (2700, 512, 1024), (777, 136, 264), (4097, 256, 128), (65, 128, 128), (1, 128, 256),
+                                    (20000, 320, 128), (3000, 2048, 256), (1500, 520, 776), (63, 512, 512), (8100, 4096, 1024)])
+def test_gemm_tn_bf16_transposed_read_kernel_equals_register_transpose_kernel(M, Nc, K, monkeypatch):
+    """k_gemm_tn_b16_tr (row-major LDS tiles, ds_read_b64_tr_b16 fragments, two buffers) against k_gemm_tn_b16 (register
+    transposes, k-major LDS image): same products in the same k order -> the weight-gradient block is bit-identical; the bias
+    column (sum_m w[m] G[m, i], accumulated from the A fragments) equals it to fp32 rounding; ragged rows / columns, strided
+    operands, with and without the ones column and row weights.  And against fp64."""
+    g = torch.Generator().manual_seed(M + Nc + K)
+    G = torch.randn(M + 2, Nc + 8, generator=g).to(DEV).bfloat16()[1:M + 1, :Nc]
+    X = torch.randn(M, K + 16, generator=g).to(DEV).bfloat16()[:, 8:K + 8]
+    w = torch.rand(M, 8, generator=g).to(DEV).bfloat16()[:, 3]
+    big = Nc >= 512 and K >= 512                  # 256 x 256 tiles: other row chunks -> the slab sums associate differently
+    for kw in (dict(), dict(ones_column=True), dict(ones_column=True, row_weight=w)):
+        monkeypatch.setenv('STIN_TN_TR', '0')
+        monkeypatch.setenv('STIN_TN_BIG', '0')
+        base = SF.gemm_tn(G, X, **kw)
+        monkeypatch.setenv('STIN_TN_TR', '1')
+        monkeypatch.delenv('STIN_TN_BIG')
+        for _ in range(2):
+            got = SF.gemm_tn(G, X, **kw)
+            assert got.shape == base.shape
+            if big:
+                assert float((got[:, :K] - base[:, :K]).abs().max()) <= 2e-5 * (float(base.abs().max()) + 1.0) * max(1.0, (M / 1000) ** 0.5)
+                monkeypatch.setenv('STIN_TN_BIG', '0')
+                assert torch.equal(SF.gemm_tn(G, X, **kw)[:, :K], base[:, :K]), sorted(kw)      # the 128 x 128 transposed-read kernel
+                monkeypatch.delenv('STIN_TN_BIG')
+            else:
+                assert torch.equal(got[:, :K], base[:, :K]), sorted(kw)
+            if kw:
+                assert float((got[:, K] - base[:, K]).abs().max()) <= 2e-5 * (float(base[:, K].abs().max()) + 1.0) * max(1.0, (M / 1000) ** 0.5)
+    want = torch.cat([G.double().t() @ X.double(), (G.double() * w.double()[:, None]).sum(0)[:, None]], 1)
+    got = SF.gemm_tn(G, X, ones_column=True, row_weight=w).double()
+    assert float((got - want).abs().max()) <= 3e-5 * (float(want.abs().max()) + 1.0) * max(1.0, (M / 1000) ** 0.5)
