@@ -27,24 +27,30 @@ def main():
     ap.add_argument('--rounds', type=int, default=5)
     args = ap.parse_args()
     lines = ['# bf16-storage NT products, fat shapes (random data, median of %d interleaved rounds x 10 launches; bf16 weights, bias, bf16 out)' % args.rounds, '',
-             '| M | Nc | K | register-staged us (TFLOP/s) | LDS-DMA 128x128 us (TFLOP/s) | frac of 2.5 PF |', '|---|---|---|---|---|---|']
+             '| M | Nc | K | register-staged us (TFLOP/s) | LDS-DMA 128x128 | LDS-DMA 256x256 | shipped rule | shipped: frac of 2.5 PF |', '|---|---|---|---|---|---|---|---|']
     for (M, Nc, K) in SHAPES:
         A = torch.randn(M, K, device=dev).bfloat16()
         W = (torch.randn(Nc, K, device=dev) * 0.05).bfloat16()
         b = torch.randn(Nc, device=dev)
         out = torch.empty(M, Nc, device=dev, dtype=torch.bfloat16)
-        res = {0: [], 1: []}
+        arms = [{'STIN_NT_GLDS': '0'}, {'STIN_NT_GLDS': '1', 'STIN_NT_BIG': '0'}, {'STIN_NT_GLDS': '1', 'STIN_NT_BIG': '1'}, {}]
+        res = [[] for _ in arms]
         for r in range(args.rounds + 1):
-            for v in (0, 1):
-                os.environ['STIN_NT_GLDS'] = str(v)
+            for v, env in enumerate(arms):
+                for k in ('STIN_NT_GLDS', 'STIN_NT_BIG'):
+                    os.environ.pop(k, None)
+                os.environ.update(env)
                 us = t(lambda: SF.gemm_nt(A, W, b, out=out))
                 if r:
                     res[v].append(us)
-        m0, m1 = statistics.median(res[0]), statistics.median(res[1])
+        for k in ('STIN_NT_GLDS', 'STIN_NT_BIG'):
+            os.environ.pop(k, None)
+        m = [statistics.median(x) for x in res]
         fl = 2.0 * M * Nc * K
-        lines.append('| %d | %d | %d | %.1f (%.0f) | %.1f (%.0f) | %.2f |' % (M, Nc, K, m0, fl / m0 / 1e6, m1, fl / m1 / 1e6, fl / m1 / 1e6 / 2500))
+        lines.append('| %d | %d | %d | %s | %.2f |' % (M, Nc, K, ' | '.join('%.1f (%.0f)' % (x, fl / x / 1e6) for x in m), fl / m[3] / 1e6 / 2500))
         print(lines[-1], flush=True)
     if args.md:
+        os.makedirs(os.path.dirname(os.path.abspath(args.md)), exist_ok=True)
         open(args.md, 'w').write('\n'.join(lines) + '\n')
 
 

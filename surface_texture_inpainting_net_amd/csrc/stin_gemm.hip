@@ -1377,7 +1377,7 @@ __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u 
 
 // Epilogue shared by the bf16-storage NT kernels: + bias * row_mask + residual in fp32, one rounding; bf16 tiles leave through
 // LDS (smem: the operand tiles, free once every wave has passed the caller's last barrier) as 16-byte row-contiguous stores.
-template <int BM, int BN, int WM, int WN, typename OUT>
+template <int BM, int BN, int WM, int WN, typename OUT, int THREADS = BLOCK>
 __device__ __forceinline__ void nt_b16_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], unsigned char* smem, int64_t m0, int n0,
                                                 const float* __restrict__ bias, const stin_bf16* __restrict__ row_mask,
                                                 int64_t ld_mask, const stin_bf16* __restrict__ res, int64_t ld_res, int64_t M,
@@ -1435,8 +1435,8 @@ __device__ __forceinline__ void nt_b16_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
         __syncthreads();
         constexpr int CHUNKS = BM * BN / 8;                       // 16-byte chunks of the output tile
 #pragma unroll
-        for (int s = 0; s < CHUNKS / BLOCK; ++s) {
-            const int c = tid + s * BLOCK;
+        for (int s = 0; s < CHUNKS / THREADS; ++s) {
+            const int c = tid + s * THREADS;
             const int lrow = c / (BN / 8), lc = (c % (BN / 8)) * 8;
             const int64_t row = m0 + lrow;
             const int col = n0 + lc;
@@ -1585,16 +1585,29 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_b16(const stin_bf16* __restri
 // Block -> tile: with a multiple of 8 column tiles every XCD owns Nc / 8 columns (its W panel, 1 MB at K = 1024 and Nc = 4096,
 // stays in that XCD's L2 while the A row tiles stream through, each read by the XCD's consecutive blocks); otherwise the
 // row-tile-per-XCD order of nt_block_tile.
-template <typename OUT>
-__global__ __launch_bounds__(BLOCK, 2) void k_gemm_nt_b16_glds(const stin_bf16* __restrict__ A, int64_t lda,
-                                                            const stin_bf16* __restrict__ W, int64_t ldw,
-                                                            const float* __restrict__ bias,
-                                                            const stin_bf16* __restrict__ row_mask, int64_t ld_mask,
-                                                            const stin_bf16* __restrict__ res, int64_t ld_res, int64_t M,
-                                                            int Nc, int K, OUT* __restrict__ C, int64_t ldc, int vec_out) {
-    constexpr int BM = 128, BN = 128, WM = 2, WN = 2, TM = 64, TN = 64, MT = 2, NT = 2;
-    constexpr int BUF = (BM + BN) * BKB * 2;                      // one k-tile of both operands: 32 KB
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
+// Tile = (WM MT 32) x (WN NT 32): 128 x 128 on 2 x 2 waves of 64 x 64 (static 64 KB, two blocks per CU) or 256 x 256 on 2 x 4 waves
+// of 128 x 64 (one block per CU; halves the operand re-reads through L2 and reads 6 KB of LDS per 8 MFMAs instead of 4 per 4).
+template <int WM, int WN, int MT, int NT>
+struct GlGeom {
+    static constexpr int BM = WM * MT * 32, BN = WN * NT * 32, THREADS = 64 * WM * WN;
+    static constexpr int BUF = (BM + BN) * BKB * 2;               // one k-tile of both operands
+    static constexpr int OUT_BYTES = BM * (BN + 32) * 2;          // the epilogue's bf16 staging image
+    static constexpr int LDS = 2 * BUF > OUT_BYTES ? 2 * BUF : OUT_BYTES;
+    static constexpr int RPP = THREADS / 8;                       // rows per staging pass (8 lanes = one 128-byte row)
+    static constexpr int NSA = BM / RPP, NSW = BN / RPP;
+};
+
+template <typename OUT, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_nt_b16_glds(const stin_bf16* __restrict__ A, int64_t lda,
+                                                                   const stin_bf16* __restrict__ W, int64_t ldw,
+                                                                   const float* __restrict__ bias,
+                                                                   const stin_bf16* __restrict__ row_mask, int64_t ld_mask,
+                                                                   const stin_bf16* __restrict__ res, int64_t ld_res, int64_t M,
+                                                                   int Nc, int K, OUT* __restrict__ C, int64_t ldc, int vec_out) {
+    typedef GlGeom<WM, WN, MT, NT> Geo;
+    constexpr int BM = Geo::BM, BN = Geo::BN, TM = MT * 32, TN = NT * 32, BUF = Geo::BUF;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char gl_smem[];
+    unsigned char* smem = gl_smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -1609,29 +1622,32 @@ __global__ __launch_bounds__(BLOCK, 2) void k_gemm_nt_b16_glds(const stin_bf16* 
     } else if (!nt_block_tile(M, Nc, BM, BN, m0, n0)) {
         return;                                                   // block-uniform
     }
-    // staging: lane -> LDS position (row tid >> 3 of a 32-row pass, 16-byte slot tid & 7), source chunk = slot ^ swizzle(row)
+    // staging: lane -> LDS position (row tid >> 3 of a pass of RPP rows, 16-byte slot tid & 7), source chunk = slot ^ swizzle(row)
     const int slot = tid & 7, r0 = tid >> 3;
-    const stin_bf16* asrc[4];
-    const stin_bf16* wsrc[4];
+    const stin_bf16* asrc[Geo::NSA];
+    const stin_bf16* wsrc[Geo::NSW];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int row = r0 + 32 * s;
-        const int chunk = slot ^ ((row >> 1) & 7);
+    for (int s = 0; s < Geo::NSA; ++s) {
+        const int row = r0 + Geo::RPP * s;
         const int64_t ar = m0 + row < M ? m0 + row : M - 1;
+        asrc[s] = A + ar * lda + (slot ^ ((row >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int s = 0; s < Geo::NSW; ++s) {
+        const int row = r0 + Geo::RPP * s;
         const int wr = n0 + row < Nc ? n0 + row : Nc - 1;
-        asrc[s] = A + ar * lda + chunk * 8;
-        wsrc[s] = W + (int64_t)wr * ldw + chunk * 8;
+        wsrc[s] = W + (int64_t)wr * ldw + (slot ^ ((row >> 1) & 7)) * 8;
     }
     auto stage = [&](int buf, int k0) {
-        unsigned char* base = smem + buf * BUF + wave * 1024;     // this wave's 8 rows of every 32-row pass
+        unsigned char* base = smem + buf * BUF + wave * 1024;     // this wave's 8 rows of every pass
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < Geo::NSA; ++s)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[s] + k0),
-                                             (__attribute__((address_space(3))) void*)(base + s * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + s * (Geo::RPP * 128)), 16, 0, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < Geo::NSW; ++s)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[s] + k0),
-                                             (__attribute__((address_space(3))) void*)(base + BM * 128 + s * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + BM * 128 + s * (Geo::RPP * 128)), 16, 0, 0);
     };
 
     f32x16 acc[MT][NT];
@@ -1643,7 +1659,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_gemm_nt_b16_glds(const stin_bf16* 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int kh = lane >> 5, li = lane & 31;
-    // fragment byte offsets inside a tile: row * 128 + ((2 ks + kh) ^ ((row >> 1) & 7)) * 16; row & 1 does not enter the swizzle
+    // fragment byte offsets inside a tile: row * 128 + ((2 ks + kh) ^ ((row >> 1) & 7)) * 16
     int aoff[MT], boff[NT], asw[MT], bsw[NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -1677,7 +1693,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_gemm_nt_b16_glds(const stin_bf16* 
         }
         __syncthreads();                                          // next tile landed (vmcnt(0) of the DMAs) and this one is free
     }
-    nt_b16_epilogue<BM, BN, WM, WN, OUT>(acc, smem, m0, n0, bias, row_mask, ld_mask, res, ld_res, M, Nc, C, ldc, vec_out);
+    nt_b16_epilogue<BM, BN, WM, WN, OUT, Geo::THREADS>(acc, smem, m0, n0, bias, row_mask, ld_mask, res, ld_res, M, Nc, C, ldc, vec_out);
 }
 
 // dW[Nc, K(+1)] = G^T [X | w] with G, X (and the optional row weight w) stored as bf16; fp32 slabs as k_gemm_tn.
@@ -2132,6 +2148,13 @@ inline bool nt_b16_glds_pays(int64_t M, int Nc, int K) {
     // a loss at K <= 512 where four to eight k-tiles do not amortise the two-buffer prologue and the output bytes dominate
     return K >= 1024 && Nc >= 256 && ((M + 127) / 128) * ((Nc + 127) / 128) >= 128;
 }
+// bf16-storage NT on the LDS-DMA kernel: 256 x 256 tiles when they still fill the chip (>= 200 tiles).  STIN_NT_BIG = 0 | 1 forces.
+inline bool nt_b16_big_tile(int64_t M, int Nc, int K) {
+    const char* e = getenv("STIN_NT_BIG");
+    if (e) return atoi(e) != 0;
+    (void)K;
+    return Nc >= 512 && ((M + 255) / 256) * ((Nc + 255) / 256) >= 200;
+}
 // bf16-storage TN: 256 x 256 tiles (k_gemm_tn_b16_tr<2, 4, 4, 2>) for the fat products.  STIN_TN_BIG = 0 | 1 forces (re-read per call;
 // the workspace bound covers both choices).
 inline bool tn_b16_big_tile(int Nc, int K) {
@@ -2527,11 +2550,29 @@ extern "C" int stin_gemm_nt_bf16(const stin_bf16_t* A_, int64_t lda, const float
     } while (0)
     // fat shapes with bf16 weights: the LDS-DMA kernel (STIN_NT_GLDS=0 keeps the register-staged tiles: tuning aid / A-B)
     if (wb && K % BKB == 0 && nt_b16_glds_pays(M, Nc, K)) {
-        const int64_t nrow = (M + 127) / 128, ncol = (Nc + 127) / 128;
-        dim3 grid(ncol % 8 == 0 ? (unsigned)(nrow * ncol) : nt_grid(M, Nc, 128, 128));
         const stin_bf16* Wb = reinterpret_cast<const stin_bf16*>(W);
-        if (c_is_f32) hipLaunchKernelGGL((k_gemm_nt_b16_glds<float>), grid, dim3(BLOCK), 0, stream, A, lda, Wb, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (float*)C, ldc, vec_out);
-        else hipLaunchKernelGGL((k_gemm_nt_b16_glds<stin_bf16>), grid, dim3(BLOCK), 0, stream, A, lda, Wb, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (stin_bf16*)C, ldc, vec_out);
+#define STIN_GLDS(OUT_, WM_, WN_, MT_, NT_)                                                                             \
+    do {                                                                                                               \
+        typedef GlGeom<WM_, WN_, MT_, NT_> Geo_;                                                                       \
+        static bool attr_set = false;                                                                                  \
+        if (!attr_set) {                                                                                               \
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_b16_glds<OUT_, WM_, WN_, MT_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo_::LDS); \
+            attr_set = true;                                                                                           \
+        }                                                                                                              \
+        const int64_t nrow = (M + Geo_::BM - 1) / Geo_::BM, ncol = (Nc + Geo_::BN - 1) / Geo_::BN;                     \
+        dim3 grid(ncol % 8 == 0 ? (unsigned)(nrow * ncol) : nt_grid(M, Nc, Geo_::BM, Geo_::BN));                       \
+        hipLaunchKernelGGL((k_gemm_nt_b16_glds<OUT_, WM_, WN_, MT_, NT_>), grid, dim3(Geo_::THREADS), Geo_::LDS, stream, A, lda, Wb, ldw, \
+                           bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, (OUT_*)C, ldc, vec_out);                \
+    } while (0)
+        const bool big = nt_b16_big_tile(M, Nc, K);
+        if (c_is_f32) {
+            if (big) STIN_GLDS(float, 2, 4, 4, 2);
+            else STIN_GLDS(float, 2, 2, 2, 2);
+        } else {
+            if (big) STIN_GLDS(stin_bf16, 2, 4, 4, 2);
+            else STIN_GLDS(stin_bf16, 2, 2, 2, 2);
+        }
+#undef STIN_GLDS
         return stin_launch_status();
     }
     if (c_is_f32) STIN_NTB_PICK(float);

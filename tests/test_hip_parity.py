@@ -299,9 +299,12 @@ def test_gemm_nt_bf16_lds_dma_kernel_equals_register_staged_kernel(M, Nc, K, mon
         monkeypatch.setenv('STIN_NT_GLDS', '0')
         base = SF.gemm_nt(A, W, **kw)
         monkeypatch.setenv('STIN_NT_GLDS', '1')
-        for _ in range(2):
-            got = SF.gemm_nt(A, W, **kw)
-            assert got.dtype == base.dtype and torch.equal(got, base), sorted(kw)
+        for big in ('0', '1'):                                  # 128 x 128 tiles on 4 waves, 256 x 256 tiles on 8 waves
+            monkeypatch.setenv('STIN_NT_BIG', big)
+            for _ in range(2):
+                got = SF.gemm_nt(A, W, **kw)
+                assert got.dtype == base.dtype and torch.equal(got, base), (big, sorted(kw))
+        monkeypatch.delenv('STIN_NT_BIG')
     wide = torch.full((M + 2, Nc + 16), 3.0, device=DEV).bfloat16()                     # output as a view into a wider matrix
     SF.gemm_nt(A, W, b, out=wide[1:M + 1, 8:Nc + 8])
     assert torch.equal(wide[1:M + 1, 8:Nc + 8], base.bfloat16() if base.dtype != torch.bfloat16 else SF.gemm_nt(A, W, b))
