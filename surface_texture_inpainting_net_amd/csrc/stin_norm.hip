@@ -16,6 +16,33 @@ template <> struct V<4> {
     template <typename T> __device__ __forceinline__ static V load(const T* p) { V r; float4 t = ld4(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r; }
     template <typename T> __device__ __forceinline__ void store(T* p) const { st4(p, make_float4(v[0], v[1], v[2], v[3])); }
 };
+// 8 channels per lane: a full 16-byte load of bf16 rows (round 3: the 4-wide form moved 8 bytes per lane on bf16 storage)
+template <> struct V<8> {
+    float v[8];
+    __device__ __forceinline__ static V load(const float* p) {
+        V r;
+        const float4 a = ld4(p), b = ld4(p + 4);
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+        return r;
+    }
+    __device__ __forceinline__ static V load(const stin_bf16* p) {
+        V r;
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+        r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+        r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+        r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+        return r;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        st4(p, make_float4(v[0], v[1], v[2], v[3]));
+        st4(p + 4, make_float4(v[4], v[5], v[6], v[7]));
+    }
+    __device__ __forceinline__ void store(stin_bf16* p) const {
+        st4(p, make_float4(v[0], v[1], v[2], v[3]));            // (the compiler merges the two 8-byte stores)
+        st4(p + 4, make_float4(v[4], v[5], v[6], v[7]));
+    }
+};
 template <> struct V<1> {
     float v[1];
     template <typename T> __device__ __forceinline__ static V load(const T* p) { V r; r.v[0] = ld1(p); return r; }
@@ -421,6 +448,21 @@ inline bool vec4_ok(int C, std::initializer_list<const void*> data, std::initial
     return true;
 }
 
+template <typename T>
+inline bool vec8_ok(int C, std::initializer_list<const void*> data, std::initializer_list<const void*> stats,
+                    std::initializer_list<int64_t> lds) {
+    if (sizeof(T) != 2 || C % 8 != 0) return false;
+    static const bool off = getenv("STIN_NORM_V8") && atoi(getenv("STIN_NORM_V8")) == 0;     // A/B switch
+    if (off) return false;
+    for (const void* p : data)
+        if (p != nullptr && !stin_aligned16(p)) return false;
+    for (const void* p : stats)
+        if (p != nullptr && !stin_aligned16(p)) return false;
+    for (int64_t ld : lds)
+        if (ld % 8 != 0) return false;
+    return true;
+}
+
 constexpr bool is_f32(const float*) { return true; }
 constexpr bool is_f32(const stin_bf16*) { return false; }
 inline const stin_bf16* b16(const stin_bf16_t* p) { return reinterpret_cast<const stin_bf16*>(p); }
@@ -492,7 +534,11 @@ int norm_fwd_impl(const T* x, int64_t ldx, const float* mean, const float* rstd,
     STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldy >= C && (res == nullptr || ldres >= C), STIN_E_SIZE);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(x && mean && rstd && y, STIN_E_NULL);
-    if (vec4_ok<T>(C, {x, res, y}, {mean, rstd}, {ldx, ldy, res ? ldres : 0})) {
+    if (vec8_ok<T>(C, {x, res, y}, {mean, rstd}, {ldx, ldy, res ? ldres : 0})) {
+        const int64_t n = N * (C / 8);
+        hipLaunchKernelGGL((k_norm_fwd<T, 8>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx,
+                           mean, rstd, gid, res, ldres, N, C, act, y, ldy);
+    } else if (vec4_ok<T>(C, {x, res, y}, {mean, rstd}, {ldx, ldy, res ? ldres : 0})) {
         const int64_t n = N * (C / 4);
         hipLaunchKernelGGL((k_norm_fwd<T, 4>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx,
                            mean, rstd, gid, res, ldres, N, C, act, y, ldy);
@@ -513,7 +559,11 @@ int norm_bwd_impl(const T* x, int64_t ldx, const T* gout, int64_t ldg, const flo
     STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldg >= C && lddx >= C, STIN_E_SIZE);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(x && gout && mean && rstd && a && k && m && dx, STIN_E_NULL);
-    if (vec4_ok<T>(C, {x, gout, dx}, {mean, rstd, a, k, m}, {ldx, ldg, lddx})) {
+    if (vec8_ok<T>(C, {x, gout, dx}, {mean, rstd, a, k, m}, {ldx, ldg, lddx})) {
+        const int64_t n = N * (C / 8);
+        hipLaunchKernelGGL((k_norm_bwd<T, 8>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx,
+                           gout, ldg, mean, rstd, a, k, m, gid, sid, N, C, act, dx, lddx);
+    } else if (vec4_ok<T>(C, {x, gout, dx}, {mean, rstd, a, k, m}, {ldx, ldg, lddx})) {
         const int64_t n = N * (C / 4);
         hipLaunchKernelGGL((k_norm_bwd<T, 4>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, x, ldx,
                            gout, ldg, mean, rstd, a, k, m, gid, sid, N, C, act, dx, lddx);
