@@ -89,7 +89,7 @@ int stin_csr_pair_from_edges_i64(const int64_t* src, const int64_t* dst, int64_t
                                  int32_t* rowptr_dst, int32_t* col_dst, float* inv_deg_dst,
                                  int32_t* rowptr_src, int32_t* col_src, int32_t* xslot, float* w_src,
                                  int32_t* bad, void* workspace, size_t workspace_bytes, stin_stream_t stream);
-/* Every CSR structure of a sample in ONE batch of 7 launches (round 3; the two entry points above are batches of one job).
+/* Every CSR structure of a sample in ONE batch of four kernel launches behind one memset of the counters (round 3; the two entry points above are batches of one job).
  * A job = one CSR grouped by a[] with the value b[] (b == NULL: the pair id itself, e.g. the children of every coarse vertex
  * of hierarchy_trace_index_l) or, with pair != 0, both CSRs of one directed edge set (a = edge_index[1] = targets,
  * b = edge_index[0] = sources; outputs as stin_csr_pair_from_edges_i64).  narrow_out (may be NULL): the int32 copy of a[]

@@ -97,7 +97,7 @@ JOBS_MAX = 16                              # STIN_PLAN_MAX_JOBS
 
 
 class PlanJobs:
-    """CSR builds collected for ONE batched launch sequence (stin_plan_build_many: 7 launches for all of them)."""
+    """CSR builds collected for ONE batched launch sequence (stin_plan_build_many: one memset + four kernels for all of them)."""
 
     def __init__(self):
         self.blobs, self.total_e, self.total_cnt, self.keep = [], 0, 0, []
@@ -411,7 +411,7 @@ class GraphPlan:
 
     def ensure(self, edge_items=(), pool_levels=()):
         """Build whatever of the listed structures is still missing, as one batch on the current stream (forward() calls
-        this once instead of building each piece at its first use: 7 launches for a whole sample)."""
+        this once instead of building each piece at its first use: five launches for a whole sample)."""
         if self._pending:
             self.join()
         todo = self._todo(edge_items, pool_levels)
@@ -427,7 +427,7 @@ class GraphPlan:
         everything queued so far.  after = an event the index tensors are complete at (a loader's upload stream): the
         build waits for it instead.  join=False leaves the compute stream alone: it waits for the build when the plan is
         first USED (a plan built for the NEXT step while the current one is still being enqueued - TrainStep.prefetch).
-        (Rounds 1-2 spread ~72 small launches over four side streams; the batched build is 7 launches on one.)"""
+        (Rounds 1-2 spread ~72 small launches over four side streams; the batched build is five launches on one.)"""
         todo = self._todo(edge_items, pool_levels)
         if not todo:
             return self
