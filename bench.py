@@ -375,8 +375,8 @@ def pin_rank_to_cores(local_rank, local_world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--vertices', type=int, default=200_000)
     ap.add_argument('--levels', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
