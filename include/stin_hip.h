@@ -582,7 +582,10 @@ typedef struct stin_net_op {
     float *dW1, *db1, *dW2, *db2, *dWs, *dbs;
     void* bwd_ws;
     stin_event_t ev_dy, ev_done;
-} stin_net_op_t;                      /* 16 int32 + float + int32 + 7 int64 + 2 uint64 + 40 pointers = 464 bytes */
+    stin_event_t ev_edge0, ev_edge1;  /* optional (block ops): recorded on `stream` right before / after the block's edge-stage launch
+                                         (forward: stin_edge_relu_mean_fwd_*, backward: stin_edge_relu_mean_bwd_mask_*) - a timing
+                                         bracket inside the call (bench.py's live roofline figure); NULL = none */
+} stin_net_op_t;                      /* 16 int32 + float + int32 + 7 int64 + 2 uint64 + 42 pointers = 480 bytes */
 int stin_net_fwd(int storage, const stin_net_op_t* ops, int n_ops, stin_stream_t stream);
 int stin_net_bwd(int storage, const stin_net_op_t* ops, int n_ops, const void* g, int64_t ldg, int prec_bwd, stin_stream_t stream,
                  stin_stream_t wgrad_stream);

@@ -50,6 +50,17 @@ extern "C" int stin_edgeconv_block_fwd_pack_offsets(int Cp, int H, int Cout, int
 // mask, agg, mean, rstd, wcatT, w2T.  Requirements of this fast path (the caller falls back to the individual entry
 // points otherwise): saved ReLU mask supported for H.  slice_quirk: statistics over the reference's linspace slices
 // (fastinstancenorm.py:53-82) instead of the true per-graph ranges - two passes, as the reference computes them.
+// Optional HIP-event bracket around the edge-stage launch of the NEXT block call on this host thread (set by stin_net_fwd / _bwd
+// from stin_net_op_t::ev_edge0 / ev_edge1, cleared right after): how bench.py times the roofline kernel inside the
+// whole-network call without leaving the fast path.
+static thread_local hipEvent_t t_edge_ev0 = nullptr, t_edge_ev1 = nullptr;
+#define STIN_EDGE_BRACKET(CALL)                                                             \
+    do {                                                                                    \
+        if (t_edge_ev0) (void)hipEventRecord(t_edge_ev0, (hipStream_t)stream);              \
+        STIN_TRY(CALL);                                                                     \
+        if (t_edge_ev1) (void)hipEventRecord(t_edge_ev1, (hipStream_t)stream);              \
+    } while (0)
+
 extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, int64_t N, int Cin, int Cp, int H, int Cout,
                                        int has_shortcut, int trans_inv, const float* W1, const float* b1, const float* W2,
                                        const float* b2, const float* Ws, const float* bs, const int32_t* rowptr_dst,
@@ -89,7 +100,7 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
         float* hf = static_cast<float*>(hE);
         STIN_TRY(stin_gemm_nt_f32(static_cast<const float*>(x), ldx, wcat, Cp, bcat, nullptr, 0, nullptr, 0, N, Yw, Cp, Yf, ldy,
                                   pf, stream));
-        STIN_TRY(stin_edge_relu_mean_fwd_f32(Yf, ldy, Yf + H, ldy, rowptr_dst, col_dst, N, H, hf, ldh, 1, mask, stream));
+        STIN_EDGE_BRACKET(stin_edge_relu_mean_fwd_f32(Yf, ldy, Yf + H, ldy, rowptr_dst, col_dst, N, H, hf, ldh, 1, mask, stream));
         // one graph, all-columns GEMM shape: the column sums of agg come out of GEMM2's epilogue (no pass over agg for them)
         const int64_t stat_groups = (B == 1 && gid == nullptr && !slice_quirk) ? stin_gemm_nt_colstats_groups(N, Cout, H, pf) : 0;
         const bool fused_stats = stat_groups > 0 && (size_t)stat_groups * 2 * Cout * sizeof(double) + 256 <= red_bytes;
@@ -122,7 +133,7 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
         stin_bf16_t* hh = static_cast<stin_bf16_t*>(hE);
         STIN_TRY(stin_gemm_nt_bf16(static_cast<const stin_bf16_t*>(x), ldx, wcat, Cp, bcat, nullptr, 0, nullptr, 0, N, Yw, Cp, Yh,
                                    ldy, wbf, stream));
-        STIN_TRY(stin_edge_relu_mean_fwd_bf16(Yh, ldy, Yh + H, ldy, rowptr_dst, col_dst, N, H, hh, ldh, 1, mask, stream));
+        STIN_EDGE_BRACKET(stin_edge_relu_mean_fwd_bf16(Yh, ldy, Yh + H, ldy, rowptr_dst, col_dst, N, H, hh, ldh, 1, mask, stream));
         STIN_TRY(stin_gemm_nt_bf16(hh, ldh, w2_op, H, b2, hh + H, ldh, nullptr, 0, N, Cout, H, agg, Cout, wbf, stream));
         if (!slice_quirk) {
             STIN_TRY(stin_colreduce_bf16(STIN_RED_MOMENTS, static_cast<const stin_bf16_t*>(agg), Cout, nullptr, 0, N, Cout, ptr_sum,
@@ -237,9 +248,9 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         // (a shortcut block's dY[:, 2H:] = g rides on the same launch when the rows allow 16-byte copies, else one 2-D memcpy)
         const bool ride = has_shortcut && N > 0 && Cout % 4 == 0 && ldg % 4 == 0 && Yw % 4 == 0 && stin_aligned16(gf) &&
                           stin_aligned16(dYf + 2 * H);
-        STIN_TRY(stin_edge_relu_mean_bwd_mask_f32(static_cast<const float*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src, col_src,
-                                                 xslot, N, H, dYf, Yw, dYf + H, Yw, ride ? gf : nullptr, ldg,
-                                                 ride ? dYf + 2 * H : nullptr, Yw, ride ? Cout : 0, stream));
+        STIN_EDGE_BRACKET(stin_edge_relu_mean_bwd_mask_f32(static_cast<const float*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src, col_src,
+                                                          xslot, N, H, dYf, Yw, dYf + H, Yw, ride ? gf : nullptr, ldg,
+                                                          ride ? dYf + 2 * H : nullptr, Yw, ride ? Cout : 0, stream));
         if (has_shortcut && N > 0 && !ride) {
             hipError_t e = hipMemcpy2DAsync(dYf + 2 * H, (size_t)Yw * 4, gf, (size_t)ldg * 4, (size_t)Cout * 4, (size_t)N,
                                             hipMemcpyDeviceToDevice, hs);
@@ -279,9 +290,9 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
                                    Cout, dhE, H, wbb, stream));
         const bool ride = has_shortcut && N > 0 && Cout % 8 == 0 && ldg % 8 == 0 && Yw % 8 == 0 && stin_aligned16(gh) &&
                           stin_aligned16(dYh + 2 * H);
-        STIN_TRY(stin_edge_relu_mean_bwd_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src,
-                                                  col_src, xslot, N, H, dYh, Yw, dYh + H, Yw, ride ? gh : nullptr, ldg,
-                                                  ride ? dYh + 2 * H : nullptr, Yw, ride ? Cout : 0, stream));
+        STIN_EDGE_BRACKET(stin_edge_relu_mean_bwd_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src,
+                                                           col_src, xslot, N, H, dYh, Yw, dYh + H, Yw, ride ? gh : nullptr, ldg,
+                                                           ride ? dYh + 2 * H : nullptr, Yw, ride ? Cout : 0, stream));
         if (has_shortcut && N > 0 && !ride) {
             hipError_t e = hipMemcpy2DAsync(dYh + 2 * H, (size_t)Yw * 2, gh, (size_t)ldg * 2, (size_t)Cout * 2, (size_t)N,
                                             hipMemcpyDeviceToDevice, hs);
@@ -355,7 +366,7 @@ extern "C" int stin_edgeconv_chain_bwd(int storage, const stin_chain_job_t* jobs
 // ---------------------------------------------------------------------------------------------------------------------
 // The graph part of the network as one op list per direction (include/stin_hip.h: stin_net_op_t).  Only loops: every op is
 // one of the existing entry points with the pointers of the host array.
-static_assert(sizeof(stin_net_op_t) == 16 * 4 + 8 + 7 * 8 + 2 * 8 + 40 * 8, "stin_net_op_t layout (functional._net_struct packs it)");
+static_assert(sizeof(stin_net_op_t) == 16 * 4 + 8 + 7 * 8 + 2 * 8 + 42 * 8, "stin_net_op_t layout (functional._net_struct packs it)");
 
 extern "C" int stin_net_fwd(int storage, const stin_net_op_t* ops, int n_ops, stin_stream_t stream) {
     STIN_REQUIRE(n_ops >= 0 && (n_ops == 0 || ops != nullptr), STIN_E_NULL);
@@ -363,11 +374,15 @@ extern "C" int stin_net_fwd(int storage, const stin_net_op_t* ops, int n_ops, st
     for (int i = 0; i < n_ops; ++i) {
         const stin_net_op_t& J = ops[i];
         if (J.kind == STIN_OP_BLOCK) {
-            STIN_TRY(stin_edgeconv_block_fwd(storage, J.x, J.ldx, J.n_out, J.Cin, J.Cp, J.H, J.Cout, J.has_shortcut, J.trans_inv, J.W1,
+            t_edge_ev0 = (hipEvent_t)J.ev_edge0;
+            t_edge_ev1 = (hipEvent_t)J.ev_edge1;
+            const int rc_blk = stin_edgeconv_block_fwd(storage, J.x, J.ldx, J.n_out, J.Cin, J.Cp, J.H, J.Cout, J.has_shortcut, J.trans_inv, J.W1,
                                              J.b1, J.W2, J.b2, J.Ws, J.bs, J.rowptr_dst, J.col_dst, J.ptr_sum, J.B, J.gid, J.inv_cnt,
                                              J.slice_quirk, J.eps, J.prec_fwd, J.fwd_split, J.bwd_split, J.wcatT, J.w2T, J.Y, J.ldy,
                                              J.hE, J.ldh, J.mask, J.agg, J.mean, J.rstd, J.out, J.ldo, J.fwd_ws, (size_t)J.fwd_ws_bytes,
-                                             stream));
+                                             stream);
+            t_edge_ev0 = t_edge_ev1 = nullptr;
+            if (rc_blk != STIN_OK) return rc_blk;
         } else if (J.kind == STIN_OP_POOL_MAX) {
             if (storage)
                 STIN_TRY(stin_pool_max_fwd_bf16(static_cast<const stin_bf16_t*>(J.x), J.ldx, J.rowptr_dst, J.col_dst, J.n_out, J.Cout,
@@ -399,12 +414,16 @@ extern "C" int stin_net_bwd(int storage, const stin_net_op_t* ops, int n_ops, co
         const stin_net_op_t& J = ops[i];
         STIN_REQUIRE(J.dx != nullptr || i == 0, STIN_E_NULL);
         if (J.kind == STIN_OP_BLOCK) {
-            STIN_TRY(stin_edgeconv_block_bwd(storage, gi, ldgi, J.x, J.ldx, J.n_out, J.Cin, J.Cp, J.H, J.Cout, J.has_shortcut, J.trans_inv,
+            t_edge_ev0 = (hipEvent_t)J.ev_edge0;
+            t_edge_ev1 = (hipEvent_t)J.ev_edge1;
+            const int rc_blk = stin_edgeconv_block_bwd(storage, gi, ldgi, J.x, J.ldx, J.n_out, J.Cin, J.Cp, J.H, J.Cout, J.has_shortcut, J.trans_inv,
                                              J.Y, J.ldy, J.hE, J.ldh, J.mask, J.agg, J.mean, J.rstd, J.wcatT, J.w2T, J.rowptr_dst,
                                              J.rowptr_src, J.col_src, J.xslot, J.w_src, J.ptr_true, J.B, J.gid, J.sid, J.inv_cnt, prec_bwd,
                                              J.bwd_split, J.dx, J.lddx, J.dW1, J.db1, J.dW2, J.db2, J.dWs, J.dbs, J.bwd_ws,
                                              (size_t)J.bwd_ws_bytes, stream, J.use_side ? wgrad_stream : nullptr, J.ev_dy, J.ev_dy,
-                                             J.ev_done, 0));
+                                             J.ev_done, 0);
+            t_edge_ev0 = t_edge_ev1 = nullptr;
+            if (rc_blk != STIN_OK) return rc_blk;
         } else if (J.kind == STIN_OP_POOL_MAX) {
             if (J.dx != nullptr) {
                 if (storage)

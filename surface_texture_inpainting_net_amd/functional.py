@@ -49,14 +49,34 @@ class KernelTimer:
     names = ()
     records = []          # (name, tag, start_event, end_event)
     max_records = 400     # thousands of outstanding timing events slow the HIP runtime down: sample, do not flood
+    in_net = False        # round 3: edge-stage brackets INSIDE the whole-network call (stin_net_op_t::ev_edge0 / 1) - the step stays
+                          # on the fast path (one C call per direction); other names still need the per-kernel path
 
     @classmethod
-    def start(cls, names, max_records=400):
+    def start(cls, names, max_records=400, in_net=False):
         cls.enabled, cls.names, cls.records, cls.max_records = True, tuple(names), [], max_records
+        cls.in_net = bool(in_net)
+
+    @classmethod
+    def per_kernel_path(cls):
+        """True while brackets are on that only the per-kernel host path can place."""
+        return cls.enabled and not cls.in_net
+
+    @classmethod
+    def edge_events(cls, name, tag):
+        """-> (ev0, ev1) raw hipEvent_t handles bracketing one edge-stage launch inside stin_net_fwd / _bwd, or (0, 0)."""
+        if not (cls.enabled and cls.in_net and name in cls.names) or len(cls.records) >= cls.max_records:
+            return 0, 0
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()                                  # (creates the handles; the call re-records them around the kernel)
+        b.record()
+        cls.records.append((name, tag, a, b))
+        return a.cuda_event, b.cuda_event
 
     @classmethod
     def stop(cls):
         cls.enabled = False
+        cls.in_net = False
         torch.cuda.synchronize()
         out = {}
         for name, tag, a, b in cls.records:
@@ -678,7 +698,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         # (instead of once per GEMM block); plain fp32 for the other precisions and for bf16-storage activations
         fsp, bsp = block_split_modes(prec_fwd, b16, Cout)
         fast = (USE_BLOCK_CALL and USE_EDGE_MASK and edge_mask_supported(H) and N > 1
-                and not KernelTimer.enabled)          # (the bench's per-kernel HIP-event brackets need the per-kernel path)
+                and not KernelTimer.per_kernel_path())   # (the bench's per-kernel HIP-event brackets need the per-kernel path)
         ctx.fast = fast
         if fast:
             lib = _lib.load()
@@ -865,7 +885,7 @@ def _chain_struct():
 def chain_eligible(blocks, x, edges_list, groups):
     """The n blocks can run as one EdgeConvChainFn: all fused EdgeConv + instance-norm blocks of the same width without
     shortcut (the bottleneck of the network), operands packed by the network's PackSet, saved-mask path available."""
-    if not (USE_CHAIN and USE_BLOCK_CALL and USE_EDGE_MASK and not KernelTimer.enabled and len(blocks) >= 2 and x.is_cuda):
+    if not (USE_CHAIN and USE_BLOCK_CALL and USE_EDGE_MASK and not KernelTimer.per_kernel_path() and len(blocks) >= 2 and x.is_cuda):
         return False
     if x.dim() != 2 or x.shape[0] <= 1 or x.dtype not in (torch.float32, torch.bfloat16):
         return False
@@ -1075,8 +1095,8 @@ def _net_struct():
     global _NET_OP
     if _NET_OP is None:
         import struct
-        _NET_OP = struct.Struct('<16ifi7q2Q40Q')             # stin_net_op_t (include/stin_hip.h): 464 bytes
-        assert _NET_OP.size == 464
+        _NET_OP = struct.Struct('<16ifi7q2Q42Q')             # stin_net_op_t (include/stin_hip.h): 480 bytes
+        assert _NET_OP.size == 480
     return _NET_OP
 
 
@@ -1088,7 +1108,7 @@ def net_eligible(steps, x):
     """steps = [('block', GraphResnetBlock, EdgeSet, NormGroups) | ('pool', PoolMap) | ('unpool', PoolMap)] can run as one
     NetFn: fused EdgeConv + instance-norm blocks on the whole-block path (saved ReLU mask available), max pooling, fp32 or
     bf16 storage; operands of every block packed by the network's PackSet or of none."""
-    if not (USE_NET_CALL and USE_BLOCK_CALL and USE_EDGE_MASK and not KernelTimer.enabled and x.is_cuda and x.dim() == 2):
+    if not (USE_NET_CALL and USE_BLOCK_CALL and USE_EDGE_MASK and not KernelTimer.per_kernel_path() and x.is_cuda and x.dim() == 2):
         return False
     if x.dtype not in (torch.float32, torch.bfloat16) or x.shape[0] <= 1:
         return False
@@ -1113,7 +1133,7 @@ def net_eligible(steps, x):
 class NetFn(torch.autograd.Function):
     """Every fused block and pool / unpool step of the network's graph part as ONE autograd node and one C call per direction
     (stin_net_fwd / _bwd: loops over the per-op entry points, same kernels in the same order -> bit-identical to the per-op
-    nodes).  All tensors backward needs live in one arena allocation, the op table is packed on the host (464 bytes per op).
+    nodes).  All tensors backward needs live in one arena allocation, the op table is packed on the host (480 bytes per op).
     args: x, meta = (steps, prec list), then the flat parameters (W1, b1, W2, b2, Ws, bs) of every block in step order."""
 
     calls = 0
@@ -1126,6 +1146,7 @@ class NetFn(torch.autograd.Function):
         x, _ = _mat(x)
         dev, dt = x.device, x.dtype
         b16 = dt == torch.bfloat16
+        sfx = '_bf16' if b16 else '_f32'
         es = x.element_size()
         pad = 8 if b16 else 4
         N0, Cin0 = x.shape
@@ -1216,7 +1237,8 @@ class NetFn(torch.autograd.Function):
                                      _ptr(g.ptr_sum), 0, _ptr(g.gid), 0, _ptr(g.inv_cnt),
                                      base + d['oY'], base + d['oH'], base + d['oM'], base + d['oA'], base + d['oS'],
                                      base + d['oS'] + B * Cout * 4, 0, 0,
-                                     0, 0, 0, 0, 0, 0, 0, 0, 0))
+                                     0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                     *KernelTimer.edge_events('stin_edge_relu_mean_fwd' + sfx, (d['N'], d['edges'].n_edges, H))))
                 xin, ldx = o, Cout
             else:
                 pool, C = d['pool'], d['C']
@@ -1230,7 +1252,7 @@ class NetFn(torch.autograd.Function):
                                      0, 0, 0, 0, 0,
                                      0, 0, 0, 0, 0, 0,
                                      (base + d['oArg']) if d['kind'] == OP_POOL_MAX else 0, _ptr(pool.trace),
-                                     0, 0, 0, 0, 0, 0, 0, 0, 0))
+                                     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
                 xin, ldx = o, C
         import ctypes
         buf = ctypes.create_string_buffer(b''.join(blob), len(plan) * stc.size)
@@ -1248,6 +1270,7 @@ class NetFn(torch.autograd.Function):
         lib = _lib.load()
         dev, dt = xp.device, xp.dtype
         b16 = dt == torch.bfloat16
+        sfx = '_bf16' if b16 else '_f32'
         es = xp.element_size()
         pad = 8 if b16 else 4
         g, ldg = _mat(g)
@@ -1339,7 +1362,8 @@ class NetFn(torch.autograd.Function):
                                      base + d['oY'], base + d['oH'], base + d['oM'], base + d['oA'], base + d['oS'],
                                      base + d['oS'] + B * Cout * 4, 0, 0,
                                      _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gs[3]), _ptr(gs[4]), _ptr(gs[5]),
-                                     p_ws + ws_off[bi], ev_dy, ev_done))
+                                     p_ws + ws_off[bi], ev_dy, ev_done,
+                                     *KernelTimer.edge_events('stin_edge_relu_mean_bwd_mask' + sfx, (d['N'], e.n_edges, H))))
                 bi += 1
             else:
                 pool, C = d['pool'], d['C']
@@ -1352,7 +1376,7 @@ class NetFn(torch.autograd.Function):
                                      0, 0, 0, 0, 0,
                                      0, 0, 0, 0, 0, 0,
                                      (base + d['oArg']) if d['kind'] == OP_POOL_MAX else 0, _ptr(pool.trace),
-                                     0, 0, 0, 0, 0, 0, 0, 0, 0))
+                                     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
         import ctypes
         buf = ctypes.create_string_buffer(b''.join(blob), len(plan) * stc.size)
         _call('stin_net_bwd', int(b16), buf, len(plan), _ptr(g), ldg, int(PREC_BWD), _stream(xp), side_stream)

@@ -201,7 +201,7 @@ class SurfaceTextureInpaintingNet(nn.Module):
     def _pack_weights(self, x, num_graphs):
         """All fused blocks' weight operands in ONE launch (functional.PackSet) instead of one tiny launch at the head of
         every block: 15 launches of ~8 us on the critical path become one.  fp32 and (round 3) bf16 storage, whole-block path only."""
-        use = (SF.USE_PACK_MANY and SF.USE_BLOCK_CALL and SF.USE_EDGE_MASK and not SF.KernelTimer.enabled and x.is_cuda and
+        use = (SF.USE_PACK_MANY and SF.USE_BLOCK_CALL and SF.USE_EDGE_MASK and not SF.KernelTimer.per_kernel_path() and x.is_cuda and
                x.dtype in (torch.float32, torch.bfloat16) and self.norm is M.FastInstanceNorm)
         b16 = x.dtype == torch.bfloat16
         # per-step validity check of the cached set: the data pointers of EVERY packed tensor, read from the modules'
