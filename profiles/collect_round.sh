@@ -8,7 +8,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 $R/bench.py --steps 30 --warmup 5 > $O/bench_final.json 2> $O/bench_final.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o run -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench_prof.json 2> $O/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o run -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_prof.json 2> $O/prof.err
 python3 $R/bench.py --steps 30 --warmup 5 --dtype bf16 --no-cpu-baseline > $O/bench_bf16.json 2> $O/bench_bf16.err
 python3 $R/bench.py --steps 30 --warmup 5 --irregular --no-cpu-baseline --no-secondary > $O/bench_irregular.json 2>> $O/configs.err
 python3 $R/bench.py --vertices 150000 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > $O/config_c2.json 2>> $O/configs.err
@@ -18,9 +18,9 @@ python3 $R/bench.py --vertices 1000000 --levels 5 --steps 8 --warmup 3 --no-cpu-
 python3 $R/bench.py --vertices 20000 --steps 40 --warmup 5 --no-cpu-baseline --no-secondary > $O/small_20k_eager.json 2>> $O/configs.err
 python3 $R/bench.py --vertices 20000 --steps 40 --warmup 5 --no-cpu-baseline --no-secondary --graph > $O/small_20k_graph.json 2>> $O/configs.err
 # rocprofv3 kernel traces of configs 2 / 3 / 5: the roofline kernel's average there must agree with the bench line's bracket
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2 -o run -- python3 $R/bench.py --vertices 150000 --steps 8 --warmup 3 --no-cpu-baseline --no-secondary > $O/prof_c2.json 2>> $O/prof.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -o run -- python3 $R/bench.py --crops 8 --levels 4 --dtype bf16 --steps 8 --warmup 3 --no-cpu-baseline --no-secondary > $O/prof_c3.json 2>> $O/prof.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5 -o run -- python3 $R/bench.py --vertices 1000000 --levels 5 --dtype bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $O/prof_c5.json 2>> $O/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2 -o run -- python3 $R/bench.py --vertices 150000 --steps 8 --warmup 5 --no-cpu-baseline --no-secondary > $O/prof_c2.json 2>> $O/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -o run -- python3 $R/bench.py --crops 8 --levels 4 --dtype bf16 --steps 8 --warmup 5 --no-cpu-baseline --no-secondary > $O/prof_c3.json 2>> $O/prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5 -o run -- python3 $R/bench.py --vertices 1000000 --levels 5 --dtype bf16 --steps 5 --warmup 5 --no-cpu-baseline --no-secondary > $O/prof_c5.json 2>> $O/prof.err
 python3 $R/profiles/gemm_shapes.py --rounds 7 --md $O/gemm_shapes.md > /dev/null 2> $O/gemm_shapes.err
 python3 $R/profiles/tn_ws_bench.py --md $O/tn_ws.md > /dev/null 2> $O/tn_ws.err
 ls -la $O

@@ -11,7 +11,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('trace')
     ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--marker', default='k_adam')
+    ap.add_argument('--marker', default='k_adam')   # (matches k_adam and k_adam4: one launch per step)
     a = ap.parse_args()
     rows = []
     for r in csv.DictReader(open(a.trace)):

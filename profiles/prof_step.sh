@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03c/prof; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -o run -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $O/bench.json 2> $O/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o run -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench.json 2> $O/err.log
 python3 $R/profiles/gaps.py $O/run_kernel_trace.csv --steps 8 | head -12
-python3 $R/profiles/summarize.py $O/run_kernel_stats.csv 13 | head -60
+python3 $R/profiles/summarize.py $O/run_kernel_stats.csv 16 | head -60

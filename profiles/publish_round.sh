@@ -39,7 +39,7 @@ def level0_fwd_avg_us(stats_csv):
 
 
 d, dd = line(S + '/bench_final.json'), line(S + '/bench_default.json')
-head = ('# Round %s, fp32 headline: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 3 '
+head = ('# Round %s, fp32 headline: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 5 '
         '--no-cpu-baseline --no-secondary` (200 704-vertex mesh, 1x MI355X; un-profiled `python bench.py --steps 30 --warmup 5`: '
         '%.2f ms/step = %.1f M vertices/s, %s_bench_final.json; the no-flag default run: %s_bench_default.json, %.2f ms).\n\n'
         'Under the profiler the host is slower than un-profiled, so the timeline below carries more idle time than the bench line; '
@@ -50,16 +50,16 @@ head = ('# Round %s, fp32 headline: `rocprofv3 --kernel-trace --stats --output-f
         'the step) - stand-alone figures are in %s_gemm_shapes.md / %s_tn_ws.md.\n\n```\n'
         % (RN[1:], d['ms_per_step'], d['value'] / 1e6, RN, RN, dd['ms_per_step'], RN, RN))
 gaps = tool('gaps.py', S + '/prof/run_kernel_trace.csv', '--steps', '8')
-summ = tool('summarize.py', S + '/prof/run_kernel_stats.csv', '13')
+summ = tool('summarize.py', S + '/prof/run_kernel_stats.csv', '16')
 open(P + '_bench_final.md', 'w').write(head + '\n'.join(gaps.splitlines()[:8]) + '\n```\n\n' + summ)
 
 # kernel tables of configs 2 / 3 / 5 and the roofline cross-check (bench line's HIP-event bracket vs rocprofv3's average)
-cfg = [('c2', 'config_c2', 'prof_c2', '2: one ~150 k-vertex scene, 3 levels, fp32', '--vertices 150000', 11),
-       ('c3', 'config_c3', 'prof_c3', '3: 8 unequal crops, 4 levels, bf16', '--crops 8 --levels 4 --dtype bf16', 11),
-       ('c5', 'config_c5_bf16', 'prof_c5', '5: 1 M vertices, 5 levels, bf16', '--vertices 1000000 --levels 5 --dtype bf16', 7)]
+cfg = [('c2', 'config_c2', 'prof_c2', '2: one ~150 k-vertex scene, 3 levels, fp32', '--vertices 150000', 14),
+       ('c3', 'config_c3', 'prof_c3', '3: 8 unequal crops, 4 levels, bf16', '--crops 8 --levels 4 --dtype bf16', 14),
+       ('c5', 'config_c5_bf16', 'prof_c5', '5: 1 M vertices, 5 levels, bf16', '--vertices 1000000 --levels 5 --dtype bf16', 11)]
 check = ['| config | kernel (bench line) | algorithmic MB / launch | bracket avg us (un-profiled run) | `roofline.frac` (JSON) | '
          'rocprofv3 avg us (calls) | frac from rocprofv3 | JSON / rocprof |', '|---|---|---|---|---|---|---|---|']
-for tag, jf, pd, title, flags, nsteps in [('hl', 'bench_final', 'prof', 'headline: 200 704 vertices, 3 levels, fp32', '', 13)] + cfg:
+for tag, jf, pd, title, flags, nsteps in [('hl', 'bench_final', 'prof', 'headline: 200 704 vertices, 3 levels, fp32', '', 16)] + cfg:
     r = line('%s/%s.json' % (S, jf))['roofline']
     us, calls = level0_fwd_avg_us('%s/%s/run_kernel_stats.csv' % (S, pd))
     f_prof = r['algorithmic_bytes'] / (us * 1e-6) / 1e9 / r['peak']

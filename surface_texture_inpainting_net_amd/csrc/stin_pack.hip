@@ -352,6 +352,62 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     const float denom = sqrtf(vh) / bc2_sqrt + eps;
     p[i] = pi + neg_step_size * mi / denom;
 }
+// the same update on four elements per lane (16-byte loads / stores; round 3: the scalar form moved 151 MB in 64 us).  Identical
+// arithmetic per element -> identical bits.
+__global__ __launch_bounds__(256) void k_adam4(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                               float4* __restrict__ v, float4* __restrict__ vmax, int64_t n4, int tail,
+                                               float neg_step_size, float one_minus_b1, float b2, float one_minus_b2, float eps,
+                                               float wd, float bc2_sqrt, int amsgrad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < tail) {                                   // the n % 4 ragged elements ride on the first lanes (no second launch)
+        float* ps = reinterpret_cast<float*>(p) + 4 * n4 + i;
+        const float* gs = reinterpret_cast<const float*>(g) + 4 * n4 + i;
+        float* ms = reinterpret_cast<float*>(m) + 4 * n4 + i;
+        float* vs = reinterpret_cast<float*>(v) + 4 * n4 + i;
+        float gi = *gs;
+        const float pi = *ps;
+        if (wd != 0.f) gi += wd * pi;
+        const float m0 = *ms;
+        const float mi = m0 + one_minus_b1 * (gi - m0);
+        const float vi = b2 * *vs + one_minus_b2 * gi * gi;
+        *ms = mi;
+        *vs = vi;
+        float vh = vi;
+        if (amsgrad) {
+            float* xs = reinterpret_cast<float*>(vmax) + 4 * n4 + i;
+            vh = fmaxf(*xs, vi);
+            *xs = vh;
+        }
+        const float denom = sqrtf(vh) / bc2_sqrt + eps;
+        *ps = pi + neg_step_size * mi / denom;
+    }
+    if (i >= n4) return;
+    const float4 g4 = g[i], p4 = p[i], m4 = m[i], v4 = v[i];
+    const float4 x4 = amsgrad ? vmax[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+    const float vv[4] = {v4.x, v4.y, v4.z, v4.w}, xx[4] = {x4.x, x4.y, x4.z, x4.w};
+    float po[4], mo[4], vo[4], xo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float gi = gg[e];
+        const float pi = pp[e];
+        if (wd != 0.f) gi += wd * pi;
+        const float m0 = mm[e];
+        const float mi = m0 + one_minus_b1 * (gi - m0);
+        const float vi = b2 * vv[e] + one_minus_b2 * gi * gi;
+        float vh = vi;
+        if (amsgrad) vh = fmaxf(xx[e], vi);
+        const float denom = sqrtf(vh) / bc2_sqrt + eps;
+        mo[e] = mi;
+        vo[e] = vi;
+        xo[e] = vh;
+        po[e] = pi + neg_step_size * mi / denom;
+    }
+    m[i] = make_float4(mo[0], mo[1], mo[2], mo[3]);
+    v[i] = make_float4(vo[0], vo[1], vo[2], vo[3]);
+    if (amsgrad) vmax[i] = make_float4(xo[0], xo[1], xo[2], xo[3]);
+    p[i] = make_float4(po[0], po[1], po[2], po[3]);
+}
 }  // namespace
 
 extern "C" size_t stin_masked_l1_workspace_bytes(int64_t N, int C) {
@@ -404,8 +460,17 @@ extern "C" int stin_adam_f32(float* p, const float* g, float* m, float* v, float
     // bias corrections in double on the host, as torch computes them (python floats)
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, vmax, n,
-                       (float)(-(lr / bc1)), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)weight_decay, (float)bc2s, amsgrad);
+    const bool vec = stin_aligned16(p) && stin_aligned16(g) && stin_aligned16(m) && stin_aligned16(v) && (!amsgrad || stin_aligned16(vmax));
+    const int64_t n4 = vec ? n / 4 : 0;
+    if (n4 > 0) {
+        hipLaunchKernelGGL(k_adam4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, reinterpret_cast<float4*>(p),
+                           reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v),
+                           reinterpret_cast<float4*>(vmax), n4, (int)(n - 4 * n4), (float)(-(lr / bc1)), (float)(1.0 - beta1),
+                           (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)bc2s, amsgrad);
+    } else {                                                            // (an unaligned buffer, or fewer than four elements)
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, p, g, m, v, vmax, n,
+                           (float)(-(lr / bc1)), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                           (float)weight_decay, (float)bc2s, amsgrad);
+    }
     return stin_launch_status();
 }
