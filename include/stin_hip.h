@@ -110,6 +110,39 @@ typedef struct stin_plan_job {
 size_t stin_plan_build_workspace_bytes(int64_t total_E, int64_t total_counters);
 int stin_plan_build_many(const stin_plan_job_t* jobs, int n_jobs, int32_t* bad, void* workspace, size_t workspace_bytes,
                          stin_stream_t stream);
+/* Vertex renumbering by locality (round 3; optional - SURVEY 7.3 "optional vertex reordering, inverted at the boundary").  The
+ * reference has no counterpart: its kernels (torch_scatter / PyG gathers, models/surfacetextureinpaintingnet.py:384-391 and the
+ * EdgeConv message passing) index rows in dataset order; on the GPU the gathered neighbour rows then all cross the fabric.
+ *   stin_vertex_order_f32: pos [n0, >= 3] (ld_pos floats per row: x, y, z at columns 0..2 of the pointer passed) -> per level
+ *     rank int32 [n + 1] (old id -> new id, rank[n] = n) and order int32 [n] (new -> old; may be NULL).  Level 0: stable sort
+ *     by the 30-bit Morton code on the bounding box; level l >= 1: stable sort by the smallest new id among the children under
+ *     levels[l].trace (the level l - 1 -> l map, int64 [n_{l-1}]).  Deterministic.
+ *   stin_relabel_many_i64: out[i] = rank[in[i]] (limit where in[i] is outside [0, limit): the CSR build then flags and drops
+ *     it exactly like an out-of-range original id) for up to 16 index arrays in one launch.  A job with rank_fine != NULL is a
+ *     TRACE (in = trace [n_fine], rank = the coarse level's): it also writes fine_out[i] = rank_fine[i] (the pair's second
+ *     member, int64 for stin_plan_build_many) and trace_out[rank_fine[i]] = out[i] (int32: new fine id -> new coarse id, 0
+ *     where out of range).  Index arrays keep their ORDER: CSR rows and children lists built from them keep the reference's. */
+typedef struct stin_order_level {
+    int64_t n;
+    const int64_t* trace;
+    int32_t* rank;
+    int32_t* order;
+} stin_order_level_t;
+size_t stin_vertex_order_workspace_bytes(int64_t n_max);
+int stin_vertex_order_f32(const float* pos, int64_t ld_pos, const stin_order_level_t* levels, int n_levels, void* workspace,
+                          size_t workspace_bytes, stin_stream_t stream);
+#define STIN_RELABEL_MAX_JOBS 16
+typedef struct stin_relabel_job {
+    const int64_t* in;
+    int64_t n;
+    const int32_t* rank;
+    int64_t limit;
+    int64_t* out;
+    const int32_t* rank_fine;
+    int64_t* fine_out;
+    int32_t* trace_out;
+} stin_relabel_job_t;                                  /* 64 bytes */
+int stin_relabel_many_i64(const stin_relabel_job_t* jobs, int n_jobs, stin_stream_t stream);
 /* dst[i] = (int32) src[i]; *bad set when a value is outside [0, limit). */
 int stin_narrow_i64_to_i32(const int64_t* src, int64_t n, int64_t limit, int32_t* dst, int32_t* bad,
                            stin_stream_t stream);

@@ -110,6 +110,9 @@ SIGNATURES['stin_edgeconv_chain_fwd'] = (c_int, [c_int, c_ptr, c_int, c_ptr, c_i
                                                  c_int, c_f32, c_size, c_ptr])
 SIGNATURES['stin_edgeconv_chain_bwd'] = (c_int, [c_int, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_int,
                                                  c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_size, c_ptr, c_ptr])
+SIGNATURES['stin_vertex_order_workspace_bytes'] = (c_size, [c_i64])
+SIGNATURES['stin_vertex_order_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_int, c_ptr, c_size, c_ptr])
+SIGNATURES['stin_relabel_many_i64'] = (c_int, [c_ptr, c_int, c_ptr])
 SIGNATURES['stin_net_fwd'] = (c_int, [c_int, c_ptr, c_int, c_ptr])
 SIGNATURES['stin_net_bwd'] = (c_int, [c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr])
 SIGNATURES['stin_plan_build_workspace_bytes'] = (c_size, [c_i64, c_i64])

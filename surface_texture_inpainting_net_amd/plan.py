@@ -328,6 +328,31 @@ class GraphPlan:
             return
         s, dev = self._sample, self.device
         a, b = self._pos_cols
+        if REORDER_IMPL != 'torch' and s.x.dtype == torch.float32 and s.x.stride(1) == 1:
+            # HIP path (csrc/stin_order.hip): bounding box, Morton keys, one radix sort per level, rank scatter - ~12 launches from
+            # one foreign call instead of ~60 framework kernels; same permutation as the torch formulation below (tested)
+            lib = _lib.load()
+            sizes = self.level_sizes
+            ranks = [torch.empty(n + 1, dtype=torch.int32, device=dev) for n in sizes]
+            order0 = torch.empty(sizes[0], dtype=torch.int32, device=dev)
+            ws_bytes = lib.stin_vertex_order_workspace_bytes(max(sizes))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            st = struct.Struct('<q3Q')
+            blob, keep = [], []
+            for lvl, n in enumerate(sizes):
+                tr = None
+                if lvl > 0:
+                    tr = s['hierarchy_trace_index_%d' % lvl].contiguous()
+                    keep.append(tr)
+                blob.append(st.pack(n, _ptr(tr), _ptr(ranks[lvl]), _ptr(order0) if lvl == 0 else 0))
+            buf = ctypes.create_string_buffer(b''.join(blob), len(blob) * st.size)
+            _lib.check(lib.stin_vertex_order_f32(s.x.data_ptr() + 4 * a, s.x.stride(0), buf, len(sizes), _ptr(ws), ws_bytes, _stream(ws)),
+                       'stin_vertex_order_f32')
+            self._order_keep = (ws, keep)
+            self._ranks = ranks
+            self.order0 = order0
+            self.rank0 = ranks[0][:-1]
+            return
         pos = s.x[:, a:b].to(torch.float32)
         lo, hi = pos.amin(0, keepdim=True), pos.amax(0, keepdim=True)
         q = ((pos - lo) / (hi - lo).clamp_min(1e-20) * 1024.0).to(torch.int64).clamp_(0, 1023)
@@ -360,6 +385,38 @@ class GraphPlan:
         self.order0 = order.to(torch.int32)
         self.rank0 = ranks[0][:-1].to(torch.int32)
 
+    def _relabel_many(self, items):
+        """items: [('e', edge tensor [2, E] int64, level) | ('p', trace [n_fine] int64, level)] -> relabelled tensors in ONE launch
+        per 16 arrays (stin_relabel_many_i64): 'e' -> new [2, E] int64; 'p' -> (coarse_new, fine_new, trace_new) as PoolMap wants."""
+        lib = _lib.load()
+        st = struct.Struct('<QqQqQQQQ')
+        blobs, outs, keep = [], [], []
+        for kind, t, level in items:
+            t = t.contiguous()
+            keep.append(t)
+            rank = self._ranks[level]
+            if kind == 'e':
+                out = torch.empty_like(t)
+                blobs.append(st.pack(_ptr(t), t.numel(), _ptr(rank), self.level_sizes[level], _ptr(out), 0, 0, 0))
+                outs.append(out)
+            else:
+                nf = t.numel()
+                coarse_new = torch.empty(max(nf, 1), dtype=torch.int64, device=self.device)[:nf]
+                fine_new = torch.empty(max(nf, 1), dtype=torch.int64, device=self.device)[:nf]
+                trace_new = torch.empty(max(nf, 1), dtype=torch.int32, device=self.device)[:nf]
+                blobs.append(st.pack(_ptr(t), nf, _ptr(rank), self.level_sizes[level], _ptr(coarse_new), _ptr(self._ranks[level - 1]),
+                                     _ptr(fine_new), _ptr(trace_new)))
+                outs.append((coarse_new, fine_new, trace_new))
+        for i in range(0, len(blobs), 16):
+            chunk = blobs[i:i + 16]
+            buf = ctypes.create_string_buffer(b''.join(chunk), len(chunk) * st.size)
+            _lib.check(lib.stin_relabel_many_i64(buf, len(chunk), _stream(self._bad)), 'stin_relabel_many_i64')
+        self._relabel_keep = keep
+        return outs
+
+    def _hip_order(self):
+        return self._reorder and self._ranks is not None and self._ranks[0].dtype == torch.int32
+
     def _relabelled(self, idx, level):
         """Index tensor of vertex ids of `level` in the new numbering; out-of-range ids map to n_level, which the CSR build
         flags and leaves out exactly as it does an out-of-range original id."""
@@ -371,6 +428,8 @@ class GraphPlan:
         ei = self._sample.edge_index if key == 'edge_index' else self._sample[key]
         if self._reorder:
             self._ensure_order()
+            if self._hip_order():
+                return self._relabel_many([('e', ei, level)])[0]
             ei = self._relabelled(ei, level)
         return ei
 
@@ -380,6 +439,8 @@ class GraphPlan:
         if not self._reorder:
             return PoolMap(trace, nf, nc, self._bad, jobs)
         self._ensure_order()
+        if self._hip_order():
+            return PoolMap(trace, nf, nc, self._bad, jobs, renumbered=self._relabel_many([('p', trace, level)])[0])
         coarse_new = self._relabelled(trace.contiguous(), level)          # [nf], original fine order
         fine_new = self._ranks[level - 1][:-1]
         trace_new = torch.empty(max(nf, 1), dtype=torch.int32, device=self.device)[:nf]
@@ -399,9 +460,25 @@ class GraphPlan:
     def _build_batch(self, todo):
         """All listed structures as ONE batch of launches (PlanJobs) on torch's current stream -> the new objects."""
         jobs, made = PlanJobs(), []
-        for kind, key, level in todo:
+        pre = None
+        if self._reorder:
+            self._ensure_order()
+            if self._hip_order():                          # every index array of the batch relabelled in one launch
+                items = []
+                for kind, key, level in todo:
+                    if kind == 'e':
+                        items.append(('e', self._sample.edge_index if key == 'edge_index' else self._sample[key], level))
+                    else:
+                        items.append(('p', self._sample['hierarchy_trace_index_%d' % level], level))
+                pre = self._relabel_many(items)
+        for i, (kind, key, level) in enumerate(todo):
             if kind == 'e':
-                obj = self._edges[key] = EdgeSet(self._edge_tensor(key, level), self.level_sizes[level], self._bad, jobs)
+                ei = pre[i] if pre is not None else self._edge_tensor(key, level)
+                obj = self._edges[key] = EdgeSet(ei, self.level_sizes[level], self._bad, jobs)
+            elif pre is not None:
+                trace = self._sample['hierarchy_trace_index_%d' % level]
+                obj = self._pools[level] = PoolMap(trace, self.level_sizes[level - 1], self.level_sizes[level], self._bad, jobs,
+                                                   renumbered=pre[i])
             else:
                 obj = self._pools[level] = self._pool_map(level, jobs)
             made.append(obj)
@@ -549,13 +626,15 @@ import os as _os
 VALIDATION = _os.environ.get('STIN_PLAN_VALIDATION', 'sync')
 # vertex renumbering by locality inside the plan build (GraphPlan._ensure_order): OFF by default, STIN_REORDER=1 enables it for
 # level-0 sizes from STIN_REORDER_MIN up.  Measured (round 3, 200 704 vertices): the edge kernels gain 0.26 ms per step (level-0
-# forward 117 -> 96 us, level 1 73 -> 61, level 2 46 -> 41) but the renumbering itself - two stable sorts per level and the
-# relabelling gathers, ~45 framework kernels on the plan stream beside the step - costs more when it is redone for EVERY step
-# (7.53 -> 7.67 ms; 1 M vertices bf16 28.0 -> 29.7).  It pays where a plan is built once and reused (a scene cache); the data
+# forward 117 -> 96 us, level 1 73 -> 61, level 2 46 -> 41) but the renumbering itself - a stable sort per level, the rank
+# scatters and the relabelling of every index array, on the plan stream beside the step - costs more when it is redone for
+# EVERY step (framework ops: 7.53 -> 7.67 ms; the HIP implementation csrc/stin_order.hip: 7.69 -> 7.79 ms, 1 M vertices bf16
+# 25.9 -> 26.8).  It pays where a plan is built once and reused (a scene cache); the data
 # pipeline's cheaper route is to renumber a scene ONCE when it is read (scene_io.load_scene(locality_order=True),
 # synthetic.renumber_by_locality) - the bench line's `vertex_locality` figure.
 REORDER = _os.environ.get('STIN_REORDER', '0') == '1'
 REORDER_MIN = int(_os.environ.get('STIN_REORDER_MIN', '65536'))
+REORDER_IMPL = _os.environ.get('STIN_REORDER_IMPL', 'hip')          # 'hip' (csrc/stin_order.hip) | 'torch' (framework ops, the cross-check)
 _PENDING_CHECKS = []
 
 

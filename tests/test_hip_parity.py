@@ -1428,3 +1428,38 @@ def test_gemm_tn_bf16_transposed_read_kernel_equals_register_transpose_kernel(M,
     want = torch.cat([G.double().t() @ X.double(), (G.double() * w.double()[:, None]).sum(0)[:, None]], 1)
     got = SF.gemm_tn(G, X, ones_column=True, row_weight=w).double()
     assert float((got - want).abs().max()) <= 3e-5 * (float(want.abs().max()) + 1.0) * max(1.0, (M / 1000) ** 0.5)
+
+
+def test_vertex_order_hip_path_equals_the_torch_formulation(monkeypatch):
+    """csrc/stin_order.hip (bounding box + Morton keys + radix sorts + batched relabelling, one foreign call each) against the
+    framework-op formulation in plan.GraphPlan._ensure_order: same permutation on every level, and the plans built from the two
+    are identical array by array (both CSRs of every edge set, cross maps, children lists, traces)."""
+    from surface_texture_inpainting_net_amd import plan as P
+    s = make_synthetic_mesh(30000, 3, seed=17, dilations=(2, 4)).to(DEV)
+    monkeypatch.setattr(P, 'REORDER', True)
+    monkeypatch.setattr(P, 'REORDER_MIN', 0)
+    edges = [('edge_index', 0), ('hierarchy_edge_index_1', 1), ('hierarchy_edge_index_2', 2), ('hierarchy_dil_2_edge_index_2', 2),
+             ('hierarchy_dil_4_edge_index_2', 2)]
+    plans = {}
+    for impl in ('torch', 'hip'):
+        monkeypatch.setattr(P, 'REORDER_IMPL', impl)
+        pl = P.GraphPlan(s, positions=(6, 9))
+        pl.ensure(edges, [1, 2])
+        pl.validate()
+        plans[impl] = pl
+    a, b = plans['torch'], plans['hip']
+    assert b._ranks[0].dtype == torch.int32 and a._ranks[0].dtype == torch.int64
+    for ra, rb in zip(a._ranks, b._ranks):
+        assert torch.equal(ra, rb.to(torch.int64))
+    assert torch.equal(a.order0, b.order0) and torch.equal(a.rank0, b.rank0)
+    assert sorted(b.order0.tolist()) == list(range(s.x.shape[0]))
+    for key, _ in edges:
+        ea, eb = a._edges[key], b._edges[key]
+        for name in ('rowptr', 'col'):
+            assert torch.equal(getattr(ea.by_dst, name), getattr(eb.by_dst, name)), (key, name)
+            assert torch.equal(getattr(ea.by_src, name), getattr(eb.by_src, name)), (key, name)
+        assert torch.equal(ea.xslot, eb.xslot) and torch.equal(ea.w_src, eb.w_src) and torch.equal(ea.inv_deg, eb.inv_deg)
+    for lvl in (1, 2):
+        pa, pb = a._pools[lvl], b._pools[lvl]
+        assert torch.equal(pa.trace, pb.trace) and torch.equal(pa.children.rowptr, pb.children.rowptr)
+        assert torch.equal(pa.children.col, pb.children.col) and torch.equal(pa.inv_count, pb.inv_count)
