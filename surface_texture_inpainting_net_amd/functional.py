@@ -690,8 +690,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         pad = 8 if b16 else 4
         Cp = (Cin + pad - 1) // pad * pad                         # inner dimension padded for the 16-byte GEMM paths
         if Cp != Cin:                                             # (the 10-channel network input -> 12; bf16: 16)
-            xp = x.new_zeros(N, Cp)
-            xp[:, :Cin] = x
+            xp = torch.nn.functional.pad(x, (0, Cp - Cin))         # one kernel (zeros + copy were two)
         else:
             xp = x
         # forward / backward weight operands, pre-split once here into the two 16-bit pieces the split GEMMs use
@@ -1152,8 +1151,7 @@ class NetFn(torch.autograd.Function):
         N0, Cin0 = x.shape
         Cp0 = (Cin0 + pad - 1) // pad * pad
         if Cp0 != Cin0:                                          # (the 10-channel network input -> 12; bf16: 16)
-            xp = x.new_zeros(N0, Cp0)
-            xp[:, :Cin0] = x
+            xp = torch.nn.functional.pad(x, (0, Cp0 - Cin0))       # one kernel (zeros + copy were two)
         else:
             xp = x
         # ---- pass 1: shapes and arena layout
@@ -1565,10 +1563,26 @@ class MaskedL1LossFn(torch.autograd.Function):
         ctx.save_for_backward(grad)
         return loss
 
+    # a caller that differentiates the loss itself with weight 1 can pass THIS tensor as the seed (`loss.backward(unit_seed(dev))`):
+    # backward then returns the stored gradient as it is - no ones-fill for the seed and no [N, C] multiply (two launches)
+    _UNIT = {}
+
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
+        u = MaskedL1LossFn._UNIT.get(g.device.index)
+        if u is not None and g.data_ptr() == u.data_ptr():
+            return grad, None, None, None
         return grad * g, None, None, None
+
+
+def unit_seed(device):
+    """The cached scalar 1.0 of `device` that MaskedL1LossFn.backward recognises (see there)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    u = MaskedL1LossFn._UNIT.get(idx)
+    if u is None:
+        u = MaskedL1LossFn._UNIT[idx] = torch.ones((), dtype=torch.float32, device=device)
+    return u
 
 
 def masked_l1_loss(out, color, mask, use_weight=True):

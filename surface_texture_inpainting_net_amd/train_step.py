@@ -523,7 +523,11 @@ class TrainStep:
                 pred = graph_forward(self.model, sample)
                 loss = compute_loss(pred, sample.color, sample.mask if self.use_mask_weighted_loss else None)
             if grad_scale == 1.0:
-                loss.backward()
+                if self.loss_fn is None and self.on_gpu and loss.dtype == torch.float32 and loss.dim() == 0:
+                    from . import functional as SF
+                    loss.backward(SF.unit_seed(loss.device))     # (recognised by the fused loss: no seed fill, no multiply)
+                else:
+                    loss.backward()
             else:
                 loss.backward(torch.full_like(loss, grad_scale))
         finally:
