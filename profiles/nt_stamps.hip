@@ -27,6 +27,8 @@ int main(int argc, char** argv) {
     hipMalloc(&stamps, nblk * 8 * 32 * 8);
     hipMemset(stamps, 0, nblk * 8 * 32 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(stin_nt_stamp_buf), &stamps, sizeof(stamps));
+    const int ablate = argc > 5 ? atoi(argv[5]) : 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(stin_nt_ablate), &ablate, sizeof(ablate));
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -46,9 +48,10 @@ int main(int argc, char** argv) {
             if (hs[i] > t1) t1 = hs[i];
         }
     printf("first stamp -> last stamp: %llu cycles\n", t1 - t0);
-    const int blocks[] = {0, 5, 100, 200, 255, 256, 270, 282};
+    const int blocks[] = {0, 100};
+    const int wv = argc > 4 ? atoi(argv[4]) : 0;                 // which wave of the block to print
     for (int bi : blocks) {
-        const unsigned long long* s = &hs[((size_t)bi * 8 + 0) * 32];
+        const unsigned long long* s = &hs[((size_t)bi * 8 + wv) * 32];
         if (!s[0]) continue;
         printf("block %3d start %7llu:", bi, s[0] - t0);
         unsigned long long prev = s[0];

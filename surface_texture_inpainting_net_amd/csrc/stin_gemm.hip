@@ -688,8 +688,13 @@ __device__ unsigned long long* stin_nt_stamp_buf = nullptr;
         if ((threadIdx.x & 63) == 0 && stin_nt_stamp_buf != nullptr && (i) < 32)                                        \
             stin_nt_stamp_buf[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#define NT_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+__device__ int stin_nt_ablate = 0;     // 1: second row group re-reads W step 0, 2: every wave does, 4: A loads re-read chunk 0, 8: no split/LDS store
+#define NT_ABLATE(bit) (stin_nt_ablate & (bit))
 #else
+#define NT_ABLATE(bit) 0
 #define NT_STAMP(i)
+#define NT_STAMP_DRAIN()
 #endif
 
 // WAVES_M = waves along the rows of the block (each wave owns 64 rows x 64 columns): the block has NW * WAVES_M waves and
@@ -969,6 +974,236 @@ __global__ __launch_bounds__(64 * NW * WAVES_M) void k_gemm_nt_wide(const float*
         }
     }
     NT_STAMP(31);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: balanced column-panel tiles (k_gemm_nt_panel).  What bounds the split-precision NT kernels at the bottleneck level
+// (M = 18 063) is the L2 -> CU path (~27-30 B/clk per CU, profiles/nt_stamps.hip), so the tile a CU owns should be as square as
+// the chip allows AND every CU should own exactly one: bytes pulled per CU = (rows + columns) x K x 4.  The all-columns kernel
+// gives a CU 128 rows x 256 columns (1.5 MB at K = 1024) and uses 142 of the 256 CUs; the strip kernel re-streams a 128-column
+// W panel for every 64-row strip.  Here
+//   * the output is cut into 128-column panels x row blocks of BM = 32 (MT0 + MT1) rows, MT0 + MT1 chosen on the host so that
+//     (row blocks) x (panels) fills the chip in a whole number of rounds (18 063 x 256: 113 blocks of 160 rows x 2 panels = 226
+//     CUs; x 512: 63 blocks of 288 rows x 4 = 252; x 1024: 504 = two rounds) - "283 tiles on 256 CUs" is gone;
+//   * a block is 8 waves = 2 row groups x 4 column tiles: wave (q, wn) owns columns [32 wn, 32 wn + 32) of the panel and MT0
+//     (q = 0) or MT1 (q = 1) 32-row tiles.  The two waves of a SIMD share its matrix pipe, so MT0 != MT1 costs nothing; they
+//     run as two role programs behind a scalar branch (separate register files for 5 and 4 accumulator tiles);
+//   * A is streamed ONCE per block through the wide kernel's double-buffered LDS image (64-wide K chunks, split into the two
+//     16-bit pieces while staging, one barrier per chunk, the next chunk's global loads issued at the top of the chunk and
+//     split + stored during its LAST k-steps: one register set);
+//   * W fragments (fragment order, STIN_GEMM_W_FRAG) go straight from L2 to registers, 2 KB per k-step per wave for 3 MT
+//     MFMAs (the strip kernel: 6); the second row group's loads of the same fragments hit the CU's vector L1;
+//   * the A fragments of a k-step are read tile by tile, one tile ahead of the MFMAs that use them (8 instead of 16 MT registers);
+//   * epilogue restaged through LDS (16-byte row-contiguous stores), optional column statistics as in the wide kernel
+//     (groups = 2 per row block).
+// Same k order, MFMA order and epilogue expression as the other split kernels: bit-identical results
+// (tests/test_hip_parity.py::test_gemm_nt_panel_kernel_equals_tiled_kernel).
+#ifndef STIN_PANEL_SCHED
+#define STIN_PANEL_SCHED 0
+#endif
+template <typename PT, int MT0, int MT1>
+__global__ __launch_bounds__(512) void k_gemm_nt_panel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Wf,
+                                                       const float* __restrict__ bias, const float* __restrict__ row_mask,
+                                                       int64_t ld_mask, const float* __restrict__ res, int64_t ld_res, int64_t M,
+                                                       int Nc, int K, float* __restrict__ C, int64_t ldc,
+                                                       double* __restrict__ colstats, int nrb, int P, int xcd_map) {
+    typedef typename PieceTraits<PT>::vec8 vec8;
+    constexpr float ASCALE = PieceTraits<PT>::ascale, WSCALE = PieceTraits<PT>::wscale;
+    constexpr int MTS = MT0 + MT1, BM = 32 * MTS, THREADS = 512;
+    constexpr int NF4 = BM * 16 / THREADS;                                      // float4 per thread and 64-wide chunk (= MTS)
+    constexpr int STEP_BYTES = BM * 32, PLANE = WD_STEPS * STEP_BYTES, BUF = 2 * PLANE;
+    static_assert(2 * BUF >= 8 * 4096, "the epilogue restages 4 KB per wave (BM = 64: the launch adds the mask's BM floats)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char panel_smem[];
+    unsigned char* smem = panel_smem;
+    // (the row mask of the block goes through a register and, after the K loop, into the then idle staging area behind the
+    // epilogue's restage slots: the block needs exactly 2 BUF bytes of LDS - 80 KB at 160 rows, two blocks per CU)
+    float* mask_s = reinterpret_cast<float*>(panel_smem + 8 * 4096);            // [BM], valid from the end of the K loop on
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = wave >> 2, wn = wave & 3;                                     // row group, column tile of the panel (wave-uniform)
+    const int kh = lane >> 5, li = lane & 31;
+    int rb, p;
+    if (xcd_map) {                                                          // row block rb on XCD rb % 8, its panels on consecutive slots
+        const int slot = blockIdx.x >> 3;
+        rb = (slot / P) * 8 + (blockIdx.x & 7);
+        p = slot % P;
+    } else {
+        rb = blockIdx.x / P;
+        p = blockIdx.x % P;
+    }
+    if (rb >= nrb) return;                                                      // block-uniform
+    NT_STAMP(0);
+    const int64_t row0 = (int64_t)rb * BM;
+    const int nchunk = K / WD_KC, KS_total = K / 16;
+    const int col0 = p * 128 + wn * 32;                                         // first column of this wave's tile
+
+    float mask_r = 1.f;
+    if (row_mask != nullptr && tid < BM) {
+        const int64_t row = row0 + tid;
+        mask_r = row_mask[(row < M ? row : M - 1) * ld_mask];
+    }
+
+    // staging map: item i = tid + s * THREADS of the chunk's BM x 16 float4: first all rows of the chunk's first 32-wide k-tile,
+    // then all rows of the second (8 lanes per row and k-tile = one 128-byte line, 8 rows per wave: the wide kernel's map)
+    int goff[NF4], soff[NF4];
+#pragma unroll
+    for (int s = 0; s < NF4; ++s) {
+        const int i = tid + s * THREADS;
+        const int h = i / (BM * 8), rem = i % (BM * 8), row = rem >> 3, kq = rem & 7;
+        const int64_t grow = row0 + row;
+        goff[s] = (int)((grow < M ? grow : M - 1) - row0) * (int)lda + h * 32 + kq * 4;     // rows past M re-read row M - 1
+        const int ks = h * 2 + (kq >> 2), kh_ = (kq >> 1) & 1;
+        soff[s] = ks * STEP_BYTES + row * 32 + ((kh_ ^ ((row >> 3) & 1)) << 4) + (kq & 1) * 8;
+    }
+    const float* Ab = A + row0 * lda;
+    float4 ra[NF4];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int s = 0; s < NF4; ++s) ra[s] = ld4(Ab + c * WD_KC + goff[s]);
+    };
+    auto sstore = [&](int buf, int s) {
+        split_store<2, PT>(ra[s], reinterpret_cast<PT*>(smem + buf * BUF + soff[s]), PLANE / 2, ASCALE);
+    };
+
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(Wf) + (int64_t)(p * 4 + wn) * KS_total * 2048;
+    const unsigned lane_off = (unsigned)lane * 32u;
+    const float sc = 1.f / (ASCALE * WSCALE);
+
+    auto role = [&](auto MTc) {
+        constexpr int MT = decltype(MTc)::value;
+        // Staging schedule (one register set): the rows of chunk c + 1 sit in `ra` when chunk c starts (requested during the
+        // second half of chunk c - 1); they are split and stored into the other LDS buffer after the row tiles' MFMAs of k-steps
+        // 0 and 1, and the loads of chunk c + 2 are issued into the same registers at the top of k-step 2: every load has half a
+        // chunk plus a barrier of lead time (the first version issued at the top of the chunk and stored 1-2 k-steps later:
+        // 3.9 k cycles per chunk of 160 x 128 x 64 where the MFMAs need 1.9 k, profiles/nt_stamps.hip).
+        constexpr int NS = 2 * MT;                                              // staging slots of a chunk
+        const int trow = q * (MT0 * 32);                                        // first block-local row of this wave's tiles
+        StFrag wf[WD_STEPS];
+#pragma unroll
+        for (int j = 0; j < WD_STEPS; ++j) wf[j] = st_wload(wb + j * 2048, lane_off);
+        gload(0);
+        f32x16 acc[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NF4; ++s) sstore(0, s);
+        gload(nchunk > 1 ? 1 : 0);
+        const unsigned char* a_frag = smem + (trow + li) * 32 + ((kh ^ ((li >> 3) & 1)) << 4);
+        __syncthreads();
+        NT_STAMP(1);
+        for (int c = 0; c < nchunk; ++c) {
+            // branch-free body: past the end of K the fetches re-read the last chunk and the staging writes a buffer nobody reads
+            const unsigned char* ab = a_frag + (c & 1) * BUF;
+            const int nxt = (c + 1 < nchunk ? c + 1 : c) * WD_STEPS;            // ring refill: same step of the next chunk (clamped)
+            // A fragments: the whole next k-step in flight (tile i of step j + 1 is requested in front of tile i's MFMAs of step j:
+            // MT tiles = 96 MT cycles of lead; one tile ahead left the matrix pipe half idle - profiles/nt_stamps.hip)
+            vec8 ch[MT], cl[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ch[i] = *reinterpret_cast<const vec8*>(ab + i * 1024);
+                cl[i] = *reinterpret_cast<const vec8*>(ab + PLANE + i * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < WD_STEPS; ++j) {
+                const vec8 b0 = __builtin_bit_cast(vec8, wf[j].hi), b1 = __builtin_bit_cast(vec8, wf[j].lo);
+                if (j == 2) gload(NT_ABLATE(4) ? 0 : (c + 2 < nchunk ? c + 2 : nchunk - 1));
+                vec8 nh[MT], nl[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    nh[i] = ch[i];
+                    nl[i] = cl[i];
+                    if (j + 1 < WD_STEPS) {
+                        nh[i] = *reinterpret_cast<const vec8*>(ab + (j + 1) * STEP_BYTES + i * 1024);
+                        nl[i] = *reinterpret_cast<const vec8*>(ab + PLANE + (j + 1) * STEP_BYTES + i * 1024);
+                    }
+                    acc[i] = mfma_k16(ch[i], b1, acc[i]);
+                    acc[i] = mfma_k16(cl[i], b0, acc[i]);
+                    acc[i] = mfma_k16(ch[i], b0, acc[i]);
+                    if (j < 2) {
+                        const int slot = j * MT + i;
+#pragma unroll
+                        for (int s = 0; s < NF4; ++s)
+                            if ((s * NS) / NF4 == slot && !NT_ABLATE(8)) sstore((c + 1) & 1, s);
+                    }
+#if STIN_PANEL_SCHED == 1
+                    // the slot's split arithmetic fills the gaps of the dependent MFMA chain: 1 MFMA, then a share of the VALU / LDS work
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);         // up to 8 VALU
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // one LDS read
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);         // one LDS write
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    ch[i] = nh[i];
+                    cl[i] = nl[i];
+                }
+                wf[j] = st_wload(wb + (int64_t)((NT_ABLATE(2) || (NT_ABLATE(1) && q)) ? 0 : nxt + j) * 2048, lane_off);
+            }
+            __syncthreads();
+            NT_STAMP(2 + (c < 26 ? c : 26));
+        }
+        if (tid < BM) mask_s[tid] = mask_r;                                     // (behind the last chunk's barrier: the buffers are idle)
+        __syncthreads();
+        // ---- epilogue: v = acc / (ascale wscale) + bias [* row mask] (+ residual), restaged per 32 x 32 tile through 4 KB of the
+        // (now idle) staging buffers: 8 lanes x 16 B per row, 8 rows per store instruction
+        float* stage_f = reinterpret_cast<float*>(smem + wave * 4096);
+        const float bv = bias != nullptr ? bias[col0 + li] : 0.f;
+        double s1 = 0.0, s2 = 0.0;
+        const int r8 = lane >> 3, c8 = lane & 7;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int lrow0 = trow + i * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int tr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const float v = acc[i][r] * sc + (row_mask != nullptr ? bv * mask_s[lrow0 + tr] : bv);
+                stage_f[tr * 32 + li] = v;
+                if (colstats != nullptr && row0 + lrow0 + tr < M) {
+                    const double d = (double)v;
+                    s1 += d;
+                    s2 += d * d;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int tr = t * 8 + r8;
+                const int64_t grow = row0 + lrow0 + tr;
+                float4 v = *reinterpret_cast<const float4*>(stage_f + tr * 32 + c8 * 4);
+                if (grow < M) {
+                    if (res != nullptr) {
+                        const float4 rv = ld4(res + grow * ld_res + col0 + c8 * 4);
+                        v.x += rv.x;
+                        v.y += rv.y;
+                        v.z += rv.z;
+                        v.w += rv.w;
+                    }
+                    st4(C + grow * ldc + col0 + c8 * 4, v);
+                }
+            }
+        }
+        if (colstats != nullptr) {                                             // block-uniform
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (kh == 0) {
+                double* dst = colstats + ((int64_t)rb * 2 + q) * 2 * Nc + col0 + li;
+                dst[0] = s1;
+                dst[Nc] = s2;
+            }
+        }
+        NT_STAMP(29);
+        NT_STAMP_DRAIN();
+        NT_STAMP(30);
+    };
+    if (q == 0) role(std::integral_constant<int, MT0>());
+    else role(std::integral_constant<int, MT1>());
 }
 
 // ----------------------------------------------------------------------------- TN
@@ -2191,6 +2426,30 @@ inline int wide_waves_m(int64_t M, int Nc) {
     if (force == 4 || force == 8) return force / nw;
     return (Nc == 256 && (M + 127) / 128 <= (int64_t)stin_cu_count()) ? 2 : 4 / nw;
 }
+// Balanced column-panel kernel (k_gemm_nt_panel): 32-row tiles per block (MT0 + MT1, 2 .. 9) so that (row blocks) x (128-column
+// panels) fills the chip in ONE round, or 0 = this shape stays on the strip / all-columns kernels.  Measured (MI355X, round 4,
+// strip / all-columns -> panel, bf16x3): 18 063 x 256 x 1024 43.4 -> 36.7-38.8 us, x 256 x 512 26.4 -> 23.3, x 512 x 256 31.3 -> 24.2,
+// x 128 x 1280 35.1 -> 28.8; grids of two and more rounds (one 147 KB block per CU at a time: nothing overlaps a block's
+// prologue and its 5 us store phase) are no faster than the strip kernel (18 063 x 1024 x 256 44.0 -> 42.9-46.7, 60 211 x 640 x 256
+// 80.6 -> 93.1) and stay there.  STIN_NT_PANEL = 0 disables, = 1 forces it for every fragment-order shape whatever the number
+// of rounds (re-read per call: profiles/gemm_shapes.py flips it).
+inline int panel_tiles(int64_t M, int Nc, int K) {
+    const char* e = getenv("STIN_NT_PANEL");
+    const int forced = e ? atoi(e) : -1;
+    if (forced == 0 || Nc % 128 != 0 || K % WD_KC != 0 || M <= 0) return 0;
+    const int P = Nc / 128;
+    const int64_t rg = (M + 31) / 32, cu = stin_cu_count();
+    const char* em = getenv("STIN_NT_PANEL_MTS");                               // tuning aid: tiles per block, 2 .. 9
+    if (em && atoi(em) >= 2 && atoi(em) <= 9) return atoi(em);
+    const int max_rounds = forced == 1 ? 64 : 1;
+    for (int rounds = 1; rounds <= max_rounds; ++rounds) {
+        const int64_t slots = cu * rounds / P;
+        if (slots < 1) continue;
+        const int64_t mts = (rg + slots - 1) / slots;
+        if (mts <= 9) return mts < 2 ? (forced == 1 ? 2 : 0) : (int)mts;
+    }
+    return 0;
+}
 inline bool tn_one_per_cu(int storage, int precision, int TI, int TJ, int64_t M) {
     return storage == 0 && precision == STIN_GEMM_BF16X3 && TI == 128 && TJ == 128 && M <= 32768;
 }
@@ -2238,7 +2497,45 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
         else STIN_NT(KERNEL, 64, 64, 2, 2, ##__VA_ARGS__);                                     \
     } while (0)
     STIN_REQUIRE(colstats == nullptr || (wfrag && Nc <= 256), STIN_E_UNSUPPORTED);
-    if (wfrag && Nc <= 256) {
+    const bool out16 = ldc % 4 == 0 && stin_aligned16(C) && (residual == nullptr || (ld_res % 4 == 0 && stin_aligned16(residual)));
+    const int pmts = (wfrag && vec && out16 && !(colstats != nullptr && residual != nullptr)) ? panel_tiles(M, Nc, K) : 0;
+    // (stin_gemm_nt_colstats_groups promised the panel kernel's group count from the shape alone)
+    STIN_REQUIRE(colstats == nullptr || pmts > 0 || !wfrag || panel_tiles(M, Nc, K) == 0, STIN_E_ALIGN);
+    if (pmts > 0) {
+        // balanced column-panel kernel (k_gemm_nt_panel)
+        const int P = Nc / 128, bm = 32 * pmts;
+        const int nrb = (int)((M + bm - 1) / bm);
+        const int xmap = nrb >= 16 ? 1 : 0;
+        const unsigned grid = (unsigned)((xmap ? ((nrb + 7) / 8) * 8 : nrb) * P);
+        const size_t lds = (size_t)bm * 512 > (size_t)(8 * 4096 + bm * 4) ? (size_t)bm * 512 : (size_t)(8 * 4096 + bm * 4);
+#define STIN_PANEL_L(PT_, A_, B_)                                                                                         \
+    do {                                                                                                                  \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set) {                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_panel<PT_, A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((k_gemm_nt_panel<PT_, A_, B_>), dim3(grid), dim3(512), lds, stream, A, lda, W, bias, row_mask, ld_mask, \
+                           residual, ld_res, M, Nc, K, C, ldc, colstats, nrb, P, xmap);                                   \
+    } while (0)
+#define STIN_PANEL(PT_)                                                                                                   \
+    do {                                                                                                                  \
+        switch (pmts) {                                                                                                   \
+            case 2: STIN_PANEL_L(PT_, 1, 1); break;                                                                       \
+            case 3: STIN_PANEL_L(PT_, 2, 1); break;                                                                       \
+            case 4: STIN_PANEL_L(PT_, 2, 2); break;                                                                       \
+            case 5: STIN_PANEL_L(PT_, 3, 2); break;                                                                       \
+            case 6: STIN_PANEL_L(PT_, 3, 3); break;                                                                       \
+            case 7: STIN_PANEL_L(PT_, 4, 3); break;                                                                       \
+            case 8: STIN_PANEL_L(PT_, 4, 4); break;                                                                       \
+            default: STIN_PANEL_L(PT_, 5, 4); break;                                                                      \
+        }                                                                                                                 \
+    } while (0)
+        if (precision == STIN_GEMM_BF16X3) STIN_PANEL(__bf16);
+        else STIN_PANEL(_Float16);
+#undef STIN_PANEL_L
+#undef STIN_PANEL
+    } else if (wfrag && Nc <= 256) {
         // all-columns kernel (k_gemm_nt_wide): Nc = 128 / 256, the fragment-order weight operand cannot be read by any other kernel
         STIN_REQUIRE(vec, STIN_E_ALIGN);
         const int wm = wide_waves_m(M, Nc);
@@ -2343,6 +2640,8 @@ extern "C" int64_t stin_gemm_nt_colstats_groups(int64_t M, int Nc, int K, int pr
     const bool ok = (precision & STIN_GEMM_W_PRESPLIT) && (precision & STIN_GEMM_W_FRAG) && Nc <= 256 && stin_w_frag_shape(Nc, K);
     const int p = precision & ~(STIN_GEMM_W_PRESPLIT | STIN_GEMM_W_FRAG);
     if (!ok || M <= 0 || (p != STIN_GEMM_BF16X3 && p != STIN_GEMM_F16X3)) return 0;
+    const int pmts = panel_tiles(M, Nc, K);                 // (the colstats launches carry 16-byte aligned rows: the same choice
+    if (pmts > 0) return 2 * ((M + 32 * pmts - 1) / (32 * pmts));   //  as gemm_nt_f32_impl) two row groups per panel-kernel row block
     return (M + 63) / 64;                                   // one statistics group per wave row group (64 rows)
 }
 extern "C" int stin_gemm_nt_colstats_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,

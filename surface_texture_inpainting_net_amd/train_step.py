@@ -443,14 +443,17 @@ class TrainStep:
 
     def __init__(self, model, lr=7e-5, weight_decay=0.0, amsgrad=True, use_mask_weighted_loss=True, group=None,
                  accumulate=1, overlap_allreduce_min_bytes=None, time_allreduce=False, graph=False, graph_cache=8,
-                 loss_fn=None, freeze_gc=True):
+                 loss_fn=None, freeze_gc=False):
         self.model = model
         # freeze_gc: the model, the optimizer state and whatever the data pipeline has built so far are long-lived; Python's
         # cyclic collector would otherwise re-scan that heap in the young-generation collections the ~100 k short-lived
         # objects of every step trigger, and its generation-2 passes land in the first tens of steps: measured at the
         # headline size 8.8 ms per step over the first 35 steps instead of 7.5 (host stalls of several ms while the GPU
-        # drains its queue).  gc.freeze() moves everything alive now into the permanent generation (nothing is leaked; cycles
-        # created later are still collected).
+        # drains its queue).  gc.freeze() moves everything alive now into the permanent generation (cycles created later are
+        # still collected).  OPT-IN (round 4; bench.py opts in): it is a process-wide side effect, and an object frozen here that
+        # later becomes cyclic garbage - an EARLIER TrainStep's parameter <-> bucket cycle in a sweep or k-fold run - would never
+        # be collected; call gc.unfreeze() (or TrainStep.close()) when such a run drops a model.
+        self._froze_gc = bool(freeze_gc)
         if freeze_gc:
             import gc
             gc.collect()
@@ -555,6 +558,17 @@ class TrainStep:
             if self._graph_pool is None:
                 self._graph_pool = ent.pool
         return ent.run(sample)
+
+    def close(self):
+        """Undo the constructor's process-wide side effect (freeze_gc=True) and break the parameter <-> bucket cycle so that a
+        dropped model's flat buffers are released by reference counting."""
+        if self._froze_gc:
+            import gc
+            gc.unfreeze()
+            self._froze_gc = False
+        for p in self.bucket.params:
+            if hasattr(p, '_stin_slot'):
+                del p._stin_slot
 
     def finish(self):
         """Resolve the deferred index checks of the steps run so far (waits for the GPU)."""

@@ -246,12 +246,14 @@ def test_gemm_nt_precision_modes(M, Nc, K):
                                     (130, 64, 36), (1000, 256, 640), (3001, 128, 320), (1, 256, 128), (63, 256, 1024),
                                     (18063, 256, 1024), (18063, 256, 512), (20001, 128, 256), (4100, 128, 1280), (200, 256, 64),
                                     (129, 128, 192), (515, 192, 256)])
-def test_gemm_nt_strip_kernel_equals_tiled_kernel(M, Nc, K):
-    """The NT kernels that read the weight operand in MFMA fragment order straight from L2 - the resident-strip kernel
+def test_gemm_nt_strip_kernel_equals_tiled_kernel(M, Nc, K, monkeypatch):
+    """(STIN_NT_PANEL=0: the round-4 column-panel kernel, which now takes some of these shapes by default, has its own test below.)
+    The NT kernels that read the weight operand in MFMA fragment order straight from L2 - the resident-strip kernel
     (k_gemm_nt_strip: 64-row strips resident in LDS, Nc >= 320, K <= 256) and the all-columns kernel (k_gemm_nt_wide:
     Nc = 128 / 256, any K, A streamed once through a double-buffered LDS chunk) - against the tiled kernel on the k-group
     layout: same arithmetic in the same order -> bit-identical.  Shapes neither takes (stin_gemm_w_is_frag) keep the
     k-group layout and the tiled kernel under the same flag.  Both against fp64."""
+    monkeypatch.setenv('STIN_NT_PANEL', '0')
     g = torch.Generator().manual_seed(M + Nc + K)
     A = torch.randn(M + 3, K + 4, generator=g).to(DEV)[1:M + 1, :K]            # a strided view: lda != K
     W = (torch.randn(Nc, K, generator=g) * 0.1).to(DEV)
@@ -410,13 +412,32 @@ def test_edgeconv_wgrad_equals_two_tn_gemms_plus_unpack(N, Cin, Cout, shortcut, 
     assert float((got[2].double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-6
 
 
+def _panel_tiles(M, Nc, K, forced, cu=256):
+    """Host mirror of panel_tiles() in csrc/stin_gemm.hip: 32-row tiles per block of the balanced column-panel NT kernel (0 = not used)."""
+    if forced == 0 or Nc % 128 or K % 64 or M <= 0:
+        return 0
+    P, rg = Nc // 128, (M + 31) // 32
+    for rounds in range(1, (64 if forced == 1 else 1) + 1):
+        slots = cu * rounds // P
+        if slots < 1:
+            continue
+        mts = (rg + slots - 1) // slots
+        if mts <= 9:
+            return (2 if forced == 1 else 0) if mts < 2 else mts
+    return 0
+
+
+@pytest.mark.parametrize('panel', ['0', '1'])
 @pytest.mark.parametrize('M,Nc,K', [(18063, 256, 512), (60211, 128, 256), (130, 256, 512), (64, 128, 256), (4097, 256, 1024),
                                     (129, 128, 256), (190, 128, 512)])
-def test_gemm_nt_with_fused_column_statistics(M, Nc, K):
+def test_gemm_nt_with_fused_column_statistics(M, Nc, K, panel, monkeypatch):
     """stin_gemm_nt_colstats_f32: GEMM2 of a block plus the first stage of the instance-norm statistics of its output in one
     launch.  The output equals the plain call bit for bit; the per-group sums are the fp64 column sums of the stored fp32
-    values (exact up to fp64 rounding); mean / rstd equal the two-kernel colreduce route to fp32 rounding."""
+    values (exact up to fp64 rounding); mean / rstd equal the two-kernel colreduce route to fp32 rounding.  Both kernels that
+    carry the epilogue: the all-columns kernel (STIN_NT_PANEL=0: one group per 64 rows) and the balanced column-panel kernel
+    (STIN_NT_PANEL=1: two groups per row block, MT0 and MT1 32-row tiles)."""
     from surface_texture_inpainting_net_amd.plan import NormGroups
+    monkeypatch.setenv('STIN_NT_PANEL', panel)
     g = torch.Generator().manual_seed(M + Nc)
     A = torch.rand(M, K + 4, generator=g).to(DEV)
     W = (torch.randn(Nc, K, generator=g) * 0.1).to(DEV)
@@ -433,13 +454,22 @@ def test_gemm_nt_with_fused_column_statistics(M, Nc, K):
     SF._call('stin_gemm_nt_colstats_f32', SF._ptr(A), A.stride(0), SF._ptr(Wf), K, SF._ptr(b), SF._ptr(A[:, K]), A.stride(0), None, 0,
              M, Nc, K, SF._ptr(C), Nc, prec, SF._ptr(guard), partial.numel() * 8, SF._stream(A))
     assert torch.equal(guard[:partial.numel()].view_as(partial), partial) and float((guard[partial.numel():] + 7.0).abs().max()) == 0.0
-    groups = (M + 63) // 64
-    assert partial.shape == (groups, 2, Nc)
-    pad = torch.zeros(groups * 64, Nc, dtype=torch.float64, device=DEV)
-    pad[:M] = C.double()
-    want = pad.view(groups, 64, Nc)
-    assert float((partial[:, 0] - want.sum(1)).abs().max()) <= 1e-11 * 64 * float(C.abs().max())
-    assert float((partial[:, 1] - (want * want).sum(1)).abs().max()) <= 1e-11 * 64 * float(C.abs().max()) ** 2
+    mts = _panel_tiles(M, Nc, K, int(panel))
+    if mts == 0:
+        bounds = [(i * 64, min(M, i * 64 + 64)) for i in range((M + 63) // 64)]
+    else:                                                   # row block rb: rows [rb BM, rb BM + 32 MT0) and [.., (rb + 1) BM)
+        bm, mt0 = 32 * mts, 32 * ((mts + 1) // 2)
+        bounds = []
+        for rb in range((M + bm - 1) // bm):
+            bounds += [(min(M, rb * bm), min(M, rb * bm + mt0)), (min(M, rb * bm + mt0), min(M, rb * bm + bm))]
+    assert partial.shape == (len(bounds), 2, Nc)
+    Cd = C.double()
+    zero = torch.zeros(Nc, dtype=torch.float64, device=DEV)
+    want1 = torch.stack([Cd[a:e].sum(0) if e > a else zero for a, e in bounds])
+    want2 = torch.stack([(Cd[a:e] ** 2).sum(0) if e > a else zero for a, e in bounds])
+    rows = max(e - a for a, e in bounds)
+    assert float((partial[:, 0] - want1).abs().max()) <= 1e-11 * rows * float(C.abs().max())
+    assert float((partial[:, 1] - want2).abs().max()) <= 1e-11 * rows * float(C.abs().max()) ** 2
     ng = NormGroups(M, torch.device(DEV))
     mean, rstd = SF.moments_final(partial, ng.inv_cnt)
     mean2, rstd2 = SF.instance_stats(C, ng)
@@ -447,6 +477,47 @@ def test_gemm_nt_with_fused_column_statistics(M, Nc, K):
     assert float((rstd / rstd2 - 1).abs().max()) <= 1e-6
     # shapes without an all-columns kernel: no fused form
     assert SF.gemm_nt_colstats(A[:, :K], SF.split_weights(W, SF.GEMM_F16X3), b, A[:, K], SF.GEMM_F16X3 | SF.GEMM_W_PRESPLIT, Nc) is None
+
+
+@pytest.mark.parametrize('M,Nc,K', [(1, 256, 128), (8187, 256, 512), (12283, 256, 1024), (16379, 256, 512), (18063, 256, 1024), (24571, 256, 512),
+                                    (28667, 256, 128), (32763, 256, 512), (36859, 256, 1024), (18063, 512, 256), (18063, 1024, 256),
+                                    (18063, 1280, 128), (18063, 128, 1280), (5000, 1024, 256), (60211, 640, 256), (777, 384, 192), (300, 128, 256)])
+def test_gemm_nt_panel_kernel_equals_tiled_kernel(M, Nc, K, monkeypatch):
+    """Round 4: the balanced column-panel NT kernel (k_gemm_nt_panel: 128-column panels x row blocks of 32 (MT0 + MT1) rows sized
+    so that the grid fills the chip in whole rounds, 8 waves = 2 row groups x 4 column tiles, A streamed once through LDS, W
+    fragments from L2) against the tiled kernel on the k-group layout AND against the strip / all-columns kernels it replaces:
+    same k order, MFMA order and epilogue expression -> bit-identical.  Every (MT0, MT1) instantiation (2 .. 9 tiles per block),
+    ragged last row blocks, single-row input, one and several rounds of blocks, strided A / residual / output views."""
+    FR = 0x400
+    frag = bool(_lib_load().stin_gemm_w_is_frag(Nc, K))
+    g = torch.Generator().manual_seed(M + Nc + K)
+    A = torch.randn(M + 3, K + 4, generator=g).to(DEV)[1:M + 1, :K]
+    W = (torch.randn(Nc, K, generator=g) * 0.1).to(DEV)
+    b = torch.randn(Nc, generator=g).to(DEV)
+    mask = (torch.rand(M, 3, generator=g) < 0.7).float().to(DEV)[:, 1]
+    res = torch.randn(M, Nc + 4, generator=g).to(DEV)[:, :Nc]
+    want = A.double() @ W.double().t()
+    scale = float(want.abs().max()) + 1.0
+    for prec in (SF.GEMM_F16X3, SF.GEMM_BF16X3):
+        Wk, Wf = SF.split_weights(W, prec), SF.split_weights(W, prec | FR)
+        for kw in (dict(), dict(bias=b, row_mask=mask), dict(bias=b, residual=res)):
+            tiled = SF.gemm_nt(A, Wk, precision=prec | SF.GEMM_W_PRESPLIT, **kw)
+            monkeypatch.setenv('STIN_NT_PANEL', '0')
+            old = SF.gemm_nt(A, Wf, precision=prec | SF.GEMM_W_PRESPLIT | FR, **kw)
+            monkeypatch.setenv('STIN_NT_PANEL', '1')
+            for _ in range(2):
+                new = SF.gemm_nt(A, Wf, precision=prec | SF.GEMM_W_PRESPLIT | FR, **kw)
+                assert torch.equal(new, tiled) and torch.equal(old, tiled), (prec, sorted(kw))
+        if frag and Nc % 128 == 0:
+            assert _panel_tiles(M, Nc, K, 1) >= 2
+            wide = torch.full((M + 2, Nc + 8), 3.0, device=DEV)              # output as a view into a wider matrix
+            SF.gemm_nt(A, Wf, b, residual=res, out=wide[1:M + 1, 4:Nc + 4], precision=prec | SF.GEMM_W_PRESPLIT | FR)
+            assert torch.equal(wide[1:M + 1, 4:Nc + 4], SF.gemm_nt(A, Wk, b, residual=res, precision=prec | SF.GEMM_W_PRESPLIT))
+            wide[1:M + 1, 4:Nc + 4] = 3.0
+            assert float((wide - 3.0).abs().max()) == 0.0
+        ref = want + b.double() * mask.double()[:, None]
+        tol = 3e-6 if prec == SF.GEMM_F16X3 else 2e-5
+        assert float((SF.gemm_nt(A, Wf, b, row_mask=mask, precision=prec | SF.GEMM_W_PRESPLIT | FR).double() - ref).abs().max()) <= tol * scale
 
 
 def _lib_load():
