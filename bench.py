@@ -188,6 +188,15 @@ def cpu_baseline(n0_target, levels, seed):
             out['all_cores'] = {'cores': ncpu, 'skipped': 'thread probe: %d threads already run at %.2f of the %d-thread rate on the '
                                 '10 k-vertex probe mesh; %d threads would only thrash the intra-op pool (round 3: 75.8 vertices/s '
                                 'from one 132 s pass)' % (th_max, probe_log[th_max] / probe_log[best_threads], best_threads, ncpu)}
+    import glob
+    committed = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_cpu_baseline_200k.json')))
+    if committed:                       # the same oracle on the HEADLINE mesh (profiles/cpu_baseline_200k.py: ~85 s, not part of the default run)
+        try:
+            c = json.load(open(committed[-1]))
+            out['headline_mesh_committed'] = {k: c.get(k) for k in ('value', 'unit', 'cores', 'cpu_model', 'sample_vertices', 'passes_s', 'warmup_s')}
+            out['headline_mesh_committed']['file'] = os.path.relpath(committed[-1], ROOT)
+        except (OSError, ValueError):
+            pass
     torch.set_num_threads(best_threads)
     out['sample'] = ('fwd+loss+bwd of the CPU oracle (unfused PyG-form restatement, torch %s CPU, fp32) on a synthetic %d-vertex '
                      '%d-level mesh: 1 warm-up at size + median of %d passes (%.2f s) with %d of %d host threads of %s (probe-best); '

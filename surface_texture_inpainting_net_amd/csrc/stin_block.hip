@@ -309,6 +309,12 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         hipError_t e = hipEventRecord((hipEvent_t)ev_done, (hipStream_t)wgrad_stream);
         if (e == hipSuccess && join) e = hipStreamWaitEvent(hs, (hipEvent_t)ev_done, 0);
         if (e != hipSuccess) return (int)e;
+    } else if (ev_done != nullptr) {
+        // (round 4) no weight-gradient stream for this block: ev_done still marks "this block's parameter gradients are
+        // written", on the compute stream - what the overlapped gradient all-reduce of a data-parallel step waits for
+        // segment by segment while the rest of stin_net_bwd's kernels are still queued (train_step.FlatGradBucket.blocks_done)
+        hipError_t e = hipEventRecord((hipEvent_t)ev_done, hs);
+        if (e != hipSuccess) return (int)e;
     }
     return STIN_OK;
 }

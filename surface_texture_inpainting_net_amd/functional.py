@@ -493,10 +493,13 @@ class _WgradSide:
         self.last_done = self.ring[0][2]
         self.hold = []                              # tensors the side stream may still be reading (dropped at the join)
 
-    def next_events(self):
+    def next_events(self, track=True):
+        """track=False: an event triple for a block that stays on the compute stream (its ev_done is recorded there): it must not
+        become `last_done`, the event the deferred join of the SIDE stream waits for."""
         self.at = (self.at + 1) % self.RING
         tri = self.ring[self.at]
-        self.last_done = tri[2]
+        if track:
+            self.last_done = tri[2]
         return tri
 
 
@@ -1326,14 +1329,33 @@ class NetFn(torch.autograd.Function):
         use = [side_ok and WGRAD_MIN_WORK <= float(d['N']) * d['Yw'] * d['Cp'] <= WGRAD_MAX_WORK for d in blocks]
         side_stream, any_side = 0, any(use)
         evs = [(0, 0)] * len(blocks)
-        if any_side:
+        # Overlapped gradient all-reduce (train_step.FlatGradBucket.enable_overlap, round 4): every block records its ev_done when
+        # its parameter gradients are written - on the weight-gradient stream, or on the compute stream for a block that does
+        # not use it - INSIDE the C call's kernel sequence, and the bucket hands each completed segment to RCCL behind exactly
+        # those events: the reduction of the decoder's gradients runs while the encoder's backward kernels are still queued.
+        bucket = None
+        if direct:
+            for p in all_params:
+                if p is not None:
+                    bucket = p._stin_slot[0]
+                    break
+        seg_events = bucket is not None and bucket.wants_block_events()
+        done_ev = [None] * len(blocks)
+        if any_side or seg_events:
             side = _wgrad_side(dev)
+        if any_side:
             side.hold.append((scratch, xp, arena, g))
             side_stream = side.stream.cuda_stream
+        if any_side or seg_events:
             for bi in reversed(range(len(blocks))):      # in BACKWARD order: side.last_done = the event recorded last
                 if use[bi]:
                     tri = side.next_events()
                     evs[bi] = (tri[1].cuda_event, tri[2].cuda_event)
+                    done_ev[bi] = tri[2]
+                elif seg_events:
+                    tri = side.next_events(track=False)
+                    evs[bi] = (0, tri[2].cuda_event)
+                    done_ev[bi] = tri[2]
             if grads is not None:
                 for t in grads:
                     if t is not None:
@@ -1389,7 +1411,10 @@ class NetFn(torch.autograd.Function):
                 if p is not None:
                     slot = p._stin_slot[0]
                     break
-            slot.block_done(sd.last_done if (sd is not None and sd.hold) else None)      # (completed segments go to RCCL now)
+            if seg_events:                   # completed segments go to RCCL now, each behind its own blocks' events
+                slot.blocks_done([([p._stin_slot[1] for p in d['params'] if p is not None], done_ev[bi]) for bi, d in enumerate(blocks)])
+            else:
+                slot.block_done(sd.last_done if (sd is not None and sd.hold) else None)
             return (dx0, None) + (None,) * len(params)
         return (dx0, None) + tuple(grads)
 

@@ -70,6 +70,8 @@ class FlatGradBucket:
         self._group = None
         self._comm_stream = None
         self.allreduce_log = None             # list: (start, end) HIP events of the end-of-backward all-reduces (bench: allreduce_us)
+        self.overlap_log = None               # list: (segment, HIP event on the communication stream in front of its all-reduce)
+        self.backward_end = None              # with overlap_log: HIP event on the compute stream behind the last backward kernel
 
     def zero(self):
         self.flat.zero_()
@@ -151,6 +153,42 @@ class FlatGradBucket:
     def _seg_slice(self, seg):
         lo, hi = seg
         return self.flat[self.offsets[lo]:self.offsets[hi - 1] + self.params[hi - 1].numel()]
+
+    def wants_block_events(self):
+        """True while segments are waiting to be reduced during this backward pass: functional.NetFn then asks stin_net_bwd for one
+        completion event per block."""
+        return bool(self.segments) and self._seg_next < len(self.segments) and self.accepting and _world(self._group) > 1
+
+    def blocks_done(self, items):
+        """functional.NetFn.backward, after ONE C call has enqueued the backward kernels of every block: items = [(parameter slot
+        indices of a block, the event recorded when that block's gradient writes are complete)].  Each segment whose parameters
+        are all written goes to RCCL on the communication stream behind the events of exactly its blocks - NOT behind the
+        compute stream's current position, which would be the end of the whole backward pass (the round-3 regression)."""
+        if not self.segments or self._seg_next >= len(self.segments) or _world(self._group) == 1:
+            return
+        ev_of = {}
+        for idxs, ev in items:
+            for i in idxs:
+                ev_of[i] = ev
+        dev = self.flat.device
+        cs = self._comm_stream
+        while self._seg_next < len(self.segments):
+            lo, hi = self.segments[self._seg_next]
+            if not all(self.written[lo:hi]):
+                break
+            if all(i in ev_of and ev_of[i] is not None for i in range(lo, hi)):
+                for ev in {id(ev_of[i]): ev_of[i] for i in range(lo, hi)}.values():
+                    cs.wait_event(ev)
+            else:                                                # a parameter written by some other node: the conservative order
+                cs.wait_stream(torch.cuda.current_stream(dev))
+            if self.overlap_log is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(cs)
+                self.overlap_log.append((self._seg_next, e))
+            with torch.cuda.stream(cs):
+                w = dist.all_reduce(self._seg_slice((lo, hi)), op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+            self._seg_work.append(w)
+            self._seg_next += 1
 
     def block_done(self, side_event=None):
         """functional.EdgeConvBlockFn.backward calls this after it has ENQUEUED a block's direct gradient writes: every
@@ -538,6 +576,9 @@ class TrainStep:
             if self.on_gpu:
                 from . import functional as SF
                 SF.wgrad_side_settle(self.bucket.flat.device)   # an aborted backward never ran its end-of-backward join
+                if self.bucket.overlap_log is not None:         # (tests / bench: where the backward pass ends on the compute stream)
+                    self.bucket.backward_end = torch.cuda.Event(enable_timing=True)
+                    self.bucket.backward_end.record()
         self.bucket.gather_grads()
         return loss.detach()
 

@@ -41,14 +41,18 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_allreduce_matches_manual_average(tmp_path):
+@pytest.mark.parametrize('world', [2, 8])
+def test_gradient_allreduce_matches_manual_average(tmp_path, world):
+    """SURVEY 8(e) validation at world 2 and at the node size the bench targets (8 ranks, tiny meshes): the reduced flat bucket
+    on every rank == the mean of the single-rank gradients of the `world` scenes, identical replicas before and after."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0 = torch.load(tmp_path / 'r0.pt')
-    r1 = torch.load(tmp_path / 'r1.pt')
-    assert torch.equal(r0['p0'], r1['p0']), 'replicas identical after the flat broadcast'
-    assert torch.equal(r0['grad'], r1['grad']), 'all-reduced gradients identical on both ranks'
-    assert torch.equal(r0['p1'], r1['p1']), 'identical Adam update on both ranks'
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / ('r%d.pt' % r)) for r in range(world)]
+    r0 = rs[0]
+    for r1 in rs[1:]:
+        assert torch.equal(r0['p0'], r1['p0']), 'replicas identical after the flat broadcast'
+        assert torch.equal(r0['grad'], r1['grad']), 'all-reduced gradients identical on every rank'
+        assert torch.equal(r0['p1'], r1['p1']), 'identical Adam update on every rank'
     assert not torch.equal(r0['p0'], r0['p1'])
     # single-process reference: mean of the two per-scene gradients at the broadcast weights
     from oracle import stin_oracle
@@ -58,13 +62,13 @@ def test_two_rank_gradient_allreduce_matches_manual_average(tmp_path):
     net = stin_oracle.define_G(**CFG)
     torch.nn.utils.vector_to_parameters(r0['p0'], net.parameters())
     grads = []
-    for rank in range(2):
+    for rank in range(world):
         net.zero_grad(set_to_none=True)
         s = make_synthetic_mesh(300 + 100 * rank, 2, seed=rank, dilations=())
         compute_loss(graph_forward(net, s), s.color, s.mask).backward()
         grads.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]))
-    want = (grads[0] + grads[1]) / 2
-    assert float((r0['grad'] - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
+    want = torch.stack(grads).double().mean(0)
+    assert float((r0['grad'].double() - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
 
 
 def test_flat_bucket_views_survive_zero_grad():

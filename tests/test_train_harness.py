@@ -223,16 +223,71 @@ def _overlap_worker(rank, world, port, out_dir, min_bytes, mix=False):
     net = S.define_G(**cfg).to(DEV)
     step = TrainStep(net, lr=1e-3, overlap_allreduce_min_bytes=min_bytes)
     s = make_synthetic_mesh(3000 + 500 * rank, 3, seed=rank, dilations=(2,)).to(DEV)
-    grads, segs = [], []
+    grads, segs, early = [], [], []
+    from surface_texture_inpainting_net_amd import functional as SF2
+    assert SF2.USE_NET_CALL, 'the test is about the whole-network node (functional.NetFn)'
     for _ in range(3):
+        step.bucket.overlap_log = []
         step(s)
+        torch.cuda.synchronize()
         grads.append(step.bucket.flat.clone().cpu())
         segs.append(len(step.bucket.segments or []))
+        # segments whose all-reduce was handed over BEFORE the last backward kernel had completed on the GPU (event order):
+        # the communication stream reached the segment's start marker earlier than the compute stream reached backward's end
+        early.append(sum(1 for _, e in step.bucket.overlap_log if e.elapsed_time(step.bucket.backward_end) > 0.0))
     step.finish()
-    torch.save({'grads': grads, 'segs': segs, 'p': torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()},
+    torch.save({'grads': grads, 'segs': segs, 'early': early, 'p': torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu()},
                os.path.join(out_dir, 'r%d_%d%s.pt' % (rank, min_bytes, '_mix' if mix else '')))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _ddp_worker(rank, world, port, out_dir, use_ddp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from surface_texture_inpainting_net_amd import functional as SF
+    from surface_texture_inpainting_net_amd import surfacetextureinpaintingnet as S
+    cfg = dict(input_nc=10, output_nc=3, ngf=32, filter_type='edgeconvtransinv', norm='instance', n_blocks=2, n_levels=1,
+               pooling_type='max')
+    torch.manual_seed(11)                                   # same initial weights on both ranks and in both modes
+    net = S.define_G(**cfg).to(DEV)
+    s = make_synthetic_mesh(2500 + 700 * rank, 2, seed=20 + rank, dilations=()).to(DEV)
+    if use_ddp:
+        ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0])
+        loss = SF.masked_l1_loss(ddp(s), s.color, s.mask, True)
+        loss.backward()
+        torch.cuda.synchronize()
+        grad = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+    else:
+        step = TrainStep(net, lr=1e-3)
+        loss = step.forward_backward(s, 1.0 / world)
+        step.bucket.all_reduce(step.group)
+        torch.cuda.synchronize()
+        grad = step.bucket.flat.clone().cpu()
+        step.finish()
+    torch.save({'grad': grad, 'loss': float(loss)}, os.path.join(out_dir, '%s%d.pt' % ('ddp' if use_ddp else 'ts', rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_distributed_data_parallel_wrapper_equals_the_flat_bucket_step(tmp_path):
+    """`torch.nn.parallel.DistributedDataParallel(model)` - how the reference's only multi-GPU user wraps its
+    model (trainers/segmentation_trainer.py:34-35) - also works around this build's model: two ranks (gloo, both on cuda:0),
+    unequal scenes; DDP's averaged gradients equal TrainStep's flat-bucket all-reduce bit for bit (two ranks: (a + b) / 2 ==
+    a / 2 + b / 2 in binary floating point), and both ranks hold the same gradients.  Under DDP the blocks stay on one stream
+    (its reducer hooks read a gradient as soon as autograd produces it)."""
+    import torch.multiprocessing as mp
+    for use_ddp in (True, False):
+        mp.spawn(_ddp_worker, args=(2, _free_port(), str(tmp_path), use_ddp), nprocs=2, join=True)
+    ddp = [torch.load(tmp_path / ('ddp%d.pt' % r)) for r in range(2)]
+    ts = [torch.load(tmp_path / ('ts%d.pt' % r)) for r in range(2)]
+    assert torch.equal(ddp[0]['grad'], ddp[1]['grad']) and torch.equal(ts[0]['grad'], ts[1]['grad'])
+    assert float(ddp[0]['grad'].abs().max()) > 0
+    assert torch.equal(ddp[0]['grad'], ts[0]['grad'])
+    assert ddp[0]['loss'] == ts[0]['loss'] and ddp[1]['loss'] == ts[1]['loss']
 
 
 @pytest.mark.gpu
@@ -246,6 +301,10 @@ def test_segmented_allreduce_during_backward_equals_the_single_tail_allreduce(tm
         res[min_bytes] = [torch.load(tmp_path / ('r%d_%d.pt' % (r, min_bytes))) for r in range(2)]
     assert res[0][0]['segs'] == [0, 0, 0]
     assert res[256 << 10][0]['segs'][1] >= 2, 'segments are learned from the first step and used from the second on'
+    # round 4: through the ONE-node backward (functional.NetFn / stin_net_bwd) the segments are launched behind per-block events
+    # recorded inside the C call - at least two of them before the call's last kernel has completed on the GPU
+    for r in range(2):
+        assert res[256 << 10][r]['early'][1] >= 2 and res[256 << 10][r]['early'][2] >= 2, res[256 << 10][r]['early']
     for r in range(2):
         for a, b in zip(res[0][r]['grads'], res[256 << 10][r]['grads']):
             assert torch.equal(a, b)                      # two ranks: a + b is order-independent -> bit-identical
