@@ -12,6 +12,7 @@ def main():
     ap.add_argument('trace')
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--marker', default='k_adam')   # (matches k_adam and k_adam4: one launch per step)
+    ap.add_argument('--context', type=float, default=0.0, help='print the kernels around every idle gap longer than this many us (last step)')
     a = ap.parse_args()
     rows = []
     for r in csv.DictReader(open(a.trace)):
@@ -44,6 +45,23 @@ def main():
     print('idle time by the kernel that follows the gap (ms/step, gaps/step, avg us):')
     for k, v in gaps.most_common(14):
         print('  %-62s %.3f  %5.1f  %.1f' % (k, v / n / 1e6, gap_n[k] / n, v / gap_n[k] / 1e3))
+    if a.context > 0:
+        context(rows, marks[-2] + 1, marks[-1] + 1, a.context)
+
+
+def context(rows, lo, hi, min_us):
+    def nm(n):
+        n = re.sub(r'^void |\(anonymous namespace\)::|at::native::', '', n)
+        return re.sub(r'\(.*', '', n)[:48]
+    seg = rows[lo:hi]
+    t0, cur_end = seg[0][0], seg[0][0]
+    for i, (s, e, name, q) in enumerate(seg):
+        if s > cur_end and (s - cur_end) / 1e3 >= min_us:
+            print('--- gap %.1f us at +%.3f ms' % ((s - cur_end) / 1e3, (cur_end - t0) / 1e6))
+            for j in range(max(0, i - 4), min(len(seg), i + 3)):
+                ss, ee, n2, q2 = seg[j]
+                print('   %s +%.3f ms  %7.1f us  q%-3s %s' % ('>>' if j == i else '  ', (ss - t0) / 1e6, (ee - ss) / 1e3, q2, nm(n2)))
+        cur_end = max(cur_end, e)
 
 
 if __name__ == '__main__':

@@ -3,7 +3,6 @@
 // Contract: include/stin_hip.h.  All of these are HBM-streaming kernels: 16-byte loads,
 // one pass over [N, C] per call.
 #include "stin_common.h"
-#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -165,199 +164,6 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce(const T* __restrict__ x, in
             }
         }
         __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 4: ONE launch per column reduction (k_colreduce_t).  The two-stage form above writes [chunks][2][C] fp64 partials
-// (2.3 MB at 18 063 x 256) and needs a second launch (k_colreduce_final / k_moments_final: 7-9 us each, 32 per training step)
-// to fold them.  Here the grid is (row chunks R) x (64-column groups) x (ranges B): a block reduces its rows for ITS 64 columns
-// (16 column lanes x float4, 16 row lanes; rows ascending per thread, fp64), writes one [2][64] partial and takes a ticket of
-// its (range, column group); the block whose ticket is the last one folds that group's R partials in a fixed order (r
-// ascending within four interleaved sub-sums, then the four in order) and applies the post-op - same final arithmetic as
-// k_colreduce_final / k_moments_final.  Deterministic: which block arrives last changes who does the fold, never its order.
-// Cross-block visibility (MI355X_MICROARCH.md, "Valid forms"): plain partial stores -> every wave's s_waitcnt vmcnt(0) ->
-// barrier -> lane 0: agent-scope release fence + vmcnt(0) -> relaxed agent-scope atomic add (the ticket); the last arriver:
-// agent-scope acquire fence + vmcnt(0) -> barrier -> plain loads.  The ticket words live in a zero-initialised __device__
-// array of the code object (no allocation): the folding block resets its word, and every launch takes the next of
-// RED_SLOTS slot rows, so launches in flight on different streams never share a word.
-constexpr int RED_GC = 64;                 // columns per block
-constexpr int RED_SLOTS = 256, RED_WORDS = 512;
-__device__ unsigned int g_red_tickets[RED_SLOTS][RED_WORDS];
-
-template <typename T, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_colreduce_t(const T* __restrict__ x, int64_t ldx, const T* __restrict__ gout, int64_t ldg,
-                                                       int64_t N, int C, const int32_t* __restrict__ ptr,
-                                                       const int32_t* __restrict__ gid, const int32_t* __restrict__ sid,
-                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       const float* __restrict__ coef, double* __restrict__ partial, int slot,
-                                                       int post, const float* __restrict__ inv_cnt, float eps,
-                                                       float* __restrict__ out0, float* __restrict__ out1) {
-    constexpr bool DOT_BN = (MODE == STIN_RED_DOT_BN || MODE == STIN_RED_DOT_BN_RELU);
-    constexpr int NOUT = (MODE == STIN_RED_DOT_ELU || MODE == STIN_RED_MOMENTS || DOT_BN) ? 2 : 1;
-    constexpr int VW = 4, CL = RED_GC / VW, RLN = BLOCK / CL;                     // 16 column lanes, 16 row lanes
-    __shared__ double sm[NOUT][RLN][RED_GC + 1];
-    __shared__ int last_s;
-    const int r = blockIdx.x, R = gridDim.x, cg = blockIdx.y, ncg = gridDim.y, b = blockIdx.z;
-    const int64_t r0 = ptr != nullptr ? ptr[b] : 0;
-    const int64_t r1 = ptr != nullptr ? ptr[b + 1] : N;
-    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
-    const int c = cg * RED_GC + cl * VW;
-    const bool live = c < C;                                                      // (C % 4 == 0: a float4 is in or out)
-    double acc0[VW], acc1[VW];
-#pragma unroll
-    for (int i = 0; i < VW; ++i) { acc0[i] = 0.0; acc1[i] = 0.0; }
-    if (live) {
-        constexpr int UR = 4;                                                      // rows in flight per thread
-        const int64_t step = (int64_t)R * RLN;
-        for (int64_t rb = r0 + (int64_t)r * RLN + rl; rb < r1; rb += UR * step) {
-            V<VW> xv[UR], go[UR];
-            int gq[UR], sq[UR];
-            bool ok[UR];
-#pragma unroll
-            for (int u = 0; u < UR; ++u) {
-                const int64_t row = rb + u * step;
-                ok[u] = row < r1;
-                const int64_t rc = ok[u] ? row : rb;
-                xv[u] = V<VW>::load(x + rc * ldx + c);
-                if (MODE == STIN_RED_DOT_ELU || DOT_BN) go[u] = V<VW>::load(gout + rc * ldg + c);
-                gq[u] = (MODE != STIN_RED_SUM && MODE != STIN_RED_MOMENTS && gid != nullptr) ? gid[rc] : 0;
-                sq[u] = (MODE == STIN_RED_COEF_XC && sid != nullptr) ? sid[rc] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < UR; ++u) {
-                if (!ok[u]) continue;
-                if (MODE == STIN_RED_SUM) {
-#pragma unroll
-                    for (int i = 0; i < VW; ++i) acc0[i] += (double)xv[u].v[i];
-                } else if (MODE == STIN_RED_MOMENTS) {
-#pragma unroll
-                    for (int i = 0; i < VW; ++i) {
-                        const double d = (double)xv[u].v[i];
-                        acc0[i] += d;
-                        acc1[i] += d * d;
-                    }
-                } else {
-                    const int g = gq[u];
-                    const V<VW> mu = V<VW>::load(mean + (int64_t)g * C + c);
-                    if (DOT_BN) {
-                        const V<VW> rs = V<VW>::load(rstd + c);
-                        const V<VW> ga = V<VW>::load(coef + c);
-                        const V<VW> be = V<VW>::load(coef + C + c);
-#pragma unroll
-                        for (int i = 0; i < VW; ++i) {
-                            const float n = (xv[u].v[i] - mu.v[i]) * rs.v[i];
-                            const float d = (MODE == STIN_RED_DOT_BN_RELU && !(ga.v[i] * n + be.v[i] > 0.f)) ? 0.f : go[u].v[i];
-                            acc0[i] += (double)(d * n);
-                            acc1[i] += (double)d;
-                        }
-                    } else if (MODE == STIN_RED_CSQ) {
-#pragma unroll
-                        for (int i = 0; i < VW; ++i) { const float d = xv[u].v[i] - mu.v[i]; acc0[i] += (double)(d * d); }
-                    } else if (MODE == STIN_RED_DOT_ELU) {
-                        const V<VW> rs = V<VW>::load(rstd + (int64_t)g * C + c);
-#pragma unroll
-                        for (int i = 0; i < VW; ++i) {
-                            const float xc = xv[u].v[i] - mu.v[i];
-                            const float dy = go[u].v[i] * elu_grad_from_pre(xc * rs.v[i]);
-                            acc0[i] += (double)(dy * xc);
-                            acc1[i] += (double)dy;
-                        }
-                    } else {  // STIN_RED_COEF_XC
-                        const V<VW> cf = V<VW>::load(coef + (int64_t)sq[u] * C + c);
-#pragma unroll
-                        for (int i = 0; i < VW; ++i) acc0[i] += (double)(cf.v[i] * (xv[u].v[i] - mu.v[i]));
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < VW; ++i) {
-        sm[0][rl][cl * VW + i] = acc0[i];
-        if (NOUT == 2) sm[NOUT - 1][rl][cl * VW + i] = acc1[i];
-    }
-    __syncthreads();
-    // partial of this block: [b][cg][r][o][64]
-    double* pg = partial + (((int64_t)b * ncg + cg) * R) * (NOUT * RED_GC);
-    if (threadIdx.x < NOUT * RED_GC) {
-        const int o = threadIdx.x / RED_GC, cc = threadIdx.x % RED_GC;
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < RLN; ++k) t += sm[o][k][cc];
-        pg[(int64_t)r * (NOUT * RED_GC) + o * RED_GC + cc] = t;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned int* word = &g_red_tickets[slot][b * ncg + cg];
-        const unsigned int t = __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (t == (unsigned int)(R - 1)) ? 1 : 0;
-        if (last) {
-            __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // ready for the slot's next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        last_s = last;
-    }
-    __syncthreads();
-    if (!last_s) return;
-    // ---- the fold: thread (part, column) sums r = part, part + 4, ... ; then the four parts in order
-    constexpr int PARTS = BLOCK / RED_GC;                                         // 4
-    const int cc = threadIdx.x % RED_GC, part = threadIdx.x / RED_GC;
-    double f[NOUT];
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) f[o] = 0.0;
-    for (int k0 = part; k0 < R; k0 += 8 * PARTS) {
-        double v[NOUT][8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u * PARTS;
-            const int kc = k < R ? k : part;
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) v[o][u] = pg[(int64_t)kc * (NOUT * RED_GC) + o * RED_GC + cc];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (k0 + u * PARTS < R) {
-#pragma unroll
-                for (int o = 0; o < NOUT; ++o) f[o] += v[o][u];
-            }
-    }
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) sm[o][part][cc] = f[o];
-    __syncthreads();
-    const int col = cg * RED_GC + cc;
-    if (part == 0 && col < C) {
-        double t[NOUT];
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-            t[o] = 0.0;
-#pragma unroll
-            for (int k = 0; k < PARTS; ++k) t[o] += sm[o][k][cc];
-        }
-        if (MODE == STIN_RED_MOMENTS) {                                           // as k_moments_final
-            const double ic = (double)inv_cnt[b];
-            const double mu = t[0] * ic;
-            double var = t[NOUT - 1] * ic - mu * mu;
-            if (var < 0.0) var = 0.0;
-            out0[(int64_t)b * C + col] = (float)mu;
-            out1[(int64_t)b * C + col] = (float)(1.0 / sqrt(var + (double)eps));
-        } else {
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) {                                      // as k_colreduce_final
-                float rr = (float)t[o];
-                if (post == STIN_POST_SCALE) rr = rr * inv_cnt[b];
-                else if (post == STIN_POST_RSTD) rr = 1.0f / sqrtf(rr * inv_cnt[b] + eps);
-                else if (post == STIN_POST_NORM_COEF) {
-                    const float rs = rstd[(int64_t)b * C + col], ic = inv_cnt[b];
-                    rr = (o == 0) ? -(rs * rs * rs) * rr * ic : -(rs * rr) * ic;
-                }
-                (o == 0 ? out0 : out1)[(int64_t)b * C + col] = rr;
-            }
-        }
     }
 }
 
@@ -685,41 +491,6 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
 
     const bool vec = vec4_ok<T>(C, {x, gout}, {mean, rstd, coef}, {ldx, gout ? ldg : 0});
     if (!vec && !is_f32((const T*)nullptr)) return STIN_E_UNSUPPORTED;
-    // one-launch form (k_colreduce_t): 16-byte rows, few enough (range, column group) pairs for one row of ticket words;
-    // STIN_RED_TICKET=0 keeps the two-launch form (A/B switch, read once)
-    static const bool ticket_on = !(getenv("STIN_RED_TICKET") && atoi(getenv("STIN_RED_TICKET")) == 0);
-    const int ncg = (C + RED_GC - 1) / RED_GC;
-    if (vec && ticket_on && (int64_t)B * ncg <= RED_WORDS && N > 0) {
-        static std::atomic<unsigned> seq{0};
-        const int slot = (int)(seq.fetch_add(1, std::memory_order_relaxed) % RED_SLOTS);
-        // row chunks: ~128 rows per block, at most ~2 blocks per CU over all column groups and ranges, and within the workspace
-        int64_t R = (N / B + 127) / 128;
-        static const int n_cu = [] {
-            int dev = 0, v = 0;
-            return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-        }();
-        const int64_t cap = (2 * (int64_t)n_cu + (int64_t)B * ncg - 1) / ((int64_t)B * ncg);
-        if (R > cap) R = cap;
-        // partial [B][ncg][R][2][64] doubles must fit the caller's workspace of max(B, MAX_SLABS) x 2 x C doubles
-        const int64_t ws_cap = (int64_t)(B > MAX_SLABS ? B : MAX_SLABS) * C / ((int64_t)ncg * RED_GC);
-        if (R > ws_cap / B) R = ws_cap / B;
-        if (R < 1) R = 1;
-        dim3 grid((unsigned)R, (unsigned)ncg, (unsigned)B);
-#define STIN_REDT_LAUNCH(M)                                                                                              \
-        hipLaunchKernelGGL((k_colreduce_t<T, M>), grid, dim3(BLOCK), 0, stream, x, ldx, gout, ldg, N, C, ptr, gid, sid, mean, rstd, coef, \
-                           partial, slot, post, inv_cnt, eps, out0, out1)
-        switch (mode) {
-            case STIN_RED_SUM: STIN_REDT_LAUNCH(STIN_RED_SUM); break;
-            case STIN_RED_CSQ: STIN_REDT_LAUNCH(STIN_RED_CSQ); break;
-            case STIN_RED_DOT_ELU: STIN_REDT_LAUNCH(STIN_RED_DOT_ELU); break;
-            case STIN_RED_MOMENTS: STIN_REDT_LAUNCH(STIN_RED_MOMENTS); break;
-            case STIN_RED_DOT_BN: STIN_REDT_LAUNCH(STIN_RED_DOT_BN); break;
-            case STIN_RED_DOT_BN_RELU: STIN_REDT_LAUNCH(STIN_RED_DOT_BN_RELU); break;
-            default: STIN_REDT_LAUNCH(STIN_RED_COEF_XC); break;
-        }
-#undef STIN_REDT_LAUNCH
-        return stin_launch_status();
-    }
     const int VW = vec ? 4 : 1;
     const int CV = C / VW;
     const int CG = CV < BLOCK ? CV : BLOCK;
