@@ -1,4 +1,5 @@
 // Profiling harness (not part of the library): the all-columns NT kernel compiled with in-kernel s_memtime stamps.
+//   (add -DSTIN_NT_ABLATE_MASK=<bits> for a compile-time ablation of the panel kernel, see stin_gemm.hip)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DSTIN_NT_STAMPS -I surface_texture_inpainting_net_amd/csrc \
 //       -c profiles/nt_stamps.hip -o /tmp/nt_stamps.o && hipcc --offload-arch=gfx950 /tmp/nt_stamps.o <stin_wgrad.o stin_pack.o stin_api.o> -o profiles/_nt_stamps
 #include "../surface_texture_inpainting_net_amd/csrc/stin_gemm.hip"
@@ -27,8 +28,7 @@ int main(int argc, char** argv) {
     hipMalloc(&stamps, nblk * 8 * 32 * 8);
     hipMemset(stamps, 0, nblk * 8 * 32 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(stin_nt_stamp_buf), &stamps, sizeof(stamps));
-    const int ablate = argc > 5 ? atoi(argv[5]) : 0;
-    hipMemcpyToSymbol(HIP_SYMBOL(stin_nt_ablate), &ablate, sizeof(ablate));
+    printf("ablation mask %d\n", (int)STIN_NT_ABLATE_MASK);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);

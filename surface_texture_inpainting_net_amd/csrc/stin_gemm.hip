@@ -689,8 +689,13 @@ __device__ unsigned long long* stin_nt_stamp_buf = nullptr;
             stin_nt_stamp_buf[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #define NT_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-__device__ int stin_nt_ablate = 0;     // 1: second row group re-reads W step 0, 2: every wave does, 4: A loads re-read chunk 0, 8: no split/LDS store
-#define NT_ABLATE(bit) (stin_nt_ablate & (bit))
+// compile-time ablation mask of the panel kernel (profiles/nt_stamps.hip builds one binary per mask; a run-time flag inside
+// the loop perturbs the code it measures): 1 second row group re-reads W step 0, 2 every wave does, 4 A loads re-read chunk 0,
+// 8 no split / LDS store, 16 no A-fragment LDS reads after the chunk's first, 32 no per-chunk barrier, 64 no MFMAs
+#ifndef STIN_NT_ABLATE_MASK
+#define STIN_NT_ABLATE_MASK 0
+#endif
+#define NT_ABLATE(bit) ((STIN_NT_ABLATE_MASK) & (bit))
 #else
 #define NT_ABLATE(bit) 0
 #define NT_STAMP(i)
@@ -1115,13 +1120,17 @@ __global__ __launch_bounds__(512) void k_gemm_nt_panel(const float* __restrict__
                 for (int i = 0; i < MT; ++i) {
                     nh[i] = ch[i];
                     nl[i] = cl[i];
-                    if (j + 1 < WD_STEPS) {
+                    if (j + 1 < WD_STEPS && !NT_ABLATE(16)) {
                         nh[i] = *reinterpret_cast<const vec8*>(ab + (j + 1) * STEP_BYTES + i * 1024);
                         nl[i] = *reinterpret_cast<const vec8*>(ab + PLANE + (j + 1) * STEP_BYTES + i * 1024);
                     }
-                    acc[i] = mfma_k16(ch[i], b1, acc[i]);
-                    acc[i] = mfma_k16(cl[i], b0, acc[i]);
-                    acc[i] = mfma_k16(ch[i], b0, acc[i]);
+                    if (!NT_ABLATE(64)) {
+                        acc[i] = mfma_k16(ch[i], b1, acc[i]);
+                        acc[i] = mfma_k16(cl[i], b0, acc[i]);
+                        acc[i] = mfma_k16(ch[i], b0, acc[i]);
+                    } else {
+                        acc[i][0] += (float)ch[i][0] + (float)cl[i][0] + (float)b0[0] + (float)b1[0];
+                    }
                     if (j < 2) {
                         const int slot = j * MT + i;
 #pragma unroll
@@ -1147,7 +1156,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_panel(const float* __restrict__
                 }
                 wf[j] = st_wload(wb + (int64_t)((NT_ABLATE(2) || (NT_ABLATE(1) && q)) ? 0 : nxt + j) * 2048, lane_off);
             }
-            __syncthreads();
+            if (!NT_ABLATE(32)) __syncthreads();
             NT_STAMP(2 + (c < 26 ? c : 26));
         }
         if (tid < BM) mask_s[tid] = mask_r;                                     // (behind the last chunk's barrier: the buffers are idle)
