@@ -482,14 +482,17 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd8(const stin_bf16* __restrict
     const int sh = ((threadIdx.x & 63) / G) * G;          // bit position of this row inside the wave ballots
     const int su = L.lg / LPS, sp = L.lg % LPS;           // neighbour / 16-byte part this lane stores
     for (int e = beg; e < end; e += U) {
-        F8 b[U][VPL];
+        // (round 4) the U neighbour rows in flight stay PACKED (4 registers per 8 channels, widened at use): half the
+        // registers of the widened form, so more rows in flight at the same occupancy
+        uint4 braw[U][VPL];
         uint4 mw[VPL];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ee = min(e + u, end - 1);
             const int64_t j = col[ee];
 #pragma unroll
-            for (int k = 0; k < VPL; ++k) b[u][k] = on[k] ? ld8(B + j * ldb + L.chan(k)) : f8zero();
+            for (int k = 0; k < VPL; ++k)
+                braw[u][k] = on[k] ? *reinterpret_cast<const uint4*>(B + j * ldb + L.chan(k)) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -499,9 +502,11 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd8(const stin_bf16* __restrict
                 uint32_t wd[WK];
 #pragma unroll
                 for (int q = 0; q < WK; ++q) wd[q] = 0u;
+                const uint32_t rw[4] = {braw[u][k].x, braw[u][k].y, braw[u][k].z, braw[u][k].w};
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float t = a[k].v[c] + b[u][k].v[c];
+                    const float bv = __uint_as_float((c & 1) ? (rw[c >> 1] & 0xffff0000u) : (rw[c >> 1] << 16));
+                    const float t = a[k].v[c] + bv;
                     acc[k].v[c] += w * fmaxf(t, 0.f);
                     if (mask != nullptr) {
                         const unsigned long long bc = __ballot(t > 0.f);
@@ -702,6 +707,8 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_pair8(const stin_bf16* 
 // 8 waves per SIMD resident (<= 64 VGPRs) rather than deep per-wave unrolling - U = 2 (71 vs 98 us at U = 4 for the
 // level-0 forward, 48 vs 104 us at U = 6 for the level-1 backward), U = 1 once a lane holds 2 or 4 chunks; the
 // streaming dA kernel keeps U = 6 / 3 / 3 / 2 / 1.
+#define STIN_FWD8_U_SMALL 2      /* H <= 512 (one 16-byte chunk per lane) */
+#define STIN_FWD8_U_BIG 1        /* H = 1024 / 2048 (2 / 4 chunks per lane) */
 #define STIN_L8(KERNEL_, G_, V_, U_, grid_, ...) hipLaunchKernelGGL((KERNEL_<G_, V_, U_>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__)
 #define STIN_DISPATCH8(H_, KERNEL, U16_, U32_, U64_, U64X2_, U64X4_, ...)                                            \
     do {                                                                                                             \
@@ -1112,7 +1119,19 @@ int edge_fwd_impl(const T* A, int64_t lda, const T* B, int64_t ldb, const int32_
         const bool wide = wide8_ok(H, {A, B, out}, {lda, ldb, ldo});
         STIN_REQUIRE(mask == nullptr || wide, STIN_E_ALIGN);
         if (wide) {
-            STIN_DISPATCH8(H, k_edge_fwd8, 2, 2, 2, 1, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+            // rows in flight per lane group: tuning aid STIN_EDGE8_U = "u16,u32,u64,u64x2,u64x4" digits, e.g. 44422 (re-read per call)
+            const char* eu = getenv("STIN_EDGE8_U");
+            const int cfg = eu ? atoi(eu) : 0;
+            auto pick = [&](int pos, int dflt) { int d = cfg; for (int i = 0; i < 4 - pos; ++i) d /= 10; d %= 10; return (cfg > 0 && d > 0) ? d : dflt; };
+            const int hsel = H == 128 ? 0 : H == 256 ? 1 : H == 512 ? 2 : H == 1024 ? 3 : 4;
+            const int u = pick(hsel, hsel <= 2 ? STIN_FWD8_U_SMALL : STIN_FWD8_U_BIG);
+#define STIN_FWD8(U_) STIN_DISPATCH8(H, k_edge_fwd8, U_, U_, U_, U_, U_, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask)
+            if (u == 1) STIN_FWD8(1);
+            else if (u == 2) STIN_FWD8(2);
+            else if (u == 3) STIN_FWD8(3);
+            else if (u == 4) STIN_FWD8(4);
+            else STIN_FWD8(6);
+#undef STIN_FWD8
             return stin_launch_status();
         }
     }

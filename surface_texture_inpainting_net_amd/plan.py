@@ -224,6 +224,27 @@ class PoolMap:
         return tuple(t for t in (c.rowptr, c.col, c.perm, c.inv_deg, self.trace) if t is not None)
 
 
+_INV_COUNT = collections.OrderedDict()
+
+
+def _inv_count_const(device, n_rows):
+    """The 1-element device tensor 1 / n_rows of a single-graph norm, from a small per-device LRU: a plan is built for every
+    sample, its levels usually repeat the sizes of earlier ones, and torch.full was one framework fill kernel per level and step
+    (4 of the 7 fills of a headline step).  Read-only for every consumer."""
+    if device.type == 'cuda' and _capturing():             # (a capture's allocations belong to the graph's private pool)
+        return torch.full((1,), 1.0 / max(int(n_rows), 1), dtype=torch.float32, device=device)
+    key = (device.type, device.index, int(n_rows))
+    t = _INV_COUNT.get(key)
+    if t is None:
+        t = torch.full((1,), 1.0 / max(int(n_rows), 1), dtype=torch.float32, device=device)
+        _INV_COUNT[key] = t
+        while len(_INV_COUNT) > 256:
+            _INV_COUNT.popitem(last=False)
+    else:
+        _INV_COUNT.move_to_end(key)
+    return t
+
+
 class NormGroups:
     """Row groups for the per-graph instance norm at one level.
 
@@ -239,7 +260,7 @@ class NormGroups:
         if batch is None:
             self.B = 1
             self.gid = self.sid = self.ptr_sum = self.ptr_true = None
-            self.inv_cnt = torch.full((1,), 1.0 / max(n_rows, 1), dtype=torch.float32, device=device)
+            self.inv_cnt = _inv_count_const(device, n_rows)
             self.quirk = False
             return
         B = int(counts.numel())
