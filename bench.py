@@ -91,7 +91,7 @@ def pmc_traffic_bytes(kernel, n, e, h):
         return None
     table = json.load(open(files[-1]))
     hits = [v for k, v in table.items() if k.startswith(prefix) or k.startswith(prefix.replace('k_edge_fwd<', 'k_edge_fwd_exact<'))]
-    return hits[0]['hbm_MB_per_launch'] * 1e6 if hits else None
+    return (hits[0].get('fabric_MB_per_launch') or hits[0].get('hbm_MB_per_launch')) * 1e6 if hits else None     # (round <= 3 files: hbm_* keys)
 
 
 def scatter_add_standalone(device, n=200_000, e=1_200_000, c=64, iters=30):
@@ -239,9 +239,23 @@ def hbm_honest_edge_kernel(device, n=1_000_000, e=6_000_000, h=128, iters=10):
     torch.cuda.synchronize()
     dt = a.elapsed_time(b) * 1e-3 / iters
     nbytes = edge_bytes('stin_edge_relu_mean_fwd_f32', n, e, h)
-    return {'kernel': 'stin_edge_relu_mean_fwd_f32[N=%d,E=%d,H=%d]' % (n, e, h), 'us': dt * 1e6, 'algorithmic_MB': nbytes / 1e6,
-            'GBps': nbytes / dt / 1e9, 'frac_of_hbm_peak': nbytes / dt / 1e9 / HBM_PEAK_GBS,
-            'note': 'gathered operand 512 MB > 256 MB Infinity Cache: served by HBM (random graph, fp32 rows)'}
+    out = {'kernel': 'stin_edge_relu_mean_fwd_f32[N=%d,E=%d,H=%d]' % (n, e, h), 'us': dt * 1e6, 'algorithmic_MB': nbytes / 1e6,
+           'GBps': nbytes / dt / 1e9, 'frac_of_hbm_peak': nbytes / dt / 1e9 / HBM_PEAK_GBS,
+           'note': 'gathered operand 512 MB > 256 MB Infinity Cache: served by HBM (random graph, fp32 rows)'}
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if files and (n, e, h) == (1_000_000, 6_000_000, 128):
+        ent = json.load(open(files[-1])).get('N1000000:k_edge_fwd_exact<float, 32, 1, 6>')
+        if ent:
+            fab = ent['fabric_MB_per_launch'] * 1e6
+            out['traffic'] = fab
+            out['traffic_over_algorithmic'] = fab / (nbytes + e * h / 8.0)
+            out['traffic_unit'] = ('FABRIC bytes per launch ((2*FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 PMC, REPLAYED from %s - not measured in '
+                                   'this run); the counters sit on the L2\'s memory side and include Infinity-Cache hits, so the HBM-served '
+                                   'share cannot be separated with them: with a 512 MB gathered operand, random row order and a 256 MB '
+                                   'cache at most half of the gathered rows can hit; fabric bytes = %.3f x (algorithmic + mask) bytes, '
+                                   'i.e. no reuse is captured in L2' % (os.path.basename(files[-1]), fab / (nbytes + e * h / 8.0)))
+    return out
 
 
 def irregular_edge_kernel(device, n0=200_000, h=128, iters=20):

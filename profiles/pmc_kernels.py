@@ -17,6 +17,23 @@ from surface_texture_inpainting_net_amd.plan import build_csr, plan_for  # noqa:
 from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh  # noqa: E402
 
 dev = torch.device('cuda:0')
+# PMC_VERTICES=1000000: the 1 M-vertex / 6 M-edge size of bench.py's `hbm_honest` (gathered operand 512 MB > Infinity Cache), forward
+# and one-launch backward only
+NV = int(os.environ.get('PMC_VERTICES', '200000'))
+if NV != 200_000:
+    g0 = torch.Generator().manual_seed(1)
+    from surface_texture_inpainting_net_amd.plan import EdgeSet  # noqa: E402
+    ei = torch.randint(0, NV, (2, 6 * NV), generator=g0).to(dev)
+    e = EdgeSet(ei, NV, torch.zeros(1, dtype=torch.int32, device=dev))
+    H = 128
+    A, B, G = (torch.randn(NV, H, device=dev) for _ in range(3))
+    out, out2 = torch.empty(NV, H + 4, device=dev), torch.empty(NV, H, device=dev)
+    mask = torch.empty(6 * NV * (H // 32), dtype=torch.int32, device=dev)
+    for _ in range(4):
+        SF.edge_relu_mean_fwd(A, B, e.by_dst, out, indicator=True, mask=mask)
+        SF.edge_relu_mean_bwd_mask(G, mask, e, out[:, :H], out2)
+    torch.cuda.synchronize()
+    sys.exit(0)
 s = make_synthetic_mesh(200_000, 1, seed=0, dilations=()).to(dev)
 plan = plan_for(s)
 e = plan.edges('edge_index', 0)

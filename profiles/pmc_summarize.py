@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""usage: pmc_summarize.py <fetch counter_collection.csv> <write counter_collection.csv> > profiles/rNN_pmc_traffic.json
-HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB, and on gfx950
-FETCH_SIZE reports exactly half of a wide (16 B/lane) coalesced read stream (MI355X_MICROARCH.md §HBM)."""
+"""usage: pmc_summarize.py <fetch counter_collection.csv> <write counter_collection.csv> [key prefix] > profiles/rNN_pmc_traffic.json
+FABRIC bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB and count the L2's memory-side
+requests - Infinity-Cache hits included, so this is traffic on the fabric, not HBM traffic proper; on gfx950 FETCH_SIZE reports
+exactly half of a wide (16 B/lane) coalesced read stream (MI355X_MICROARCH.md §HBM).  (Round 4: the keys were called hbm_* before.)"""
 import collections
 import csv
 import json
@@ -31,12 +32,13 @@ def main():
     f = per_kernel(sys.argv[1], 'FETCH_SIZE')
     w = per_kernel(sys.argv[2], 'WRITE_SIZE')
     out = {}
+    prefix = sys.argv[3] if len(sys.argv) > 3 else ''
     for k in sorted(set(f) & set(w)):
         if not k.startswith('k_'):
             continue
-        out[k] = {'FETCH_SIZE_KiB': f[k], 'WRITE_SIZE_KiB': w[k],
-                  'hbm_read_MB_corrected': 2 * f[k] * 1024 / 1e6, 'hbm_write_MB': w[k] * 1024 / 1e6,
-                  'hbm_MB_per_launch': (2 * f[k] + w[k]) * 1024 / 1e6}
+        out[prefix + k] = {'FETCH_SIZE_KiB': f[k], 'WRITE_SIZE_KiB': w[k],
+                           'fabric_read_MB_corrected': 2 * f[k] * 1024 / 1e6, 'fabric_write_MB': w[k] * 1024 / 1e6,
+                           'fabric_MB_per_launch': (2 * f[k] + w[k]) * 1024 / 1e6}
     json.dump(out, sys.stdout, indent=1)
 
 
