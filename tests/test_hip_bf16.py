@@ -258,8 +258,12 @@ def test_bf16_network_is_deterministic_and_trains():
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
 
 
-def test_bf16_training_curve_tracks_fp32():
-    """200 Adam steps (lr 5e-5) of the shipped 3-D config on a 20 164-vertex mesh with a smooth (learnable) colour field and
+@pytest.mark.parametrize('seed', [3, 4, 5])
+@pytest.mark.parametrize('shape', ['scene', 'crops'])
+def test_bf16_training_curve_tracks_fp32(shape, seed):
+    """(round 4: three initialisation seeds, and BASELINE config 3's shape - batches of 8 unequal crops, 4 graph levels, per-graph
+    instance norm with the linspace slices - beside the single scene.)
+    200 Adam steps (lr 5e-5) of the shipped 3-D config on a 20 164-vertex mesh with a smooth (learnable) colour field and
     four hole masks, same initial weights and data order: bf16 storage against fp32 storage, with fp32 storage + exact-fp32
     GEMMs as the CONTROL (two fp32 evaluation orders drift apart too - the network's decisions amplify any perturbation, see
     tests/tools/bf16_design_probe.py).  Measured on MI355X: control +1.0 % / +1.9 %, bf16 +2.1 % / +0.1 % (seeds 3 / 4) in the
@@ -271,16 +275,25 @@ def test_bf16_training_curve_tracks_fp32():
                                                                                     'bf16_training_curve.py'))
     tool = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tool)
-    samples = [s.to(DEV) for s in tool.learnable_samples(20_000)]
-    curves = {m: tool.curve(samples, 200, m, seed=3, lr=5e-5) for m in ('f32', 'f32-exact-gemm', 'bf16')}
+    if shape == 'scene':
+        samples, cfg = [s.to(DEV) for s in tool.learnable_samples(20_000)], None
+    else:
+        samples, cfg = [s.to(DEV) for s in tool.learnable_crop_batches()], dict(tool.CFG, n_levels=3)
+    curves = {m: tool.curve(samples, 200, m, seed=seed, lr=5e-5, cfg=cfg) for m in ('f32', 'f32-exact-gemm', 'bf16')}
     head = {m: float(c[:50].mean()) for m, c in curves.items()}
     tail = {m: float(c[-50:].mean()) for m, c in curves.items()}
-    print('\nmean loss steps 0-49 %s\nmean loss steps 150-199 %s' % (head, tail))
+    print('\n%s seed %d: mean loss steps 0-49 %s\nmean loss steps 150-199 %s' % (shape, seed, head, tail))
     assert all(bool(torch.isfinite(c).all()) for c in curves.values())
-    assert tail['f32'] < 0.25 * head['f32'], 'the task must actually train'
-    assert abs(head['bf16'] - head['f32']) <= 1e-2 * head['f32']
-    assert abs(tail['bf16'] - tail['f32']) <= 4e-2 * tail['f32']
-    assert abs(tail['f32-exact-gemm'] - tail['f32']) <= 4e-2 * tail['f32'], 'control drifted: the bar above is not meaningful'
+    # Measured on MI355X, round 4 (tail = mean loss of steps 150-199, relative to fp32 storage):
+    #   scene  seeds 3 / 4 / 5: bf16 +2.9 % / +1.1 % / +3.3 %, control (exact-fp32 GEMMs) +2.6 % / -0.6 % / -2.5 %, head <= 0.3 %
+    #   crops  seeds 3 / 4 / 5: bf16 -6.4 % / -2.6 % / +2.1 %, control -2.9 % / +0.7 % / -3.3 %, head <= 1.2 %
+    # (the crop batches change every step and hold 8 small graphs: a noisier loss, and it falls to 0.32 of its start in 200 steps
+    #  where the single scene reaches 0.17).  Stated bars = bench.py's `dtype_tolerance`.
+    trains, head_bar, tail_bar, ctrl_bar = (0.25, 1e-2, 4e-2, 4e-2) if shape == 'scene' else (0.40, 1.5e-2, 8e-2, 5e-2)
+    assert tail['f32'] < trains * head['f32'], 'the task must actually train'
+    assert abs(head['bf16'] - head['f32']) <= head_bar * head['f32']
+    assert abs(tail['bf16'] - tail['f32']) <= tail_bar * tail['f32']
+    assert abs(tail['f32-exact-gemm'] - tail['f32']) <= ctrl_bar * tail['f32'], 'control drifted: the bar above is not meaningful'
 
 
 def test_bf16_mode_is_refused_for_unsupported_variants():

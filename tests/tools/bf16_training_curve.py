@@ -44,9 +44,36 @@ def learnable_samples(vertices, n_masks=4, seed=11):
     return out
 
 
-def curve(samples, steps, mode, seed=3, lr=2e-4):
+def learnable_crop_batches(n_batches=4, levels=4, seed=21):
+    """BASELINE config 3's shape: batches of 8 unequal crops (1.5-4.5 k vertices each), `levels` graph levels, smooth colour
+    fields and hole masks as in learnable_samples."""
+    from surface_texture_inpainting_net_amd.data import collate
+    rng = np.random.default_rng(seed)
+    out = []
+    for b in range(n_batches):
+        crops = []
+        for i in range(8):
+            n = int(rng.integers(1500, 4500))
+            base = make_synthetic_mesh(n, levels, seed=seed * 100 + b * 8 + i, dilations=(2, 4, 8, 16))
+            p = base.x[:, 6:9] * 1.5
+            rgb = torch.stack([torch.sin(6.0 * p[:, 0] + 2.0 * p[:, 1]), torch.cos(5.0 * p[:, 1] - 3.0 * p[:, 2]),
+                               torch.sin(4.0 * (p[:, 0] + p[:, 2]))], 1) * 0.8
+            centres = p[rng.integers(0, base.x.shape[0], size=4)]
+            hole = (torch.cdist(p, centres).min(1).values < 0.12)
+            known = (~hole).to(base.x.dtype)[:, None]
+            x = base.x.clone()
+            x[:, :3] = rgb * known
+            x[:, 9:10] = known
+            s = type(base)(**{k: base[k] for k in base.keys()})
+            s['x'], s['color'], s['mask'] = x, rgb.to(base.x.dtype), hole.long()[:, None]
+            crops.append(s)
+        out.append(collate(crops))
+    return out
+
+
+def curve(samples, steps, mode, seed=3, lr=2e-4, cfg=None):
     torch.manual_seed(seed)
-    net = S.define_G(**CFG).to('cuda:0')
+    net = S.define_G(**(cfg or CFG)).to('cuda:0')
     old = SF.PREC_FWD, SF.PREC_BWD
     if mode == 'bf16':
         net.set_activation_dtype(torch.bfloat16)
