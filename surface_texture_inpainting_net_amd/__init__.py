@@ -21,6 +21,13 @@ def enable_graph_replay():
         return True
     if _torch.cuda.is_initialized():
         return False
+    # torch.cuda.is_initialized() only knows about torch's own lazy init: under a profiler whose preloaded library has already
+    # brought the HIP runtime up (rocprofv3 with --pmc does), setting the flag now may be too late to take effect - refuse
+    # rather than report the replay path safe
+    pre = _os.environ.get('LD_PRELOAD', '')
+    if any(k in pre for k in ('rocprofiler', 'roctracer', 'rocprof')) or any(k.startswith(('ROCPROFILER_', 'ROCPROF_', 'ROCP_TOOL')) for k in _os.environ):
+        if _os.environ.get(_FLAG) != '0':
+            return False
     _os.environ[_FLAG] = '0'
     _state['safe'] = True
     return True

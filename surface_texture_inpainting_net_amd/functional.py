@@ -513,7 +513,7 @@ def _wgrad_side(dev):
 USE_DIRECT_GRADS = os.environ.get('STIN_DIRECT_GRADS', '1') == '1'
 
 
-def _direct_grad_views(params):
+def _direct_grad_views(params, dry_run=False):
     """(dW1, db1, dW2, db2, dWs, dbs) as the parameters' views in an accepting train_step.FlatGradBucket, or None.
     The backward then OVERWRITES those views (one backward per step, every weight used by one block) and returns no
     gradient to autograd for them: no per-parameter accumulate node, no copy into the bucket afterwards, and nothing of
@@ -532,6 +532,8 @@ def _direct_grad_views(params):
         out.append(bucket.views[slot[1]])
     if bucket is None:
         return None
+    if dry_run:                  # eligibility probe only (a node that covers several blocks decides for ALL of them first)
+        return out
     for p in params:
         if p is not None:
             bucket.written[p._stin_slot[1]] = True
@@ -1002,16 +1004,11 @@ class EdgeConvChainFn(torch.autograd.Function):
         dx = torch.empty(N, C, dtype=dt, device=dev) if need_dx else None
         scratch = torch.empty(2, N, C, dtype=dt, device=dev)
         # gradients: straight into an accepting TrainStep bucket (all blocks or none), else fresh tensors handed to autograd
-        direct = []
-        for i in range(n):
-            W1, b1, W2, b2 = params[4 * i:4 * i + 4]
-            d = _direct_grad_views((W1, b1, W2, b2, None, None))
-            if d is None:
-                break
-            direct.append(d)
+        direct = []                                        # (all blocks probed before the bucket's bookkeeping changes, as in NetFn)
+        if all(_direct_grad_views(tuple(params[4 * i:4 * i + 4]) + (None, None), dry_run=True) is not None for i in range(n)):
+            direct = [_direct_grad_views(tuple(params[4 * i:4 * i + 4]) + (None, None)) for i in range(n)]
         if len(direct) != n:
-            if direct:
-                raise RuntimeError('EdgeConvChainFn: only some blocks of the chain could write their gradients into the bucket')
+            direct = []
             grads = []
             for i in range(n):
                 W1, b1, W2, b2 = params[4 * i:4 * i + 4]
@@ -1280,16 +1277,14 @@ class NetFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         blocks = [d for d in plan if d['kind'] == OP_BLOCK]
         # gradients: straight into an accepting TrainStep bucket (all blocks or none), else fresh tensors handed to autograd
+        # (probe every block BEFORE any bucket bookkeeping changes: with a frozen or unslotted parameter in one block - a frozen
+        # decoder, say - the whole node hands fresh tensors to autograd instead of leaving `written` half set and raising)
         direct = []
-        for d in blocks:
-            dv = _direct_grad_views(d['params'])
-            if dv is None:
-                break
-            direct.append(dv)
+        if all(_direct_grad_views(d['params'], dry_run=True) is not None for d in blocks):
+            direct = [_direct_grad_views(d['params']) for d in blocks]
         grads = None
         if len(direct) != len(blocks):
-            if direct:
-                raise RuntimeError('NetFn: only some blocks could write their gradients into the bucket')
+            direct = []
             grads = []
             for d in blocks:
                 W1, b1, W2, b2, Ws, bs = d['params']

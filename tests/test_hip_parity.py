@@ -1288,6 +1288,37 @@ def test_train_step_direct_bucket_gradients_equal_autograd_gradients(dtype):
         off += p.numel()
 
 
+def test_train_step_with_a_frozen_middle_block_trains_the_rest():
+    """A partially frozen model (the bottleneck's middle block here, requires_grad=False before the TrainStep is built): the
+    whole-network node probes every block BEFORE it touches the bucket's bookkeeping and, finding one block without a slot, hands
+    fresh gradient tensors to autograd for all of them (round-3 advisor: it used to raise with `written` half set).  The
+    gradients of the trainable parameters equal plain autograd's, the frozen ones get none, repeated steps work."""
+    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 4])
+    torch.manual_seed(13)
+    net = S.define_G(**cfg).to(DEV)
+    frozen = [p for k, p in net.named_parameters() if k.startswith('bottleneck_blocks.1.')]
+    assert frozen
+    for p in frozen:
+        p.requires_grad_(False)
+    s = make_synthetic_mesh(8_000, 3, seed=14, dilations=(2, 4)).to(DEV)
+    step = TrainStep(net, lr=0.0)
+    for _ in range(3):
+        step(s)
+    got = step.bucket.flat.clone()
+    assert all(p.grad is None for p in frozen)
+    for p in net.parameters():
+        p.grad = None
+    SF.masked_l1_loss(net(s), s.color, s.mask, True).backward()
+    off = 0
+    for p in step.bucket.params:
+        want = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.equal(got[off:off + p.numel()].view_as(p), want)
+        off += p.numel()
+    assert all(p.grad is None for p in frozen)
+
+
 def test_training_loop_memory_is_stable_over_changing_scene_sizes():
     """The allocator pool must reach a steady state when scenes of different sizes alternate (a training epoch): the
     weight-gradient side stream keeps its inputs alive by reference until the end-of-backward join instead of

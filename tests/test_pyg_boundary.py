@@ -140,3 +140,42 @@ def test_train_step_on_a_pyg_semantics_batch(graph):
     assert results[0][0] == results[1][0]
     for a, b in zip(results[0][1], results[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_eager_forward_in_the_default_user_environment(tmp_path):
+    """tests/conftest.py opts the whole pytest process into the ROCm 7.2 graph-replay workaround (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0,
+    needed by the TrainStep(graph=True) tests and only settable before the first HIP call), so no test of this process sees the
+    environment an eager user has.  This one runs a fresh interpreter WITHOUT the flag: the package must leave the environment
+    alone on import, report the replay path unsafe, and produce the fixture's forward output and finite gradients eagerly."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+assert 'DEBUG_CLR_GRAPH_PACKET_CAPTURE' not in os.environ
+sys.path.insert(0, %r)
+import torch
+import surface_texture_inpainting_net_amd as pkg
+assert 'DEBUG_CLR_GRAPH_PACKET_CAPTURE' not in os.environ and not pkg.graph_replay_safe()
+from surface_texture_inpainting_net_amd import surfacetextureinpaintingnet as S
+from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
+from surface_texture_inpainting_net_amd.train_step import TrainStep
+torch.manual_seed(5)
+net = S.define_G(input_nc=10, output_nc=3, ngf=32, filter_type='edgeconvtransinv', norm='instance', n_blocks=2, n_levels=1, pooling_type='max').to('cuda:0')
+s = make_synthetic_mesh(3000, 2, seed=1, dilations=()).to('cuda:0')
+a = net(s); b = net(s)
+assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+step = TrainStep(net, lr=1e-3)
+l = [float(step(s)) for _ in range(4)]
+assert l[-1] < l[0], l
+try:
+    TrainStep(net, graph=True)
+    raise SystemExit('TrainStep(graph=True) must refuse to run without the replay workaround')
+except RuntimeError:
+    pass
+print('OK')
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('DEBUG_CLR_GRAPH_PACKET_CAPTURE', 'STIN_GRAPH_REPLAY')}
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
