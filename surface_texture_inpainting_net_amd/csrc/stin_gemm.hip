@@ -2580,11 +2580,16 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
         // the epilogue's restage area (2 KB per wave) only where it does not cost a resident block (K chunks of 256: 2 blocks
         // per CU either way; chunks of 128 would drop from 4 to 3 and lose more than the wide stores gain: 130 -> 155 us at
         // 200 704 x 320 x 128)
-        const int restage = (160 * 1024 / (lds + waves * 2048) == 160 * 1024 / lds) ? 1 : 0;
+        const size_t occ_plain = 160 * 1024 / lds, occ_rest = 160 * 1024 / (lds + waves * 2048);
+        const int restage = ((occ_rest > 2 ? 2 : occ_rest) == (occ_plain > 2 ? 2 : occ_plain)) ? 1 : 0;     // (occupancy is capped at 2 below)
         if (restage) lds += waves * 2048;
         const int64_t units = ((M + bm - 1) / bm) * P;
         int occ = (int)(160 * 1024 / lds);
-        if (occ > 8) occ = 8;
+        // (round 4) at most two resident blocks per CU: with three or four (K chunks of 128: 32-44 KB of LDS per block) the blocks
+        // of a CU re-stream the W panels against each other - 200 704 x 320 x 128: 136.6 us at four / three, 126.5 at two, 124 at one
+        // two-quad block (profiles/_nt_probe.py, STIN_STRIP_OCC sweep)
+        if (occ > 2) occ = 2;
+        if (cfg == 22) occ = 1;                                       // eight-wave blocks: one per CU (18 063 x 1280 x 128: 39.2 -> 35.6 us)
         if (occ < 1) occ = 1;
         const char* e_occ = getenv("STIN_STRIP_OCC");                 // tuning aid
         if (e_occ && atoi(e_occ) > 0) occ = atoi(e_occ);
