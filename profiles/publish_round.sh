@@ -2,8 +2,8 @@
 # Copy one collect_round.sh result directory (gpurun_out/<dir>) into the tracked profiles/<round>_* files.
 #   bash profiles/publish_round.sh r03 [r03]        (source directory under gpurun_out/, round prefix)
 set -e
-S=gpurun_out/${1:-r03}
-RN=${2:-r03}
+S=gpurun_out/${1:-r04}
+RN=${2:-r04}
 P=profiles/$RN
 cp $S/bench_default.json ${P}_bench_default.json; cp $S/bench_final.json ${P}_bench_final.json; cp $S/bench_bf16.json ${P}_bench_bf16.json
 cp $S/bench_irregular.json ${P}_bench_irregular.json
@@ -94,7 +94,7 @@ out += ['', '## `roofline.frac`: the bench line\'s bracket against rocprofv3', '
         'the next step\'s plan build - the round-2 artefact that read 0.26 at config 5); the rocprofv3 column is the average of the same '
         'kernel over every profiled step of a separate run (`%s_config_c{2,3,5}_kernel_stats.csv` / `.md`, `%s_bench_final_kernel_stats.csv`), '
         'where prefetch is on: its level-0 launches can overlap the plan build of the next step.' % (RN, RN), ''] + check
-out += ['', 'Round 2 for comparison (r02_configs.md): config 2 6.85 ms, config 3 6.54 ms, config 5 28.95 ms (bf16) / 45.64 ms (fp32), headline 8.16-8.30 ms, bf16 5.86 ms, 20 k eager 4.09 ms.',
+out += ['', 'Round 3 for comparison (r03_configs.md): config 2 6.12 ms, config 3 5.9-6.2 ms, config 5 26.4-27.0 ms (bf16), headline 7.5-7.7 ms, bf16 5.36 ms, 20 k eager 2.8-3.7 ms.',
         '', 'JSON lines: `%s_config_{c2,c3,c5_bf16,c5_f32}.json`, `%s_bench_{bf16,irregular}.json`, `%s_small_20k_{eager,graph}.json`.' % (RN, RN, RN)]
 open(P + '_configs.md', 'w').write('\n'.join(out) + '\n')
 print(d['ms_per_step'], dd['ms_per_step'])
