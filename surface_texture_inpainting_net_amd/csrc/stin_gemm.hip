@@ -2294,6 +2294,108 @@ __global__ __launch_bounds__(64 * WI * WJ) void k_gemm_tn_b16_tr(const stin_bf16
     }
 }
 
+// ----------------------------------------------------------------------------- TN, skinny K (round 4)
+// dW[Nc, K] = G^T [X | w] with K <= 16 (the first block of the network: [dA | dB | g] against the 12 padded input channels,
+// 200 704 x 320 x 12).  On the MFMA kernels above this shape stages 128 x 64 tiles that are four fifths empty and streams G at
+// 2.5 TB/s (102 us for 267 MB).  It is pure streaming with 13 multiply-adds per G element, so: no matrix cores, no LDS staging -
+// a block owns ALL Nc columns of a chunk of rows; thread (row lane, column lane) holds 4 columns x (KP + 1) fp32 accumulators,
+// loads one 16-byte piece of a G row and the row's K values of X (the same addresses for every column lane of the row lane: L1
+// hits) per trip, UR rows in flight; rows ascending per thread, then the row lanes in order through LDS - fixed order, exact fp32
+// products (precision >= every split mode).  Partial results go to the usual slab layout ([Nc][Kq] + bias [Nc] per chunk), so
+// k_reduce_slabs / k_wgrad_finalize fold them unchanged.
+template <int KP>
+__global__ __launch_bounds__(BLOCK) void k_gemm_tn_skinny(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X, int64_t ldx,
+                                                         int64_t M, int Nc, int K, int Kq, int has_bias,
+                                                         const float* __restrict__ row_weight, int64_t ld_weight, int rows_per_chunk,
+                                                         float* __restrict__ slab) {
+    constexpr int UR = 8;
+    const int CL = Nc / 4, RL = BLOCK / CL;                                   // column lanes per row, row lanes (BLOCK - CL RL threads idle)
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const bool live = rl < RL;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < M ? r0 + rows_per_chunk : M;
+    const int nrows = (int)(r1 - r0);
+    // the chunk's [X | w] rows once into LDS ((KP + 4) floats per row: K values, the row weight, padding to 16 bytes): the inner
+    // loop then issues ONE global load per row (the G piece) and reads its X row as LDS broadcasts
+    extern __shared__ __attribute__((aligned(16))) float sk_smem[];           // [rows_per_chunk][KP + 4], later [Nc][KP + 1]
+    constexpr int XP = KP + 4;
+    for (int i = threadIdx.x; i < nrows * (KP / 4); i += BLOCK) {
+        const int r = i / (KP / 4), q = i % (KP / 4);
+        *reinterpret_cast<float4*>(sk_smem + r * XP + q * 4) = ld4(X + (r0 + r) * ldx + q * 4);
+    }
+    for (int r = threadIdx.x; r < nrows; r += BLOCK) sk_smem[r * XP + KP] = row_weight != nullptr ? row_weight[(r0 + r) * ld_weight] : 1.f;
+    __syncthreads();
+    float acc[4][KP + 1];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int k = 0; k <= KP; ++k) acc[c][k] = 0.f;
+    if (live) {
+        const float* Gp = G + r0 * ldg + cl * 4;
+        for (int rb = rl; rb < nrows; rb += UR * RL) {
+            float4 g[UR];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int r = rb + u * RL;
+                g[u] = ld4(Gp + (int64_t)(r < nrows ? r : rb) * ldg);
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int r = rb + u * RL;
+                if (r >= nrows) continue;
+                const float* xr = sk_smem + r * XP;
+                const float gv[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+                const float w = xr[KP];
+#pragma unroll
+                for (int q = 0; q < KP / 4; ++q) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xr + q * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc[c][4 * q + 0] += gv[c] * xv.x;
+                        acc[c][4 * q + 1] += gv[c] * xv.y;
+                        acc[c][4 * q + 2] += gv[c] * xv.z;
+                        acc[c][4 * q + 3] += gv[c] * xv.w;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c][KP] += gv[c] * w;
+            }
+        }
+    }
+    __syncthreads();                                                          // (the X image is dead: its space takes the column sums)
+    // row lanes in order: row lane 0 stores its sums into the block's [Nc][KP + 1] image, 1 .. RL - 1 add in turn (fixed order)
+    for (int t = 0; t < RL; ++t) {
+        if (live && rl == t) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int k = 0; k <= KP; ++k) {
+                    float* dst = sk_smem + (cl * 4 + c) * (KP + 1) + k;
+                    *dst = t == 0 ? acc[c][k] : *dst + acc[c][k];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = slab + (int64_t)blockIdx.x * tn_chunk_stride(Nc, Kq);
+    for (int i = threadIdx.x; i < Nc * Kq; i += BLOCK) {
+        const int c = i / Kq, k = i % Kq;
+        out[i] = k < K ? sk_smem[c * (KP + 1) + k] : 0.f;
+    }
+    if (has_bias)
+        for (int c = threadIdx.x; c < Nc; c += BLOCK) out[(int64_t)Nc * Kq + c] = sk_smem[c * (KP + 1) + KP];
+}
+inline bool tn_skinny_shape(int storage, int Nc, int K, int64_t ldg, int64_t ldx, const void* G, const void* X) {
+    static const bool on = !(getenv("STIN_TN_SKINNY") && atoi(getenv("STIN_TN_SKINNY")) == 0);     // A/B switch (read once)
+    return on && storage == 0 && K <= 16 && K % 4 == 0 && Nc % 4 == 0 && Nc >= 64 && Nc <= 4 * BLOCK && ldg % 4 == 0 && ldx % 4 == 0 &&
+           stin_aligned16(G) && stin_aligned16(X);
+}
+inline int tn_skinny_rows(int64_t M) {                                         // ~1024 chunks, a multiple of 32 rows, at least 128
+    static const int want = getenv("STIN_TN_SKINNY_CHUNKS") ? atoi(getenv("STIN_TN_SKINNY_CHUNKS")) : 1024;   // tuning aid (read once); 256 / 512 / 1024 / 2048 chunks: 106 / 75 / 72 / 79 us at 200 704 x 320 x 12
+    int64_t rows = (M + want - 1) / want;
+    rows = (rows + 31) / 32 * 32;
+    return (int)(rows < 128 ? 128 : rows);
+}
+
 // dW[row][col] = sum_c slab[c][row][col] (and the bias column from the chunk's bias block): 16 chunk-lanes x 16 float4
 // groups per block, each chunk-lane walks the chunk list with stride 16 (4 x 16-byte loads in flight), then a
 // fixed-order LDS reduction over the chunk-lanes -> deterministic.
@@ -2680,6 +2782,11 @@ extern "C" size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int one
         const int64_t c = (M + rows - 1) / rows;
         if (c > chunks) chunks = c;
     }
+    if (K <= 16) {                                               // k_gemm_tn_skinny's chunking (fp32 rows)
+        const int rows = tn_skinny_rows(M);
+        const int64_t c = (M + rows - 1) / rows;
+        if (c > chunks) chunks = c;
+    }
     if (Nc >= 256 && K >= 256) {                                 // the 256 x 256 tiles of the bf16-storage products: fewer tiles, more chunks
         const int rows = tn_rows_per_chunk(M, ((Nc + 255) / 256) * ((K + 255) / 256), true);
         const int64_t c = (M + rows - 1) / rows;
@@ -2713,6 +2820,11 @@ int stin_tn_problem_init(stin_tn_problem* p, int storage, const void* G, int64_t
     p->tiles_i = (Nc + p->TI - 1) / p->TI;
     p->tiles_j = (K + p->TJ - 1) / p->TJ;
     p->rows_per_chunk = tn_rows_per_chunk(M, p->tiles_i * p->tiles_j, big || tn_one_per_cu(storage, precision, p->TI, p->TJ, M));
+    if (tn_skinny_shape(storage, Nc, K, ldg, ldx, G, X)) {         // k_gemm_tn_skinny: a block owns all columns of its row chunk
+        p->TI = p->TJ = 0;
+        p->tiles_i = p->tiles_j = 1;
+        p->rows_per_chunk = tn_skinny_rows(M);
+    }
     p->chunks = M > 0 ? (M + p->rows_per_chunk - 1) / p->rows_per_chunk : 0;
     p->Kq = (K + 3) & ~3;
     p->has_bias = ones_column ? 1 : 0;
@@ -2768,6 +2880,20 @@ int stin_tn_slabs(const stin_tn_problem* p, int storage, int precision, stin_str
         return stin_launch_status();
     }
     const float *G = p->G, *X = p->X, *row_weight = p->row_w;
+    if (TI == 0) {                                                 // skinny K (set by stin_tn_problem_init): exact fp32 on the VALU
+        const int kp = (K + 3) & ~3;
+        const size_t lds_x = (size_t)rows * (kp + 4) * sizeof(float), lds_o = (size_t)Nc * (kp + 1) * sizeof(float);
+        const size_t lds = lds_x > lds_o ? lds_x : lds_o;
+#define STIN_TNS(KP_)                                                                                                 \
+    hipLaunchKernelGGL((k_gemm_tn_skinny<KP_>), dim3((unsigned)chunks), dim3(BLOCK), lds, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, \
+                       row_weight, ld_weight, rows, slab)
+        if (K <= 4) STIN_TNS(4);
+        else if (K <= 8) STIN_TNS(8);
+        else if (K <= 12) STIN_TNS(12);
+        else STIN_TNS(16);
+#undef STIN_TNS
+        return stin_launch_status();
+    }
     if (precision == STIN_GEMM_BF16X3 && TI == 128 && TJ == 128 && vec && stin_tn_ws_enabled()) {
         stin_tn_batch batch;
         batch.p[0] = *p;
