@@ -418,6 +418,11 @@ int stin_masked_l1_loss_f32(const float* out, const float* color, const int64_t*
 size_t stin_total_variation_workspace_bytes(int64_t N);
 int stin_total_variation_f32(const float* x, int64_t ldx, const int32_t* rowptr_dst, const int32_t* col_dst, int64_t N, int C,
                              float* out, void* workspace, size_t workspace_bytes, stin_stream_t stream);
+/* graph Laplace of the same metrics module (utils/metrics/graph_metrics.py:6-16, GraphLaplaceOperator: propagate [1 | x] with
+ * aggr = 'add', then prop[:, 1:] - prop[:, 0:1] * x): out[i, c] = sum_{j in N(i)} x[j, c] - deg_i x[i, c] over the destination CSR,
+ * fp32 adds in edge order - the numbers of the reference's composition, bit for bit. */
+int stin_graph_laplace_f32(const float* x, int64_t ldx, const int32_t* rowptr_dst, const int32_t* col_dst, int64_t N, int C,
+                           float* out, int64_t ldo, stin_stream_t stream);
 int stin_adam_f32(float* p, const float* g, float* m, float* v, float* vmax, int64_t n, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int step, int amsgrad, stin_stream_t stream);
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     'stin_masked_l1_loss_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'stin_total_variation_workspace_bytes': (c_size, [c_i64]),
     'stin_total_variation_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_size, c_ptr]),
+    'stin_graph_laplace_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     'stin_adam_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f64, c_f64, c_f64, c_f64, c_f64, c_int, c_int,
                               c_ptr]),
 }

@@ -432,6 +432,34 @@ extern "C" int stin_masked_l1_loss_f32(const float* out, const float* color, con
     return stin_launch_status();
 }
 
+// graph Laplace of the trainer's per-step metric (utils/metrics/graph_metrics.py:6-16): out[i, c] = sum_{j in N(i)} x[j, c] - deg_i x[i, c].
+// The reference propagates [1 | x] with aggr = 'add' (a scatter-add in edge order) and subtracts prop[:, 0] * x: here one thread per
+// (vertex, channel) walks the destination-CSR row in the same order (fp32 adds in edge order; the degree is exact) - bit for bit the
+// same numbers as the torch.cat + segment-sum + elementwise composition it replaces, without the [N, C + 1] temporaries.
+__global__ __launch_bounds__(256) void k_graph_laplace(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, int64_t N, int C, float* __restrict__ out,
+                                                       int64_t ldo) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= N * C) return;
+    const int64_t i = t / C;
+    const int c = (int)(t % C);
+    const int beg = rowptr[i], end = rowptr[i + 1];
+    float s = 0.f;
+    for (int e = beg; e < end; ++e) s += x[(int64_t)col[e] * ldx + c];
+    out[i * ldo + c] = s - (float)(end - beg) * x[i * ldx + c];
+}
+
+extern "C" int stin_graph_laplace_f32(const float* x, int64_t ldx, const int32_t* rowptr_dst, const int32_t* col_dst, int64_t N, int C,
+                                      float* out, int64_t ldo, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N >= 0 && C > 0 && ldx >= C && ldo >= C, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(x && rowptr_dst && col_dst && out, STIN_E_NULL);
+    const int64_t blocks = (N * C + 255) / 256;
+    hipLaunchKernelGGL(k_graph_laplace, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, x, ldx, rowptr_dst, col_dst, N, C, out, ldo);
+    return stin_launch_status();
+}
+
 extern "C" size_t stin_total_variation_workspace_bytes(int64_t N) {
     if (N < 0) return 0;
     return (size_t)((N + 255) / 256 + 1) * sizeof(double) + 256;

@@ -21,8 +21,16 @@ def grayscale(x):
 
 
 def graph_laplace(x, edge_index):
-    """sum_{j in N(i)} x_j - deg_i x_i   (graph_metrics.py:6-16)."""
+    """sum_{j in N(i)} x_j - deg_i x_i   (graph_metrics.py:6-16): one HIP pass over the destination CSR (stin_graph_laplace_f32; the
+    metric is evaluated under no_grad by the trainer); a tensor that needs a gradient takes the differentiable segment-sum form."""
     e = _edges(edge_index, x.shape[0])
+    if x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad):
+        from .plan import _ptr, _stream
+        xm, ldx = SF._mat(x.detach())
+        out = torch.empty(xm.shape[0], xm.shape[1], dtype=torch.float32, device=x.device)
+        SF._call('stin_graph_laplace_f32', _ptr(xm), ldx, _ptr(e.by_dst.rowptr), _ptr(e.by_dst.col), xm.shape[0], xm.shape[1], _ptr(out),
+                 out.stride(0), _stream(xm))
+        return out
     xi = torch.cat([x.new_ones(x.shape[0], 1), x], dim=1).contiguous()
     prop = SF.segment_sum(xi, e.by_dst.rowptr, e.by_dst.col, e.n, mean=False)
     return prop[:, 1:] - prop[:, 0:1] * x

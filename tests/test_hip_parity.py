@@ -872,6 +872,14 @@ def test_graph_metrics_against_reference_fixture():
     assert torch.allclose(metrics.graph_laplace_variance(pred, ei).cpu(), z['lap_var'], rtol=1e-5)
     assert torch.allclose(metrics.graph_total_variation(pred, ei).cpu(), z['tv'], rtol=1e-5)
     assert torch.allclose(metrics.psnr(pred, z['color'].to(DEV), data_range=2.0).cpu(), z['psnr'], rtol=1e-5)
+    # round 4: the Laplace operator is one HIP pass (stin_graph_laplace_f32) - bit for bit the reference's composition (propagate [1 | x]
+    # with aggr = 'add' in edge order, prop[:, 1:] - prop[:, 0:1] * x), which a tensor that needs a gradient still takes; also on a
+    # 3-channel strided view and on a graph with empty rows
+    g = torch.Generator().manual_seed(3)
+    for x, e in ((metrics.grayscale(pred), ei), (torch.randn(5000, 7, generator=g).to(DEV)[:, 2:5], torch.randint(0, 5000, (2, 21000), generator=g).to(DEV))):
+        fast = metrics.graph_laplace(x, e)
+        slow = metrics.graph_laplace(x.clone().requires_grad_(True), e)
+        assert slow.requires_grad and not fast.requires_grad and torch.equal(fast, slow.detach())
 
 
 # ------------------------------------------- full-size (BASELINE.json) property checks
