@@ -744,9 +744,14 @@ def main():
                  'measured': 'fwd max-abs 7.4e-2, mean-abs 9.9e-3, loss 2e-4, grad rel-L2 16 % on the 15-block network '
                              '(tests/test_hip_bf16.py::test_bf16_network_vs_fp32_oracle_stated_tolerance); 1 M vertices / 5 levels vs the '
                              'fp32-storage run: max-abs <= 0.25, mean-abs <= 3e-2',
-                 'training_curve_200_steps_vs_fp32': {'single_scene': {'first_50_steps': 1e-2, 'last_50_steps': 4e-2, 'measured_last_50': '+1.1 .. +3.3 % (control: -2.5 .. +2.6 %)'},
-                                                      'crop_batches_4_levels': {'first_50_steps': 1.5e-2, 'last_50_steps': 8e-2, 'measured_last_50': '-6.4 .. +2.1 % (control: -3.3 .. +0.7 %)'},
-                                                      'test': 'tests/test_hip_bf16.py::test_bf16_training_curve_tracks_fp32 (3 seeds each)'},
+                 'training_curve_200_steps': {'statement': 'mean loss of the last 50 of 200 Adam steps within `last_50_steps` of the NEARER of two '
+                                                           'fp32-storage runs (shipped split GEMMs / exact-fp32 GEMMs), which themselves end up to '
+                                                           '`fp32_orders_apart` apart: the trajectories are chaotic',
+                                              'single_scene': {'first_50_steps': 1e-2, 'last_50_steps': 5e-2, 'fp32_orders_apart': 8e-2,
+                                                               'measured': 'bf16 +1.1 .. +3.3 %, fp32 orders -4.3 .. +2.6 % (3 seeds, 2 code states)'},
+                                              'crop_batches_4_levels': {'first_50_steps': 2e-2, 'last_50_steps': 8e-2, 'fp32_orders_apart': 12e-2,
+                                                                        'measured': 'bf16 -6.4 .. +2.7 %, fp32 orders -8.1 .. +0.7 %'},
+                                              'test': 'tests/test_hip_bf16.py::test_bf16_training_curve_tracks_fp32 (3 seeds each)'},
                  'note': 'bf16 ACTIVATION STORAGE (fp32 accumulate, statistics, master weights): a stated-tolerance mode of configs 3 / 5, '
                          'never the headline; one forward rounding per block already gives ~10 % gradient rel-L2 on this network '
                          '(profiles/r02_bf16_sensitivity.md) - what certifies the mode is the training curve'}),
