@@ -94,6 +94,47 @@ def pmc_traffic_bytes(kernel, n, e, h):
     return (hits[0].get('fabric_MB_per_launch') or hits[0].get('hbm_MB_per_launch')) * 1e6 if hits else None     # (round <= 3 files: hbm_* keys)
 
 
+def measure_fabric_traffic(kernel_prefix='k_edge_fwd_exact<float, 32, 1, 6>'):
+    """LIVE `roofline.traffic` (round 4): two child processes - `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (they do not fit
+    one TCC pass) with `--kernel-trace` only - over profiles/pmc_kernels.py restricted to the level-0 forward edge kernel of the
+    headline mesh; bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB per the gfx950 corrections of MI355X_MICROARCH.md.  Children, not an
+    exec: this process keeps its GPU context.  -> (bytes per launch, note) or (None, reason)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not on PATH'
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix='stin_pmc_', dir='/tmp')
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR='/tmp', PMC_ONLY_FWD='1')
+            r = subprocess.run(['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'run', '--',
+                                sys.executable, os.path.join(ROOT, 'profiles', 'pmc_kernels.py')], cwd='/tmp', env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, 'rocprofv3 --pmc %s pass failed (rc %d)' % (counter, r.returncode)
+            acc = []
+            for row in csv.DictReader(open(files[0])):
+                if row.get('Counter_Name') != counter:
+                    continue
+                name = re.sub(r'\(anonymous namespace\)::|^void ', '', row['Kernel_Name'])
+                if name.startswith(kernel_prefix):
+                    acc.append(float(row['Counter_Value']))
+            if not acc:
+                return None, 'kernel %s not in the %s pass' % (kernel_prefix, counter)
+            vals[counter] = sum(acc[-3:]) / len(acc[-3:])
+    except Exception as exc:                                # noqa: BLE001 - a secondary leg must not lose the line
+        return None, '%s: %s' % (type(exc).__name__, exc)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, 'measured in this run'
+
+
 def scatter_add_standalone(device, n=200_000, e=1_200_000, c=64, iters=30):
     """The standalone scatter-add of BASELINE.md §4: src[E, C] -> out[N, C], index in arbitrary edge order."""
     from surface_texture_inpainting_net_amd import functional as SF
@@ -454,6 +495,8 @@ def main():
     ap.add_argument('--crops', type=int, default=0,
                     help='BASELINE config 3: a collated batch of this many unequal crops (12-28k vertices each) per step '
                          'instead of one scene (NOT the headline); combine with --levels 4 --dtype bf16')
+    ap.add_argument('--no-live-traffic', action='store_true', help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic '
+                    'live (about 20 s); the figure replayed from profiles/r*_pmc_traffic.json stands then')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the passes after the timed region (fwd+loss+bwd-only loop, GEMM table, standalone kernels, CPU '
                          'baseline) - profiling runs: keeps the kernel mix = the step')
@@ -790,6 +833,16 @@ def main():
                            'time_weighted_frac_of_roofline': sum(r['roofline_bound_us'] * r['launches'] for r in gemms) /
                                                              sum(r['avg_us'] * r['launches'] for r in gemms),
                            'kernels': gemms[:24]}
+        if world == 1 and not args.no_secondary and args.dtype == 'f32' and (n0, e0) == (200704, 1200642) and not args.no_live_traffic:
+            live, why = measure_fabric_traffic()
+            if live is not None:
+                out['roofline']['traffic'] = live
+                out['roofline']['traffic_unit'] = ('FABRIC bytes per launch incl. Infinity-Cache hits ((2*FETCH_SIZE + WRITE_SIZE) KiB), MEASURED in '
+                                                   'this run: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) over the '
+                                                   'same kernel at the same shape (profiles/pmc_kernels.py, PMC_ONLY_FWD=1), mean of the last 3 launches')
+                out['roofline']['traffic_over_algorithmic'] = live / (out['roofline']['algorithmic_bytes'] + e0 * 128 / 8.0)
+            else:
+                out['roofline']['traffic_live_pass'] = 'not available (%s): the replayed figure stands' % why
         if world == 1 and not args.no_secondary:
             out['scatter_add'] = scatter_add_standalone(device)
             out['hbm_honest'] = hbm_honest_edge_kernel(device)

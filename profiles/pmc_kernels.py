@@ -34,6 +34,8 @@ if NV != 200_000:
         SF.edge_relu_mean_bwd_mask(G, mask, e, out[:, :H], out2)
     torch.cuda.synchronize()
     sys.exit(0)
+# PMC_ONLY_FWD=1: the level-0 forward edge kernel of the headline mesh only (what bench.py's live `roofline.traffic` leg profiles)
+ONLY_FWD = os.environ.get('PMC_ONLY_FWD', '0') == '1'
 s = make_synthetic_mesh(200_000, 1, seed=0, dilations=()).to(dev)
 plan = plan_for(s)
 e = plan.edges('edge_index', 0)
@@ -42,6 +44,12 @@ A, B, G = (torch.randn(n, H, device=dev) for _ in range(3))
 out = torch.empty(n, H, device=dev)
 out2 = torch.empty(n, H, device=dev)
 mask = torch.empty(e.n_edges * (H // 32), dtype=torch.int32, device=dev)
+if ONLY_FWD:
+    out4 = torch.empty(n, H + 4, device=dev)
+    for _ in range(5):
+        SF.edge_relu_mean_fwd(A, B, e.by_dst, out4, indicator=True, mask=mask)
+    torch.cuda.synchronize()
+    sys.exit(0)
 for _ in range(5):
     SF.edge_relu_mean_fwd(A, B, e.by_dst, out, mask=mask)          # as the training step runs it (writes the mask)
     SF.edge_relu_mean_bwd_dst_mask(G, mask, e.by_dst, out)
