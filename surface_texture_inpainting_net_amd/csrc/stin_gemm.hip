@@ -988,24 +988,25 @@ __global__ __launch_bounds__(64 * NW * WAVES_M) void k_gemm_nt_wide(const float*
 // gives a CU 128 rows x 256 columns (1.5 MB at K = 1024) and uses 142 of the 256 CUs; the strip kernel re-streams a 128-column
 // W panel for every 64-row strip.  Here
 //   * the output is cut into 128-column panels x row blocks of BM = 32 (MT0 + MT1) rows, MT0 + MT1 chosen on the host so that
-//     (row blocks) x (panels) fills the chip in a whole number of rounds (18 063 x 256: 113 blocks of 160 rows x 2 panels = 226
-//     CUs; x 512: 63 blocks of 288 rows x 4 = 252; x 1024: 504 = two rounds) - "283 tiles on 256 CUs" is gone;
+//     (row blocks) x (panels) fills the chip in ONE round (panel_tiles(): 18 063 x 256: 113 blocks of 160 rows x 2 panels = 226
+//     CUs; x 512: 63 blocks of 288 rows x 4 = 252) - "283 tiles on 256 CUs" is gone; shapes that would need two or more rounds
+//     measured no better than the strip kernel (one 147 KB block per CU at a time: nothing overlaps a block's prologue and its
+//     store phase) and stay there;
 //   * a block is 8 waves = 2 row groups x 4 column tiles: wave (q, wn) owns columns [32 wn, 32 wn + 32) of the panel and MT0
 //     (q = 0) or MT1 (q = 1) 32-row tiles.  The two waves of a SIMD share its matrix pipe, so MT0 != MT1 costs nothing; they
-//     run as two role programs behind a scalar branch (separate register files for 5 and 4 accumulator tiles);
+//     run as two role programs behind a scalar branch (5 and 4 accumulator tiles at most);
 //   * A is streamed ONCE per block through the wide kernel's double-buffered LDS image (64-wide K chunks, split into the two
-//     16-bit pieces while staging, one barrier per chunk, the next chunk's global loads issued at the top of the chunk and
-//     split + stored during its LAST k-steps: one register set);
-//   * W fragments (fragment order, STIN_GEMM_W_FRAG) go straight from L2 to registers, 2 KB per k-step per wave for 3 MT
-//     MFMAs (the strip kernel: 6); the second row group's loads of the same fragments hit the CU's vector L1;
-//   * the A fragments of a k-step are read tile by tile, one tile ahead of the MFMAs that use them (8 instead of 16 MT registers);
+//     16-bit pieces while staging, one barrier per chunk, ONE register set: the rows of chunk c + 1 are split + stored behind the
+//     row tiles' MFMAs of k-steps 0 and 1, the rows of chunk c + 2 requested at the top of k-step 2);
+//   * W fragments (fragment order, STIN_GEMM_W_FRAG) go straight from L2 to registers through a 4-step ring, 2 KB per k-step per
+//     wave for 3 MT MFMAs (the strip kernel: 6); the second row group requests the same fragments (copying them once per block
+//     into LDS by LDS-DMA instead measured SLOWER, profiles/r04_nt_panel.md);
+//   * the A fragments of the whole next k-step are in flight during a k-step's MFMAs;
 //   * epilogue restaged through LDS (16-byte row-contiguous stores), optional column statistics as in the wide kernel
 //     (groups = 2 per row block).
+// What bounds it (in-kernel stamps + compile-time ablations, STIN_NT_ABLATE_MASK): profiles/r04_nt_panel.md.
 // Same k order, MFMA order and epilogue expression as the other split kernels: bit-identical results
 // (tests/test_hip_parity.py::test_gemm_nt_panel_kernel_equals_tiled_kernel).
-#ifndef STIN_PANEL_SCHED
-#define STIN_PANEL_SCHED 0
-#endif
 template <typename PT, int MT0, int MT1>
 __global__ __launch_bounds__(512) void k_gemm_nt_panel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Wf,
                                                        const float* __restrict__ bias, const float* __restrict__ row_mask,
@@ -1080,8 +1081,8 @@ __global__ __launch_bounds__(512) void k_gemm_nt_panel(const float* __restrict__
         // Staging schedule (one register set): the rows of chunk c + 1 sit in `ra` when chunk c starts (requested during the
         // second half of chunk c - 1); they are split and stored into the other LDS buffer after the row tiles' MFMAs of k-steps
         // 0 and 1, and the loads of chunk c + 2 are issued into the same registers at the top of k-step 2: every load has half a
-        // chunk plus a barrier of lead time (the first version issued at the top of the chunk and stored 1-2 k-steps later:
-        // 3.9 k cycles per chunk of 160 x 128 x 64 where the MFMAs need 1.9 k, profiles/nt_stamps.hip).
+        // chunk plus a barrier of lead time.  (The first version issued at the top of the chunk and stored 1-2 k-steps later; the
+        // stamps read 3.9 k cycles per chunk of 160 x 128 x 64 with either schedule - load latency is not what the loop waits for.)
         constexpr int NS = 2 * MT;                                              // staging slots of a chunk
         const int trow = q * (MT0 * 32);                                        // first block-local row of this wave's tiles
         StFrag wf[WD_STEPS];
@@ -1104,7 +1105,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_panel(const float* __restrict__
             const unsigned char* ab = a_frag + (c & 1) * BUF;
             const int nxt = (c + 1 < nchunk ? c + 1 : c) * WD_STEPS;            // ring refill: same step of the next chunk (clamped)
             // A fragments: the whole next k-step in flight (tile i of step j + 1 is requested in front of tile i's MFMAs of step j:
-            // MT tiles = 96 MT cycles of lead; one tile ahead left the matrix pipe half idle - profiles/nt_stamps.hip)
+            // MT tiles = 96 MT cycles of lead; one tile ahead measured the same time - the LDS round trip is not the bound either)
             vec8 ch[MT], cl[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -1137,16 +1138,6 @@ __global__ __launch_bounds__(512) void k_gemm_nt_panel(const float* __restrict__
                         for (int s = 0; s < NF4; ++s)
                             if ((s * NS) / NF4 == slot && !NT_ABLATE(8)) sstore((c + 1) & 1, s);
                     }
-#if STIN_PANEL_SCHED == 1
-                    // the slot's split arithmetic fills the gaps of the dependent MFMA chain: 1 MFMA, then a share of the VALU / LDS work
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);         // up to 8 VALU
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // one LDS read
-                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);         // one LDS write
-                    }
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
