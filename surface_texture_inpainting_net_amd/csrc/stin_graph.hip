@@ -13,6 +13,26 @@ constexpr int BLOCK = 256;
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// streamed (non-temporal) 16-byte stores for rows nobody re-reads while they are cache-resident (h rows, ReLU masks of the forward
+// edge kernels): they should not displace the gathered operand from L2 / the Infinity Cache.  STIN_EDGE_FWD_NT=0 at compile time
+// restores plain stores.
+#ifndef STIN_EDGE_FWD_NT
+#define STIN_EDGE_FWD_NT 1
+#endif
+typedef unsigned int u32x4_st __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_stream(void* p, uint4 v) {
+#if STIN_EDGE_FWD_NT
+    u32x4_st t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_st*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void st4_stream(float* p, float4 v) {
+    st16_stream(p, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
+}
+__device__ __forceinline__ void st4_stream(stin_bf16* p, float4 v) { st4(p, v); }     // (8-byte bf16 rows: the 4-channel kernels keep plain stores)
+
 template <typename T> struct is_f32_type { static constexpr bool value = false; };
 template <> struct is_f32_type<float> { static constexpr bool value = true; };
 
@@ -111,7 +131,7 @@ __device__ __forceinline__ void edge_fwd_body(const T* __restrict__ A, int64_t l
 #pragma unroll
                 for (int k = 0; k < VPL; ++k) {
                     uint32_t* m = mask + (int64_t)(e + uu) * mwords + k * (G / 8) + ((G == 32) ? 0 : (L.lg & 1) * 4);
-                    *reinterpret_cast<uint4*>(m) = mw[k];
+                    st16_stream(m, mw[k]);
                 }
             }
         }
@@ -120,7 +140,7 @@ __device__ __forceinline__ void edge_fwd_body(const T* __restrict__ A, int64_t l
     const float s = (float)(deg > 0 ? deg : 1);      // true division, as torch_scatter's scatter_mean (sum / count)
 #pragma unroll
     for (int k = 0; k < VPL; ++k)
-        if (on[k]) st4(out + L.row * ldo + L.chan(k), make_float4(acc[k].x / s, acc[k].y / s, acc[k].z / s, acc[k].w / s));
+        if (on[k]) st4_stream(out + L.row * ldo + L.chan(k), make_float4(acc[k].x / s, acc[k].y / s, acc[k].z / s, acc[k].w / s));
     if (indicator && L.lg == 0) st4(out + L.row * ldo + H, make_float4(deg > 0 ? 1.f : 0.f, 0.f, 0.f, 0.f));
 }
 template <typename T, int G, int VPL, int U>
@@ -445,6 +465,9 @@ __device__ __forceinline__ uint32_t pk2(float lo, float hi) {
 __device__ __forceinline__ void st8(stin_bf16* p, const F8& a) {
     *reinterpret_cast<uint4*>(p) = make_uint4(pk2(a.v[0], a.v[1]), pk2(a.v[2], a.v[3]), pk2(a.v[4], a.v[5]), pk2(a.v[6], a.v[7]));
 }
+__device__ __forceinline__ void st8_stream(stin_bf16* p, const F8& a) {
+    st16_stream(p, make_uint4(pk2(a.v[0], a.v[1]), pk2(a.v[2], a.v[3]), pk2(a.v[4], a.v[5]), pk2(a.v[6], a.v[7])));
+}
 
 template <int G>
 struct Lane8 {
@@ -525,7 +548,7 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd8(const stin_bf16* __restrict
         if (mask != nullptr && su < U && e + su < end) {
 #pragma unroll
             for (int k = 0; k < VPL; ++k)
-                *reinterpret_cast<uint4*>(mask + (int64_t)(e + su) * mwords + k * WK + 4 * sp) = mw[k];
+                st16_stream(mask + (int64_t)(e + su) * mwords + k * WK + 4 * sp, mw[k]);
         }
     }
     const int deg = end - beg;
@@ -536,7 +559,7 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd8(const stin_bf16* __restrict
             F8 o;
 #pragma unroll
             for (int c = 0; c < 8; ++c) o.v[c] = acc[k].v[c] / s;
-            st8(out + L.row * ldo + L.chan(k), o);
+            st8_stream(out + L.row * ldo + L.chan(k), o);
         }
     if (indicator && L.lg == 0) st4(out + L.row * ldo + H, make_float4(deg > 0 ? 1.f : 0.f, 0.f, 0.f, 0.f));
 }
