@@ -32,6 +32,17 @@ __device__ __forceinline__ void st4_stream(float* p, float4 v) {
     st16_stream(p, make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
 }
 __device__ __forceinline__ void st4_stream(stin_bf16* p, float4 v) { st4(p, v); }     // (8-byte bf16 rows: the 4-channel kernels keep plain stores)
+// ... and the destination operand A[i, :] of the forward edge kernel is read exactly ONCE (by the lane group that owns row i), while
+// every B row is gathered ~deg times: A goes through non-temporal loads so that it does not displace B either
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+#if STIN_EDGE_FWD_NT
+    const u32x4_st t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_st*>(p));
+    return make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]));
+#else
+    return ld4(p);
+#endif
+}
+__device__ __forceinline__ float4 ld4_stream(const stin_bf16* p) { return ld4(p); }
 
 template <typename T> struct is_f32_type { static constexpr bool value = false; };
 template <> struct is_f32_type<float> { static constexpr bool value = true; };
@@ -82,7 +93,7 @@ __device__ __forceinline__ void edge_fwd_body(const T* __restrict__ A, int64_t l
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
         on[k] = EXACT || L.chan(k) < H;
-        a[k] = on[k] ? ld4(A + L.row * lda + L.chan(k)) : f4zero();
+        a[k] = on[k] ? ld4_stream(A + L.row * lda + L.chan(k)) : f4zero();
         acc[k] = f4zero();
     }
     const int mwords = H >> 5;                            // mask words per edge slot
