@@ -2471,7 +2471,8 @@ inline int tn_rows_per_chunk(int64_t M, int tiles, bool one_per_cu = false) {
     if (chunks > 8) chunks = (chunks + 7) / 8 * 8;          // whole rounds of 8 chunks (one per XCD, see the kernels' block map)
     int64_t rows = (M + chunks - 1) / chunks;
     if (rows < 4 * TN_R) rows = 4 * TN_R;
-    if (rows > 128 * TN_R) rows = 128 * TN_R;
+    static const int max_rows = getenv("STIN_TN_MAXROWS") ? atoi(getenv("STIN_TN_MAXROWS")) : 128 * TN_R;   // tuning aid
+    if (rows > max_rows) rows = max_rows;
     rows = (rows + TN_R - 1) / TN_R * TN_R;
     return (int)rows;
 }
