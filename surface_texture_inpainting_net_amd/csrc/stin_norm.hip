@@ -3,6 +3,7 @@
 // Contract: include/stin_hip.h.  All of these are HBM-streaming kernels: 16-byte loads,
 // one pass over [N, C] per call.
 #include "stin_common.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -164,6 +165,196 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce(const T* __restrict__ x, in
             }
         }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: ONE launch per column reduction (k_colreduce_t).  The two-stage form above writes [chunks][2][C] fp64 partials and
+// needs a second launch (k_colreduce_final / k_moments_final: 6-8 us each inside a step) to fold them.  Here the grid is
+// (row chunks R) x (GC-column groups) x (ranges B): a block reduces its rows for ITS GC columns (GC / 4 column lanes x float4,
+// 1024 / GC row lanes; rows ascending per thread, fp64), publishes one [NOUT][GC] partial and takes a ticket of its (range,
+// column group); the block whose ticket is the last one folds that group's R partials in a fixed order (r ascending within
+// 256 / GC interleaved sub-sums, then those in order) and applies the post-op - the final arithmetic of k_colreduce_final /
+// k_moments_final.  Deterministic: which block arrives last changes who folds, never the order of the additions.
+// Cross-block visibility without a release fence (a `fence(release, agent)` writes back the XCD's whole dirty L2 - the first
+// version of this kernel paid 6-10 us for it, profiles/r04_ticket_colreduce.md): the partials are WRITE-THROUGH (`sc1`) stores
+// -> every storing wave drains `s_waitcnt vmcnt(0)` -> barrier -> one lane's relaxed agent-scope atomic add (the ticket) ->
+// the last arriver reads the partials with `sc1` loads only (MI355X_MICROARCH.md "Valid forms", row: one lane of each storing
+// workgroup adds to ONE counter / the workgroup whose add came last loads after its add returned, the other waves after a barrier).
+// The ticket words live in a zero-initialised __device__ array of the code object; the folding block resets its word, and every
+// launch takes the next of RED_SLOTS slot rows, so launches in flight on different streams never share a word.
+constexpr int RED_SLOTS = 256, RED_WORDS = 512;
+__device__ unsigned int g_red_tickets[RED_SLOTS][RED_WORDS];
+
+template <typename T, int MODE, int GC>
+__global__ __launch_bounds__(BLOCK) void k_colreduce_t(const T* __restrict__ x, int64_t ldx, const T* __restrict__ gout, int64_t ldg,
+                                                       int64_t N, int C, const int32_t* __restrict__ ptr,
+                                                       const int32_t* __restrict__ gid, const int32_t* __restrict__ sid,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ coef, double* partial, int slot,
+                                                       int post, const float* __restrict__ inv_cnt, float eps,
+                                                       float* __restrict__ out0, float* __restrict__ out1) {
+    constexpr bool DOT_BN = (MODE == STIN_RED_DOT_BN || MODE == STIN_RED_DOT_BN_RELU);
+    constexpr int NOUT = (MODE == STIN_RED_DOT_ELU || MODE == STIN_RED_MOMENTS || DOT_BN) ? 2 : 1;
+    constexpr int VW = 4, CL = GC / VW, RLN = BLOCK / CL;                          // column lanes, row lanes
+    __shared__ double sm[NOUT][RLN][GC + 1];
+    __shared__ int last_s;
+    const int r = blockIdx.x, R = gridDim.x, cg = blockIdx.y, ncg = gridDim.y, b = blockIdx.z;
+    const int64_t r0 = ptr != nullptr ? ptr[b] : 0;
+    const int64_t r1 = ptr != nullptr ? ptr[b + 1] : N;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int c = cg * GC + cl * VW;
+    const bool live = c < C;                                                      // (C % 4 == 0: a float4 is in or out)
+    double acc0[VW], acc1[VW];
+#pragma unroll
+    for (int i = 0; i < VW; ++i) { acc0[i] = 0.0; acc1[i] = 0.0; }
+    if (live) {
+        constexpr int UR = 4;                                                      // rows in flight per thread
+        const int64_t step = (int64_t)R * RLN;
+        for (int64_t rb = r0 + (int64_t)r * RLN + rl; rb < r1; rb += UR * step) {
+            V<VW> xv[UR], go[UR];
+            int gq[UR], sq[UR];
+            bool ok[UR];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int64_t row = rb + u * step;
+                ok[u] = row < r1;
+                const int64_t rc = ok[u] ? row : rb;
+                xv[u] = V<VW>::load(x + rc * ldx + c);
+                if (MODE == STIN_RED_DOT_ELU || DOT_BN) go[u] = V<VW>::load(gout + rc * ldg + c);
+                gq[u] = (MODE != STIN_RED_SUM && MODE != STIN_RED_MOMENTS && gid != nullptr) ? gid[rc] : 0;
+                sq[u] = (MODE == STIN_RED_COEF_XC && sid != nullptr) ? sid[rc] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                if (!ok[u]) continue;
+                if (MODE == STIN_RED_SUM) {
+#pragma unroll
+                    for (int i = 0; i < VW; ++i) acc0[i] += (double)xv[u].v[i];
+                } else if (MODE == STIN_RED_MOMENTS) {
+#pragma unroll
+                    for (int i = 0; i < VW; ++i) {
+                        const double d = (double)xv[u].v[i];
+                        acc0[i] += d;
+                        acc1[i] += d * d;
+                    }
+                } else {
+                    const int g = gq[u];
+                    const V<VW> mu = V<VW>::load(mean + (int64_t)g * C + c);
+                    if (DOT_BN) {
+                        const V<VW> rs = V<VW>::load(rstd + c);
+                        const V<VW> ga = V<VW>::load(coef + c);
+                        const V<VW> be = V<VW>::load(coef + C + c);
+#pragma unroll
+                        for (int i = 0; i < VW; ++i) {
+                            const float n = (xv[u].v[i] - mu.v[i]) * rs.v[i];
+                            const float d = (MODE == STIN_RED_DOT_BN_RELU && !(ga.v[i] * n + be.v[i] > 0.f)) ? 0.f : go[u].v[i];
+                            acc0[i] += (double)(d * n);
+                            acc1[i] += (double)d;
+                        }
+                    } else if (MODE == STIN_RED_CSQ) {
+#pragma unroll
+                        for (int i = 0; i < VW; ++i) { const float d = xv[u].v[i] - mu.v[i]; acc0[i] += (double)(d * d); }
+                    } else if (MODE == STIN_RED_DOT_ELU) {
+                        const V<VW> rs = V<VW>::load(rstd + (int64_t)g * C + c);
+#pragma unroll
+                        for (int i = 0; i < VW; ++i) {
+                            const float xc = xv[u].v[i] - mu.v[i];
+                            const float dy = go[u].v[i] * elu_grad_from_pre(xc * rs.v[i]);
+                            acc0[i] += (double)(dy * xc);
+                            acc1[i] += (double)dy;
+                        }
+                    } else {  // STIN_RED_COEF_XC
+                        const V<VW> cf = V<VW>::load(coef + (int64_t)sq[u] * C + c);
+#pragma unroll
+                        for (int i = 0; i < VW; ++i) acc0[i] += (double)(cf.v[i] * (xv[u].v[i] - mu.v[i]));
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VW; ++i) {
+        sm[0][rl][cl * VW + i] = acc0[i];
+        if (NOUT == 2) sm[NOUT - 1][rl][cl * VW + i] = acc1[i];
+    }
+    __syncthreads();
+    // partial of this block: [b][cg][r][o][GC], published write-through
+    double* pg = partial + (((int64_t)b * ncg + cg) * R) * (NOUT * GC);
+    if (threadIdx.x < NOUT * GC) {
+        const int o = threadIdx.x / GC, cc = threadIdx.x % GC;
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < RLN; ++k) t += sm[o][k][cc];
+        __hip_atomic_store(pg + (int64_t)r * (NOUT * GC) + o * GC + cc, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // every storing wave drains its sc1 stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int* word = &g_red_tickets[slot][b * ncg + cg];
+        const unsigned int t = __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned int)(R - 1)) ? 1 : 0;
+        if (last) __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the slot's next launch
+        last_s = last;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    // ---- the fold (sc1 loads only): thread (part, column) sums r = part, part + PARTS, ... ; then the parts in order
+    constexpr int PARTS = BLOCK / GC;
+    const int cc = threadIdx.x % GC, part = threadIdx.x / GC;
+    double f[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) f[o] = 0.0;
+    constexpr int FU = 16;                                                        // partials in flight per thread and output
+    for (int k0 = part; k0 < R; k0 += FU * PARTS) {
+        double v[NOUT][FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int k = k0 + u * PARTS;
+            const int kc = k < R ? k : part;
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+                v[o][u] = __hip_atomic_load(pg + (int64_t)kc * (NOUT * GC) + o * GC + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u)
+            if (k0 + u * PARTS < R) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) f[o] += v[o][u];
+            }
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) sm[o][part][cc] = f[o];
+    __syncthreads();
+    const int col = cg * GC + cc;
+    if (part == 0 && col < C) {
+        double t[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            t[o] = 0.0;
+#pragma unroll
+            for (int k = 0; k < PARTS; ++k) t[o] += sm[o][k][cc];
+        }
+        if (MODE == STIN_RED_MOMENTS) {                                           // as k_moments_final
+            const double ic = (double)inv_cnt[b];
+            const double mu = t[0] * ic;
+            double var = t[NOUT - 1] * ic - mu * mu;
+            if (var < 0.0) var = 0.0;
+            out0[(int64_t)b * C + col] = (float)mu;
+            out1[(int64_t)b * C + col] = (float)(1.0 / sqrt(var + (double)eps));
+        } else {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {                                      // as k_colreduce_final
+                float rr = (float)t[o];
+                if (post == STIN_POST_SCALE) rr = rr * inv_cnt[b];
+                else if (post == STIN_POST_RSTD) rr = 1.0f / sqrtf(rr * inv_cnt[b] + eps);
+                else if (post == STIN_POST_NORM_COEF) {
+                    const float rs = rstd[(int64_t)b * C + col], ic = inv_cnt[b];
+                    rr = (o == 0) ? -(rs * rs * rs) * rr * ic : -(rs * rr) * ic;
+                }
+                (o == 0 ? out0 : out1)[(int64_t)b * C + col] = rr;
+            }
+        }
     }
 }
 
@@ -468,6 +659,15 @@ constexpr bool is_f32(const stin_bf16*) { return false; }
 inline const stin_bf16* b16(const stin_bf16_t* p) { return reinterpret_cast<const stin_bf16*>(p); }
 inline stin_bf16* b16(stin_bf16_t* p) { return reinterpret_cast<stin_bf16*>(p); }
 
+inline int norm_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return n;
+}
+
 template <typename T>
 int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg, int64_t N, int C, const int32_t* ptr,
                    int B, const int32_t* gid, const int32_t* sid, const float* mean, const float* rstd,
@@ -491,6 +691,52 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
 
     const bool vec = vec4_ok<T>(C, {x, gout}, {mean, rstd, coef}, {ldx, gout ? ldg : 0});
     if (!vec && !is_f32((const T*)nullptr)) return STIN_E_UNSUPPORTED;
+    // one-launch form (k_colreduce_t): 16-byte fp32 rows, few enough (range, column group) pairs for one row of ticket words;
+    // STIN_RED_TICKET=0 keeps the two-launch form (A/B switch, read once).  Column groups of 64 / 32 / 16 so that narrow
+    // matrices still fold on four blocks side by side.
+    static const bool ticket_on = !(getenv("STIN_RED_TICKET") && atoi(getenv("STIN_RED_TICKET")) == 0);
+    if (vec && ticket_on && is_f32((const T*)nullptr) && N > 0) {
+        const int GC = C >= 256 ? 64 : (C >= 128 ? 32 : 16);
+        const int ncg = (C + GC - 1) / GC;
+        if ((int64_t)B * ncg <= RED_WORDS) {
+            static std::atomic<unsigned> seq{0};
+            const int slot = (int)(seq.fetch_add(1, std::memory_order_relaxed) % RED_SLOTS);
+            const int RLN = BLOCK / (GC / 4);
+            // row chunks: ~8 row trips per block, at most ~2 blocks per CU over all column groups and ranges, and within the workspace
+            int64_t R = (N / B + (int64_t)RLN * 8 - 1) / ((int64_t)RLN * 8);
+            static const int per_cu = (getenv("STIN_RED_PER_CU") && atoi(getenv("STIN_RED_PER_CU")) > 0) ? atoi(getenv("STIN_RED_PER_CU")) : 2;   // tuning aid
+            const int64_t cap = (per_cu * (int64_t)norm_cu_count() + (int64_t)B * ncg - 1) / ((int64_t)B * ncg);
+            if (R > cap) R = cap;
+            // partial [B][ncg][R][2][GC] doubles must fit the caller's workspace of max(B, MAX_SLABS) x 2 x C doubles
+            const int64_t ws_cap = (int64_t)(B > MAX_SLABS ? B : MAX_SLABS) * C / ((int64_t)ncg * GC);
+            if (R > ws_cap / B) R = ws_cap / B;
+            if (R < 1) R = 1;
+            dim3 grid((unsigned)R, (unsigned)ncg, (unsigned)B);
+#define STIN_REDT_L(M, G)                                                                                                \
+            hipLaunchKernelGGL((k_colreduce_t<T, M, G>), grid, dim3(BLOCK), 0, stream, x, ldx, gout, ldg, N, C, ptr, gid, sid, mean, rstd, coef, \
+                               partial, slot, post, inv_cnt, eps, out0, out1)
+#define STIN_REDT_LAUNCH(M)                                                                                              \
+            do {                                                                                                         \
+                if (GC == 64) STIN_REDT_L(M, 64);                                                                        \
+                else if (GC == 32) STIN_REDT_L(M, 32);                                                                   \
+                else STIN_REDT_L(M, 16);                                                                                 \
+            } while (0)
+            if constexpr (is_f32((const T*)nullptr)) {
+                switch (mode) {
+                    case STIN_RED_SUM: STIN_REDT_LAUNCH(STIN_RED_SUM); break;
+                    case STIN_RED_CSQ: STIN_REDT_LAUNCH(STIN_RED_CSQ); break;
+                    case STIN_RED_DOT_ELU: STIN_REDT_LAUNCH(STIN_RED_DOT_ELU); break;
+                    case STIN_RED_MOMENTS: STIN_REDT_LAUNCH(STIN_RED_MOMENTS); break;
+                    case STIN_RED_DOT_BN: STIN_REDT_LAUNCH(STIN_RED_DOT_BN); break;
+                    case STIN_RED_DOT_BN_RELU: STIN_REDT_LAUNCH(STIN_RED_DOT_BN_RELU); break;
+                    default: STIN_REDT_LAUNCH(STIN_RED_COEF_XC); break;
+                }
+            }
+#undef STIN_REDT_LAUNCH
+#undef STIN_REDT_L
+            return stin_launch_status();
+        }
+    }
     const int VW = vec ? 4 : 1;
     const int CV = C / VW;
     const int CG = CV < BLOCK ? CV : BLOCK;
