@@ -332,6 +332,29 @@ int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, i
                      int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
                      int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream);
 
+/* The same product with the weight gradient dW [Nc, K] (row pitch lddw >= K) and the bias gradient db [Nc] as SEPARATE
+ * destinations (ones column implied): what torch.nn.Linear's backward hands to weight.grad / bias.grad
+ * (models/surfacetextureinpaintingnet.py:461-466 `final_linear1`, and every generic nn.Linear of the build) without an
+ * [Nc, K + 1] intermediate and the two slicing copies behind it. */
+int stin_gemm_tn_wb_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
+                        const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw, float* db, int precision,
+                        void* workspace, size_t workspace_bytes, stin_stream_t stream);
+
+/* The network's last layer in one launch per direction: y = tanh(x W^T + b), W [Nc, K], Nc <= 4 output (colour) channels,
+ * K % 4 == 0, K <= 256 (STIN_E_UNSUPPORTED otherwise: callers fall back to stin_gemm_nt_* + a tanh) - replaces
+ * `torch.tanh(self.final_linear2(vertex_features))` of models/surfacetextureinpaintingnet.py:470-471 and its autograd backward.
+ *   fwd: x [N, K] rows (ldx), y [N, Nc] fp32 contiguous.  Exact fp32 products, per-row sums in a fixed order.
+ *   bwd: g = dL/dy [N, Nc] and y [N, Nc] fp32 contiguous; dz = g (1 - y^2); dx [N, K] = dz W (NULL: not wanted),
+ *        dW [Nc, K] = dz^T x, db [Nc] = column sums of dz (NULL: no bias) - block partials folded in a fixed order by the last
+ *        block to arrive (deterministic, one launch); workspace >= stin_linear_tanh_bwd_workspace_bytes.
+ * The bf16 variants read / write bf16 activation rows (x, dx); W, b, g, y and the gradients stay fp32. */
+size_t stin_linear_tanh_bwd_workspace_bytes(int64_t N, int K, int Nc);
+int stin_linear_tanh_fwd_f32(const float* x, int64_t ldx, const float* W, const float* b, int64_t N, int K, int Nc, float* y,
+                             stin_stream_t stream);
+int stin_linear_tanh_bwd_f32(const float* g, const float* y, const float* x, int64_t ldx, const float* W, int64_t N, int K, int Nc,
+                             float* dx, int64_t lddx, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                             stin_stream_t stream);
+
 /* BatchNorm1d-with-affine over ALL rows, optionally followed by ReLU, for the per-edge MLP of SingleConvMeshNet
  * (models/modules/edge_conv_filter.py:34-44: Lin - BatchNorm1d - ReLU - Lin - BatchNorm1d over the E edge rows):
  *   fwd: y = act(gamma * (x - mean) * rstd + beta)            mean / rstd [C] from stin_colreduce_f32(STIN_RED_MOMENTS)
@@ -493,6 +516,15 @@ int stin_gemm_nt_bf16(const stin_bf16_t* A, int64_t lda, const float* W, int64_t
 int stin_gemm_tn_bf16(const stin_bf16_t* G, int64_t ldg, const stin_bf16_t* X, int64_t ldx, int64_t M, int Nc, int K,
                       int ones_column, const stin_bf16_t* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
                       void* workspace, size_t workspace_bytes, stin_stream_t stream);
+/* (bf16 activation rows: stin_gemm_tn_wb_f32 and the stin_linear_tanh_* pair above) */
+int stin_gemm_tn_wb_bf16(const stin_bf16_t* G, int64_t ldg, const stin_bf16_t* X, int64_t ldx, int64_t M, int Nc, int K,
+                         const stin_bf16_t* row_weight, int64_t ld_weight, float* dW, int64_t lddw, float* db,
+                         void* workspace, size_t workspace_bytes, stin_stream_t stream);
+int stin_linear_tanh_fwd_bf16(const stin_bf16_t* x, int64_t ldx, const float* W, const float* b, int64_t N, int K, int Nc,
+                              float* y, stin_stream_t stream);
+int stin_linear_tanh_bwd_bf16(const float* g, const float* y, const stin_bf16_t* x, int64_t ldx, const float* W, int64_t N, int K,
+                              int Nc, stin_bf16_t* dx, int64_t lddx, float* dW, float* db, void* workspace,
+                              size_t workspace_bytes, stin_stream_t stream);
 
 /* ------------------------------------------------------ whole-block launch sequences --
  * One GraphResnetBlock (EdgeConv(mean) -> instance norm -> ELU -> + residual,

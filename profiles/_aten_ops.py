@@ -54,8 +54,10 @@ class Trace(TorchDispatchMode):
 
 # (the backward pass runs in autograd's thread: dispatch modes are thread-local, so the forward and the optimizer are what this
 # sees; backward-side framework ops are listed by the profiler pass below)
-with Trace() as tr:
-    one()
+# backward in the calling thread, so that the dispatch mode (thread-local) sees the backward-side framework ops too
+with torch.autograd.set_multithreading_enabled(False):
+    with Trace() as tr:
+        one()
 torch.cuda.synchronize()
 for (name, where), n in tr.hits.most_common(40):
     print('%3d  %-34s %s' % (n, name, where))

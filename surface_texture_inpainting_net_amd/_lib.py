@@ -68,6 +68,17 @@ SIGNATURES = {
     'stin_gemm_tn_workspace_bytes': (c_size, [c_i64, c_int, c_int, c_int]),
     'stin_gemm_tn_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64,
                                  c_int, c_ptr, c_size, c_ptr]),
+    'stin_gemm_tn_wb_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
+                                    c_int, c_ptr, c_size, c_ptr]),
+    'stin_gemm_tn_wb_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
+                                     c_ptr, c_size, c_ptr]),
+    'stin_linear_tanh_bwd_workspace_bytes': (c_size, [c_i64, c_int, c_int]),
+    'stin_linear_tanh_fwd_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    'stin_linear_tanh_fwd_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    'stin_linear_tanh_bwd_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr,
+                                         c_ptr, c_size, c_ptr]),
+    'stin_linear_tanh_bwd_bf16': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_ptr,
+                                          c_ptr, c_size, c_ptr]),
     'stin_edgeconv_pack_f32': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr,
                                        c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr]),
     'stin_gemm_split_weights_f32': (c_int, [c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),

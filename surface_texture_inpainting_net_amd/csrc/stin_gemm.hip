@@ -2393,7 +2393,8 @@ inline int tn_skinny_rows(int64_t M) {                                         /
 constexpr int RS_COLS = 16, RS_KL = 16;
 __device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 __global__ __launch_bounds__(BLOCK) void k_reduce_slabs(const float* __restrict__ slab, int64_t chunks, int Nc, int K, int Kq,
-                                                        int has_bias, float* __restrict__ out, int64_t ldo) {
+                                                        int has_bias, float* __restrict__ out, int64_t ldo,
+                                                        float* __restrict__ bias_out) {
     __shared__ float4 sm[RS_KL][RS_COLS + 1];
     const int tx = threadIdx.x % RS_COLS, ty = threadIdx.x / RS_COLS;
     const int64_t cs = tn_chunk_stride(Nc, Kq);
@@ -2431,7 +2432,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_slabs(const float* __restrict_
             const int64_t i = 4 * (g - nw4);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (i + e < Nc) out[(i + e) * ldo + K] = v[e];
+                if (i + e < Nc) {
+                    if (bias_out != nullptr) bias_out[i + e] = v[e];          // (stin_gemm_tn_wb_*: db as its own vector)
+                    else out[(i + e) * ldo + K] = v[e];
+                }
         }
     }
 }
@@ -2919,12 +2923,12 @@ int stin_tn_slabs(const stin_tn_problem* p, int storage, int precision, stin_str
     return stin_launch_status();
 }
 
-extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
-                                int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
-                                int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+static int gemm_tn_f32_impl(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
+                           int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw, float* db,
+                           int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
-    const int Kp = K + (ones_column ? 1 : 0);
+    const int Kp = K + ((ones_column && db == nullptr) ? 1 : 0);
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && ldg >= Nc && ldx >= K && lddw >= Kp, STIN_E_SIZE);
     STIN_REQUIRE(dW && workspace && (M == 0 || (G && X)), STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_gemm_tn_workspace_bytes(M, Nc, K, ones_column), STIN_E_WORKSPACE);
@@ -2938,8 +2942,23 @@ extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int
     if (rc != STIN_OK) return rc;
     const int64_t n4 = (int64_t)Nc * p.Kq / 4 + (p.has_bias ? (Nc + 3) / 4 : 0);
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n4 + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, p.chunks, Nc, K,
-                       p.Kq, p.has_bias, dW, lddw);
+                       p.Kq, p.has_bias, dW, lddw, db);
     return stin_launch_status();
+}
+extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
+                                int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw,
+                                int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+    return gemm_tn_f32_impl(G, ldg, X, ldx, M, Nc, K, ones_column, row_weight, ld_weight, dW, lddw, nullptr, precision, workspace,
+                            workspace_bytes, stream_);
+}
+// weight gradient dW [Nc, K] (row pitch lddw >= K) and bias gradient db [Nc] as SEPARATE destinations - e.g. the views of an
+// nn.Linear's weight.grad / bias.grad in a flat gradient bucket: no [Nc, K + 1] intermediate and no slicing copies afterwards
+extern "C" int stin_gemm_tn_wb_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
+                                   const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw, float* db, int precision,
+                                   void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+    STIN_REQUIRE(db != nullptr, STIN_E_NULL);
+    return gemm_tn_f32_impl(G, ldg, X, ldx, M, Nc, K, 1, row_weight, ld_weight, dW, lddw, db, precision, workspace, workspace_bytes,
+                            stream_);
 }
 
 // ------------------------------------------------------------------ bf16-storage entry points
@@ -3013,12 +3032,12 @@ extern "C" int stin_gemm_nt_bf16(const stin_bf16_t* A_, int64_t lda, const float
     return stin_launch_status();
 }
 
-extern "C" int stin_gemm_tn_bf16(const stin_bf16_t* G_, int64_t ldg, const stin_bf16_t* X_, int64_t ldx, int64_t M, int Nc,
-                                 int K, int ones_column, const stin_bf16_t* row_weight_, int64_t ld_weight, float* dW,
-                                 int64_t lddw, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+static int gemm_tn_bf16_impl(const stin_bf16_t* G_, int64_t ldg, const stin_bf16_t* X_, int64_t ldx, int64_t M, int Nc,
+                            int K, int ones_column, const stin_bf16_t* row_weight_, int64_t ld_weight, float* dW,
+                            int64_t lddw, float* db, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
-    const int Kp = K + (ones_column ? 1 : 0);
+    const int Kp = K + ((ones_column && db == nullptr) ? 1 : 0);
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && ldg >= Nc && ldx >= K && lddw >= Kp, STIN_E_SIZE);
     STIN_REQUIRE(dW && workspace && (M == 0 || (G_ && X_)), STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_gemm_tn_workspace_bytes(M, Nc, K, ones_column), STIN_E_WORKSPACE);
@@ -3030,6 +3049,18 @@ extern "C" int stin_gemm_tn_bf16(const stin_bf16_t* G_, int64_t ldg, const stin_
     if (rc != STIN_OK) return rc;
     const int64_t n4 = (int64_t)Nc * p.Kq / 4 + (p.has_bias ? (Nc + 3) / 4 : 0);
     hipLaunchKernelGGL(k_reduce_slabs, dim3((unsigned)((n4 + RS_COLS - 1) / RS_COLS)), dim3(BLOCK), 0, stream, slab, p.chunks, Nc, K,
-                       p.Kq, p.has_bias, dW, lddw);
+                       p.Kq, p.has_bias, dW, lddw, db);
     return stin_launch_status();
+}
+extern "C" int stin_gemm_tn_bf16(const stin_bf16_t* G_, int64_t ldg, const stin_bf16_t* X_, int64_t ldx, int64_t M, int Nc,
+                                 int K, int ones_column, const stin_bf16_t* row_weight_, int64_t ld_weight, float* dW,
+                                 int64_t lddw, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+    return gemm_tn_bf16_impl(G_, ldg, X_, ldx, M, Nc, K, ones_column, row_weight_, ld_weight, dW, lddw, nullptr, workspace,
+                             workspace_bytes, stream_);
+}
+extern "C" int stin_gemm_tn_wb_bf16(const stin_bf16_t* G_, int64_t ldg, const stin_bf16_t* X_, int64_t ldx, int64_t M, int Nc,
+                                    int K, const stin_bf16_t* row_weight_, int64_t ld_weight, float* dW, int64_t lddw, float* db,
+                                    void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+    STIN_REQUIRE(db != nullptr, STIN_E_NULL);
+    return gemm_tn_bf16_impl(G_, ldg, X_, ldx, M, Nc, K, 1, row_weight_, ld_weight, dW, lddw, db, workspace, workspace_bytes, stream_);
 }

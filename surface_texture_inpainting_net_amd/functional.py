@@ -421,14 +421,38 @@ def gemm_tn(G, X, ones_column=False, row_weight=None, precision=GEMM_F32):
     return out
 
 
+def gemm_tn_wb(G, X, dW, db, precision=GEMM_F32):
+    """dW[Nc, K] = G^T X and db[Nc] = column sums of G, written into the two given fp32 tensors (contiguous; e.g. the views of
+    an nn.Linear's gradients in a TrainStep bucket) - no [Nc, K + 1] intermediate and no slicing copies (stin_gemm_tn_wb_*)."""
+    lib = _lib.load()
+    G, ldg = _mat(G)
+    X, ldx = _mat(X)
+    _same(G, X)
+    M, Nc = G.shape
+    K = X.shape[1]
+    assert X.shape[0] == M and tuple(dW.shape) == (Nc, K) and db.numel() == Nc and dW.is_contiguous() and db.is_contiguous()
+    ws_bytes = lib.stin_gemm_tn_workspace_bytes(M, Nc, K, 1)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)
+    if G.dtype == torch.bfloat16:
+        _call('stin_gemm_tn_wb_bf16', _ptr(G), ldg, _ptr(X), ldx, M, Nc, K, None, 0, _ptr(dW), K, _ptr(db), _ptr(ws), ws_bytes,
+              _stream(G), tag=(M, Nc, K))
+    else:
+        _call('stin_gemm_tn_wb_f32', _ptr(G), ldg, _ptr(X), ldx, M, Nc, K, None, 0, _ptr(dW), K, _ptr(db), int(precision), _ptr(ws),
+              ws_bytes, _stream(G), tag=(M, Nc, K))
+
+
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b on the MFMA kernels (the tail Linears and the generic filter paths)."""
+    """y = x W^T + b on the MFMA kernels (the tail Linears and the generic filter paths).  wT: the weight already
+    transposed ([K, Nc] fp32, written by the network's PackSet beside the block operands) - without it the backward
+    transposes the weight itself.  Gradients of weight / bias go straight into an accepting TrainStep bucket."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, out_fp32=False, precision=None):
+    def forward(ctx, x, weight, bias, out_fp32=False, precision=None, wT=None):
         x, _ = _mat(x)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
+        ctx.wT = wT
         return gemm_nt(x, weight, bias, precision=PREC_FWD if precision is None else precision,
                        out_dtype=torch.float32 if out_fp32 else None)
 
@@ -438,17 +462,89 @@ class LinearFn(torch.autograd.Function):
         if g.dtype != x.dtype:                     # fp32 network output on bf16-storage activations
             g = g.to(x.dtype)
         g, _ = _mat(g)
-        dwb = gemm_tn(g, x, ones_column=ctx.has_bias, precision=PREC_BWD)
-        dx = gemm_nt(g, weight.t().contiguous(), precision=PREC_BWD)
-        if ctx.has_bias:
-            return dx, dwb[:, :-1].contiguous(), dwb[:, -1].contiguous(), None, None
-        return dx, dwb, None, None, None
+        wT = ctx.wT if ctx.wT is not None else weight.t().contiguous()
+        dx = gemm_nt(g, wT, precision=PREC_BWD) if ctx.needs_input_grad[0] else None
+        if not ctx.has_bias:
+            return dx, gemm_tn(g, x, ones_column=False, precision=PREC_BWD), None, None, None, None
+        direct = _direct_grad_views(ctx.params) if g.is_cuda else None
+        if direct is not None:                     # written where the optimizer reads them: nothing for autograd to copy
+            gemm_tn_wb(g, x, direct[0], direct[1], precision=PREC_BWD)
+            return dx, None, None, None, None, None
+        if g.is_cuda:
+            dW = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
+            db = torch.empty(weight.shape[0], dtype=torch.float32, device=g.device)
+            gemm_tn_wb(g, x, dW, db, precision=PREC_BWD)
+            return dx, dW, db, None, None, None
+        dwb = gemm_tn(g, x, ones_column=True, precision=PREC_BWD)
+        return dx, dwb[:, :-1].contiguous(), dwb[:, -1].contiguous(), None, None, None
 
 
-def linear(x, weight, bias=None, out_fp32=False, precision=None):
+def linear_tanh_eligible(x, weight, bias):
+    """The one-launch last layer (stin_linear_tanh_*): at most 4 output channels from K <= 256 channels, 16-byte rows."""
+    Nc, K = weight.shape
+    return (USE_TAIL_KERNEL and x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and x.stride(1) == 1 and
+            x.stride(0) % 4 == 0 and K % 4 == 0 and K <= 256 and 1 <= Nc <= 4 and Nc * K + Nc <= 1024 and
+            weight.dtype == torch.float32 and weight.is_contiguous() and (bias is None or bias.is_contiguous()) and
+            x.data_ptr() % (16 if x.dtype == torch.float32 else 8) == 0)
+
+
+USE_TAIL_KERNEL = os.environ.get('STIN_TAIL_KERNEL', '1') != '0'
+
+
+class LinearTanhFn(torch.autograd.Function):
+    """tanh(x W^T + b) -> fp32 [N, Nc], the network's last layer (reference models/surfacetextureinpaintingnet.py:470-471), one
+    launch per direction (csrc/stin_tail.hip).  Gradients of W / b go straight into an accepting TrainStep bucket."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, K = x.shape
+        Nc = weight.shape[0]
+        y = torch.empty(N, Nc, dtype=torch.float32, device=x.device)
+        sfx = '_bf16' if x.dtype == torch.bfloat16 else '_f32'
+        _call('stin_linear_tanh_fwd' + sfx, _ptr(x), x.stride(0), _ptr(weight), _ptr(bias), N, K, Nc, _ptr(y), _stream(x), tag=(N, Nc, K))
+        ctx.save_for_backward(x, weight, y)
+        ctx.params = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        lib = _lib.load()
+        N, K = x.shape
+        Nc = weight.shape[0]
+        g = g.contiguous()
+        if g.dtype != torch.float32:
+            g = g.float()
+        dev = x.device
+        dx = torch.empty(N, K, dtype=x.dtype, device=dev) if ctx.needs_input_grad[0] else None
+        direct = _direct_grad_views(ctx.params)
+        if direct is not None:
+            dW, db = direct
+        else:
+            dW = torch.empty(Nc, K, dtype=torch.float32, device=dev)
+            db = torch.empty(Nc, dtype=torch.float32, device=dev) if ctx.params[1] is not None else None
+        ws_bytes = lib.stin_linear_tanh_bwd_workspace_bytes(N, K, Nc)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        sfx = '_bf16' if x.dtype == torch.bfloat16 else '_f32'
+        _call('stin_linear_tanh_bwd' + sfx, _ptr(g), _ptr(y), _ptr(x), x.stride(0), _ptr(weight), N, K, Nc, _ptr(dx), K, _ptr(dW),
+              _ptr(db), _ptr(ws), ws_bytes, _stream(x), tag=(N, Nc, K))
+        if direct is not None:
+            return dx, None, None
+        return dx, dW, db
+
+
+def linear_tanh(x, weight, bias=None, precision=None):
+    """tanh(x W^T + b) as fp32: the one-launch kernel where the shape allows it (exact fp32 products), else the GEMM
+    (`precision` as in linear()) + torch.tanh."""
+    if linear_tanh_eligible(x, weight, bias):
+        return LinearTanhFn.apply(x, weight, bias)
+    return torch.tanh(linear(x, weight, bias, out_fp32=True, precision=precision))
+
+
+def linear(x, weight, bias=None, out_fp32=False, precision=None, wT=None):
     """x W^T + b.  out_fp32: fp32 result from bf16-storage activations (the network's final output).
-    precision: forward matrix-core path (None = PREC_FWD); see forward_precision()."""
-    return LinearFn.apply(x, weight, bias, out_fp32, precision)
+    precision: forward matrix-core path (None = PREC_FWD); see forward_precision().  wT: see LinearFn."""
+    return LinearFn.apply(x, weight, bias, out_fp32, precision, wT)
 
 
 def forward_precision(unbounded_input):
@@ -621,11 +717,11 @@ class PackSet:
     and wcatT | w2T), a job table in device memory written once.  specs: [(W1, b1, W2, b2, Ws, bs, trans_inv, prec_fwd, B)]
     in block order, fp32 storage.  Valid while the parameters stay where they are (`matches`)."""
 
-    def __init__(self, specs, dev, b16=False):
+    def __init__(self, specs, dev, b16=False, transposes=()):
         import ctypes
         import struct
         lib = _lib.load()
-        self.key = self.key_of(specs) + (bool(b16),)
+        self.key = self.key_of(specs) + (bool(b16),) + tuple((_ptr(W), tuple(W.shape)) for W in transposes)
         self.b16 = bool(b16)
         self.buffers = []                      # per block: (ws, wts, fwd_split, bwd_split, wcatT view, w2T view, b16)
         blob, self.max_elems = b'', 0
@@ -654,16 +750,26 @@ class PackSet:
             self.max_elems = max(self.max_elems, Yw * Cp + H * Cout)
             # (the two backward operands as ready-made views: no tensor views are created inside autograd.Function.forward)
             self.buffers.append((ws, wts, fsp, bsp, wts[:Yw * Cp].view(Cp, Yw), wts[Yw * Cp:].view(H, Cout), bool(b16)))
+        # plain transposes riding on the same launch (the tail Linear's backward operand W^T): a job whose first operand is
+        # empty (Cin = Cp = 0) and whose "second Linear" is the weight - the pack writes w2T [K, Nc] = W^T in plain fp32
+        self.transposed = []
+        for W in transposes:
+            Nc, K = W.shape
+            assert W.is_contiguous() and W.dtype == torch.float32
+            wT = torch.empty(K, Nc, dtype=torch.float32, device=dev)
+            blob += struct.pack('<10Q8i', 0, 0, 0, 0, _ptr(W), 0, 0, 0, _ptr(wT), 0, 0, 0, K, Nc, 0, 0, 0, 0)
+            self.max_elems = max(self.max_elems, K * Nc)
+            self.transposed.append(wT)
         self.jobs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-        self.n = len(specs)
+        self.n = len(specs) + len(transposes)
 
     @staticmethod
     def key_of(specs):
         return tuple((_ptr(W1), _ptr(b1), _ptr(W2), _ptr(Ws), _ptr(bs), tuple(W1.shape), tuple(W2.shape), bool(t), int(pf), int(B),
                       PREC_BWD, WEIGHT_PRESPLIT, GEMM_W_FRAG) for (W1, b1, W2, b2, Ws, bs, t, pf, B) in specs)
 
-    def matches(self, specs, b16=False):
-        return self.key == self.key_of(specs) + (bool(b16),)
+    def matches(self, specs, b16=False, transposes=()):
+        return self.key == self.key_of(specs) + (bool(b16),) + tuple((_ptr(W), tuple(W.shape)) for W in transposes)
 
     def run(self):
         _call('stin_edgeconv_pack_many_f32', _ptr(self.jobs), self.n, self.max_elems, _stream(self.jobs))

@@ -101,7 +101,7 @@ class SurfaceTextureInpaintingNet(nn.Module):
             self.norm, self.using_norm = M.SingleBatchGraphNorm, True
         else:
             self.norm, self.using_norm = M.Identity, False
-        self._pack_set, self._pack_key, self._pack_probe = None, None, None
+        self._pack_set, self._pack_key, self._pack_probe, self._tail_wT = None, None, None, None
         self._pooling_type = pooling_type
         self.checkpoint_bottleneck = checkpoint_bottleneck          # accepted for config compatibility: the HIP
         self.num_blocks_per_uncheckpointed_block = num_blocks_per_uncheckpointed_block  # blocks save only per-vertex
@@ -223,12 +223,15 @@ class SurfaceTextureInpaintingNet(nn.Module):
                     for t in lin._parameters.values():
                         if t is not None:
                             ptrs.append(t.data_ptr())
+        tail_w = self.final_linear1._parameters['weight']             # its transpose (backward operand) rides on the pack launch
+        ptrs.append(tail_w.data_ptr())
         key = (use, tuple(ptrs), int(num_graphs), SF.PREC_FWD, SF.PREC_BWD, SF.GEMM_W_FRAG, SF.WEIGHT_PRESPLIT, b16)
         if key == self._pack_key:
             if use:
                 self._pack_set.run()
             return
         self._pack_key = key
+        self._tail_wT = None
         blocks = [b for grp in (self.input_blocks, self.encoder_blocks, self.bottleneck_blocks, self.decoder_blocks,
                                 self.output_blocks) for b in grp]
         specs = None
@@ -244,11 +247,13 @@ class SurfaceTextureInpaintingNet(nn.Module):
                 b._prepacked = None
             return
         ps = self._pack_set
-        if ps is None or not ps.matches(specs, b16):
-            ps = self._pack_set = SF.PackSet(specs, x.device, b16)
+        tr = (tail_w,) if (tail_w.is_contiguous() and tail_w.dtype == torch.float32) else ()
+        if ps is None or not ps.matches(specs, b16, tr):
+            ps = self._pack_set = SF.PackSet(specs, x.device, b16, tr)
         ps.run()
         for b, buf in zip(blocks, ps.buffers):
             b._prepacked = buf
+        self._tail_wT = ps.transposed[0] if tr else None
 
     def _norm_arg(self, plan, level, whole_batch=False):
         """What a block's norm receives: NormGroups for the instance norm; for the other norms the
@@ -374,12 +379,13 @@ class SurfaceTextureInpaintingNet(nn.Module):
         else:
             out = self._forward_per_block(out, plan, e0, bn_edges, num_levels)
         tail_prec = SF.forward_precision(not self.using_norm)
-        out = SF.linear(out, self.final_linear1.weight, self.final_linear1.bias, precision=tail_prec)
+        out = SF.linear(out, self.final_linear1.weight, self.final_linear1.bias, precision=tail_prec,
+                        wT=self._tail_wT if self._pack_key is not None and self._pack_key[0] else None)
         if self.norm is M.FastInstanceNorm:                         # per-graph branch even for B = 1 (:465, Q3)
             out = SF.InstanceNormActResFn.apply(out, None, plan.norm_groups(0), True, self.final_norm1.eps)
         else:
             out = F.elu(self.final_norm1(out, batch=sample.batch))
-        out = torch.tanh(SF.linear(out, self.final_linear2.weight, self.final_linear2.bias, out_fp32=True, precision=tail_prec))
+        out = SF.linear_tanh(out, self.final_linear2.weight, self.final_linear2.bias, precision=tail_prec)
         if plan.order0 is not None:                                           # ... and leave it: outputs in the sample's vertex order
             out = SF.PermuteRowsFn.apply(out, plan.rank0, plan.order0)
         plan.validate()

@@ -549,6 +549,58 @@ def test_gemm_nt_on_strided_views_and_linear_autograd():
     assert float((gb - w.sum(0)).abs().max()) <= 1e-4
 
 
+@pytest.mark.parametrize('N,K,Nc', [(1, 64, 3), (37, 64, 3), (5000, 64, 3), (200_704, 64, 3), (3000, 128, 4), (777, 256, 1), (1234, 20, 2)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_last_layer_linear_tanh_one_launch_kernels(N, K, Nc, dtype):
+    """tanh(x W^T + b) and its backward (stin_linear_tanh_*, csrc/stin_tail.hip) against fp64 on the same inputs:
+    forward <= 2e-6, dx / dW / db within summation-order noise of the fp64 result; strided input rows; deterministic."""
+    g = torch.Generator().manual_seed(N + K + Nc)
+    big = (torch.randn(N, K + 8, generator=g) * 0.7).to(DEV).to(dtype)
+    x = big[:, 4:4 + K]                                  # strided rows (ld K + 8), 16-byte (fp32) / 8-byte (bf16) aligned
+    x = x.detach().requires_grad_(True)
+    lin = torch.nn.Linear(K, Nc).to(DEV)
+    assert SF.linear_tanh_eligible(x, lin.weight, lin.bias)
+    y = SF.linear_tanh(x, lin.weight, lin.bias)
+    assert y.dtype == torch.float32 and y.shape == (N, Nc)
+    xd = x.detach().double().requires_grad_(True)
+    Wd, bd = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+    yd = torch.tanh(xd @ Wd.t() + bd)
+    assert float((y.double() - yd).abs().max()) <= 2e-6
+    w = torch.randn(N, Nc, generator=g).to(DEV)
+    gx, gw, gb = torch.autograd.grad((y * w).sum(), [x, lin.weight, lin.bias])
+    rx, rw, rb = torch.autograd.grad((yd * w.double()).sum(), [xd, Wd, bd])
+    tol_x = 1e-5 if dtype == torch.float32 else 1e-2
+    assert float((gx.double() - rx).abs().max()) <= tol_x * max(1.0, float(rx.abs().max()))
+    scale_w = float((w.double().abs().t() @ x.detach().double().abs()).max()) + 1e-30        # sum of magnitudes: fp32 noise floor
+    assert float((gw.double() - rw).abs().max()) <= 2e-6 * scale_w
+    assert float((gb.double() - rb).abs().max()) <= 2e-6 * (float(w.abs().sum(0).max()) + 1e-30)
+    y2 = SF.linear_tanh(x, lin.weight, lin.bias)
+    gx2, gw2, gb2 = torch.autograd.grad((y2 * w).sum(), [x, lin.weight, lin.bias])
+    assert torch.equal(y, y2) and torch.equal(gx, gx2) and torch.equal(gw, gw2) and torch.equal(gb, gb2)
+
+
+def test_linear_backward_separate_weight_and_bias_gradients_and_pretransposed_weight():
+    """LinearFn's backward: dW / db through stin_gemm_tn_wb_* (no [Nc, K + 1] intermediate) equal the sliced stin_gemm_tn_f32
+    result bit for bit, and a pre-transposed weight operand (PackSet's riding transpose) gives the same input gradient."""
+    g = torch.Generator().manual_seed(11)
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.randn(4000, 64, generator=g).to(DEV).to(dtype)
+        G = torch.randn(4000, 64, generator=g).to(DEV).to(dtype)
+        dwb = SF.gemm_tn(G, x, ones_column=True, precision=SF.PREC_BWD)
+        dW, db = torch.empty(64, 64, device=DEV), torch.empty(64, device=DEV)
+        SF.gemm_tn_wb(G, x, dW, db, precision=SF.PREC_BWD)
+        assert torch.equal(dW, dwb[:, :-1]) and torch.equal(db, dwb[:, -1])
+    lin = torch.nn.Linear(64, 64).to(DEV)
+    xs = torch.randn(3000, 64, generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn(3000, 64, generator=g).to(DEV)
+    ps = SF.PackSet([], torch.device(DEV), False, (lin.weight,))
+    ps.run()
+    assert torch.equal(ps.transposed[0], lin.weight.detach().t().contiguous())
+    a = torch.autograd.grad((SF.linear(xs, lin.weight, lin.bias) * w).sum(), [xs, lin.weight, lin.bias])
+    b = torch.autograd.grad((SF.linear(xs, lin.weight, lin.bias, wT=ps.transposed[0]) * w).sum(), [xs, lin.weight, lin.bias])
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+
+
 # --------------------------------------------------------- segment sum / pool / unpool
 @pytest.mark.parametrize('C', [1, 3, 8, 64, 100, 256])
 def test_segment_sum_matches_scatter_and_is_linear(C):
