@@ -355,6 +355,11 @@ int stin_linear_tanh_bwd_f32(const float* g, const float* y, const float* x, int
                              float* dx, int64_t lddx, float* dW, float* db, void* workspace, size_t workspace_bytes,
                              stin_stream_t stream);
 
+/* out [N, Cp] (contiguous) = [x [N, Cin] (row pitch ldx) | zeros]: the network input - 10 channels per vertex,
+ * datasets/scannetcolorgraph_dataloader.py:83-156 - padded to the 16-byte rows the first block's GEMM reads. */
+int stin_pad_rows_f32(const float* x, int64_t ldx, int64_t N, int Cin, int Cp, float* out, stin_stream_t stream);
+int stin_pad_rows_bf16(const stin_bf16_t* x, int64_t ldx, int64_t N, int Cin, int Cp, stin_bf16_t* out, stin_stream_t stream);
+
 /* BatchNorm1d-with-affine over ALL rows, optionally followed by ReLU, for the per-edge MLP of SingleConvMeshNet
  * (models/modules/edge_conv_filter.py:34-44: Lin - BatchNorm1d - ReLU - Lin - BatchNorm1d over the E edge rows):
  *   fwd: y = act(gamma * (x - mean) * rstd + beta)            mean / rstd [C] from stin_colreduce_f32(STIN_RED_MOMENTS)

@@ -72,6 +72,8 @@ SIGNATURES = {
                                     c_int, c_ptr, c_size, c_ptr]),
     'stin_gemm_tn_wb_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr,
                                      c_ptr, c_size, c_ptr]),
+    'stin_pad_rows_f32': (c_int, [c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    'stin_pad_rows_bf16': (c_int, [c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr]),
     'stin_linear_tanh_bwd_workspace_bytes': (c_size, [c_i64, c_int, c_int]),
     'stin_linear_tanh_fwd_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
     'stin_linear_tanh_fwd_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),

@@ -217,6 +217,17 @@ __global__ __launch_bounds__(TL_BWD_BLOCK) void k_linear_tanh_bwd(const float* _
     }
 }
 
+// out[n, 0:Cp) = [x[n, 0:Cin) | 0]: the network input (10 channels: reference datasets/scannetcolorgraph_dataloader.py x layout)
+// padded to the 16-byte rows the first block's GEMM reads - one launch instead of the framework's fill + copy pair
+template <typename T>
+__global__ __launch_bounds__(256) void k_pad_rows(const T* __restrict__ x, int64_t ldx, int64_t N, int Cin, int Cp, T* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * Cp) return;
+    const int64_t r = t / Cp;
+    const int c = (int)(t % Cp);
+    out[t] = c < Cin ? x[r * ldx + c] : (T)0.f;
+}
+
 inline int tail_cu_count() {
     static int n = 0;
     if (n == 0) {
@@ -341,4 +352,22 @@ extern "C" int stin_linear_tanh_bwd_bf16(const float* g, const float* y, const s
                                          size_t workspace_bytes, stin_stream_t stream) {
     return linear_tanh_bwd_impl<stin_bf16>(g, y, reinterpret_cast<const stin_bf16*>(x), ldx, W, N, K, Nc,
                                            reinterpret_cast<stin_bf16*>(dx), lddx, dW, db, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int stin_pad_rows_f32(const float* x, int64_t ldx, int64_t N, int Cin, int Cp, float* out, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N >= 0 && Cin > 0 && Cp >= Cin && ldx >= Cin, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(x && out, STIN_E_NULL);
+    hipLaunchKernelGGL(k_pad_rows<float>, dim3((unsigned)((N * Cp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, N, Cin, Cp, out);
+    return stin_launch_status();
+}
+extern "C" int stin_pad_rows_bf16(const stin_bf16_t* x, int64_t ldx, int64_t N, int Cin, int Cp, stin_bf16_t* out, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N >= 0 && Cin > 0 && Cp >= Cin && ldx >= Cin, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(x && out, STIN_E_NULL);
+    hipLaunchKernelGGL(k_pad_rows<stin_bf16>, dim3((unsigned)((N * Cp + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const stin_bf16*>(x), ldx, N, Cin, Cp, reinterpret_cast<stin_bf16*>(out));
+    return stin_launch_status();
 }

@@ -801,7 +801,8 @@ class EdgeConvBlockFn(torch.autograd.Function):
         pad = 8 if b16 else 4
         Cp = (Cin + pad - 1) // pad * pad                         # inner dimension padded for the 16-byte GEMM paths
         if Cp != Cin:                                             # (the 10-channel network input -> 12; bf16: 16)
-            xp = torch.nn.functional.pad(x, (0, Cp - Cin))         # one kernel (zeros + copy were two)
+            xp = torch.empty(x.shape[0], Cp, dtype=x.dtype, device=dev)
+            _call('stin_pad_rows' + ('_bf16' if b16 else '_f32'), _ptr(x), x.stride(0), x.shape[0], Cin, Cp, _ptr(xp), _stream(x))
         else:
             xp = x
         # forward / backward weight operands, pre-split once here into the two 16-bit pieces the split GEMMs use
@@ -1257,7 +1258,8 @@ class NetFn(torch.autograd.Function):
         N0, Cin0 = x.shape
         Cp0 = (Cin0 + pad - 1) // pad * pad
         if Cp0 != Cin0:                                          # (the 10-channel network input -> 12; bf16: 16)
-            xp = torch.nn.functional.pad(x, (0, Cp0 - Cin0))       # one kernel (zeros + copy were two)
+            xp = torch.empty(N0, Cp0, dtype=x.dtype, device=x.device)
+            _call('stin_pad_rows' + sfx, _ptr(x), x.stride(0), N0, Cin0, Cp0, _ptr(xp), _stream(x))   # one launch (F.pad: fill + copy)
         else:
             xp = x
         # ---- pass 1: shapes and arena layout

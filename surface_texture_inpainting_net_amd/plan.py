@@ -72,6 +72,28 @@ def _upload(host_tensor, device):
     return dev
 
 
+FLAG_POOL = 4096
+_FLAG_POOLS = {}
+
+
+def _flag_word(device):
+    """-> a [1] int32 view of the device's zero-initialised flag pool (round-robin)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ent = _FLAG_POOLS.get(key)
+    if ent is None:
+        if _capturing():
+            raise RuntimeError('the first plan of a device must be built outside a HIP-graph capture (flag pool allocation)')
+        pool = torch.zeros(FLAG_POOL, dtype=torch.int32, device=device)
+        torch.cuda.current_stream(device).synchronize()        # side streams may use a word before the creating stream is joined
+        ent = _FLAG_POOLS[key] = [pool, 0]
+    ent[1] = (ent[1] + 1) % FLAG_POOL
+    if ent[1] == 0 and not _capturing():
+        # once per FLAG_POOL plans: words dirtied by plans that were never validated (validate=False) come back clean; every
+        # plan old enough to share a word with a new one has long reported
+        ent[0].zero_()
+    return ent[0][ent[1]:ent[1] + 1]
+
+
 _SIDE_STREAMS = {}
 
 
@@ -305,17 +327,10 @@ class GraphPlan:
         self._sample = sample
         # out-of-range flag, zeroed on a side stream so that side-stream builds (prefetch) never have to wait for the
         # compute still queued on the main stream; the main stream joins it here (one event wait)
-        main = torch.cuda.current_stream(self.device)
-        if _capturing():                                  # inside a HIP-graph capture everything stays on the captured stream
-            self._bad = torch.zeros(1, dtype=torch.int32, device=self.device)
-            self._bad_ready = None
-        else:
-            s0 = _side_streams(self.device)[0]
-            with torch.cuda.stream(s0):
-                self._bad = torch.zeros(1, dtype=torch.int32, device=self.device)
-            self._bad.record_stream(main)
-            self._bad_ready = s0.record_event()
-            main.wait_event(self._bad_ready)
+        # out-of-range flag: one word of a per-device pool that is zeroed ONCE (round 4: a fresh torch.zeros per plan was a fill
+        # kernel + an event pair per step).  Kernels only ever set a flag on an index error, and the error path clears the
+        # word again before it raises (_clear_flag), so a word handed out again FLAG_POOL plans later is zero.
+        self._bad = _flag_word(self.device)
         self._pending = []
         self._edges = {}
         self._pools = {}
@@ -624,6 +639,7 @@ class GraphPlan:
                 _PENDING_CHECKS.append(self)
             return
         if int(self._bad.item()) != 0:
+            self._bad.zero_()                                  # the pool word goes back clean
             raise IndexError('edge / trace index out of range for the level sizes in sample.num_vertices')
         self._validated = True
 
@@ -636,6 +652,7 @@ class GraphPlan:
         bad = int(self._flag_host[0])
         self._flag_host = None
         if bad != 0:
+            self._bad.zero_()                                  # the pool word goes back clean
             raise IndexError('edge / trace index out of range for the level sizes in sample.num_vertices '
                              '(reported by the deferred plan validation of an earlier forward call)')
         self._validated = True
