@@ -492,12 +492,15 @@ struct Lane8 {
     __device__ __forceinline__ int chan(int k) const { return (k * G + lg) * 8; }
 };
 
-template <int G, int VPL, int U>
-__global__ __launch_bounds__(BLOCK) void k_edge_fwd8(const stin_bf16* __restrict__ A, int64_t lda,
-                                                     const stin_bf16* __restrict__ B, int64_t ldb,
-                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                     int64_t N, int H, stin_bf16* __restrict__ out, int64_t ldo, int indicator,
-                                                     uint32_t* __restrict__ mask) {
+// Every launch of the 8-channel kernels is EXACT: H == 8 G VPL (STIN_DISPATCH8 / wide8_ok admit H = 128 .. 2048 only), so no
+// lane is idle and no load is predicated.  (Round 4: the per-chunk `chan < H` predicates of the first version put every
+// neighbour-row load behind its own branch; hipcc then issued index load -> wait -> row load -> index load -> wait ..., i.e. ONE
+// row in flight per lane group whatever U said - the kernel ran at 0.60-0.76 of peak where its fp32 twin reaches 0.88.)
+template <int G, int VPL, int U, bool MASK>
+__device__ __forceinline__ void edge_fwd8_body(const stin_bf16* __restrict__ A, int64_t lda, const stin_bf16* __restrict__ B,
+                                               int64_t ldb, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                               int64_t N, int H, stin_bf16* __restrict__ out, int64_t ldo, int indicator,
+                                               uint32_t* __restrict__ mask) {
     constexpr int WK = G / 4;                 // mask words per lane chunk k (8 channels x G lanes / 32)
     constexpr int LPS = WK / 4;               // lanes that store one neighbour's words of one k (16 bytes each)
     static_assert(U * LPS <= G, "not enough lanes to store the mask words of U neighbours");
@@ -505,32 +508,28 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd8(const stin_bf16* __restrict
     if (L.row >= N) return;
     const int beg = rowptr[L.row], end = rowptr[L.row + 1];
     F8 a[VPL], acc[VPL];
-    bool on[VPL];
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
-        on[k] = L.chan(k) < H;
-        a[k] = on[k] ? ld8(A + L.row * lda + L.chan(k)) : f8zero();
+        a[k] = ld8(A + L.row * lda + L.chan(k));
         acc[k] = f8zero();
     }
     const int mwords = H >> 5;
     const int sh = ((threadIdx.x & 63) / G) * G;          // bit position of this row inside the wave ballots
     const int su = L.lg / LPS, sp = L.lg % LPS;           // neighbour / 16-byte part this lane stores
     for (int e = beg; e < end; e += U) {
-        // (round 4) the U neighbour rows in flight stay PACKED (4 registers per 8 channels, widened at use): half the
-        // registers of the widened form, so more rows in flight at the same occupancy
+        // all U neighbour indices first, then all U rows: U rows in flight, kept PACKED (4 registers per 8 channels, widened at use)
+        int64_t j[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) j[u] = col[min(e + u, end - 1)];
         uint4 braw[U][VPL];
         uint4 mw[VPL];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ee = min(e + u, end - 1);
-            const int64_t j = col[ee];
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int k = 0; k < VPL; ++k)
-                braw[u][k] = on[k] ? *reinterpret_cast<const uint4*>(B + j * ldb + L.chan(k)) : make_uint4(0u, 0u, 0u, 0u);
-        }
+            for (int k = 0; k < VPL; ++k) braw[u][k] = *reinterpret_cast<const uint4*>(B + j[u] * ldb + L.chan(k));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float w = (e + u < end) ? 1.f : 0.f;
+            const bool valid = e + u < end;
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {
                 uint32_t wd[WK];
@@ -541,22 +540,23 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd8(const stin_bf16* __restrict
                 for (int c = 0; c < 8; ++c) {
                     const float bv = __uint_as_float((c & 1) ? (rw[c >> 1] & 0xffff0000u) : (rw[c >> 1] << 16));
                     const float t = a[k].v[c] + bv;
-                    acc[k].v[c] += w * fmaxf(t, 0.f);
-                    if (mask != nullptr) {
-                        const unsigned long long bc = __ballot(t > 0.f);
+                    const bool pos = t > 0.f;
+                    acc[k].v[c] += (valid && pos) ? t : 0.f;        // = w ReLU(t), w = [the slot is an edge of this row]
+                    if (MASK) {
+                        const unsigned long long bc = __ballot(pos);
                         if (G == 16) wd[c >> 1] |= ((uint32_t)(bc >> sh) & 0xffffu) << ((c & 1) * 16);
                         else if (G == 32) wd[c] = (uint32_t)(bc >> sh);
                         else { wd[c] = (uint32_t)bc; wd[8 + c] = (uint32_t)(bc >> 32); }
                     }
                 }
-                if (mask != nullptr && su == u) {
+                if (MASK && su == u) {
 #pragma unroll
                     for (int q = 0; q < LPS; ++q)
                         if (sp == q) mw[k] = make_uint4(wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]);
                 }
             }
         }
-        if (mask != nullptr && su < U && e + su < end) {
+        if (MASK && su < U && e + su < end) {
 #pragma unroll
             for (int k = 0; k < VPL; ++k)
                 st16_stream(mask + (int64_t)(e + su) * mwords + k * WK + 4 * sp, mw[k]);
@@ -565,14 +565,22 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd8(const stin_bf16* __restrict
     const int deg = end - beg;
     const float s = (float)(deg > 0 ? deg : 1);
 #pragma unroll
-    for (int k = 0; k < VPL; ++k)
-        if (on[k]) {
-            F8 o;
+    for (int k = 0; k < VPL; ++k) {
+        F8 o;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) o.v[c] = acc[k].v[c] / s;
-            st8_stream(out + L.row * ldo + L.chan(k), o);
-        }
+        for (int c = 0; c < 8; ++c) o.v[c] = acc[k].v[c] / s;
+        st8_stream(out + L.row * ldo + L.chan(k), o);
+    }
     if (indicator && L.lg == 0) st4(out + L.row * ldo + H, make_float4(deg > 0 ? 1.f : 0.f, 0.f, 0.f, 0.f));
+}
+template <int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_fwd8(const stin_bf16* __restrict__ A, int64_t lda,
+                                                     const stin_bf16* __restrict__ B, int64_t ldb,
+                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                     int64_t N, int H, stin_bf16* __restrict__ out, int64_t ldo, int indicator,
+                                                     uint32_t* __restrict__ mask) {
+    if (mask != nullptr) edge_fwd8_body<G, VPL, U, true>(A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+    else edge_fwd8_body<G, VPL, U, false>(A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
 }
 
 // this lane's 8 mask words (one per channel) of slot `m` for chunk k, and the bit to test
@@ -601,13 +609,10 @@ __device__ __forceinline__ void edge_bwd_dst_mask8_body(unsigned vblock, const s
     const int beg = rowptr[L.row], end = rowptr[L.row + 1];
     const int mwords = H >> 5;
     int cnt[VPL][8];
-    bool on[VPL];
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-        on[k] = L.chan(k) < H;
+    for (int k = 0; k < VPL; ++k)
 #pragma unroll
         for (int c = 0; c < 8; ++c) cnt[k][c] = 0;
-    }
     for (int e = beg; e < end; e += U) {
         uint32_t wv[U][VPL][8];
         int bit = 0;
@@ -630,14 +635,13 @@ __device__ __forceinline__ void edge_bwd_dst_mask8_body(unsigned vblock, const s
     const int deg = end - beg;
     const float s = 1.0f / (float)(deg > 0 ? deg : 1);
 #pragma unroll
-    for (int k = 0; k < VPL; ++k)
-        if (on[k]) {
-            const F8 g = ld8(Gr + L.row * ldg + L.chan(k));
-            F8 o;
+    for (int k = 0; k < VPL; ++k) {
+        const F8 g = ld8(Gr + L.row * ldg + L.chan(k));
+        F8 o;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) o.v[c] = g.v[c] * s * (float)cnt[k][c];
-            st8(dA + L.row * ldda + L.chan(k), o);
-        }
+        for (int c = 0; c < 8; ++c) o.v[c] = g.v[c] * s * (float)cnt[k][c];
+        st8(dA + L.row * ldda + L.chan(k), o);
+    }
 }
 template <int G, int VPL, int U>
 __global__ __launch_bounds__(BLOCK) void k_edge_bwd_dst_mask8(const stin_bf16* __restrict__ Gr, int64_t ldg,
@@ -660,27 +664,29 @@ __device__ __forceinline__ void edge_bwd_src_mask8_body(unsigned vblock, const s
     const int beg = rowptr[L.row], end = rowptr[L.row + 1];
     const int mwords = H >> 5;
     F8 acc[VPL];
-    bool on[VPL];
 #pragma unroll
-    for (int k = 0; k < VPL; ++k) {
-        on[k] = L.chan(k) < H;
-        acc[k] = f8zero();
-    }
+    for (int k = 0; k < VPL; ++k) acc[k] = f8zero();
     for (int e = beg; e < end; e += U) {
         F8 g[U][VPL];
         uint32_t wv[U][VPL][8];
         float w[U];
+        int64_t ii[U], xs[U];
         int bit = 0;
+        // indices of all U slots first, then their rows and mask words: U gathers in flight (see edge_fwd8_body)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ee = min(e + u, end - 1);
-            const int64_t i = col[ee];
-            const int64_t xs = xslot[ee];
-            w[u] = (e + u < end) ? w_slot[ee] : 0.f;
+            ii[u] = col[ee];
+            xs[u] = xslot[ee];
+            const float ws = w_slot[ee];
+            w[u] = (e + u < end) ? ws : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {
-                g[u][k] = on[k] ? ld8(Gr + i * ldg + L.chan(k)) : f8zero();
-                mask_words8<G>(mask + xs * mwords, k, L.lg, wv[u][k], bit);
+                g[u][k] = ld8(Gr + ii[u] * ldg + L.chan(k));
+                mask_words8<G>(mask + xs[u] * mwords, k, L.lg, wv[u][k], bit);
             }
         }
 #pragma unroll
@@ -691,8 +697,7 @@ __device__ __forceinline__ void edge_bwd_src_mask8_body(unsigned vblock, const s
                 for (int c = 0; c < 8; ++c) acc[k].v[c] += ((wv[u][k][c] >> bit) & 1u) ? w[u] * g[u][k].v[c] : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < VPL; ++k)
-        if (on[k]) st8(dB + L.row * lddb + L.chan(k), acc[k]);
+    for (int k = 0; k < VPL; ++k) st8(dB + L.row * lddb + L.chan(k), acc[k]);
 }
 template <int G, int VPL, int U>
 __global__ __launch_bounds__(BLOCK) void k_edge_bwd_src_mask8(const stin_bf16* __restrict__ Gr, int64_t ldg,
@@ -736,13 +741,19 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_pair8(const stin_bf16* 
     }
 }
 
-// H in {128, 256, 512, 1024, 2048}: G = H/8 capped at 64, VPL = H / (8 G); U as in STIN_DISPATCH for the same row bytes
-// U (neighbour rows in flight per lane group) tuned on MI355X: with 8 channels per lane the gather kernels want all
-// 8 waves per SIMD resident (<= 64 VGPRs) rather than deep per-wave unrolling - U = 2 (71 vs 98 us at U = 4 for the
-// level-0 forward, 48 vs 104 us at U = 6 for the level-1 backward), U = 1 once a lane holds 2 or 4 chunks; the
-// streaming dA kernel keeps U = 6 / 3 / 3 / 2 / 1.
-#define STIN_FWD8_U_SMALL 2      /* H <= 512 (one 16-byte chunk per lane) */
-#define STIN_FWD8_U_BIG 1        /* H = 1024 / 2048 (2 / 4 chunks per lane) */
+// H in {128, 256, 512, 1024, 2048}: G = H/8 capped at 64, VPL = H / (8 G).
+// U (neighbour rows in flight per lane group), MI355X, after the predicate-free rewrite (round 4, profiles/_edge8_sweep.py and
+// _edge8_bwd_sweep.py; regular and Delaunay meshes): forward U = 2 up to H = 1024 (200 704 x 128: 63 us at U = 2, 65 / 68 / 66 at
+// 3 / 4 / 6; the Delaunay mesh 71 / 71 / 73 / 97 - a row whose degree is not a multiple of U re-loads its last neighbour; 1 M
+// vertices would take U = 6: 316 vs 342 us, not worth the irregular-mesh loss), U = 1 at H = 2048 (41 us vs 44 / 59 at 2 / 3);
+// backward gathering role 2 / 2 / 2 / 1 / 1, streaming dA role 6 / 3 / 3 / 2 / 1.
+#define STIN_BWD8_US_16 2
+#define STIN_BWD8_US_32 2
+#define STIN_BWD8_US_64 2
+#define STIN_BWD8_US_64X2 1
+#define STIN_BWD8_US_64X4 1
+#define STIN_FWD8_U_SMALL 2      /* H <= 1024 (one or two 16-byte chunks per lane) */
+#define STIN_FWD8_U_BIG 1        /* H = 2048 (4 chunks per lane) */
 #define STIN_L8(KERNEL_, G_, V_, U_, grid_, ...) hipLaunchKernelGGL((KERNEL_<G_, V_, U_>), rows_grid(grid_), dim3(BLOCK), 0, stream, __VA_ARGS__)
 #define STIN_DISPATCH8(H_, KERNEL, U16_, U32_, U64_, U64X2_, U64X4_, ...)                                            \
     do {                                                                                                             \
@@ -1158,7 +1169,7 @@ int edge_fwd_impl(const T* A, int64_t lda, const T* B, int64_t ldb, const int32_
             const int cfg = eu ? atoi(eu) : 0;
             auto pick = [&](int pos, int dflt) { int d = cfg; for (int i = 0; i < 4 - pos; ++i) d /= 10; d %= 10; return (cfg > 0 && d > 0) ? d : dflt; };
             const int hsel = H == 128 ? 0 : H == 256 ? 1 : H == 512 ? 2 : H == 1024 ? 3 : 4;
-            const int u = pick(hsel, hsel <= 2 ? STIN_FWD8_U_SMALL : STIN_FWD8_U_BIG);
+            const int u = pick(hsel, hsel <= 3 ? STIN_FWD8_U_SMALL : STIN_FWD8_U_BIG);
 #define STIN_FWD8(U_) STIN_DISPATCH8(H, k_edge_fwd8, U_, U_, U_, U_, U_, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask)
             if (u == 1) STIN_FWD8(1);
             else if (u == 2) STIN_FWD8(2);
@@ -1265,11 +1276,26 @@ int edge_bwd_mask_pair8_impl(const stin_bf16* G, int64_t ldg, const uint32_t* ma
                            rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src, ld_cps,        \
                            cp_dst, ld_cpd, Ccp);                                                                               \
     } while (0)
-    if (H == 128) STIN_PAIR8(16, 1, 6, 2);            // (UD, US) as the separate kernels' dispatch
-    else if (H == 256) STIN_PAIR8(32, 1, 3, 2);
-    else if (H == 512) STIN_PAIR8(64, 1, 3, 2);
-    else if (H == 1024) STIN_PAIR8(64, 2, 2, 1);
-    else STIN_PAIR8(64, 4, 1, 1);
+    // (UD, US): rows in flight of the streaming / the gathering role.  Tuning aid STIN_EDGE8_US = digits "u16,u32,u64,u64x2,u64x4"
+    // for the gathering role, as STIN_EDGE8_U for the forward kernel (re-read per call).
+    const char* eu = getenv("STIN_EDGE8_US");
+    const int cfg = eu ? atoi(eu) : 0;
+    auto pick = [&](int pos, int dflt) { int d = cfg; for (int i = 0; i < 4 - pos; ++i) d /= 10; d %= 10; return (cfg > 0 && d > 0) ? d : dflt; };
+#define STIN_PAIR8_U(G_, V_, UD_, POS_, DFLT_)                  \
+    do {                                                        \
+        const int us_ = pick(POS_, DFLT_);                      \
+        if (us_ == 1) STIN_PAIR8(G_, V_, UD_, 1);               \
+        else if (us_ == 2) STIN_PAIR8(G_, V_, UD_, 2);          \
+        else if (us_ == 3) STIN_PAIR8(G_, V_, UD_, 3);          \
+        else if (us_ == 4) STIN_PAIR8(G_, V_, UD_, 4);          \
+        else STIN_PAIR8(G_, V_, UD_, 6);                        \
+    } while (0)
+    if (H == 128) STIN_PAIR8_U(16, 1, 6, 0, STIN_BWD8_US_16);
+    else if (H == 256) STIN_PAIR8_U(32, 1, 3, 1, STIN_BWD8_US_32);
+    else if (H == 512) STIN_PAIR8_U(64, 1, 3, 2, STIN_BWD8_US_64);
+    else if (H == 1024) STIN_PAIR8_U(64, 2, 2, 3, STIN_BWD8_US_64X2);
+    else STIN_PAIR8_U(64, 4, 1, 4, STIN_BWD8_US_64X4);
+#undef STIN_PAIR8_U
 #undef STIN_PAIR8
     return stin_launch_status();
 }
