@@ -247,7 +247,8 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_src(const T* __restrict__ A,
         for (int u = 0; u < U; ++u) {
             const int ee = min(e + u, end - 1);
             const int64_t i = col[ee];
-            w[u] = (e + u < end) ? inv_deg[i] : 0.f;
+            const float wi = inv_deg[i];
+            w[u] = (e + u < end) ? wi : 0.f;
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {
                 a[u][k] = on[k] ? ld4(A + i * lda + L.chan(k)) : f4zero();
@@ -370,10 +371,11 @@ __device__ __forceinline__ void edge_bwd_src_mask_body(unsigned vblock, const T*
             const int ee = min(e + u, end - 1);
             const int64_t i = col[ee];
             const int64_t xs = xslot[ee];
-            w[u] = (e + u < end) ? w_slot[ee] : 0.f;
+            const float ws = w_slot[ee];                 // (unconditional: a load behind `e + u < end` is a branch, and hipcc then
+            w[u] = (e + u < end) ? ws : 0.f;             //  drains the loads in flight before the next slot's gathers)
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {
-                g[u][k] = on[k] ? ld4(Gr + i * ldg + L.chan(k)) : f4zero();
+                g[u][k] = ld4(Gr + i * ldg + L.chan(k));
                 const uint32_t* m = mask + xs * mwords + k * (G / 8);
                 if (WPC == 1) {
                     const uint4 q = *reinterpret_cast<const uint4*>(m);
