@@ -355,6 +355,14 @@ int stin_linear_tanh_bwd_f32(const float* g, const float* y, const float* x, int
                              float* dx, int64_t lddx, float* dW, float* db, void* workspace, size_t workspace_bytes,
                              stin_stream_t stream);
 
+/* dst[n, c] += alpha * src[n, c] * [rowptr[n + 1] > rowptr[n]] for c in [c0, c1), in place: the translation-invariant SAGE
+ * message of models/modules/sage_conv_filter.py:87-90 (x_j[:, 3:9] -= x_i[:, 3:9]) under the mean aggregation, applied to the
+ * aggregated rows (alpha = -1, rowptr = destination CSR) and, in the backward pass, to the input gradient. */
+int stin_cols_axpy_rowmask_f32(float* dst, int64_t ldd, const float* src, int64_t lds, const int32_t* rowptr, int64_t N, int c0,
+                               int c1, float alpha, stin_stream_t stream);
+int stin_cols_axpy_rowmask_bf16(stin_bf16_t* dst, int64_t ldd, const stin_bf16_t* src, int64_t lds, const int32_t* rowptr,
+                                int64_t N, int c0, int c1, float alpha, stin_stream_t stream);
+
 /* out [N, Cp] (contiguous) = [x [N, Cin] (row pitch ldx) | zeros]: the network input - 10 channels per vertex,
  * datasets/scannetcolorgraph_dataloader.py:83-156 - padded to the 16-byte rows the first block's GEMM reads. */
 int stin_pad_rows_f32(const float* x, int64_t ldx, int64_t N, int Cin, int Cp, float* out, stin_stream_t stream);
@@ -701,6 +709,24 @@ int stin_dilated_walk_f32(const int32_t* rowptr, const int32_t* col, const int32
 int stin_dilated_walk_f64(const int32_t* rowptr, const int32_t* col, const int32_t* row_of, const double* pos,
                           const double* nrm, int64_t N, int64_t E, const int32_t* dilations, int n_dil, int32_t* out,
                           stin_stream_t stream);
+
+/* Voxel (Rossignac) vertex clustering, preprocessing/graph_level_generation.py:193-244 (`vertex_clustering`):
+ *   bins = coords // voxel (numpy's floor division, fp64), coarse ids = np.unique(bins, axis=0)'s lexicographic bin order,
+ *   trace[v] = coarse id of vertex v, new_coords[c] = fp64 mean of the members' coordinates (in vertex order) as fp32.
+ * coords [N, 3] fp64 row-major; trace [N] int64; new_coords [N, 3] fp32 (the first Nc rows are written);
+ * state: 5 x int64 DEVICE words written by the call - state[3] != 0: unsupported input (a non-finite coordinate or more
+ * than 2^21 bins along an axis), state[4] = Nc.  Stable radix sort of one 63-bit key per vertex + scan: deterministic.
+ * stin_coalesce_pairs_i64 = pyg.utils.coalesce on (a[e], b[e]) pairs (graph_level_generation.py:236-241 on the coarse edges,
+ * graph_dilation.py:53-56): optionally mapped through map[] first (the trace), self loops dropped when drop_loops, sorted by
+ * (a, b), duplicates removed; values in [0, n); out_a / out_b [E] int64 (the first state[4] entries are written);
+ * state[3] != 0: an index was outside [0, n). */
+size_t stin_voxel_cluster_workspace_bytes(int64_t N);
+int stin_voxel_cluster_f64(const double* coords, int64_t N, double voxel, int64_t* trace, float* new_coords, int64_t* state,
+                           void* workspace, size_t workspace_bytes, stin_stream_t stream);
+size_t stin_coalesce_workspace_bytes(int64_t E);
+int stin_coalesce_pairs_i64(const int64_t* a, const int64_t* b, const int64_t* map, int64_t E, int64_t n, int drop_loops,
+                            int64_t* out_a, int64_t* out_b, int64_t* state, void* workspace, size_t workspace_bytes,
+                            stin_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -228,6 +228,21 @@ __global__ __launch_bounds__(256) void k_pad_rows(const T* __restrict__ x, int64
     out[t] = c < Cin ? x[r * ldx + c] : (T)0.f;
 }
 
+// dst[n, c] += alpha * src[n, c] * [row n has an in-edge]  for c in [c0, c1): the translation-invariant SAGE message
+// x_j[:, 3:9] - x_i[:, 3:9] (models/modules/sage_conv_filter.py:87-90) under the mean aggregation is
+// mean_j x_j - x_i [deg_i > 0] on those columns - applied in place to the aggregated rows (alpha = -1), and to the input
+// gradient in the backward pass.  One thread per (row, column) of the slice.
+template <typename T>
+__global__ __launch_bounds__(256) void k_cols_axpy_rowmask(T* __restrict__ dst, int64_t ldd, const T* __restrict__ src, int64_t lds_,
+                                                           const int32_t* __restrict__ rowptr, int64_t N, int c0, int c1, float alpha) {
+    const int W = c1 - c0;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * W) return;
+    const int64_t n = t / W;
+    const int c = c0 + (int)(t % W);
+    if (rowptr[n + 1] > rowptr[n]) st1(dst + n * ldd + c, ld1(dst + n * ldd + c) + alpha * ld1(src + n * lds_ + c));
+}
+
 inline int tail_cu_count() {
     static int n = 0;
     if (n == 0) {
@@ -369,5 +384,26 @@ extern "C" int stin_pad_rows_bf16(const stin_bf16_t* x, int64_t ldx, int64_t N, 
     STIN_REQUIRE(x && out, STIN_E_NULL);
     hipLaunchKernelGGL(k_pad_rows<stin_bf16>, dim3((unsigned)((N * Cp + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const stin_bf16*>(x), ldx, N, Cin, Cp, reinterpret_cast<stin_bf16*>(out));
+    return stin_launch_status();
+}
+
+extern "C" int stin_cols_axpy_rowmask_f32(float* dst, int64_t ldd, const float* src, int64_t lds_, const int32_t* rowptr, int64_t N,
+                                          int c0, int c1, float alpha, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N >= 0 && c0 >= 0 && c1 >= c0 && ldd >= c1 && lds_ >= c1, STIN_E_SIZE);
+    if (N == 0 || c1 == c0) return STIN_OK;
+    STIN_REQUIRE(dst && src && rowptr, STIN_E_NULL);
+    hipLaunchKernelGGL(k_cols_axpy_rowmask<float>, dim3((unsigned)((N * (c1 - c0) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, ldd,
+                       src, lds_, rowptr, N, c0, c1, alpha);
+    return stin_launch_status();
+}
+extern "C" int stin_cols_axpy_rowmask_bf16(stin_bf16_t* dst, int64_t ldd, const stin_bf16_t* src, int64_t lds_, const int32_t* rowptr,
+                                           int64_t N, int c0, int c1, float alpha, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N >= 0 && c0 >= 0 && c1 >= c0 && ldd >= c1 && lds_ >= c1, STIN_E_SIZE);
+    if (N == 0 || c1 == c0) return STIN_OK;
+    STIN_REQUIRE(dst && src && rowptr, STIN_E_NULL);
+    hipLaunchKernelGGL(k_cols_axpy_rowmask<stin_bf16>, dim3((unsigned)((N * (c1 - c0) + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<stin_bf16*>(dst), ldd, reinterpret_cast<const stin_bf16*>(src), lds_, rowptr, N, c0, c1, alpha);
     return stin_launch_status();
 }

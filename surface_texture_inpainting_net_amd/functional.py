@@ -1558,20 +1558,36 @@ class EdgeReluMeanFn(torch.autograd.Function):
         return dA, dB, None
 
 
+def _cols_axpy_rowmask(dst, src, rowptr, c0, c1, alpha):
+    """dst[:, c0:c1] += alpha * src[:, c0:c1] on the rows that have an in-edge, in place (stin_cols_axpy_rowmask_*)."""
+    _same(dst, src)
+    _call('stin_cols_axpy_rowmask' + _sfx(dst), _ptr(dst), dst.stride(0), _ptr(src), src.stride(0), _ptr(rowptr), dst.shape[0], int(c0),
+          int(c1), float(alpha), _stream(dst))
+
+
 class NeighborMeanFn(torch.autograd.Function):
-    """agg_i = mean_{j in N(i)} x_j (SAGEConv aggregation; sum for mean=False)."""
+    """agg_i = mean_{j in N(i)} x_j (SAGEConv aggregation; sum for mean=False).  sub_cols = (c0, c1): the translation-invariant
+    message x_j[:, c0:c1] - x_i[:, c0:c1] on those columns (models/modules/sage_conv_filter.py:87-90), i.e.
+    agg[:, c0:c1] -= x_i[:, c0:c1] on rows with an in-edge - one in-place HIP pass per direction."""
 
     @staticmethod
-    def forward(ctx, x, edges, mean):
-        ctx.edges, ctx.mean = edges, mean
-        return segment_sum(x, edges.by_dst.rowptr, edges.by_dst.col, edges.n, mean=mean)
+    def forward(ctx, x, edges, mean, sub_cols=None):
+        ctx.edges, ctx.mean, ctx.sub_cols = edges, mean, sub_cols
+        agg = segment_sum(x, edges.by_dst.rowptr, edges.by_dst.col, edges.n, mean=mean)
+        if sub_cols is not None:
+            xm = x if (x.dim() == 2 and x.stride(1) == 1) else x.contiguous()
+            _cols_axpy_rowmask(agg, xm, edges.by_dst.rowptr, sub_cols[0], sub_cols[1], -1.0)
+        return agg
 
     @staticmethod
     def backward(ctx, g):
         e = ctx.edges
-        if ctx.mean:
-            g = g * e.inv_deg.view(-1, 1)
-        return segment_sum(g, e.by_src.rowptr, e.by_src.col, e.n, mean=False), None, None
+        gs = g * e.inv_deg.view(-1, 1) if ctx.mean else g
+        dx = segment_sum(gs, e.by_src.rowptr, e.by_src.col, e.n, mean=False)
+        if ctx.sub_cols is not None:
+            gm = g if (g.dim() == 2 and g.stride(1) == 1) else g.contiguous()
+            _cols_axpy_rowmask(dx, gm, e.by_dst.rowptr, ctx.sub_cols[0], ctx.sub_cols[1], -1.0)
+        return dx, None, None, None
 
 
 class ScatterAddFn(torch.autograd.Function):

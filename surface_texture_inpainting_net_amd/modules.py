@@ -124,12 +124,9 @@ class SAGEConv(nn.Module):
 
     def forward(self, x, edge_index, size=None):
         edges = _as_edges(edge_index, x.shape[0])
-        agg = SF.NeighborMeanFn.apply(x, edges, True)
-        if self.trans_inv:
-            # message: x_j[:, 3:9] -= x_i[:, 3:9] (models/modules/sage_conv_filter.py:87-90); under the mean this is
-            # agg[:, 3:9] - x_i[:, 3:9] * [deg_i > 0]
-            has_in = (edges.by_dst.rowptr[1:] > edges.by_dst.rowptr[:-1]).to(x.dtype).unsqueeze(1)
-            agg = torch.cat([agg[:, :3], agg[:, 3:9] - x[:, 3:9] * has_in, agg[:, 9:]], dim=1)
+        # trans_inv message: x_j[:, 3:9] -= x_i[:, 3:9] (models/modules/sage_conv_filter.py:87-90); under the mean this is
+        # agg[:, 3:9] - x_i[:, 3:9] * [deg_i > 0] - one in-place HIP pass inside the aggregation node
+        agg = SF.NeighborMeanFn.apply(x, edges, True, (3, 9) if self.trans_inv else None)
         prec = getattr(self, 'fwd_precision', None)
         return SF.linear(agg, self.lin_l.weight, self.lin_l.bias, precision=prec) + SF.linear(x, self.lin_r.weight, precision=prec)
 

@@ -5,8 +5,8 @@
   the reference (~30 min per ScanNet scene, README.md:89) become ONE launch of ``stin_dilated_walk_*`` (one thread per
   directed edge) plus a sort/unique per dilation.
 * ``vertex_clustering`` - ``preprocessing/graph_level_generation.vertex_clustering`` (:193-244), the Rossignac voxel
-  clustering alternative to QEM for building the hierarchy (trace + coarse edges + coarse coordinates); index
-  arithmetic only, expressed with device-side sort/unique.
+  clustering alternative to QEM for building the hierarchy (trace + coarse edges + coarse coordinates): one 63-bit voxel key
+  per vertex, a stable radix sort and a scan (``stin_voxel_cluster_f64``), the coarse edges through ``stin_coalesce_pairs_i64``.
 
 Both take and return tensors in the reference's own formats.  QEM decimation itself stays out of scope (it shells out
 to vcglib's ``tridecimator``).
@@ -19,12 +19,28 @@ from . import _lib
 from .plan import _ptr, _stream
 
 
-def coalesce(edge_index, num_nodes):
-    """pyg.utils.coalesce: sort by (row 0, row 1) and drop duplicates.  [2, E] int64 -> [2, E'] int64."""
+def coalesce(edge_index, num_nodes, vertex_map=None, drop_loops=False):
+    """pyg.utils.coalesce: sort by (row 0, row 1) and drop duplicates.  [2, E] int64 CUDA -> [2, E'] int64.
+    vertex_map: both endpoints go through this int64 map first (a trace: the coarse edges of a clustering);
+    drop_loops: pairs with equal endpoints are left out.  One radix sort + scan on the GPU (stin_coalesce_pairs_i64)."""
     if edge_index.numel() == 0:
         return edge_index.reshape(2, 0)
-    key = torch.unique(edge_index[0] * num_nodes + edge_index[1], sorted=True)
-    return torch.stack([torch.div(key, num_nodes, rounding_mode='floor'), key % num_nodes])
+    if not edge_index.is_cuda:
+        raise TypeError('coalesce runs on the GPU only')
+    lib = _lib.load()
+    ei = edge_index.long().contiguous()
+    E, dev = ei.shape[1], ei.device
+    out = torch.empty(2, E, dtype=torch.int64, device=dev)
+    state = torch.empty(5, dtype=torch.int64, device=dev)
+    ws_bytes = lib.stin_coalesce_workspace_bytes(E)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    vm = vertex_map.contiguous() if vertex_map is not None else None
+    _lib.check(lib.stin_coalesce_pairs_i64(_ptr(ei[0]), _ptr(ei[1]), _ptr(vm), E, int(num_nodes), int(bool(drop_loops)), _ptr(out[0]),
+                                           _ptr(out[1]), _ptr(state), _ptr(ws), ws_bytes, _stream(ei)), 'stin_coalesce_pairs_i64')
+    st = state.cpu()
+    if int(st[3]) != 0:
+        raise IndexError('coalesce: an endpoint lies outside [0, %d)' % num_nodes)
+    return out[:, :int(st[4])]
 
 
 def dilated_edges(edge_index, pos, normals, dilations):
@@ -75,13 +91,22 @@ def vertex_clustering(coords, edge_index, voxel_size):
     Coarse ids follow the lexicographic order of the voxel bins (``np.unique(bins, axis=0)``)."""
     if not coords.is_cuda:
         raise TypeError('vertex_clustering runs on the GPU only')
-    c64 = coords.double()
-    bins = torch.div(c64, float(voxel_size), rounding_mode='floor')
-    _, trace = torch.unique(bins, dim=0, return_inverse=True)
-    trace = trace.reshape(-1)
-    nc = int(trace.max()) + 1 if trace.numel() else 0
-    ce = torch.stack([trace[edge_index[0]], trace[edge_index[1]]]) if edge_index.numel() else edge_index.reshape(2, 0)
-    ce = coalesce(ce[:, ce[0] != ce[1]], max(nc, 1))
-    sums = torch.zeros(nc, 3, dtype=torch.float64, device=coords.device).index_add_(0, trace, c64)
-    cnt = torch.bincount(trace, minlength=nc).clamp(min=1).double().unsqueeze(1)
-    return (sums / cnt).float(), trace, ce.t().contiguous()
+    lib = _lib.load()
+    c64 = coords.double().contiguous()
+    n, dev = c64.shape[0], c64.device
+    trace = torch.empty(n, dtype=torch.int64, device=dev)
+    new_coords = torch.empty(max(n, 1), 3, dtype=torch.float32, device=dev)
+    state = torch.empty(5, dtype=torch.int64, device=dev)
+    ws_bytes = lib.stin_voxel_cluster_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.stin_voxel_cluster_f64(_ptr(c64), n, float(voxel_size), _ptr(trace), _ptr(new_coords), _ptr(state), _ptr(ws),
+                                          ws_bytes, _stream(c64)), 'stin_voxel_cluster_f64')
+    st = state.cpu()
+    if int(st[3]) != 0:
+        raise ValueError('vertex_clustering: non-finite coordinates or more than 2^21 voxels along an axis')
+    nc = int(st[4])
+    if edge_index.numel():
+        ce = coalesce(edge_index, max(nc, 1), vertex_map=trace, drop_loops=True)
+    else:
+        ce = edge_index.reshape(2, 0)
+    return new_coords[:nc], trace, ce.t().contiguous()
