@@ -15,7 +15,8 @@ import os
 import torch  # noqa: F401  (side effect: loads the HIP runtime torch uses)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libstin_hip.so')
+# (STIN_LIB_PATH: an alternative build of the same library, for same-box A/B runs of compile-time switches)
+LIB_PATH = os.environ.get('STIN_LIB_PATH') or os.path.join(_HERE, 'libstin_hip.so')
 
 c_i64, c_i32, c_int, c_f32, c_f64 = ctypes.c_int64, ctypes.c_int32, ctypes.c_int, ctypes.c_float, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t

@@ -50,6 +50,17 @@ template <> struct V<1> {
     template <typename T> __device__ __forceinline__ void store(T* p) const { st1(p, v[0]); }
 };
 
+// The statistics / normalisation kernels are short launches on the step's critical path that often run beside the long blocks
+// of the weight-gradient stream: STIN_CRIT_PRIO > 0 (compile time) raises their waves' issue priority over those (tuning aid).
+#ifndef STIN_CRIT_PRIO
+#define STIN_CRIT_PRIO 0
+#endif
+__device__ __forceinline__ void crit_prio() {
+#if STIN_CRIT_PRIO > 0
+    __builtin_amdgcn_s_setprio(STIN_CRIT_PRIO);
+#endif
+}
+
 __device__ __forceinline__ float elu_grad_from_pre(float n) { return n > 0.f ? 1.f : __expf(n); }
 
 // grid = (chunks, B). partial layout: [b][chunk][o][C] doubles, o in {0,1}.
@@ -197,6 +208,7 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce_t(const T* __restrict__ x, 
     constexpr bool DOT_BN = (MODE == STIN_RED_DOT_BN || MODE == STIN_RED_DOT_BN_RELU);
     constexpr int NOUT = (MODE == STIN_RED_DOT_ELU || MODE == STIN_RED_MOMENTS || DOT_BN) ? 2 : 1;
     constexpr int VW = 4, CL = GC / VW, RLN = BLOCK / CL;                          // column lanes, row lanes
+    crit_prio();
     __shared__ double sm[NOUT][RLN][GC + 1];
     __shared__ int last_s;
     const int r = blockIdx.x, R = gridDim.x, cg = blockIdx.y, ncg = gridDim.y, b = blockIdx.z;
@@ -424,6 +436,7 @@ __global__ void k_moments_final(const double* __restrict__ partial, int nch, int
                                 const float* __restrict__ inv_cnt, float eps, float* __restrict__ mean,
                                 float* __restrict__ rstd) {
     __shared__ double sm[2][FIN_KL][FIN_COLS + 1];
+    crit_prio();
     const int tx = threadIdx.x % FIN_COLS, ty = threadIdx.x / FIN_COLS;
     const int c = blockIdx.x * FIN_COLS + tx, b = blockIdx.z;
     double s1 = 0.0, s2 = 0.0;
@@ -481,6 +494,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm_fwd(const T* __restrict__ x, int
                                                     const int32_t* __restrict__ gid, const T* __restrict__ res,
                                                     int64_t ldres, int64_t N, int C, int act, T* __restrict__ y,
                                                     int64_t ldy) {
+    crit_prio();
     const int CV = C / VW;
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= N * CV) return;
@@ -513,6 +527,7 @@ __global__ __launch_bounds__(BLOCK) void k_norm_bwd(const T* __restrict__ x, int
                                                     const float* __restrict__ m, const int32_t* __restrict__ gid,
                                                     const int32_t* __restrict__ sid, int64_t N, int C, int act,
                                                     T* __restrict__ dx, int64_t lddx) {
+    crit_prio();
     const int CV = C / VW;
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= N * CV) return;
