@@ -368,6 +368,22 @@ int stin_cols_axpy_rowmask_bf16(stin_bf16_t* dst, int64_t ldd, const stin_bf16_t
 int stin_pad_rows_f32(const float* x, int64_t ldx, int64_t N, int Cin, int Cp, float* out, stin_stream_t stream);
 int stin_pad_rows_bf16(const stin_bf16_t* x, int64_t ldx, int64_t N, int Cin, int Cp, stin_bf16_t* out, stin_stream_t stream);
 
+/* stin_gemm_nt_f32 (pre-split fragment-order weights) plus the FIRST stage of the instance-norm + ELU backward statistics of the
+ * layer whose output gradient this product IS - inside the block backward the input gradient of block k (dY Wcat, + g for an
+ * identity shortcut; models/surfacetextureinpaintingnet.py:507-521) is the output gradient of block k - 1, whose
+ * FastInstanceNorm backward (models/modules/fastinstancenorm.py:42-107 through autograd) starts with two column sums over
+ * (nx = that block's pre-norm rows, g).  partial [groups][2][Nc] doubles: per row group sum of dy (nx - nmean) and of dy with
+ * dy = C ELU'((nx - nmean) nrstd); groups = stin_gemm_nt_dotelu_groups (0: shape / precision not served - keep
+ * stin_colreduce_f32(STIN_RED_DOT_ELU)).  stin_norm_coef_from_partials_f32 folds them in a fixed order into the coefficients
+ * k, m [C] of stin_norm_act_bwd_f32 for ONE graph (inv_cnt[0] = 1 / rows): the tail of stin_colreduce_f32(.., STIN_POST_NORM_COEF). */
+int64_t stin_gemm_nt_dotelu_groups(int64_t M, int Nc, int K, int precision);
+int stin_gemm_nt_dotelu_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* residual,
+                            int64_t ld_res, int64_t M, int Nc, int K, float* C, int64_t ldc, int precision, const float* nx,
+                            int64_t ld_nx, const float* nmean, const float* nrstd, double* partial, size_t partial_bytes,
+                            stin_stream_t stream);
+int stin_norm_coef_from_partials_f32(const double* partial, int64_t groups, int C, const float* rstd, const float* inv_cnt,
+                                     float* k, float* m, stin_stream_t stream);
+
 /* BatchNorm1d-with-affine over ALL rows, optionally followed by ReLU, for the per-edge MLP of SingleConvMeshNet
  * (models/modules/edge_conv_filter.py:34-44: Lin - BatchNorm1d - ReLU - Lin - BatchNorm1d over the E edge rows):
  *   fwd: y = act(gamma * (x - mean) * rstd + beta)            mean / rstd [C] from stin_colreduce_f32(STIN_RED_MOMENTS)

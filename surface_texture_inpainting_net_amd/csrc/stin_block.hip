@@ -170,7 +170,39 @@ extern "C" size_t stin_edgeconv_block_bwd_workspace_bytes(int64_t N, int Cp, int
 // Backward of the same block.  g = dL/dout [N, Cout]; dx may be NULL (block input needs no gradient).  Gradients of the
 // reference-layout parameters are written to dW1 [H, Cin or 2 Cin], db1 [H], dW2 [Cout, H], db2 [Cout], dWs [Cout, Cin],
 // dbs [Cout] (bias / shortcut outputs may be NULL when the parameter does not exist).
-extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, const void* x, int64_t ldx, int64_t N, int Cin,
+// Hand-off between consecutive blocks of stin_net_bwd (round 4).  The input gradient dx of block k is the output gradient of
+// block k - 1, whose instance-norm backward starts with two column sums over (agg_{k-1}, dx): when block k's dx product runs on
+// the panel kernel those sums ride on its epilogue (stin_gemm_nt_dotelu_f32) and block k - 1 only folds the partials
+// (stin_norm_coef_from_partials_f32) - one short, contention-sensitive launch less on the critical path per hand-off.
+struct BwdLink {
+    // producer side (this block's dx product computes the NEXT block-in-backward-order's statistics)
+    const float* next_agg = nullptr;
+    int64_t next_ld = 0;
+    const float* next_mean = nullptr;
+    const float* next_rstd = nullptr;
+    double* next_partial = nullptr;
+    size_t next_partial_bytes = 0;
+    int64_t produced_groups = 0;         // out: > 0 when the partials were written
+    // consumer side (this block's statistics were computed by the block before it in backward order)
+    const double* pre_partial = nullptr;
+    int64_t pre_groups = 0;
+};
+
+// where stin_edgeconv_block_bwd's workspace keeps its column-reduction scratch (the partials of a hand-off are written there)
+static void* bwd_ws_red(void* workspace, int64_t N, int Cp, int H, int Cout, int has_shortcut, int B, int storage, size_t* red_bytes) {
+    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+    const size_t es = storage ? 2 : 4;
+    char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    (void)carve(p, (size_t)N * Cout * es);
+    (void)carve(p, (size_t)N * H * es);
+    (void)carve(p, (size_t)N * Yw * es);
+    for (int i = 0; i < 5; ++i) (void)carve(p, (size_t)B * Cout * 4);
+    *red_bytes = stin_colreduce_workspace_bytes(Cout, B);
+    (void)Cp;
+    return p;
+}
+
+static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x, int64_t ldx, int64_t N, int Cin,
                                        int Cp, int H, int Cout, int has_shortcut, int trans_inv, const void* Y, int64_t ldy,
                                        const void* hE, int64_t ldh, const uint32_t* mask, const void* agg, const float* mean,
                                        const float* rstd, const float* wcatT, const float* w2T, const int32_t* rowptr_dst,
@@ -179,7 +211,7 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
                                        const int32_t* sid, const float* inv_cnt, int prec_bwd, int bwd_split, void* dx, int64_t lddx, float* dW1,
                                        float* db1, float* dW2, float* db2, float* dWs, float* dbs, void* workspace,
                                        size_t workspace_bytes, stin_stream_t stream, stin_stream_t wgrad_stream,
-                                       stin_event_t ev_dagg, stin_event_t ev_dy, stin_event_t ev_done, int join) {
+                                       stin_event_t ev_dagg, stin_event_t ev_dy, stin_event_t ev_done, int join, BwdLink* link) {
     (void)Y;
     (void)ldy;
     STIN_REQUIRE(storage == 0 || storage == 1, STIN_E_UNSUPPORTED);
@@ -225,7 +257,10 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         const float* hf = static_cast<const float*>(hE);
         float* dYf = static_cast<float*>(dY);
         // instance norm + ELU backward: two column sums finalised straight into the k / m coefficients, one elementwise pass
-        if (!sid) {
+        if (link != nullptr && link->pre_partial != nullptr && link->pre_groups > 0 && !sid && B == 1 && gid == nullptr) {
+            // the two column sums came out of the previous block's dx product (BwdLink): fold its partials
+            STIN_TRY(stin_norm_coef_from_partials_f32(link->pre_partial, link->pre_groups, Cout, rstd, inv_cnt, kk, mm, stream));
+        } else if (!sid) {
             STIN_TRY(stin_colreduce_f32(STIN_RED_DOT_ELU, static_cast<const float*>(agg), Cout, gf, ldg, N, Cout, ptr_true, B, gid,
                                         nullptr, mean, rstd, nullptr, STIN_POST_NORM_COEF, inv_cnt, 0.f, kk, mm, red_ws, red_bytes,
                                         stream));
@@ -262,9 +297,20 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         STIN_TRY(fork(ev_dy));
         STIN_TRY(stin_edgeconv_wgrad(0, dagg, Cout, hf, ldh, dYf, Yw, x, ldx, N, Cin, Cp, H, Cout, has_shortcut, trans_inv, prec_bwd,
                                      dW1, db1, dW2, db2, dWs, dbs, tn_ws, tn_bytes, ws_));
-        if (dx != nullptr)
-            STIN_TRY(stin_gemm_nt_f32(dYf, Yw, wcatT, Yw, nullptr, nullptr, 0, has_shortcut ? nullptr : gf, ldg, N, Cp, Yw,
-                                      static_cast<float*>(dx), lddx, pb, stream));
+        if (dx != nullptr) {
+            const bool link_ok = link != nullptr && link->next_agg != nullptr && link->next_ld % 4 == 0 && stin_aligned16(link->next_agg) &&
+                                 stin_aligned16(link->next_mean) && stin_aligned16(link->next_rstd) && link->next_partial != nullptr;
+            const int64_t lg = link_ok ? stin_gemm_nt_dotelu_groups(N, Cp, Yw, pb) : 0;
+            if (lg > 0 && (size_t)lg * 2 * Cp * sizeof(double) <= link->next_partial_bytes) {
+                STIN_TRY(stin_gemm_nt_dotelu_f32(dYf, Yw, wcatT, Yw, nullptr, has_shortcut ? nullptr : gf, ldg, N, Cp, Yw,
+                                                 static_cast<float*>(dx), lddx, pb, link->next_agg, link->next_ld, link->next_mean,
+                                                 link->next_rstd, link->next_partial, link->next_partial_bytes, stream));
+                link->produced_groups = lg;
+            } else {
+                STIN_TRY(stin_gemm_nt_f32(dYf, Yw, wcatT, Yw, nullptr, nullptr, 0, has_shortcut ? nullptr : gf, ldg, N, Cp, Yw,
+                                          static_cast<float*>(dx), lddx, pb, stream));
+            }
+        }
     } else {
         const stin_bf16_t* gh = static_cast<const stin_bf16_t*>(g);
         const stin_bf16_t* hh = static_cast<const stin_bf16_t*>(hE);
@@ -317,6 +363,22 @@ extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, 
         if (e != hipSuccess) return (int)e;
     }
     return STIN_OK;
+}
+
+extern "C" int stin_edgeconv_block_bwd(int storage, const void* g, int64_t ldg, const void* x, int64_t ldx, int64_t N, int Cin,
+                                       int Cp, int H, int Cout, int has_shortcut, int trans_inv, const void* Y, int64_t ldy,
+                                       const void* hE, int64_t ldh, const uint32_t* mask, const void* agg, const float* mean,
+                                       const float* rstd, const float* wcatT, const float* w2T, const int32_t* rowptr_dst,
+                                       const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot,
+                                       const float* w_src, const int32_t* ptr_true, int B, const int32_t* gid,
+                                       const int32_t* sid, const float* inv_cnt, int prec_bwd, int bwd_split, void* dx, int64_t lddx, float* dW1,
+                                       float* db1, float* dW2, float* db2, float* dWs, float* dbs, void* workspace,
+                                       size_t workspace_bytes, stin_stream_t stream, stin_stream_t wgrad_stream,
+                                       stin_event_t ev_dagg, stin_event_t ev_dy, stin_event_t ev_done, int join) {
+    return block_bwd_impl(storage, g, ldg, x, ldx, N, Cin, Cp, H, Cout, has_shortcut, trans_inv, Y, ldy, hE, ldh, mask, agg, mean, rstd,
+                          wcatT, w2T, rowptr_dst, rowptr_src, col_src, xslot, w_src, ptr_true, B, gid, sid, inv_cnt, prec_bwd, bwd_split,
+                          dx, lddx, dW1, db1, dW2, db2, dWs, dbs, workspace, workspace_bytes, stream, wgrad_stream, ev_dagg, ev_dy,
+                          ev_done, join, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ chains of blocks
@@ -416,20 +478,47 @@ extern "C" int stin_net_bwd(int storage, const stin_net_op_t* ops, int n_ops, co
     STIN_REQUIRE(storage == 0 || storage == 1, STIN_E_UNSUPPORTED);
     const void* gi = g;
     int64_t ldgi = ldg;
+    const double* pre_partial = nullptr;       // statistics of op i computed by op i + 1's dx product (BwdLink)
+    int64_t pre_groups = 0;
     for (int i = n_ops - 1; i >= 0; --i) {
         const stin_net_op_t& J = ops[i];
         STIN_REQUIRE(J.dx != nullptr || i == 0, STIN_E_NULL);
         if (J.kind == STIN_OP_BLOCK) {
             t_edge_ev0 = (hipEvent_t)J.ev_edge0;
             t_edge_ev1 = (hipEvent_t)J.ev_edge1;
-            const int rc_blk = stin_edgeconv_block_bwd(storage, gi, ldgi, J.x, J.ldx, J.n_out, J.Cin, J.Cp, J.H, J.Cout, J.has_shortcut, J.trans_inv,
+            BwdLink link;
+            link.pre_partial = pre_partial;
+            link.pre_groups = pre_groups;
+            pre_partial = nullptr;
+            pre_groups = 0;
+            if (storage == 0 && i > 0 && J.dx != nullptr && ops[i - 1].kind == STIN_OP_BLOCK) {
+                // op i - 1 is a block whose output is this block's input: single graph, no slice quirk, same rows, and this
+                // block's input width is that block's output width (no channel padding in between)
+                const stin_net_op_t& Pn = ops[i - 1];
+                if (Pn.B == 1 && Pn.gid == nullptr && Pn.sid == nullptr && Pn.n_out == J.n_out && Pn.Cout == J.Cp && J.Cin == J.Cp &&
+                    Pn.bwd_ws != nullptr) {
+                    size_t rb = 0;
+                    void* red = bwd_ws_red(Pn.bwd_ws, Pn.n_out, Pn.Cp, Pn.H, Pn.Cout, Pn.has_shortcut, Pn.B, storage, &rb);
+                    link.next_agg = static_cast<const float*>(Pn.agg);
+                    link.next_ld = Pn.Cout;
+                    link.next_mean = Pn.mean;
+                    link.next_rstd = Pn.rstd;
+                    link.next_partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(red) + 255) & ~(uintptr_t)255);
+                    link.next_partial_bytes = rb > 256 ? rb - 256 : 0;
+                }
+            }
+            const int rc_blk = block_bwd_impl(storage, gi, ldgi, J.x, J.ldx, J.n_out, J.Cin, J.Cp, J.H, J.Cout, J.has_shortcut, J.trans_inv,
                                              J.Y, J.ldy, J.hE, J.ldh, J.mask, J.agg, J.mean, J.rstd, J.wcatT, J.w2T, J.rowptr_dst,
                                              J.rowptr_src, J.col_src, J.xslot, J.w_src, J.ptr_true, J.B, J.gid, J.sid, J.inv_cnt, prec_bwd,
                                              J.bwd_split, J.dx, J.lddx, J.dW1, J.db1, J.dW2, J.db2, J.dWs, J.dbs, J.bwd_ws,
                                              (size_t)J.bwd_ws_bytes, stream, J.use_side ? wgrad_stream : nullptr, J.ev_dy, J.ev_dy,
-                                             J.ev_done, 0);
+                                             J.ev_done, 0, &link);
             t_edge_ev0 = t_edge_ev1 = nullptr;
             if (rc_blk != STIN_OK) return rc_blk;
+            if (link.produced_groups > 0) {
+                pre_partial = link.next_partial;
+                pre_groups = link.produced_groups;
+            }
         } else if (J.kind == STIN_OP_POOL_MAX) {
             if (J.dx != nullptr) {
                 if (storage)

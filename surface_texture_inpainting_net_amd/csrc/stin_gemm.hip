@@ -1007,12 +1007,27 @@ __global__ __launch_bounds__(64 * NW * WAVES_M) void k_gemm_nt_wide(const float*
 // What bounds it (in-kernel stamps + compile-time ablations, STIN_NT_ABLATE_MASK): profiles/r04_nt_panel.md.
 // Same k order, MFMA order and epilogue expression as the other split kernels: bit-identical results
 // (tests/test_hip_parity.py::test_gemm_nt_panel_kernel_equals_tiled_kernel).
+// Optional epilogue of the panel kernel (round 4): the FIRST stage of the instance-norm + ELU backward statistics of the layer
+// that consumes this product as its output gradient.  With g = the stored values (residual included), x / mean / rstd that
+// layer's pre-norm activations and statistics: dy = g ELU'((x - mean) rstd), partial sums of dy (x - mean) and of dy per column
+// and row group in fp64 -> colstats [group][2][Nc] (the layout of the moment statistics; k_colreduce_final folds either).
+// The block backward hands the input gradient dx of block k straight to block k - 1: its separate pass over (agg, g) - a short
+// launch that runs 3x slower beside the weight-gradient stream than alone - rides on the rows while they are in registers.
+struct NtDotElu {
+    const float* x;          // NULL: off
+    int64_t ldx;
+    const float* mean;
+    const float* rstd;
+};
+__device__ __forceinline__ float nt_elu_grad_from_pre(float n) { return n > 0.f ? 1.f : __expf(n); }     // (= stin_norm.hip)
+
 template <typename PT, int MT0, int MT1>
 __global__ __launch_bounds__(512) void k_gemm_nt_panel(const float* __restrict__ A, int64_t lda, const float* __restrict__ Wf,
                                                        const float* __restrict__ bias, const float* __restrict__ row_mask,
                                                        int64_t ld_mask, const float* __restrict__ res, int64_t ld_res, int64_t M,
                                                        int Nc, int K, float* __restrict__ C, int64_t ldc,
-                                                       double* __restrict__ colstats, int nrb, int P, int xcd_map) {
+                                                       double* __restrict__ colstats, int nrb, int P, int xcd_map,
+                                                       const NtDotElu de) {
     typedef typename PieceTraits<PT>::vec8 vec8;
     constexpr float ASCALE = PieceTraits<PT>::ascale, WSCALE = PieceTraits<PT>::wscale;
     constexpr int MTS = MT0 + MT1, BM = 32 * MTS, THREADS = 512;
@@ -1158,6 +1173,13 @@ __global__ __launch_bounds__(512) void k_gemm_nt_panel(const float* __restrict__
         const float bv = bias != nullptr ? bias[col0 + li] : 0.f;
         double s1 = 0.0, s2 = 0.0;
         const int r8 = lane >> 3, c8 = lane & 7;
+        const bool dotelu = de.x != nullptr;                                    // block-uniform
+        double d0[4] = {0.0, 0.0, 0.0, 0.0}, d1[4] = {0.0, 0.0, 0.0, 0.0};
+        float4 dmu = make_float4(0.f, 0.f, 0.f, 0.f), drs = dmu;
+        if (dotelu) {
+            dmu = ld4(de.mean + col0 + c8 * 4);
+            drs = ld4(de.rstd + col0 + c8 * 4);
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int lrow0 = trow + i * 32;
@@ -1166,7 +1188,7 @@ __global__ __launch_bounds__(512) void k_gemm_nt_panel(const float* __restrict__
                 const int tr = (r & 3) + 8 * (r >> 2) + 4 * kh;
                 const float v = acc[i][r] * sc + (row_mask != nullptr ? bv * mask_s[lrow0 + tr] : bv);
                 stage_f[tr * 32 + li] = v;
-                if (colstats != nullptr && row0 + lrow0 + tr < M) {
+                if (colstats != nullptr && !dotelu && row0 + lrow0 + tr < M) {
                     const double d = (double)v;
                     s1 += d;
                     s2 += d * d;
@@ -1186,10 +1208,39 @@ __global__ __launch_bounds__(512) void k_gemm_nt_panel(const float* __restrict__
                         v.w += rv.w;
                     }
                     st4(C + grow * ldc + col0 + c8 * 4, v);
+                    if (dotelu) {
+                        const float4 xa = ld4(de.x + grow * de.ldx + col0 + c8 * 4);
+                        const float gv[4] = {v.x, v.y, v.z, v.w}, xv[4] = {xa.x, xa.y, xa.z, xa.w};
+                        const float mu[4] = {dmu.x, dmu.y, dmu.z, dmu.w}, rs[4] = {drs.x, drs.y, drs.z, drs.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float xc = xv[e] - mu[e];
+                            const float dy = gv[e] * nt_elu_grad_from_pre(xc * rs[e]);
+                            d0[e] += (double)(dy * xc);
+                            d1[e] += (double)dy;
+                        }
+                    }
                 }
             }
         }
-        if (colstats != nullptr) {                                             // block-uniform
+        if (dotelu) {                                                          // block-uniform: fold the 8 row lanes of every column quad
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int m = 8; m < 64; m <<= 1) {
+                    d0[e] += __shfl_xor(d0[e], m);
+                    d1[e] += __shfl_xor(d1[e], m);
+                }
+            }
+            if (r8 == 0) {
+                double* dst = colstats + ((int64_t)rb * 2 + q) * 2 * Nc + col0 + c8 * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dst[e] = d0[e];
+                    dst[Nc + e] = d1[e];
+                }
+            }
+        } else if (colstats != nullptr) {                                      // block-uniform
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
             if (kh == 0) {
@@ -2566,7 +2617,8 @@ inline bool tn_one_per_cu(int storage, int precision, int TI, int TJ, int64_t M)
 // colstats != NULL: the launch must be the all-columns kernel (its blocks own whole rows) - STIN_E_UNSUPPORTED otherwise
 static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                             const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
-                            int Nc, int K, float* C, int64_t ldc, int precision, double* colstats, stin_stream_t stream_) {
+                            int Nc, int K, float* C, int64_t ldc, int precision, double* colstats, stin_stream_t stream_,
+                            const NtDotElu* dotelu = nullptr) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
@@ -2603,9 +2655,15 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
         else if (force_tile == 2) STIN_NT(KERNEL, 128, 64, 2, 2, ##__VA_ARGS__);  \
         else STIN_NT(KERNEL, 64, 64, 2, 2, ##__VA_ARGS__);                                     \
     } while (0)
-    STIN_REQUIRE(colstats == nullptr || (wfrag && Nc <= 256), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(colstats == nullptr || (wfrag && (Nc <= 256 || dotelu != nullptr)), STIN_E_UNSUPPORTED);
     const bool out16 = ldc % 4 == 0 && stin_aligned16(C) && (residual == nullptr || (ld_res % 4 == 0 && stin_aligned16(residual)));
-    const int pmts = (wfrag && vec && out16 && !(colstats != nullptr && residual != nullptr)) ? panel_tiles(M, Nc, K) : 0;
+    const int pmts = (wfrag && vec && out16 && !(colstats != nullptr && residual != nullptr && dotelu == nullptr)) ? panel_tiles(M, Nc, K) : 0;
+    STIN_REQUIRE(dotelu == nullptr || (pmts > 0 && colstats != nullptr), STIN_E_UNSUPPORTED);      // (the panel kernel's epilogue only)
+    NtDotElu de_arg;
+    de_arg.x = nullptr;
+    de_arg.ldx = 0;
+    de_arg.mean = de_arg.rstd = nullptr;
+    if (dotelu != nullptr) de_arg = *dotelu;
     // (stin_gemm_nt_colstats_groups promised the panel kernel's group count from the shape alone)
     STIN_REQUIRE(colstats == nullptr || pmts > 0 || !wfrag || panel_tiles(M, Nc, K) == 0, STIN_E_ALIGN);
     if (pmts > 0) {
@@ -2623,7 +2681,7 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
             attr_set = true;                                                                                              \
         }                                                                                                                 \
         hipLaunchKernelGGL((k_gemm_nt_panel<PT_, A_, B_>), dim3(grid), dim3(512), lds, stream, A, lda, W, bias, row_mask, ld_mask, \
-                           residual, ld_res, M, Nc, K, C, ldc, colstats, nrb, P, xmap);                                   \
+                           residual, ld_res, M, Nc, K, C, ldc, colstats, nrb, P, xmap, de_arg);                           \
     } while (0)
 #define STIN_PANEL(PT_)                                                                                                   \
     do {                                                                                                                  \
@@ -2765,6 +2823,36 @@ extern "C" int stin_gemm_nt_colstats_f32(const float* A, int64_t lda, const floa
     STIN_REQUIRE(colstats != nullptr, STIN_E_NULL);
     STIN_REQUIRE(colstats_bytes >= (size_t)groups * 2 * (size_t)Nc * sizeof(double), STIN_E_WORKSPACE);
     return gemm_nt_f32_impl(A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc, precision, colstats, stream);
+}
+
+// The GEMM plus the first stage of the instance-norm + ELU BACKWARD statistics of the layer whose output gradient it produces
+// (NtDotElu above): partial [groups][2][Nc] doubles, groups = stin_gemm_nt_dotelu_groups (0: this shape / precision is not served
+// by the panel kernel - the caller keeps its separate reduction).  Second stage: stin_norm_coef_from_partials_f32.
+extern "C" int64_t stin_gemm_nt_dotelu_groups(int64_t M, int Nc, int K, int precision) {
+    const bool ok = (precision & STIN_GEMM_W_PRESPLIT) && (precision & STIN_GEMM_W_FRAG) && stin_w_frag_shape(Nc, K);
+    const int p = precision & ~(STIN_GEMM_W_PRESPLIT | STIN_GEMM_W_FRAG);
+    if (!ok || M <= 0 || (p != STIN_GEMM_BF16X3 && p != STIN_GEMM_F16X3)) return 0;
+    const char* e = getenv("STIN_DOTELU_FUSED");                           // A/B switch, re-read per call (tests flip it)
+    if (e != nullptr && atoi(e) == 0) return 0;
+    const int pmts = panel_tiles(M, Nc, K);
+    return pmts > 0 ? 2 * ((M + 32 * pmts - 1) / (32 * pmts)) : 0;
+}
+extern "C" int stin_gemm_nt_dotelu_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                                       const float* residual, int64_t ld_res, int64_t M, int Nc, int K, float* C, int64_t ldc,
+                                       int precision, const float* nx, int64_t ld_nx, const float* nmean, const float* nrstd,
+                                       double* partial, size_t partial_bytes, stin_stream_t stream) {
+    const int64_t groups = stin_gemm_nt_dotelu_groups(M, Nc, K, precision);
+    STIN_REQUIRE(groups > 0, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(nx && nmean && nrstd && partial, STIN_E_NULL);
+    STIN_REQUIRE(ld_nx >= Nc, STIN_E_SIZE);
+    STIN_REQUIRE(ld_nx % 4 == 0 && stin_aligned16(nx) && stin_aligned16(nmean) && stin_aligned16(nrstd), STIN_E_ALIGN);
+    STIN_REQUIRE(partial_bytes >= (size_t)groups * 2 * (size_t)Nc * sizeof(double), STIN_E_WORKSPACE);
+    NtDotElu de;
+    de.x = nx;
+    de.ldx = ld_nx;
+    de.mean = nmean;
+    de.rstd = nrstd;
+    return gemm_nt_f32_impl(A, lda, W, ldw, bias, nullptr, 0, residual, ld_res, M, Nc, K, C, ldc, precision, partial, stream, &de);
 }
 
 extern "C" size_t stin_gemm_tn_workspace_bytes(int64_t M, int Nc, int K, int ones_column) {

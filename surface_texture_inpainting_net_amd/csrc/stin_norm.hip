@@ -865,6 +865,19 @@ extern "C" int stin_colreduce_bf16(int mode, const stin_bf16_t* x, int64_t ldx, 
                                      inv_cnt, eps, out0, out1, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// Second stage of the fused GEMM + backward statistics (stin_gemm_nt_dotelu_f32): partial [groups][2][C] doubles (sum of
+// dy xc, sum of dy per row group) -> the instance-norm backward coefficients k = -rstd^3 T1 / n, m = -rstd S0 / n of ONE graph -
+// what stin_colreduce_f32(STIN_RED_DOT_ELU, post = STIN_POST_NORM_COEF) ends with (same kernel, same float operations).
+extern "C" int stin_norm_coef_from_partials_f32(const double* partial, int64_t groups, int C, const float* rstd,
+                                                const float* inv_cnt, float* k, float* m, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(groups > 0 && groups < ((int64_t)1 << 30) && C > 0, STIN_E_SIZE);
+    STIN_REQUIRE(partial && rstd && inv_cnt && k && m, STIN_E_NULL);
+    hipLaunchKernelGGL(k_colreduce_final, dim3((unsigned)((C + FIN_COLS - 1) / FIN_COLS), 2u, 1u), dim3(BLOCK), 0, (hipStream_t)stream,
+                       partial, (int)groups, 2, C, 1, (int)STIN_POST_NORM_COEF, inv_cnt, 0.f, rstd, k, m);
+    return stin_launch_status();
+}
+
 // Second stage of the fused GEMM + statistics (stin_gemm_nt_colstats_f32): partial [groups][2][C] doubles (sum, sum of
 // squares per row group) -> mean, rstd [C] of ONE instance of N rows (inv_cnt[0] = 1 / N), same final arithmetic as the
 // MOMENTS mode of stin_colreduce_f32.

@@ -323,6 +323,34 @@ def gemm_nt_colstats(A, W, bias, row_mask, precision, n_cols):
     return C, partial
 
 
+def gemm_nt_dotelu(A, W, residual, precision, n_cols, nx, nmean, nrstd):
+    """A W^T (+ residual) AND the first stage of the instance-norm + ELU backward statistics of the layer whose output gradient
+    the product is (nx / nmean / nrstd: that layer's pre-norm rows and statistics), or None when the shape is not served by the
+    panel kernel.  -> (C, partial [groups, 2, n_cols] float64).  (stin_gemm_nt_dotelu_f32; test / probe helper - the block
+    backward calls it inside stin_net_bwd.)"""
+    A, lda = _mat(A)
+    M, K = A.shape
+    lib = _lib.load()
+    groups = int(lib.stin_gemm_nt_dotelu_groups(M, n_cols, K, int(precision))) if A.dtype == torch.float32 else 0
+    if groups <= 0:
+        return None
+    C = torch.empty(M, n_cols, dtype=torch.float32, device=A.device)
+    partial = torch.empty(groups, 2, n_cols, dtype=torch.float64, device=A.device)
+    res, ldr = (residual, residual.stride(0)) if residual is not None else (None, 0)
+    _call('stin_gemm_nt_dotelu_f32', _ptr(A), lda, _ptr(W), K, None, _ptr(res), ldr, M, n_cols, K, _ptr(C), n_cols, int(precision),
+          _ptr(nx), nx.stride(0), _ptr(nmean), _ptr(nrstd), _ptr(partial), partial.numel() * 8, _stream(A), tag=(M, n_cols, K))
+    return C, partial
+
+
+def norm_coef_from_partials(partial, rstd, inv_cnt):
+    """Second stage: the instance-norm backward coefficients k, m [1, C] of one graph from gemm_nt_dotelu's partials."""
+    groups, _, C = partial.shape
+    out = torch.empty(2, 1, C, dtype=torch.float32, device=partial.device)
+    _call('stin_norm_coef_from_partials_f32', _ptr(partial), groups, C, _ptr(rstd), _ptr(inv_cnt), _ptr(out[0]), _ptr(out[1]),
+          _stream(partial))
+    return out[0], out[1]
+
+
 def moments_final(partial, inv_cnt, eps=EPS):
     """Second stage: mean, rstd [1, C] of one instance (inv_cnt [1] = 1 / rows)."""
     groups, _, C = partial.shape

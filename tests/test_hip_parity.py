@@ -479,6 +479,52 @@ def test_gemm_nt_with_fused_column_statistics(M, Nc, K, panel, monkeypatch):
     assert SF.gemm_nt_colstats(A[:, :K], SF.split_weights(W, SF.GEMM_F16X3), b, A[:, K], SF.GEMM_F16X3 | SF.GEMM_W_PRESPLIT, Nc) is None
 
 
+@pytest.mark.parametrize('M,Nc,K,res', [(18063, 256, 1024, True), (18063, 256, 1024, False), (4097, 256, 512, True), (130, 128, 256, True),
+                                        (8190, 512, 256, False), (33, 256, 512, True)])
+def test_gemm_nt_with_fused_norm_backward_statistics(M, Nc, K, res, monkeypatch):
+    """stin_gemm_nt_dotelu_f32: the input-gradient product of a block plus the first stage of the NEXT block-in-backward-order's
+    instance-norm + ELU backward statistics in one launch (round 4 hand-off, stin_block.hip BwdLink).  The product equals the plain
+    call bit for bit; the partial sums are the fp64 column sums of dy xc / dy per row group of the panel kernel; the folded
+    coefficients k, m equal the separate stin_colreduce_f32(DOT_ELU, NORM_COEF) route to fp32 rounding."""
+    from surface_texture_inpainting_net_amd.plan import NormGroups
+    monkeypatch.setenv('STIN_NT_PANEL', '1')
+    g = torch.Generator().manual_seed(M + Nc + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(DEV)
+    W = (torch.randn(Nc, K, generator=g) * 0.05).to(DEV)
+    R = torch.randn(M, Nc, generator=g).to(DEV) if res else None
+    nx = (torch.randn(M, Nc, generator=g) * 1.5 + 0.3).to(DEV)
+    prec = SF.GEMM_BF16X3 | SF.GEMM_W_PRESPLIT | 0x400
+    Wf = SF.split_weights(W, SF.GEMM_BF16X3 | 0x400)
+    ng = NormGroups(M, torch.device(DEV))
+    mean, rstd = SF.instance_stats(nx, ng)
+    plain = SF.gemm_nt(A, Wf, None, precision=prec, residual=R)
+    got = SF.gemm_nt_dotelu(A, Wf, R, prec, Nc, nx, mean, rstd)
+    assert got is not None
+    C, partial = got
+    assert torch.equal(C, plain)
+    mts = _panel_tiles(M, Nc, K, 1)
+    bm, mt0 = 32 * mts, 32 * ((mts + 1) // 2)
+    bounds = []
+    for rb in range((M + bm - 1) // bm):
+        bounds += [(min(M, rb * bm), min(M, rb * bm + mt0)), (min(M, rb * bm + mt0), min(M, rb * bm + bm))]
+    assert partial.shape == (len(bounds), 2, Nc)
+    xc = nx - mean
+    pre = xc * rstd
+    dy = C * torch.where(pre > 0, torch.ones_like(pre), torch.exp(pre))
+    t0, t1 = (dy * xc).double(), dy.double()
+    zero = torch.zeros(Nc, dtype=torch.float64, device=DEV)
+    want0 = torch.stack([t0[a:e].sum(0) if e > a else zero for a, e in bounds])
+    want1 = torch.stack([t1[a:e].sum(0) if e > a else zero for a, e in bounds])
+    rows = max(e - a for a, e in bounds)
+    scale = float(t0.abs().max()) + float(t1.abs().max()) + 1e-30
+    assert float((partial[:, 0] - want0).abs().max()) <= 1e-5 * rows * scale          # (__expf vs torch.exp in fp32: ~1e-6 relative)
+    assert float((partial[:, 1] - want1).abs().max()) <= 1e-5 * rows * scale
+    k, m = SF.norm_coef_from_partials(partial, rstd, ng.inv_cnt)
+    k2, m2 = SF.colreduce(SF.RED_DOT_ELU, nx, ng, ng.ptr_true, gout=C, mean=mean, rstd=rstd, post=SF.POST_NORM_COEF)
+    assert float((k - k2).abs().max()) <= 2e-6 * float(k2.abs().max()) + 1e-12
+    assert float((m - m2).abs().max()) <= 2e-6 * float(m2.abs().max()) + 1e-12
+
+
 @pytest.mark.parametrize('M,Nc,K', [(1, 256, 128), (8187, 256, 512), (12283, 256, 1024), (16379, 256, 512), (18063, 256, 1024), (24571, 256, 512),
                                     (28667, 256, 128), (32763, 256, 512), (36859, 256, 1024), (18063, 512, 256), (18063, 1024, 256),
                                     (18063, 1280, 128), (18063, 128, 1280), (5000, 1024, 256), (60211, 640, 256), (777, 384, 192), (300, 128, 256)])
@@ -1236,6 +1282,46 @@ def test_bottleneck_chain_equals_per_block_nodes_bitwise(batched, dtype):
     assert len(want) == len(got)
     for i, (a, b) in enumerate(zip(got, want)):
         assert torch.equal(a, b), i
+
+
+def test_block_handoff_statistics_from_the_gradient_product_equal_the_separate_reduction(monkeypatch):
+    """stin_net_bwd's block-to-block hand-off (stin_block.hip BwdLink): with the panel kernel serving the input-gradient
+    products, the instance-norm backward sums of block k - 1 ride on block k's dx product.  Same training run with the
+    hand-off on and off (STIN_DOTELU_FUSED): losses, input gradient and every parameter gradient agree to fp32 rounding of the
+    two fp64 summation orders (in practice bit for bit), and the fused route was really taken (fewer reduction launches)."""
+    from surface_texture_inpainting_net_amd.train_step import TrainStep
+    monkeypatch.setenv('STIN_NT_PANEL', '1')
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=4, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 4, 1])
+    s = make_synthetic_mesh(9000, 3, seed=31, dilations=(2, 4)).to(DEV)
+
+    def run(fused):
+        monkeypatch.setenv('STIN_DOTELU_FUSED', '1' if fused else '0')
+        torch.manual_seed(5)
+        net = S.define_G(**cfg).to(DEV)
+        x = s.x.clone().requires_grad_(True)
+        s2 = type(s)(**{k: (x if k == 'x' else s[k]) for k in s.keys()})
+        s2._nv_host = s._nv_host
+        out = net(s2)
+        out.float().square().mean().backward()
+        res = [out.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+        step = TrainStep(net, lr=1e-3)
+        losses = [float(step(s)) for _ in range(3)]
+        step.finish()
+        return res + [torch.tensor(losses)]
+
+    want, got = run(False), run(True)
+    worst = 0.0
+    for a, b in zip(got, want):
+        scale = float(b.abs().max()) + 1e-30
+        worst = max(worst, float((a - b).abs().max()) / scale)
+    assert worst <= 1e-6, worst
+    lib = _lib_load()
+    N2 = int(s.num_vertices.reshape(-1)[-1])
+    prec = SF.PREC_BWD | SF.GEMM_W_PRESPLIT | SF.GEMM_W_FRAG
+    assert int(lib.stin_gemm_nt_dotelu_groups(N2, 256, 1024, prec)) > 0, 'the bottleneck dx product must be served by the panel kernel'
+    monkeypatch.setenv('STIN_DOTELU_FUSED', '0')
+    assert int(lib.stin_gemm_nt_dotelu_groups(N2, 256, 1024, prec)) == 0
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
