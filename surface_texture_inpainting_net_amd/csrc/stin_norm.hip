@@ -711,7 +711,7 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
     // STIN_RED_TICKET=0 keeps the two-launch form (A/B switch, read once).  Column groups of 64 / 32 / 16 so that narrow
     // matrices still fold on four blocks side by side.
     static const bool ticket_on = !(getenv("STIN_RED_TICKET") && atoi(getenv("STIN_RED_TICKET")) == 0);
-    if (vec && ticket_on && is_f32((const T*)nullptr) && N > 0) {
+    if (vec && ticket_on && N > 0) {                                // (fp32 and bf16 rows: 4 channels per lane either way)
         const int GC = C >= 256 ? 64 : (C >= 128 ? 32 : 16);
         const int ncg = (C + GC - 1) / GC;
         if ((int64_t)B * ncg <= RED_WORDS) {
@@ -737,7 +737,7 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
                 else if (GC == 32) STIN_REDT_L(M, 32);                                                                   \
                 else STIN_REDT_L(M, 16);                                                                                 \
             } while (0)
-            if constexpr (is_f32((const T*)nullptr)) {
+            {
                 switch (mode) {
                     case STIN_RED_SUM: STIN_REDT_LAUNCH(STIN_RED_SUM); break;
                     case STIN_RED_CSQ: STIN_REDT_LAUNCH(STIN_RED_CSQ); break;
