@@ -1,6 +1,7 @@
 // Small parameter-side kernels: (un)packing of the EdgeConv weights into the per-vertex GEMM operands of
 // the restructured block and the instance-norm backward coefficients.  One launch each
 // instead of dozens of tiny framework ops per block and step.
+#include <cstdlib>
 #include "stin_common.h"
 
 namespace {
@@ -97,20 +98,137 @@ __device__ __forceinline__ void pack_body(int64_t t, const float* __restrict__ W
     }
 }
 
+// ---- round 4: the same pack with EIGHT consecutive k-elements of a destination row per thread.  pack_body writes one element per
+// thread - 2-byte stores into the fragment / k-group layouts and 4-byte stores strided by a whole row into the transposed
+// operands: ~80 us for the 32 MB of operands of the headline network at the head of every step, where the bytes take ~10.
+// Here a thread forms 8 values and stores them as whole 16 / 32-byte pieces of the destination layout; the transposed operands
+// read their sources coalesced ACROSS threads (consecutive threads = consecutive source columns).  Same values, same roundings,
+// same layouts: bit-identical buffers (tests/test_hip_parity.py::test_pack8_equals_the_elementwise_pack).
+__device__ __forceinline__ uint32_t pk16(uint16_t lo, uint16_t hi) { return (uint32_t)lo | ((uint32_t)hi << 16); }
+__device__ __forceinline__ void split16(float v, int prec, uint16_t& hi, uint16_t& lo) {
+    if (prec == STIN_GEMM_F16X3) {
+        const float s = v * 64.f;
+        const _Float16 h = (_Float16)s;
+        const _Float16 l = (_Float16)(s - (float)h);
+        hi = *reinterpret_cast<const uint16_t*>(&h);
+        lo = *reinterpret_cast<const uint16_t*>(&l);
+    } else {
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        hi = *reinterpret_cast<const uint16_t*>(&h);
+        lo = *reinterpret_cast<const uint16_t*>(&l);
+    }
+}
+// elements [c0, c0 + 8) of row r (c0 % 8 == 0) of an [nc, kk] operand, in the layout `mode` asks for (put_weight x 8)
+__device__ __forceinline__ void put_weight8(float* __restrict__ base, int64_t row_off, int c0, const float (&v)[8], int mode, int r,
+                                            int nc, int kk) {
+    if ((mode & STIN_GEMM_W_FRAG) && stin_w_frag_shape(nc, kk)) {
+        const int prec = mode & ~STIN_GEMM_W_FRAG;
+        const int64_t lane_slot = ((int64_t)(r >> 5) * (kk >> 4) + (c0 >> 4)) * 64 + ((c0 >> 3) & 1) * 32 + (r & 31);
+        uint16_t hi[8], lo[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split16(v[e], prec, hi[e], lo[e]);
+        uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + lane_slot * 16);
+        dst[0] = make_uint4(pk16(hi[0], hi[1]), pk16(hi[2], hi[3]), pk16(hi[4], hi[5]), pk16(hi[6], hi[7]));
+        dst[1] = make_uint4(pk16(lo[0], lo[1]), pk16(lo[2], lo[3]), pk16(lo[4], lo[5]), pk16(lo[6], lo[7]));
+        return;
+    }
+    mode &= ~STIN_GEMM_W_FRAG;
+    if (mode == 0) {
+        float4* dst = reinterpret_cast<float4*>(base + row_off + c0);
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+        return;
+    }
+    if (mode == STIN_GEMM_W_BF16) {
+        uint16_t h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const __bf16 b = (__bf16)v[e];
+            h[e] = *reinterpret_cast<const uint16_t*>(&b);
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + row_off + c0) =
+            make_uint4(pk16(h[0], h[1]), pk16(h[2], h[3]), pk16(h[4], h[5]), pk16(h[6], h[7]));
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {                                   // k-group layout: 16 bytes = [hi x 4 | lo x 4] per 4 elements
+        uint16_t hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split16(v[4 * g + e], mode, hi[e], lo[e]);
+        *reinterpret_cast<uint4*>(base + row_off + c0 + 4 * g) =
+            make_uint4(pk16(hi[0], hi[1]), pk16(hi[2], hi[3]), pk16(lo[0], lo[1]), pk16(lo[2], lo[3]));
+    }
+}
+
+__device__ __forceinline__ bool pack8_shape(int Cp, int H, int Cout, int has_shortcut) {
+    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+    return Cp % 8 == 0 && Yw % 8 == 0 && H % 8 == 0 && Cout % 8 == 0;
+}
+
+__device__ __forceinline__ void pack_body8(int64_t t, const float* __restrict__ W1, const float* __restrict__ b1,
+                                           const float* __restrict__ Ws, const float* __restrict__ bs,
+                                           const float* __restrict__ W2, int Cin, int Cp, int H, int Cout, int has_shortcut,
+                                           int trans_inv, float* __restrict__ wcat, float* __restrict__ bcat,
+                                           float* __restrict__ wcatT, float* __restrict__ w2T, float* __restrict__ w2s,
+                                           int fwd_mode, int bwd_mode) {
+    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+    const int ld1 = trans_inv ? Cin : 2 * Cin;
+    auto val = [&](int r, int c) -> float {                        // wcat[r][c] (pack_body's expression)
+        if (c >= Cin) return 0.f;
+        if (r < H) return trans_inv ? -W1[(int64_t)r * ld1 + c] : W1[(int64_t)r * ld1 + c] - W1[(int64_t)r * ld1 + Cin + c];
+        if (r < 2 * H) return trans_inv ? W1[(int64_t)(r - H) * ld1 + c] : W1[(int64_t)(r - H) * ld1 + Cin + c];
+        return Ws[(int64_t)(r - 2 * H) * Cin + c];
+    };
+    const int64_t nA = (int64_t)Yw * (Cp / 8), nB = (int64_t)Cp * (Yw / 8), nC = (int64_t)H * (Cout / 8),
+                  nD = w2s != nullptr ? (int64_t)Cout * (H / 8) : 0;
+    float v[8];
+    if (t < nA) {                                                  // wcat rows: 8 consecutive input channels
+        const int r = (int)(t / (Cp / 8)), c0 = (int)(t % (Cp / 8)) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = val(r, c0 + e);
+        put_weight8(wcat, (int64_t)r * Cp, c0, v, fwd_mode, r, Yw, Cp);
+        if (c0 == 0) bcat[r] = r < H ? (b1 != nullptr ? b1[r] : 0.f) : (r < 2 * H ? 0.f : (bs != nullptr ? bs[r - 2 * H] : 0.f));
+    } else if ((t -= nA) < nB) {                                   // wcatT rows (= input channel c): 8 consecutive output rows; c fastest
+        const int c = (int)(t % Cp), r0 = (int)(t / Cp) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = val(r0 + e, c);
+        put_weight8(wcatT, (int64_t)c * Yw, r0, v, bwd_mode, c, Cp, Yw);
+    } else if ((t -= nB) < nC) {                                   // w2T rows (= hidden channel k): 8 consecutive outputs; k fastest
+        const int k = (int)(t % H), o0 = (int)(t / H) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = W2[(int64_t)(o0 + e) * H + k];
+        put_weight8(w2T, (int64_t)k * Cout, o0, v, bwd_mode, k, H, Cout);
+    } else if ((t -= nC) < nD) {                                   // w2s rows (= output o): 8 consecutive hidden channels
+        const int o = (int)(t / (H / 8)), k0 = (int)(t % (H / 8)) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = W2[(int64_t)o * H + k0 + e];
+        put_weight8(w2s, (int64_t)o * H, k0, v, fwd_mode, o, Cout, H);
+    }
+}
+
 __global__ void k_pack(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ Ws,
                        const float* __restrict__ bs, const float* __restrict__ W2, int Cin, int Cp, int H, int Cout,
                        int has_shortcut, int trans_inv, float* __restrict__ wcat, float* __restrict__ bcat,
                        float* __restrict__ wcatT, float* __restrict__ w2T, float* __restrict__ w2s, int fwd_mode,
-                       int bwd_mode) {
-    pack_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, W1, b1, Ws, bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat,
-              bcat, wcatT, w2T, w2s, fwd_mode, bwd_mode);
+                       int bwd_mode, int pack8) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pack8 && pack8_shape(Cp, H, Cout, has_shortcut))
+        pack_body8(t, W1, b1, Ws, bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T, w2s, fwd_mode, bwd_mode);
+    else
+        pack_body(t, W1, b1, Ws, bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T, w2s, fwd_mode, bwd_mode);
 }
 
 // Every block of a network in ONE launch: blockIdx.y picks the job (a table in device memory, written once per model).
-__global__ void k_pack_many(const stin_pack_job_t* __restrict__ jobs) {
+__global__ void k_pack_many(const stin_pack_job_t* __restrict__ jobs, int pack8) {
     const stin_pack_job_t j = jobs[blockIdx.y];
-    pack_body((int64_t)blockIdx.x * blockDim.x + threadIdx.x, j.W1, j.b1, j.Ws, j.bs, j.W2, j.Cin, j.Cp, j.H, j.Cout,
-              j.has_shortcut, j.trans_inv, j.wcat, j.bcat, j.wcatT, j.w2T, j.w2s, j.fwd_split, j.bwd_split);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pack8 && pack8_shape(j.Cp, j.H, j.Cout, j.has_shortcut))       // (block-uniform: one job per blockIdx.y)
+        pack_body8(t, j.W1, j.b1, j.Ws, j.bs, j.W2, j.Cin, j.Cp, j.H, j.Cout, j.has_shortcut, j.trans_inv, j.wcat, j.bcat, j.wcatT, j.w2T,
+                   j.w2s, j.fwd_split, j.bwd_split);
+    else
+        pack_body(t, j.W1, j.b1, j.Ws, j.bs, j.W2, j.Cin, j.Cp, j.H, j.Cout, j.has_shortcut, j.trans_inv, j.wcat, j.bcat, j.wcatT, j.w2T,
+                  j.w2s, j.fwd_split, j.bwd_split);
 }
 
 // dwb [Yw, Cin + 1] (weight grad | bias grad of the packed operand) -> grads of the reference-layout
@@ -167,6 +285,12 @@ __global__ void k_norm_coef_m_quirk(const float* __restrict__ S0, const float* _
 }
 }  // namespace
 
+// STIN_PACK8=0 keeps the one-element-per-thread pack (A/B and test switch, re-read per call)
+static inline int pack8_on() {
+    const char* e = getenv("STIN_PACK8");
+    return (e != nullptr && atoi(e) == 0) ? 0 : 1;
+}
+
 static inline bool split_mode_ok(int m) {
     if (m == 0) return true;
     m &= ~STIN_GEMM_W_FRAG;
@@ -202,7 +326,7 @@ extern "C" int stin_edgeconv_pack_f32(const float* W1, const float* b1, const fl
     const int Yw = 2 * H + (has_shortcut ? Cout : 0);
     const int64_t n = (int64_t)Yw * Cp + (int64_t)H * Cout;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream_, W1, b1, Ws,
-                       bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T, w2s, fwd_split, bwd_split);
+                       bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T, w2s, fwd_split, bwd_split, pack8_on());
     return stin_launch_status();
 }
 
@@ -213,7 +337,7 @@ extern "C" int stin_edgeconv_pack_many_f32(const stin_pack_job_t* jobs_device, i
     if (n_jobs == 0 || max_elems == 0) return STIN_OK;
     STIN_REQUIRE(jobs_device != nullptr, STIN_E_NULL);
     hipLaunchKernelGGL(k_pack_many, dim3((unsigned)((max_elems + BLOCK - 1) / BLOCK), (unsigned)n_jobs), dim3(BLOCK), 0,
-                       (hipStream_t)stream_, jobs_device);
+                       (hipStream_t)stream_, jobs_device, pack8_on());
     return stin_launch_status();
 }
 

@@ -1162,6 +1162,41 @@ def test_weight_gradient_side_stream_is_bit_identical_in_every_autograd_mode():
         SF.USE_WGRAD_STREAM, SF.WGRAD_MIN_WORK = old, old_min
 
 
+@pytest.mark.parametrize('Cin,H,Cout,shortcut,trans_inv', [(256, 512, 256, False, False), (128, 512, 256, True, False),
+                                                           (64, 128, 64, False, True), (128, 128, 64, True, False),
+                                                           (64, 256, 128, True, False), (16, 24, 8, False, False), (8, 8, 8, True, True)])
+@pytest.mark.parametrize('modes', ['f16x3+frag / bf16x3+frag', 'f16x3 / bf16x3', 'plain', 'bf16 rows'])
+def test_pack8_equals_the_elementwise_pack(Cin, H, Cout, shortcut, trans_inv, modes, monkeypatch):
+    """stin_edgeconv_pack_f32 with eight elements of a destination row per thread (round 4, pack_body8) writes the same bytes as
+    the one-element-per-thread pack (STIN_PACK8=0) into all five operands, for every storage mode a block uses: fragment-order
+    and k-group split layouts, plain fp32, plain bf16 - and the plain-transpose pseudo job of functional.PackSet."""
+    F16, BF16, FRAG, WB16 = SF.GEMM_F16X3, SF.GEMM_BF16X3, 0x400, SF.GEMM_W_BF16
+    fm, bm = {'f16x3+frag / bf16x3+frag': (F16 | FRAG, BF16 | FRAG), 'f16x3 / bf16x3': (F16, BF16), 'plain': (0, 0),
+              'bf16 rows': (WB16, WB16)}[modes]
+    g = torch.Generator().manual_seed(Cin + H + Cout)
+    Cp = Cin
+    W1 = torch.randn(H, Cin if trans_inv else 2 * Cin, generator=g).to(DEV)
+    b1 = torch.randn(H, generator=g).to(DEV)
+    W2 = torch.randn(Cout, H, generator=g).to(DEV)
+    Ws = torch.randn(Cout, Cin, generator=g).to(DEV) if shortcut else None
+    bs = torch.randn(Cout, generator=g).to(DEV) if shortcut else None
+    Yw = 2 * H + (Cout if shortcut else 0)
+
+    def run(flag):
+        monkeypatch.setenv('STIN_PACK8', flag)
+        bufs = [torch.full((n,), -3.0, device=DEV) for n in (Yw * Cp, Yw, Yw * Cp, H * Cout, Cout * H)]
+        SF._call('stin_edgeconv_pack_f32', SF._ptr(W1), SF._ptr(b1), SF._ptr(Ws), SF._ptr(bs), SF._ptr(W2), Cin, Cp, H, Cout, int(shortcut),
+                 int(trans_inv), SF._ptr(bufs[0]), SF._ptr(bufs[1]), SF._ptr(bufs[2]), SF._ptr(bufs[3]), SF._ptr(bufs[4]), fm, bm,
+                 SF._stream(W1))
+        return [b.view(torch.int32).clone() for b in bufs]
+
+    want, got = run('0'), run('1')
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    ps = SF.PackSet([], torch.device(DEV), False, (W2,))
+    ps.run()
+    assert torch.equal(ps.transposed[0], W2.t().contiguous())
+
+
 @pytest.mark.parametrize('batched', [False, True])
 def test_pack_many_equals_the_per_block_pack(batched):
     """functional.PackSet: the weight operands of every fused block packed by ONE launch at the start of forward (persistent
