@@ -2455,6 +2455,18 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_slabs(const float* __restrict_
     if (g < nw4 + nb4) {
         const float* p = slab + 4 * g;
         int64_t c = ty;
+        for (; c + 15 * RS_KL < chunks; c += 16 * RS_KL) {          // (sixteen loads in flight on long chunk lists; same addition order)
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = ld4(p + (c + u * RS_KL) * cs);
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                add4(s0, v[u]);
+                add4(s1, v[u + 1]);
+                add4(s2, v[u + 2]);
+                add4(s3, v[u + 3]);
+            }
+        }
         for (; c + 3 * RS_KL < chunks; c += 4 * RS_KL) {
             add4(s0, ld4(p + c * cs));
             add4(s1, ld4(p + (c + RS_KL) * cs));

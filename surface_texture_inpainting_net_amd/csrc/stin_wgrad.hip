@@ -342,6 +342,21 @@ __global__ __launch_bounds__(FN_BLOCK) void k_wgrad_finalize(const WgFinal f) {
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
         if (p != nullptr) {
             int64_t c = ty;
+            // (round 4) sixteen slab loads in flight per thread where the chunk list is long (the first block's skinny product
+            // writes ~900 chunks: with four in flight this fold is 14-28 dependent trips to the fabric - 200 us at the very end of
+            // the backward pass under rocprofv3, 11 us now; stand-alone and in the un-profiled step the difference is small); the additions keep the order of the four-at-a-time loop below: bit-identical sums
+            for (; c + 15 * FN_KL < chunks; c += 16 * FN_KL) {
+                float4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = ld4(p + (c + u * FN_KL) * cs);
+#pragma unroll
+                for (int u = 0; u < 16; u += 4) {
+                    add4(s0, v[u]);
+                    add4(s1, v[u + 1]);
+                    add4(s2, v[u + 2]);
+                    add4(s3, v[u + 3]);
+                }
+            }
             for (; c + 3 * FN_KL < chunks; c += 4 * FN_KL) {
                 add4(s0, ld4(p + c * cs));
                 add4(s1, ld4(p + (c + FN_KL) * cs));
