@@ -1183,6 +1183,18 @@ int edge_fwd_impl(const T* A, int64_t lda, const T* B, int64_t ldb, const int32_
         }
     }
     if (vec && mask != nullptr) {                    // mask shapes are exact multiples of the lane geometry
+        // tuning aid (re-read per call): STIN_EDGE_U512 = neighbour rows in flight of the fp32 forward at H = 512 (2-KB rows)
+        const char* eu = is_f32((const T*)nullptr) && H == 512 ? getenv("STIN_EDGE_U512") : nullptr;
+        const int u512 = eu ? atoi(eu) : 0;
+        if constexpr (is_f32((const T*)nullptr)) {
+            if (u512 == 3 || u512 == 4 || u512 == 6) {
+                const unsigned grid_ = grid_rows(N, 64);
+                if (u512 == 3) hipLaunchKernelGGL((k_edge_fwd_exact<T, 64, 2, 3>), rows_grid(grid_), dim3(BLOCK), 0, stream, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+                else if (u512 == 4) hipLaunchKernelGGL((k_edge_fwd_exact<T, 64, 2, 4>), rows_grid(grid_), dim3(BLOCK), 0, stream, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+                else hipLaunchKernelGGL((k_edge_fwd_exact<T, 64, 2, 6>), rows_grid(grid_), dim3(BLOCK), 0, stream, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+                return stin_launch_status();
+            }
+        }
         STIN_DISPATCH(H, k_edge_fwd_exact, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
     } else if (vec) {
         STIN_DISPATCH(H, k_edge_fwd, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
@@ -1251,7 +1263,16 @@ int edge_bwd_mask_pair_impl(const float* G, int64_t ldg, const uint32_t* mask, c
                        ld_cps, cp_dst, ld_cpd, Ccp)
     if (g == 32) STIN_PAIR(32, 1, 6);                 // H = 128
     else if (vpl == 1) STIN_PAIR(64, 1, 4);           // 256
-    else if (vpl == 2) STIN_PAIR(64, 2, 2);           // 512
+    else if (vpl == 2) {                              // 512 (tuning aid STIN_EDGE_US512: rows in flight of the gathering role)
+        const char* eu = getenv("STIN_EDGE_US512");
+        const int us = eu ? atoi(eu) : 0;
+#define STIN_PAIR_U(US_) hipLaunchKernelGGL((k_edge_bwd_mask_pair<T, 64, 2, 2, US_>), pair_grid(nb), dim3(BLOCK), 0, stream, G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src, ld_cps, cp_dst, ld_cpd, Ccp)
+        if (us == 1) STIN_PAIR(64, 2, 2);             // (STIN_U(2, 2) = 1 row: the round-2 choice)
+        else if (us == 3) STIN_PAIR_U(3);
+        else if (us == 4) STIN_PAIR_U(4);
+        else STIN_PAIR_U(2);                          // 18 063 x 512: 56.8 us at 1, 54.0 at 2, 56.1 / 58.8 at 3 / 4 (profiles/_edge512_sweep.py)
+#undef STIN_PAIR_U
+    }
     else if (vpl <= 4) STIN_PAIR(64, 4, 2);           // 1024
     else STIN_PAIR(64, 8, 1);                         // 2048
 #undef STIN_PAIR
