@@ -132,6 +132,90 @@ __global__ __launch_bounds__(T) void k_rank(const Batch b, const int32_t* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same plans from ONE stable radix sort instead of returning atomics.  The counting sort above issues two
+// returning device-scope atomics per edge on random rows (~21 G atomics/s: k_count alone 200 us for the headline scene) beside
+// the first kernels of the step it is prefetched for; here every (edge, side) becomes an item with key = the global index of its
+// row's counter (c_off[job] + side * N + row; out-of-range pairs get the key past the last row) and value = its item index, one
+// rocPRIM radix sort over the bits that are needed groups the items by row IN ORIGINAL ORDER (stable) - rowptr is a binary
+// search per row, every output a gather.  No atomics except the out-of-range flag; identical results (k_rank's order is the
+// stable order): tests/test_hip_parity.py::test_plan_build_by_sort_equals_the_counting_sort.
+//   items [0, total_E): side 0 of global edge g;  items [total_E, 2 total_E): side 1 of global edge g - total_E (pair jobs only;
+//   the slots of non-pair jobs carry the invalid key)
+__global__ __launch_bounds__(T) void k_sort_keys(const Batch b, int64_t total_E, uint32_t invalid, uint32_t* __restrict__ keys,
+                                                 uint32_t* __restrict__ vals, int32_t* __restrict__ bad) {
+    const int ji = job_of(b.e_blk, b.n);
+    const stin_plan_job_t& J = b.j[ji];
+    const int64_t e = (int64_t)(blockIdx.x - b.e_blk[ji]) * T + threadIdx.x;
+    if (e >= J.E) return;
+    const int64_t g = b.e_off[ji] + e;
+    const int64_t ka = J.a[e];
+    bool oob = (ka < 0) | (ka >= J.N);
+    int64_t kb = 0;
+    if (J.b != nullptr) {
+        kb = J.b[e];
+        oob |= (kb < 0) | (kb >= J.b_limit);
+    }
+    if (J.narrow_out != nullptr) J.narrow_out[e] = oob ? 0 : (int32_t)ka;
+    if (oob && bad != nullptr) atomicOr(bad, 1);
+    // counter layout of the counting sort: [0] = 0, [1 + n] = row n of side 0, [1 + N + n] = row n of side 1
+    keys[g] = oob ? invalid : (uint32_t)(b.c_off[ji] + ka);
+    vals[g] = (uint32_t)g;
+    keys[total_E + g] = (oob || !J.pair) ? invalid : (uint32_t)(b.c_off[ji] + J.N + kb);
+    vals[total_E + g] = (uint32_t)(total_E + g);
+}
+
+__device__ __forceinline__ int32_t lower_bound_u32(const uint32_t* __restrict__ a, int64_t n, uint32_t key) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return (int32_t)lo;
+}
+
+// start[k] = first sorted position with key >= k, for every counter index k in [0, total_cnt]: exactly the exclusive prefix
+// sums the counting sort's scan produces (start[c_off + n] = first entry of row n of side 0, start[c_off + N + n] of side 1), so
+// k_rows turns them into rowptr0 / rowptr1 / inv_deg0 unchanged
+__global__ __launch_bounds__(T) void k_sort_start(const uint32_t* __restrict__ skeys, int64_t items, int64_t total_cnt,
+                                                  int32_t* __restrict__ start) {
+    const int64_t k = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (k > total_cnt) return;
+    start[k] = lower_bound_u32(skeys, items, (uint32_t)k);
+}
+
+// sorted position p -> the CSR entry of its item.  side 0 (phase 0): col0 / perm0 and the edge's destination-CSR slot;
+// side 1 (phase 1, after phase 0): col1, xslot, w_src
+__global__ __launch_bounds__(T) void k_sort_out(const Batch b, int64_t total_E, int64_t items, uint32_t invalid,
+                                                const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                                                const int32_t* __restrict__ start, int32_t* __restrict__ slot_of_edge, int phase) {
+    const int64_t p = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (p >= items) return;
+    if (skeys[p] == invalid) return;
+    const uint32_t item = svals[p];
+    const int side = item >= (uint32_t)total_E ? 1 : 0;
+    if (side != phase) return;
+    const int64_t g = (int64_t)item - (side ? total_E : 0);
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < b.n && g >= b.e_off[ji + 1]) ++ji;
+    const stin_plan_job_t& J = b.j[ji];
+    const int32_t e = (int32_t)(g - b.e_off[ji]);
+    if (side == 0) {
+        const int32_t slot0 = (int32_t)p - start[b.c_off[ji]];
+        J.col0[slot0] = J.b != nullptr ? (int32_t)J.b[e] : e;
+        if (J.perm0 != nullptr) J.perm0[slot0] = e;
+        slot_of_edge[g] = slot0;
+    } else {
+        const int32_t slot1 = (int32_t)p - start[b.c_off[ji] + J.N];
+        const int64_t ka = J.a[e];
+        J.col1[slot1] = (int32_t)ka;
+        if (J.xslot != nullptr) J.xslot[slot1] = slot_of_edge[g];
+        if (J.w_src != nullptr) J.w_src[slot1] = J.inv_deg0[ka];
+    }
+}
+
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + T - 1) / T); }
 
@@ -142,8 +226,16 @@ size_t scan_temp_bytes(int64_t n) {
     return bytes;
 }
 
+size_t sort_temp_bytes(int64_t items) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                    (size_t)(items > 0 ? items : 1), 0, 32, (hipStream_t)0);
+    return bytes;
+}
+
 struct Layout {
     size_t cnt, pos0, pos1, id0, id1, scan, total;
+    size_t keys0, keys1, vals0, vals1, slot, bases, sort;      // the sort-based build (the same workspace serves either)
 };
 Layout layout(int64_t total_E, int64_t total_cnt) {
     Layout L;
@@ -155,8 +247,23 @@ Layout layout(int64_t total_E, int64_t total_cnt) {
     L.id0 = off;  off += align_up(e * sizeof(int32_t));
     L.id1 = off;  off += align_up(e * sizeof(int32_t));
     L.scan = off; off += align_up(scan_temp_bytes((int64_t)c));
-    L.total = off + 256;
+    const size_t count_total = off;
+    off = 0;
+    L.keys0 = off; off += align_up(2 * e * sizeof(uint32_t));
+    L.keys1 = off; off += align_up(2 * e * sizeof(uint32_t));
+    L.vals0 = off; off += align_up(2 * e * sizeof(uint32_t));
+    L.vals1 = off; off += align_up(2 * e * sizeof(uint32_t));
+    L.slot = off;  off += align_up(e * sizeof(int32_t));
+    L.bases = off; off += align_up((c + 1) * sizeof(int32_t));                  // start[0 .. total_cnt]
+    L.sort = off;  off += align_up(sort_temp_bytes((int64_t)(2 * e)));
+    L.total = (off > count_total ? off : count_total) + 256;
     return L;
+}
+
+// STIN_PLAN_SORT=0 keeps the counting sort (A/B and test switch, re-read per call)
+inline bool plan_sort_on() {
+    const char* e = getenv("STIN_PLAN_SORT");
+    return !(e != nullptr && atoi(e) == 0);
 }
 
 int check_job(const stin_plan_job_t& J) {
@@ -206,9 +313,39 @@ int build(const stin_plan_job_t* jobs, int n_jobs, int32_t* bad, void* workspace
     int32_t* id0 = reinterpret_cast<int32_t*>(ws + L.id0);
     int32_t* id1 = reinterpret_cast<int32_t*>(ws + L.id1);
 
+    const unsigned e_blocks = b.e_blk[n_jobs], c_blocks = b.c_blk[n_jobs];
+    if (plan_sort_on() && total_cnt < ((int64_t)1 << 31) - 2) {
+        uint32_t* keys0 = reinterpret_cast<uint32_t*>(ws + L.keys0);
+        uint32_t* keys1 = reinterpret_cast<uint32_t*>(ws + L.keys1);
+        uint32_t* vals0 = reinterpret_cast<uint32_t*>(ws + L.vals0);
+        uint32_t* vals1 = reinterpret_cast<uint32_t*>(ws + L.vals1);
+        int32_t* slot = reinterpret_cast<int32_t*>(ws + L.slot);
+        int32_t* start = reinterpret_cast<int32_t*>(ws + L.bases);
+        const int64_t items = 2 * total_E;
+        const uint32_t invalid = (uint32_t)total_cnt;                          // one past the last counter: sorts behind every row
+        int bits = 1;
+        while (bits < 32 && ((uint64_t)1 << bits) <= (uint64_t)invalid) ++bits;
+        if (e_blocks > 0) {
+            hipLaunchKernelGGL(k_sort_keys, dim3(e_blocks), dim3(T), 0, stream, b, total_E, invalid, keys0, vals0, bad);
+            size_t sb = sort_temp_bytes(items);
+            const hipError_t es = rocprim::radix_sort_pairs(ws + L.sort, sb, keys0, keys1, vals0, vals1, (size_t)items, 0, (unsigned)bits, stream);
+            if (es != hipSuccess) return (int)es;
+        }
+        // (no edges at all: every probe finds position 0 in an empty list - rowptr all zero)
+        hipLaunchKernelGGL(k_sort_start, dim3(grid_for(total_cnt + 1)), dim3(T), 0, stream, keys1, e_blocks > 0 ? items : 0, total_cnt, start);
+        hipLaunchKernelGGL(k_rows, dim3(c_blocks), dim3(T), 0, stream, b, start);
+        if (e_blocks > 0) {
+            const unsigned ib = grid_for(items);
+            hipLaunchKernelGGL(k_sort_out, dim3(ib), dim3(T), 0, stream, b, total_E, items, invalid, keys1, vals1, start, slot, 0);
+            bool any_pair = false;
+            for (int i = 0; i < n_jobs; ++i) any_pair |= jobs[i].pair != 0;
+            if (any_pair)
+                hipLaunchKernelGGL(k_sort_out, dim3(ib), dim3(T), 0, stream, b, total_E, items, invalid, keys1, vals1, start, slot, 1);
+        }
+        return stin_launch_status();
+    }
     hipError_t err = hipMemsetAsync(cnt, 0, (size_t)total_cnt * sizeof(int32_t), stream);
     if (err != hipSuccess) return (int)err;
-    const unsigned e_blocks = b.e_blk[n_jobs], c_blocks = b.c_blk[n_jobs];
     if (e_blocks > 0) hipLaunchKernelGGL(k_count, dim3(e_blocks), dim3(T), 0, stream, b, cnt, pos0, pos1, bad);
     size_t scan_bytes = scan_temp_bytes(total_cnt);
     err = rocprim::inclusive_scan(ws + L.scan, scan_bytes, cnt, cnt, (size_t)total_cnt, rocprim::plus<int32_t>(), stream);

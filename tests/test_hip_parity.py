@@ -70,6 +70,42 @@ def test_edge_csr_pair_bit_exact(n, e):
     assert int(bad.item()) == 0
 
 
+def test_plan_build_by_sort_equals_the_counting_sort(monkeypatch):
+    """stin_plan_build_many by ONE stable radix sort (round 4, the default) against the counting sort with returning atomics
+    (STIN_PLAN_SORT=0): every output of a whole scene's batched build - both CSRs of every edge set, cross map, source weights,
+    pool maps with the narrowed trace - identical, including dropped out-of-range pairs, empty rows and an empty edge set."""
+    s = make_synthetic_mesh(9000, 3, seed=5, dilations=(2, 4))
+    ei0 = s.edge_index.clone()
+    ei0[0, 17] = 10 ** 9                      # one out-of-range source, one negative target
+    ei0[1, 4000] = -3
+    jobs_in = [(ei0, int(s.num_vertices[0, 0])), (s['hierarchy_edge_index_1'], int(s.num_vertices[0, 1])),
+               (torch.zeros(2, 0, dtype=torch.long), 50), (torch.randint(0, 7, (2, 300)), 400)]
+
+    def run(flag):
+        monkeypatch.setenv('STIN_PLAN_SORT', flag)
+        out = []
+        bad = _bad()
+        from surface_texture_inpainting_net_amd.plan import PlanJobs
+        jb = PlanJobs()
+        sets = [EdgeSet(ei.to(DEV), n, bad, jobs=jb) for ei, n in jobs_in]
+        pm = PoolMap(s['hierarchy_trace_index_1'].to(DEV), int(s.num_vertices[0, 0]), int(s.num_vertices[0, 1]), bad, jb)
+        jb.run(bad, torch.device(DEV))
+        torch.cuda.synchronize()
+        for es in sets:                           # (slots behind the last valid entry - dropped pairs - are never written: compare what is)
+            nd, ns = int(es.by_dst.rowptr[-1]), int(es.by_src.rowptr[-1])
+            out += [es.by_dst.rowptr, es.by_dst.col[:nd], es.by_src.rowptr, es.by_src.col[:ns], es.xslot[:ns], es.w_src[:ns], es.inv_deg]
+        out += [pm.children.rowptr, pm.children.col, pm.trace]
+        single = build_csr(torch.tensor([3, 1, 3, 0, 3], device=DEV), torch.tensor([9, 8, 7, 6, 5], device=DEV), 5, 10, bad, want_perm=True)
+        out += [single.rowptr, single.col, single.perm, single.inv_deg, bad]
+        return [t.clone() for t in out]
+
+    want, got = run('0'), run('1')
+    assert len(want) == len(got)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), i
+    assert int(got[-1].item()) != 0           # the out-of-range pairs were flagged by both
+
+
 def test_csr_flags_out_of_range_indices():
     key = torch.tensor([0, 1, 5, 2], device=DEV)
     bad = _bad()
