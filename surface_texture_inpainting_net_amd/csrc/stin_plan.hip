@@ -260,10 +260,13 @@ Layout layout(int64_t total_E, int64_t total_cnt) {
     return L;
 }
 
-// STIN_PLAN_SORT=0 keeps the counting sort (A/B and test switch, re-read per call)
-inline bool plan_sort_on() {
+// STIN_PLAN_SORT = 0 keeps the counting sort, 1 forces the sort form (A/B and test switch, re-read per call); default: the sort
+// form from 400 k edges per batch up - below that the atomics are few and the sort's extra launches (five rocPRIM kernels and
+// seven memsets) cost a launch-bound step more than they save (20 k-vertex crop under HIP-graph replay: 2.56 vs 2.65 ms)
+inline bool plan_sort_on(int64_t total_E) {
     const char* e = getenv("STIN_PLAN_SORT");
-    return !(e != nullptr && atoi(e) == 0);
+    if (e != nullptr) return atoi(e) != 0;
+    return total_E >= 400000;
 }
 
 int check_job(const stin_plan_job_t& J) {
@@ -314,7 +317,7 @@ int build(const stin_plan_job_t* jobs, int n_jobs, int32_t* bad, void* workspace
     int32_t* id1 = reinterpret_cast<int32_t*>(ws + L.id1);
 
     const unsigned e_blocks = b.e_blk[n_jobs], c_blocks = b.c_blk[n_jobs];
-    if (plan_sort_on() && total_cnt < ((int64_t)1 << 31) - 2) {
+    if (plan_sort_on(total_E) && total_cnt < ((int64_t)1 << 31) - 2) {
         uint32_t* keys0 = reinterpret_cast<uint32_t*>(ws + L.keys0);
         uint32_t* keys1 = reinterpret_cast<uint32_t*>(ws + L.keys1);
         uint32_t* vals0 = reinterpret_cast<uint32_t*>(ws + L.vals0);
