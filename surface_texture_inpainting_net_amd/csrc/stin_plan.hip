@@ -142,8 +142,9 @@ __global__ __launch_bounds__(T) void k_rank(const Batch b, const int32_t* __rest
 // stable order): tests/test_hip_parity.py::test_plan_build_by_sort_equals_the_counting_sort.
 //   items [0, total_E): side 0 of global edge g;  items [total_E, 2 total_E): side 1 of global edge g - total_E (pair jobs only;
 //   the slots of non-pair jobs carry the invalid key)
-__global__ __launch_bounds__(T) void k_sort_keys(const Batch b, int64_t total_E, uint32_t invalid, uint32_t* __restrict__ keys,
-                                                 uint32_t* __restrict__ vals, int32_t* __restrict__ bad) {
+typedef unsigned long long u64;
+__global__ __launch_bounds__(T) void k_sort_keys(const Batch b, int64_t total_E, uint32_t invalid, u64* __restrict__ items,
+                                                 int32_t* __restrict__ bad) {
     const int ji = job_of(b.e_blk, b.n);
     const stin_plan_job_t& J = b.j[ji];
     const int64_t e = (int64_t)(blockIdx.x - b.e_blk[ji]) * T + threadIdx.x;
@@ -159,17 +160,16 @@ __global__ __launch_bounds__(T) void k_sort_keys(const Batch b, int64_t total_E,
     if (J.narrow_out != nullptr) J.narrow_out[e] = oob ? 0 : (int32_t)ka;
     if (oob && bad != nullptr) atomicOr(bad, 1);
     // counter layout of the counting sort: [0] = 0, [1 + n] = row n of side 0, [1 + N + n] = row n of side 1
-    keys[g] = oob ? invalid : (uint32_t)(b.c_off[ji] + ka);
-    vals[g] = (uint32_t)g;
-    keys[total_E + g] = (oob || !J.pair) ? invalid : (uint32_t)(b.c_off[ji] + J.N + kb);
-    vals[total_E + g] = (uint32_t)(total_E + g);
+    // one 64-bit item = key in the high word (the sort looks at those bits only), item id in the low word: the id rides along
+    items[g] = ((u64)(oob ? invalid : (uint32_t)(b.c_off[ji] + ka)) << 32) | (u64)(uint32_t)g;
+    items[total_E + g] = ((u64)((oob || !J.pair) ? invalid : (uint32_t)(b.c_off[ji] + J.N + kb)) << 32) | (u64)(uint32_t)(total_E + g);
 }
 
-__device__ __forceinline__ int32_t lower_bound_u32(const uint32_t* __restrict__ a, int64_t n, uint32_t key) {
+__device__ __forceinline__ int32_t lower_bound_key(const u64* __restrict__ a, int64_t n, uint32_t key) {
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (a[mid] < key) lo = mid + 1;
+        if ((uint32_t)(a[mid] >> 32) < key) lo = mid + 1;
         else hi = mid;
     }
     return (int32_t)lo;
@@ -178,22 +178,24 @@ __device__ __forceinline__ int32_t lower_bound_u32(const uint32_t* __restrict__ 
 // start[k] = first sorted position with key >= k, for every counter index k in [0, total_cnt]: exactly the exclusive prefix
 // sums the counting sort's scan produces (start[c_off + n] = first entry of row n of side 0, start[c_off + N + n] of side 1), so
 // k_rows turns them into rowptr0 / rowptr1 / inv_deg0 unchanged
-__global__ __launch_bounds__(T) void k_sort_start(const uint32_t* __restrict__ skeys, int64_t items, int64_t total_cnt,
+__global__ __launch_bounds__(T) void k_sort_start(const u64* __restrict__ sorted, int64_t items, int64_t total_cnt,
                                                   int32_t* __restrict__ start) {
     const int64_t k = (int64_t)blockIdx.x * T + threadIdx.x;
     if (k > total_cnt) return;
-    start[k] = lower_bound_u32(skeys, items, (uint32_t)k);
+    start[k] = lower_bound_key(sorted, items, (uint32_t)k);
 }
 
-// sorted position p -> the CSR entry of its item.  side 0 (phase 0): col0 / perm0 and the edge's destination-CSR slot;
-// side 1 (phase 1, after phase 0): col1, xslot, w_src
+// sorted position p -> the CSR entry of its item (after k_rows: w_src reads inv_deg0).  side 0 (phase 0): col0 / perm0 and the
+// edge's destination-CSR slot; side 1 (phase 1, after phase 0): col1, xslot, w_src.  (One pass that finds the destination slot by
+// a binary search in the edge's destination row instead of the scratch array measured slower: 84 us vs 2 x 38.)
 __global__ __launch_bounds__(T) void k_sort_out(const Batch b, int64_t total_E, int64_t items, uint32_t invalid,
-                                                const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
-                                                const int32_t* __restrict__ start, int32_t* __restrict__ slot_of_edge, int phase) {
+                                                const u64* __restrict__ sorted, const int32_t* __restrict__ start,
+                                                int32_t* __restrict__ slot_of_edge, int phase) {
     const int64_t p = (int64_t)blockIdx.x * T + threadIdx.x;
     if (p >= items) return;
-    if (skeys[p] == invalid) return;
-    const uint32_t item = svals[p];
+    const u64 it = sorted[p];
+    if ((uint32_t)(it >> 32) == invalid) return;
+    const uint32_t item = (uint32_t)it;
     const int side = item >= (uint32_t)total_E ? 1 : 0;
     if (side != phase) return;
     const int64_t g = (int64_t)item - (side ? total_E : 0);
@@ -228,8 +230,8 @@ size_t scan_temp_bytes(int64_t n) {
 
 size_t sort_temp_bytes(int64_t items) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                    (size_t)(items > 0 ? items : 1), 0, 32, (hipStream_t)0);
+    (void)rocprim::radix_sort_keys(nullptr, bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                   (size_t)(items > 0 ? items : 1), 32, 64, (hipStream_t)0);
     return bytes;
 }
 
@@ -318,10 +320,8 @@ int build(const stin_plan_job_t* jobs, int n_jobs, int32_t* bad, void* workspace
 
     const unsigned e_blocks = b.e_blk[n_jobs], c_blocks = b.c_blk[n_jobs];
     if (plan_sort_on(total_E) && total_cnt < ((int64_t)1 << 31) - 2) {
-        uint32_t* keys0 = reinterpret_cast<uint32_t*>(ws + L.keys0);
-        uint32_t* keys1 = reinterpret_cast<uint32_t*>(ws + L.keys1);
-        uint32_t* vals0 = reinterpret_cast<uint32_t*>(ws + L.vals0);
-        uint32_t* vals1 = reinterpret_cast<uint32_t*>(ws + L.vals1);
+        u64* it0 = reinterpret_cast<u64*>(ws + L.keys0);                        // (keys0 | keys1 and vals0 | vals1 are adjacent: 2 x 16 e bytes)
+        u64* it1 = reinterpret_cast<u64*>(ws + L.vals0);
         int32_t* slot = reinterpret_cast<int32_t*>(ws + L.slot);
         int32_t* start = reinterpret_cast<int32_t*>(ws + L.bases);
         const int64_t items = 2 * total_E;
@@ -329,21 +329,21 @@ int build(const stin_plan_job_t* jobs, int n_jobs, int32_t* bad, void* workspace
         int bits = 1;
         while (bits < 32 && ((uint64_t)1 << bits) <= (uint64_t)invalid) ++bits;
         if (e_blocks > 0) {
-            hipLaunchKernelGGL(k_sort_keys, dim3(e_blocks), dim3(T), 0, stream, b, total_E, invalid, keys0, vals0, bad);
+            hipLaunchKernelGGL(k_sort_keys, dim3(e_blocks), dim3(T), 0, stream, b, total_E, invalid, it0, bad);
             size_t sb = sort_temp_bytes(items);
-            const hipError_t es = rocprim::radix_sort_pairs(ws + L.sort, sb, keys0, keys1, vals0, vals1, (size_t)items, 0, (unsigned)bits, stream);
+            const hipError_t es = rocprim::radix_sort_keys(ws + L.sort, sb, it0, it1, (size_t)items, 32u, 32u + (unsigned)bits, stream);
             if (es != hipSuccess) return (int)es;
         }
         // (no edges at all: every probe finds position 0 in an empty list - rowptr all zero)
-        hipLaunchKernelGGL(k_sort_start, dim3(grid_for(total_cnt + 1)), dim3(T), 0, stream, keys1, e_blocks > 0 ? items : 0, total_cnt, start);
+        hipLaunchKernelGGL(k_sort_start, dim3(grid_for(total_cnt + 1)), dim3(T), 0, stream, it1, e_blocks > 0 ? items : 0, total_cnt, start);
         hipLaunchKernelGGL(k_rows, dim3(c_blocks), dim3(T), 0, stream, b, start);
         if (e_blocks > 0) {
             const unsigned ib = grid_for(items);
-            hipLaunchKernelGGL(k_sort_out, dim3(ib), dim3(T), 0, stream, b, total_E, items, invalid, keys1, vals1, start, slot, 0);
+            hipLaunchKernelGGL(k_sort_out, dim3(ib), dim3(T), 0, stream, b, total_E, items, invalid, it1, start, slot, 0);
             bool any_pair = false;
             for (int i = 0; i < n_jobs; ++i) any_pair |= jobs[i].pair != 0;
             if (any_pair)
-                hipLaunchKernelGGL(k_sort_out, dim3(ib), dim3(T), 0, stream, b, total_E, items, invalid, keys1, vals1, start, slot, 1);
+                hipLaunchKernelGGL(k_sort_out, dim3(ib), dim3(T), 0, stream, b, total_E, items, invalid, it1, start, slot, 1);
         }
         return stin_launch_status();
     }
