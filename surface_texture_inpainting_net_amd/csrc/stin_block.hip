@@ -245,9 +245,19 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
     if (side) STIN_REQUIRE(ev_dy && ev_done, STIN_E_NULL);
     (void)ev_dagg;                             // (round 2 forked the dW2 product here; both products now start behind ev_dy)
     stin_stream_t ws_ = side ? wgrad_stream : stream;
+    // the fork event is bound to the edge-stage kernel's own completion signal where that launch is the last one before the fork
+    // (STIN_LAUNCH_STOP, stin_common.h; STIN_FORK_BIND=0: always an event record)
+    static const bool bind_env = [] { const char* e = getenv("STIN_FORK_BIND"); return e == nullptr || atoi(e) != 0; }();
+    bool bind_on = false;
+    if (side && bind_env) {                    // (a stream being captured into a hipGraph keeps the event-record node)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        bind_on = hipStreamIsCapturing(hs, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+    }
+    struct StopEventGuard { ~StopEventGuard() { stin_tl_stop_event = nullptr; } } stop_event_guard;   // never left set on an error return
+    bool bound = false;
     auto fork = [&](stin_event_t ev) -> int {
         if (!side) return STIN_OK;
-        hipError_t e = hipEventRecord((hipEvent_t)ev, hs);
+        hipError_t e = bound ? hipSuccess : hipEventRecord((hipEvent_t)ev, hs);
         if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)wgrad_stream, (hipEvent_t)ev, 0);
         return (int)e;
     };
@@ -283,6 +293,7 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
         // (a shortcut block's dY[:, 2H:] = g rides on the same launch when the rows allow 16-byte copies, else one 2-D memcpy)
         const bool ride = has_shortcut && N > 0 && Cout % 4 == 0 && ldg % 4 == 0 && Yw % 4 == 0 && stin_aligned16(gf) &&
                           stin_aligned16(dYf + 2 * H);
+        if (side && bind_on && N > 0 && (!has_shortcut || ride) && t_edge_ev1 == nullptr) stin_tl_stop_event = (hipEvent_t)ev_dy;
         STIN_EDGE_BRACKET(stin_edge_relu_mean_bwd_mask_f32(static_cast<const float*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src, col_src,
                                                           xslot, N, H, dYf, Yw, dYf + H, Yw, ride ? gf : nullptr, ldg,
                                                           ride ? dYf + 2 * H : nullptr, Yw, ride ? Cout : 0, stream));
@@ -294,6 +305,8 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
         // first Linear (+ shortcut): packed weight gradient and the block-input gradient (+ identity residual)
         // all weight gradients: both transposed products in one grid + one finalize launch (stin_wgrad.hip), off the
         // critical path dx <- g on the caller's weight-gradient stream
+        bound = side && bind_on && N > 0 && (!has_shortcut || ride) && t_edge_ev1 == nullptr && stin_tl_stop_event == nullptr;
+        stin_tl_stop_event = nullptr;
         STIN_TRY(fork(ev_dy));
         STIN_TRY(stin_edgeconv_wgrad(0, dagg, Cout, hf, ldh, dYf, Yw, x, ldx, N, Cin, Cp, H, Cout, has_shortcut, trans_inv, prec_bwd,
                                      dW1, db1, dW2, db2, dWs, dbs, tn_ws, tn_bytes, ws_));
@@ -336,6 +349,7 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
                                    Cout, dhE, H, wbb, stream));
         const bool ride = has_shortcut && N > 0 && Cout % 8 == 0 && ldg % 8 == 0 && Yw % 8 == 0 && stin_aligned16(gh) &&
                           stin_aligned16(dYh + 2 * H);
+        if (side && bind_on && N > 0 && (!has_shortcut || ride) && t_edge_ev1 == nullptr) stin_tl_stop_event = (hipEvent_t)ev_dy;
         STIN_EDGE_BRACKET(stin_edge_relu_mean_bwd_mask_bf16(static_cast<const stin_bf16_t*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src,
                                                            col_src, xslot, N, H, dYh, Yw, dYh + H, Yw, ride ? gh : nullptr, ldg,
                                                            ride ? dYh + 2 * H : nullptr, Yw, ride ? Cout : 0, stream));
@@ -344,6 +358,8 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
                                             hipMemcpyDeviceToDevice, hs);
             if (e != hipSuccess) return (int)e;
         }
+        bound = side && bind_on && N > 0 && (!has_shortcut || ride) && t_edge_ev1 == nullptr && stin_tl_stop_event == nullptr;
+        stin_tl_stop_event = nullptr;
         STIN_TRY(fork(ev_dy));
         STIN_TRY(stin_edgeconv_wgrad(1, dagg, Cout, hh, ldh, dYh, Yw, x, ldx, N, Cin, Cp, H, Cout, has_shortcut, trans_inv, prec_bwd,
                                      dW1, db1, dW2, db2, dWs, dbs, tn_ws, tn_bytes, ws_));

@@ -1,6 +1,7 @@
 // Shared helpers for the libstin_hip.so translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/stin_hip.h"
 
@@ -14,6 +15,23 @@
 // hipGetLastError() is per-thread sticky state shared with every other HIP user in the process
 // (PyTorch included): drop whatever an earlier, unrelated call left behind before we launch.
 static inline void stin_clear_stale_error() { (void)hipGetLastError(); }
+
+// Fork without a marker packet (round 4).  hipEventRecord on the compute stream puts a barrier packet behind the kernel and the
+// next kernel waits for the command processor to retire it: ~4 us of idle compute stream per fork (profiles/_fork_bind_probe.hip:
+// record + wait + side kernel 16.1 us per link of an 11.0 us chain, event bound to the kernel's own completion signal 12.0).  A
+// caller that wants "this launch is done" as an event sets stin_tl_stop_event; a launch site that supports it passes the event as
+// hipExtLaunchKernelGGL's stopEvent and clears the variable (= "bound"); the caller records the event the ordinary way if the
+// variable is still set afterwards.
+extern thread_local hipEvent_t stin_tl_stop_event;
+#define STIN_LAUNCH_STOP(KERNEL, GRID, BLOCK_, STREAM, ...)                                                          \
+    do {                                                                                                             \
+        if (stin_tl_stop_event != nullptr) {                                                                         \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK_, 0, STREAM, nullptr, stin_tl_stop_event, 0, __VA_ARGS__);     \
+            stin_tl_stop_event = nullptr;                                                                            \
+        } else {                                                                                                     \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK_, 0, STREAM, __VA_ARGS__);                                        \
+        }                                                                                                            \
+    } while (0)
 
 static inline int stin_launch_status() {
     hipError_t e = hipGetLastError();

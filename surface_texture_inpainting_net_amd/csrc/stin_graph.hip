@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include "stin_common.h"
 
+thread_local hipEvent_t stin_tl_stop_event = nullptr;   // (stin_common.h)
+
 namespace {
 
 constexpr int BLOCK = 256;
@@ -1258,15 +1260,15 @@ int edge_bwd_mask_pair_impl(const float* G, int64_t ldg, const uint32_t* mask, c
     const int c4 = H / 4, g = stin_group_lanes(c4), vpl = (c4 + g - 1) / g;
     const unsigned nb = grid_rows(N, g);
 #define STIN_PAIR(G_, VPL_, BASE_)                                                                                       \
-    hipLaunchKernelGGL((k_edge_bwd_mask_pair<T, G_, VPL_, STIN_U(BASE_, 1), STIN_U(BASE_, 2)>), pair_grid(nb), dim3(BLOCK), 0,  \
-                       stream, G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src,       \
-                       ld_cps, cp_dst, ld_cpd, Ccp)
+    STIN_LAUNCH_STOP((k_edge_bwd_mask_pair<T, G_, VPL_, STIN_U(BASE_, 1), STIN_U(BASE_, 2)>), pair_grid(nb), dim3(BLOCK),      \
+                     stream, G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src,       \
+                     ld_cps, cp_dst, ld_cpd, Ccp)
     if (g == 32) STIN_PAIR(32, 1, 6);                 // H = 128
     else if (vpl == 1) STIN_PAIR(64, 1, 4);           // 256
     else if (vpl == 2) {                              // 512 (tuning aid STIN_EDGE_US512: rows in flight of the gathering role)
         const char* eu = getenv("STIN_EDGE_US512");
         const int us = eu ? atoi(eu) : 0;
-#define STIN_PAIR_U(US_) hipLaunchKernelGGL((k_edge_bwd_mask_pair<T, 64, 2, 2, US_>), pair_grid(nb), dim3(BLOCK), 0, stream, G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src, ld_cps, cp_dst, ld_cpd, Ccp)
+#define STIN_PAIR_U(US_) STIN_LAUNCH_STOP((k_edge_bwd_mask_pair<T, 64, 2, 2, US_>), pair_grid(nb), dim3(BLOCK), stream, G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src, ld_cps, cp_dst, ld_cpd, Ccp)
         if (us == 1) STIN_PAIR(64, 2, 2);             // (STIN_U(2, 2) = 1 row: the round-2 choice)
         else if (us == 3) STIN_PAIR_U(3);
         else if (us == 4) STIN_PAIR_U(4);
@@ -1295,7 +1297,7 @@ int edge_bwd_mask_pair8_impl(const stin_bf16* G, int64_t ldg, const uint32_t* ma
 #define STIN_PAIR8(G_, V_, UD_, US_)                                                                                          \
     do {                                                                                                                      \
         const unsigned nb = grid_rows(N, G_);                                                                                 \
-        hipLaunchKernelGGL((k_edge_bwd_mask_pair8<G_, V_, UD_, US_>), pair_grid(nb), dim3(BLOCK), 0, stream, G, ldg, mask,     \
+        STIN_LAUNCH_STOP((k_edge_bwd_mask_pair8<G_, V_, UD_, US_>), pair_grid(nb), dim3(BLOCK), stream, G, ldg, mask,          \
                            rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src, ld_cps,        \
                            cp_dst, ld_cpd, Ccp);                                                                               \
     } while (0)

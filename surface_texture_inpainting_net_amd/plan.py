@@ -340,6 +340,8 @@ class GraphPlan:
         self._validation = validation or VALIDATION          # 'sync' | 'deferred', see validate()
         self._validated = False
         self._flag_host = None
+        self._gen = 0                      # bumped by every build that can set the out-of-range flag; _flag_gen = the one the pending copy saw
+        self._flag_gen = -1
         # vertex renumbering by locality ("optional vertex reordering, inverted at the boundary"): see _ensure_order
         self._pos_cols = positions
         self._ranks = None                 # per level: int64 [n_l + 1], old id -> new id (last entry = n_l: the out-of-range sentinel)
@@ -520,6 +522,7 @@ class GraphPlan:
             made.append(obj)
         jobs.run(self._bad, self.device)
         self._validated = False
+        self._gen += 1
         return made
 
     def ensure(self, edge_items=(), pool_levels=()):
@@ -554,6 +557,10 @@ class GraphPlan:
             s.wait_stream(main)
         with torch.cuda.stream(s):
             made = self._build_batch(todo)
+            if self._validate and self._validation == 'deferred':
+                # (round 4) the flag travels to the host from the BUILD stream: the compute stream sees neither the 4-byte copy nor
+                # an event record (10 us of its time per step); validate() only copies again if something was built lazily since
+                self._copy_flag()
         for obj in made:
             for t in obj.tensors():
                 t.record_stream(main)            # allocated on s, consumed on the compute stream: defer reuse accordingly
@@ -580,6 +587,7 @@ class GraphPlan:
         if key not in self._edges:
             self._edges[key] = EdgeSet(self._edge_tensor(key, level), self.level_sizes[level], self._bad)
             self._validated = False
+            self._gen += 1
         return self._edges[key]
 
     def edges_from_tensor(self, edge_index, n):
@@ -587,6 +595,7 @@ class GraphPlan:
         if key not in self._edges:
             self._edges[key] = EdgeSet(edge_index, n, self._bad)
             self._validated = False
+            self._gen += 1
         return self._edges[key]
 
     def pool(self, level):
@@ -596,6 +605,7 @@ class GraphPlan:
         if level not in self._pools:
             self._pools[level] = self._pool_map(level)
             self._validated = False
+            self._gen += 1
         return self._pools[level]
 
     def batch_vector(self, level):
@@ -632,16 +642,23 @@ class GraphPlan:
         if not self._validate or self._validated:
             return
         if self._validation == 'deferred':
-            if self._flag_host is None:
-                self._flag_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-                self._flag_host.copy_(self._bad, non_blocking=True)
-                self._flag_event = torch.cuda.current_stream(self.device).record_event()
-                _PENDING_CHECKS.append(self)
+            if self._flag_host is None or self._flag_gen != self._gen:
+                self._copy_flag()
             return
         if int(self._bad.item()) != 0:
             self._bad.zero_()                                  # the pool word goes back clean
             raise IndexError('edge / trace index out of range for the level sizes in sample.num_vertices')
         self._validated = True
+
+    def _copy_flag(self):
+        """Deferred validation: the flag word as it stands on the CURRENT stream -> pinned host memory, behind an event.  The flag is
+        sticky until it is checked, so a later copy (after a lazy build) supersedes an earlier one."""
+        self._flag_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self._flag_host.copy_(self._bad, non_blocking=True)
+        self._flag_event = torch.cuda.current_stream(self.device).record_event()
+        self._flag_gen = self._gen
+        if not any(p is self for p in _PENDING_CHECKS):
+            _PENDING_CHECKS.append(self)
 
     def _check_now(self, wait):
         if self._flag_host is None or self._validated:
@@ -654,8 +671,8 @@ class GraphPlan:
         if bad != 0:
             self._bad.zero_()                                  # the pool word goes back clean
             raise IndexError('edge / trace index out of range for the level sizes in sample.num_vertices '
-                             '(reported by the deferred plan validation of an earlier forward call)')
-        self._validated = True
+                             '(reported by the deferred plan validation: of an earlier forward call, or of a plan that was built ahead)')
+        self._validated = self._flag_gen == self._gen          # (a lazy build after the copy is checked by the next copy)
         return True
 
 

@@ -1147,6 +1147,51 @@ def test_deferred_plan_validation_reports_bad_indices_one_call_later():
         check_deferred(wait=True)
 
 
+def test_deferred_validation_of_a_plan_built_ahead_travels_on_the_build_stream():
+    """A plan built ahead of its step (net.build_plan = GraphPlan.prefetch(join=False)) under 'deferred' validation copies its flag
+    word to the host from the BUILD stream: forward() adds no copy of its own (same pinned word afterwards) unless something was
+    built lazily since, and a bad index is still reported - at the latest by the next check."""
+    from surface_texture_inpainting_net_amd.plan import check_deferred
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=1, n_levels=1,
+               pooling_type='max', dilations=[1])
+    torch.manual_seed(3)
+    net = S.define_G(**cfg).to(DEV)
+    net.plan_validation = 'deferred'
+    good = make_synthetic_mesh(3000, 2, seed=1, dilations=()).to(DEV)
+    bad = make_synthetic_mesh(3000, 2, seed=2, dilations=()).to(DEV)
+    bad.edge_index[1, 5] = bad.x.shape[0] + 7
+    check_deferred(wait=True)
+    with torch.no_grad():
+        plan = net.build_plan(good, inputs_ready=True)
+        good._plan_cache = plan
+        word, gen = plan._flag_host, plan._flag_gen
+        assert word is not None and gen == plan._gen
+        net(good)
+        assert plan._flag_host is word or plan._validated          # no second copy: the build stream's is the pending one
+        check_deferred(wait=True)
+        assert plan._validated
+        plan = net.build_plan(bad, inputs_ready=True)
+        bad._plan_cache = plan
+        with pytest.raises(IndexError, match='deferred'):        # by the call that uses the plan when the copy has landed by
+            out = net(bad)                                       # then (nothing faulted either way), else by the next check
+            assert bool(torch.isfinite(out).all())
+            check_deferred(wait=True)
+        check_deferred(wait=True)
+        # a structure built lazily AFTER the copy gets a copy of its own at validate()
+        plan = net.build_plan(good, inputs_ready=True)
+        torch.cuda.synchronize()
+        check_deferred(wait=True)
+        assert plan._validated
+        extra = bad.edge_index.clone()
+        plan.edges_from_tensor(extra, good.x.shape[0])            # out-of-range pair, built on the compute stream
+        assert not plan._validated and plan._flag_gen != plan._gen
+        plan.validate()
+        assert plan._flag_gen == plan._gen
+        with pytest.raises(IndexError, match='deferred'):
+            check_deferred(wait=True)
+        check_deferred(wait=True)
+
+
 def test_norm_backward_coefficients_fused_into_the_reduction_equal_the_separate_kernel():
     """STIN_POST_NORM_COEF (what the whole-block backward uses) = DOT_ELU sums followed by stin_norm_bwd_coef_f32, bit for bit."""
     n, C = 9000, 64
