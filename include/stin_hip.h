@@ -235,6 +235,12 @@ int stin_batch_pool_i64(const int64_t* batch, const int32_t* rowptr, const int32
                         int64_t* out, stin_stream_t stream);
 int stin_gather_i64(const int64_t* src, const int32_t* idx, int64_t n_out, int64_t* out,
                     stin_stream_t stream);
+/* Row ids of a batched FastInstanceNorm level in one pass (round 4; was five framework launches per level and step): gid[r] =
+ * (int32) batch[r], and - sid != NULL - sid[r] = the reference's linspace slice of row r = the number of boundaries
+ * ptr_sum[1 .. B] that are <= r (models/modules/fastinstancenorm.py:53-82 sums over torch.linspace(0, N, B + 1) slices;
+ * ptr_sum: device int32 [B + 1]).  B <= 8192. */
+int stin_norm_group_ids_i64(const int64_t* batch, const int32_t* ptr_sum, int B, int64_t n_rows, int32_t* gid, int32_t* sid,
+                            stin_stream_t stream);
 
 /* ----------------------------------------------- norm statistics and epilogues --
  * Column reductions over contiguous row ranges ptr[b]..ptr[b+1] (ptr == NULL: one

@@ -56,6 +56,7 @@ SIGNATURES = {
     'stin_pool_max_bwd_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     'stin_gather_rows_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     'stin_batch_pool_i64': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    'stin_norm_group_ids_i64': (c_int, [c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr]),
     'stin_gather_i64': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     'stin_colreduce_workspace_bytes': (c_size, [c_int, c_int]),
     'stin_colreduce_f32': (c_int, [c_int, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr,

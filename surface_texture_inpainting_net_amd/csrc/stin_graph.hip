@@ -1062,6 +1062,30 @@ __global__ void k_batch_pool(const int64_t* __restrict__ batch, const int32_t* _
     out[r] = best;
 }
 
+// Row ids of a batched instance norm in one pass: gid[r] = (int32) batch[r]; sid[r] = the number of slice boundaries
+// ptr_sum[1 .. B] that are <= r (= torch.searchsorted(ptr_sum[1:], r, right=True): the reference's linspace slice of row r,
+// fastinstancenorm.py:53-82).  B + 1 boundaries in LDS, binary search.
+__global__ __launch_bounds__(BLOCK) void k_norm_group_ids(const int64_t* __restrict__ batch, const int32_t* __restrict__ ptr_sum, int B,
+                                                         int64_t N, int32_t* __restrict__ gid, int32_t* __restrict__ sid) {
+    extern __shared__ int32_t ids_ptr[];                                          // ptr_sum[1 .. B]
+    if (sid != nullptr) {
+        for (int i = threadIdx.x; i < B; i += BLOCK) ids_ptr[i] = ptr_sum[i + 1];
+        __syncthreads();
+    }
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= N) return;
+    gid[r] = (int32_t)batch[r];
+    if (sid != nullptr) {
+        int lo = 0, hi = B;                                                       // first index with ids_ptr[i] > r
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int64_t)ids_ptr[mid] <= r) lo = mid + 1;
+            else hi = mid;
+        }
+        sid[r] = lo;
+    }
+}
+
 __global__ void k_gather_i64(const int64_t* __restrict__ src, const int32_t* __restrict__ idx, int64_t N,
                              int64_t* __restrict__ out) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1603,6 +1627,17 @@ extern "C" int stin_batch_pool_i64(const int64_t* batch, const int32_t* rowptr, 
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(batch && rowptr && col && out, STIN_E_NULL);
     hipLaunchKernelGGL(k_batch_pool, dim3(grid_elems(N)), dim3(BLOCK), 0, (hipStream_t)stream_, batch, rowptr, col, N, out);
+    return stin_launch_status();
+}
+
+extern "C" int stin_norm_group_ids_i64(const int64_t* batch, const int32_t* ptr_sum, int B, int64_t N, int32_t* gid, int32_t* sid,
+                                       stin_stream_t stream_) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N >= 0 && B > 0 && B <= 8192, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(batch && gid && (sid == nullptr || ptr_sum != nullptr), STIN_E_NULL);
+    hipLaunchKernelGGL(k_norm_group_ids, dim3(grid_elems(N)), dim3(BLOCK), (size_t)B * sizeof(int32_t), (hipStream_t)stream_, batch,
+                       ptr_sum, B, N, gid, sid);
     return stin_launch_status();
 }
 

@@ -268,16 +268,19 @@ def instance_norm_act_bwd(x, gout, mean, rstd, groups, act=True, out=None):
     else:
         # without activation dY = gout: sum dY*xc and sum dY via the same kernel with rstd = 0 -> ELU'(0)=1
         T1, S0 = colreduce(RED_DOT_ELU, x, groups, groups.ptr_true, gout=gout, mean=mean, rstd=torch.zeros_like(rstd))
-    inv_cnt = groups.inv_cnt.view(-1, 1)
     if not groups.quirk:                                            # sum_g xc = 0 when slices == graphs
         k = torch.empty_like(rstd)
         m = torch.empty_like(rstd)
         _call('stin_norm_bwd_coef_f32', _ptr(T1), _ptr(S0), _ptr(rstd), _ptr(groups.inv_cnt), rstd.shape[0], C, _ptr(k),
               _ptr(m), _stream(x))
     else:
-        k = -(rstd * rstd * rstd) * T1 * inv_cnt                   # indexed by the SUM slice (sid)
-        U = colreduce(RED_COEF_XC, x, groups, groups.ptr_true, mean=mean, coef=k, use_sid=True)
+        # k = -(rstd^3) T1 / n, indexed by the SUM slice (sid): the coefficient kernel's k (its m is overwritten below) - the same
+        # float operations as the four framework launches this replaces, as stin_edgeconv_block_bwd's slice-quirk path does
+        k = torch.empty_like(rstd)
         m = torch.empty_like(rstd)
+        _call('stin_norm_bwd_coef_f32', _ptr(T1), _ptr(S0), _ptr(rstd), _ptr(groups.inv_cnt), rstd.shape[0], C, _ptr(k),
+              _ptr(m), _stream(x))
+        U = colreduce(RED_COEF_XC, x, groups, groups.ptr_true, mean=mean, coef=k, use_sid=True)
         _call('stin_norm_bwd_coef_m_quirk_f32', _ptr(S0), _ptr(U), _ptr(rstd), _ptr(groups.inv_cnt), rstd.shape[0], C, _ptr(m),
               _stream(x))
     dx = out if out is not None else torch.empty(N, C, dtype=x.dtype, device=x.device)

@@ -287,7 +287,6 @@ class NormGroups:
             return
         B = int(counts.numel())
         self.B = B
-        self.gid = batch.to(torch.int32).contiguous()
         true_ptr = torch.zeros(B + 1, dtype=torch.int64)
         true_ptr[1:] = torch.cumsum(counts.to(torch.int64), 0)
         if linspace_quirk:
@@ -299,11 +298,22 @@ class NormGroups:
         # GPU has drained everything queued before it - once per level and step)
         ptrs = _upload(torch.stack([true_ptr, sum_ptr]).to(torch.int32), device)
         self.ptr_true, self.ptr_sum = ptrs[0], ptrs[1]
-        if self.quirk:      # slice id per row = number of slice boundaries <= row (on the device: no host-side expansion)
-            rows = torch.arange(n_rows, device=device, dtype=torch.int64)
-            self.sid = torch.searchsorted(self.ptr_sum[1:].to(torch.int64), rows, right=True).to(torch.int32)
+        if torch.device(device).type == 'cuda' and batch.dtype == torch.int64 and B <= 8192:
+            # graph id and slice id (= number of slice boundaries <= row) per row in ONE launch (stin_norm_group_ids_i64; the
+            # framework route below is five launches - cast, arange, cast, searchsorted, cast - per level and step)
+            batch = batch.contiguous()
+            self.gid = torch.empty(n_rows, dtype=torch.int32, device=device)
+            self.sid = torch.empty(n_rows, dtype=torch.int32, device=device) if self.quirk else self.gid
+            _lib.check(_lib.load().stin_norm_group_ids_i64(_ptr(batch), _ptr(self.ptr_sum), B, n_rows, _ptr(self.gid),
+                                                          _ptr(self.sid) if self.quirk else None, _stream(batch)),
+                       'stin_norm_group_ids_i64')
         else:
-            self.sid = self.gid
+            self.gid = batch.to(torch.int32).contiguous()
+            if self.quirk:      # slice id per row = number of slice boundaries <= row (on the device: no host-side expansion)
+                rows = torch.arange(n_rows, device=device, dtype=torch.int64)
+                self.sid = torch.searchsorted(self.ptr_sum[1:].to(torch.int64), rows, right=True).to(torch.int32)
+            else:
+                self.sid = self.gid
         self.inv_cnt = _upload(1.0 / counts.to(torch.float32).clamp(min=1), device)
 
 

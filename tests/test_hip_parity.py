@@ -1118,6 +1118,29 @@ def test_plan_prefetch_on_side_streams_equals_lazy_build():
             assert torch.equal(pm.trace, lazy._pools[lvl].trace) and torch.equal(pm.children.col, lazy._pools[lvl].children.col)
 
 
+@pytest.mark.parametrize('counts', [[3000, 1, 2500, 0, 1700], [5], [64] * 7, [1000, 1000, 1000, 1000], [7, 100000, 3]])
+def test_norm_group_ids_kernel_equals_the_framework_route(counts):
+    """plan.NormGroups of a batch: graph id and linspace-slice id per row from ONE launch (stin_norm_group_ids_i64) - the ids the
+    framework route (cast, arange, cast, searchsorted(right=True), cast) gives, bit for bit; uneven graphs exercise the slice quirk
+    (models/modules/fastinstancenorm.py:53-82), equal ones and B = 1 the no-quirk branch, empty graphs the repeated boundaries."""
+    from surface_texture_inpainting_net_amd.plan import NormGroups
+    dev = torch.device(DEV)
+    cnt = torch.tensor(counts, dtype=torch.int64)
+    n = int(cnt.sum())
+    batch = torch.repeat_interleave(torch.arange(len(counts)), cnt).to(dev)
+    ng = NormGroups(n, dev, batch, cnt, linspace_quirk=True)
+    assert ng.gid.dtype == torch.int32 and torch.equal(ng.gid, batch.to(torch.int32))
+    sum_ptr = torch.linspace(0, n, len(counts) + 1, dtype=torch.int).to(torch.int64)
+    true_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(cnt, 0)])
+    assert ng.quirk == bool((sum_ptr != true_ptr).any())
+    want = torch.searchsorted(sum_ptr[1:].to(dev), torch.arange(n, device=dev), right=True).to(torch.int32)
+    if ng.quirk:
+        assert ng.sid.dtype == torch.int32 and torch.equal(ng.sid, want)
+    else:
+        assert ng.sid is ng.gid and torch.equal(ng.gid, want)
+    assert torch.equal(ng.ptr_sum.cpu().long(), sum_ptr) and torch.equal(ng.ptr_true.cpu().long(), true_ptr)
+
+
 def test_deferred_plan_validation_reports_bad_indices_one_call_later():
     """plan_validation='deferred' (what TrainStep selects): no host sync in forward; an out-of-range index raises the
     reference's IndexError at the next forward / check instead of inside the call that used it."""
