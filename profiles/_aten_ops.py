@@ -17,12 +17,25 @@ from surface_texture_inpainting_net_amd.train_step import TrainStep  # noqa: E40
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--vertices', type=int, default=200_000)
+ap.add_argument('--crops', type=int, default=0)
+ap.add_argument('--levels', type=int, default=3)
+ap.add_argument('--dtype', default='f32')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 torch.manual_seed(49)
-net = S.define_G(**CONFIG_3D).to(dev)
+cfg = dict(CONFIG_3D)
+if a.levels != 3:
+    cfg['n_levels'] = a.levels - 1
+net = S.define_G(**cfg).to(dev)
+if a.dtype == 'bf16':
+    net.set_activation_dtype(torch.bfloat16)
 step = TrainStep(net, lr=7e-5, amsgrad=True)
-sample = make_synthetic_mesh(a.vertices, 3, seed=0).to(dev)
+if a.crops:
+    from surface_texture_inpainting_net_amd.data import collate  # noqa: E402
+    sizes = [12_000 + (16_000 * i) // max(a.crops - 1, 1) for i in range(a.crops)]
+    sample = collate([make_synthetic_mesh(n, a.levels, seed=i) for i, n in enumerate(sizes)]).to(dev)
+else:
+    sample = make_synthetic_mesh(a.vertices, a.levels, seed=0).to(dev)
 pending = None
 def one():
     global pending
