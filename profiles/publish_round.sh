@@ -97,5 +97,16 @@ out += ['', '## `roofline.frac`: the bench line\'s bracket against rocprofv3', '
 out += ['', 'Round 3 for comparison (r03_configs.md): config 2 6.12 ms, config 3 5.9-6.2 ms, config 5 26.4-27.0 ms (bf16), headline 7.5-7.7 ms, bf16 5.36 ms, 20 k eager 2.8-3.7 ms.',
         '', 'JSON lines: `%s_config_{c2,c3,c5_bf16,c5_f32}.json`, `%s_bench_{bf16,irregular}.json`, `%s_small_20k_{eager,graph}.json`.' % (RN, RN, RN)]
 open(P + '_configs.md', 'w').write('\n'.join(out) + '\n')
+# SingleConvMeshNet: the bench line and the kernel table of the same command
+import os
+if os.path.exists(S + '/scmn.json') and os.path.exists(S + '/prof_scmn/run_kernel_stats.csv'):
+    sc = line(S + '/scmn.json')
+    open(P + '_scmn.json', 'w').write(json.dumps(sc) + '\n')
+    open(P + '_scmn_kernel_stats.csv', 'w').write(open(S + '/prof_scmn/run_kernel_stats.csv').read())
+    head = ('# Round %s: SingleConvMeshNet (SURVEY 8f rank 3) training step, %d vertices, filters 64/128/256, 2 propagation steps, fp32, '
+            'Adam: `python profiles/scmn_bench.py` = %.2f ms per step = %.1f M vertices/s, %.2f GB peak (round 1: 22.6 ms; `%s_scmn.json`); '
+            'kernel table of the same command under `rocprofv3 --kernel-trace --stats` (13 steps incl. warm-up)\n\n' % (
+                RN[1:], sc['vertices'], sc['ms_per_step'], sc['vertices_per_s'] / 1e6, sc['peak_gb'], RN))
+    open(P + '_scmn.md', 'w').write(head + tool('summarize.py', S + '/prof_scmn/run_kernel_stats.csv', '13'))
 print(d['ms_per_step'], dd['ms_per_step'])
 PY

@@ -120,6 +120,7 @@ class _RowStatsNormFn(torch.autograd.Function):
         ctx.groups, ctx.bn2 = groups, bn2
         m1, r1 = mean.view(-1), rstd.view(-1)
         ctx.mark_non_differentiable(m1, r1)
+        ctx.set_materialize_grads(False)          # (no zero tensors for the statistics outputs' gradients: two fill launches per call)
         return y, m1, r1
 
     @staticmethod
@@ -148,6 +149,7 @@ class _BatchNormActFn(torch.autograd.Function):
         ctx.groups, ctx.relu, ctx.bn2 = groups, relu, bn2
         m1, r1 = mean.view(-1), rstd.view(-1)
         ctx.mark_non_differentiable(m1, r1)
+        ctx.set_materialize_grads(False)          # (no zero tensors for the statistics outputs' gradients: two fill launches per call)
         return y, m1, r1
 
     @staticmethod
@@ -189,6 +191,7 @@ class _BatchNormMeanFn(torch.autograd.Function):
         ctx.ei, ctx.groups_n, ctx.bn2 = ei, groups_n, bn2
         m1, r1 = mean.view(-1), rstd.view(-1)
         ctx.mark_non_differentiable(m1, r1)
+        ctx.set_materialize_grads(False)          # (no zero tensors for the statistics outputs' gradients: two fill launches per call)
         return out, m1, r1
 
     @staticmethod
