@@ -2616,7 +2616,10 @@ inline int panel_tiles(int64_t M, int Nc, int K) {
         const int64_t slots = cu * rounds / P;
         if (slots < 1) continue;
         const int64_t mts = (rg + slots - 1) / slots;
-        if (mts <= 9) return mts < 2 ? (forced == 1 ? 2 : 0) : (int)mts;
+        // (fewer row groups than slots - the coarse levels of a small crop, 1 806 x 256 x 1024: the finest blocks, 64 rows; the
+        // all-columns kernel ran that shape on 15 workgroups, 41.8 us; STIN_NT_PANEL_SMALL=0 keeps it there)
+        static const bool small_on = !(getenv("STIN_NT_PANEL_SMALL") && atoi(getenv("STIN_NT_PANEL_SMALL")) == 0);
+        if (mts <= 9) return mts < 2 ? ((forced == 1 || small_on) ? 2 : 0) : (int)mts;
     }
     return 0;
 }
