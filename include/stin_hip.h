@@ -739,14 +739,15 @@ int stin_dilated_walk_f64(const int32_t* rowptr, const int32_t* col, const int32
  * state: 5 x int64 DEVICE words written by the call - state[3] != 0: unsupported input (a non-finite coordinate or more
  * than 2^21 bins along an axis), state[4] = Nc.  Stable radix sort of one 63-bit key per vertex + scan: deterministic.
  * stin_coalesce_pairs_i64 = pyg.utils.coalesce on (a[e], b[e]) pairs (graph_level_generation.py:236-241 on the coarse edges,
- * graph_dilation.py:53-56): optionally mapped through map[] first (the trace), self loops dropped when drop_loops, sorted by
+ * graph_dilation.py:53-56): optionally mapped through map[map_n] first (the trace), self loops dropped when drop_loops, sorted by
  * (a, b), duplicates removed; values in [0, n); out_a / out_b [E] int64 (the first state[4] entries are written);
- * state[3] != 0: an index was outside [0, n). */
+ * state[3] != 0: an index was outside [0, n), or - with a map - a raw endpoint outside [0, map_n) (checked BEFORE map[] is read:
+ * the torch formulation trace[edge_index[0]] this replaces raises there). */
 size_t stin_voxel_cluster_workspace_bytes(int64_t N);
 int stin_voxel_cluster_f64(const double* coords, int64_t N, double voxel, int64_t* trace, float* new_coords, int64_t* state,
                            void* workspace, size_t workspace_bytes, stin_stream_t stream);
 size_t stin_coalesce_workspace_bytes(int64_t E);
-int stin_coalesce_pairs_i64(const int64_t* a, const int64_t* b, const int64_t* map, int64_t E, int64_t n, int drop_loops,
+int stin_coalesce_pairs_i64(const int64_t* a, const int64_t* b, const int64_t* map, int64_t map_n, int64_t E, int64_t n, int drop_loops,
                             int64_t* out_a, int64_t* out_b, int64_t* state, void* workspace, size_t workspace_bytes,
                             stin_stream_t stream);
 

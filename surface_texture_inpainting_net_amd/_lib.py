@@ -79,7 +79,7 @@ SIGNATURES = {
     'stin_voxel_cluster_workspace_bytes': (c_size, [c_i64]),
     'stin_voxel_cluster_f64': (c_int, [c_ptr, c_i64, c_f64, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'stin_coalesce_workspace_bytes': (c_size, [c_i64]),
-    'stin_coalesce_pairs_i64': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    'stin_coalesce_pairs_i64': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     'stin_gemm_nt_dotelu_groups': (c_i64, [c_i64, c_int, c_int, c_int]),
     'stin_gemm_nt_dotelu_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_int,
                                         c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),

@@ -105,12 +105,20 @@ __global__ __launch_bounds__(T) void k_cluster_out(const double* __restrict__ co
 }
 
 __global__ __launch_bounds__(T) void k_pair_keys(const int64_t* __restrict__ a, const int64_t* __restrict__ b,
-                                                 const int64_t* __restrict__ map, int64_t E, int64_t n, int drop_loops,
+                                                 const int64_t* __restrict__ map, int64_t map_n, int64_t E, int64_t n, int drop_loops,
                                                  u64* __restrict__ keys, long long* __restrict__ state) {
     const int64_t e = (int64_t)blockIdx.x * T + threadIdx.x;
     if (e >= E) return;
     int64_t x = a[e], y = b[e];
-    if (map != nullptr) { x = map[x]; y = map[y]; }
+    if (map != nullptr) {
+        if (x < 0 || y < 0 || x >= map_n || y >= map_n) {     // the raw endpoints index map[]: checked before they do
+            atomicOr(reinterpret_cast<u64*>(state + 3), 1ull);
+            keys[e] = KEY_DROP;
+            return;
+        }
+        x = map[x];
+        y = map[y];
+    }
     if (x < 0 || y < 0 || x >= n || y >= n) {
         atomicOr(reinterpret_cast<u64*>(state + 3), 1ull);
         keys[e] = KEY_DROP;
@@ -217,13 +225,14 @@ extern "C" size_t stin_coalesce_workspace_bytes(int64_t E) { return E < 0 ? 0 : 
 // Unique (a, b) pairs sorted by (a, b): a / b [E] int64, optionally mapped through map[] first (the coarse ids of the two
 // endpoints), pairs with a == b left out when drop_loops; values must lie in [0, n), n < 2^31.  out_a / out_b [>= count] int64
 // (E entries suffice); state as above: [3] != 0 an index was out of range, [4] = count.
-extern "C" int stin_coalesce_pairs_i64(const int64_t* a, const int64_t* b, const int64_t* map, int64_t E, int64_t n, int drop_loops,
+extern "C" int stin_coalesce_pairs_i64(const int64_t* a, const int64_t* b, const int64_t* map, int64_t map_n, int64_t E, int64_t n, int drop_loops,
                                        int64_t* out_a, int64_t* out_b, int64_t* state, void* workspace, size_t workspace_bytes,
                                        stin_stream_t stream_) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(E >= 0 && E < ((int64_t)1 << 31) && n >= 0 && n < ((int64_t)1 << 31), STIN_E_SIZE);
     STIN_REQUIRE(state != nullptr, STIN_E_NULL);
+    STIN_REQUIRE(map == nullptr || map_n >= 0, STIN_E_SIZE);
     long long* st = reinterpret_cast<long long*>(state);
     hipError_t e = hipMemsetAsync(st, 0, 5 * sizeof(long long), stream);
     if (e != hipSuccess) return (int)e;
@@ -234,7 +243,7 @@ extern "C" int stin_coalesce_pairs_i64(const int64_t* a, const int64_t* b, const
     char* w = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     u64 *k0 = reinterpret_cast<u64*>(w + L.keys0), *k1 = reinterpret_cast<u64*>(w + L.keys1);
     int32_t *head = reinterpret_cast<int32_t*>(w + L.head), *scan = reinterpret_cast<int32_t*>(w + L.scan);
-    hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(E)), dim3(T), 0, stream, a, b, map, E, n, drop_loops, k0, st);
+    hipLaunchKernelGGL(k_pair_keys, dim3(grid_for(E)), dim3(T), 0, stream, a, b, map, map_n, E, n, drop_loops, k0, st);
     size_t tb = sort_temp_bytes(E, false);
     e = rocprim::radix_sort_keys(w + L.temp, tb, k0, k1, (size_t)E, 0, 64, stream);
     if (e != hipSuccess) return (int)e;

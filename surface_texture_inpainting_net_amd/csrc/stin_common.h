@@ -51,6 +51,20 @@ __host__ __device__ static inline bool stin_w_frag_shape(int Nc, int K) {
     return Nc % 32 == 0 && K >= 128 && K <= 256 && Nc >= 320;
 }
 
+// Ticket words of the one-launch reductions (stin_norm.hip k_colreduce_t, stin_tail.hip k_linear_tanh_bwd) live in a global
+// array of `slots` rows and every launch takes the next row, so launches in flight never share a word.  A launch that is being
+// CAPTURED into a hipGraph bakes its row into the graph and will run at every replay - possibly beside eager launches whose
+// rotating counter has come round to the same row.  Captured launches therefore rotate through the upper half of the rows and
+// eager launches through the lower half: the two populations never meet.
+#include <atomic>
+static inline int stin_ticket_slot(std::atomic<unsigned>& seq_eager, std::atomic<unsigned>& seq_captured, int slots, hipStream_t stream) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    const unsigned half = (unsigned)slots / 2;
+    if (capturing) return (int)(half + seq_captured.fetch_add(1, std::memory_order_relaxed) % half);
+    return (int)(seq_eager.fetch_add(1, std::memory_order_relaxed) % half);
+}
+
 static inline bool stin_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Lanes that cooperate on one feature row: smallest power of two >= ceil(C/4), capped at a wave.

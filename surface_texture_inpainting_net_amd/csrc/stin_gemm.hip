@@ -2435,6 +2435,10 @@ inline int tn_skinny_rows(int64_t M) {                                         /
     static const int want = getenv("STIN_TN_SKINNY_CHUNKS") ? atoi(getenv("STIN_TN_SKINNY_CHUNKS")) : 1024;   // tuning aid (read once); 256 / 512 / 1024 / 2048 chunks: 106 / 75 / 72 / 79 us at 200 704 x 320 x 12
     int64_t rows = (M + want - 1) / want;
     rows = (rows + 31) / 32 * 32;
+    // the chunk's [X | w] image is rows x (KP + 4 <= 20) floats of dynamic LDS: capped at 512 rows = 40 KB (below the 64 KB a
+    // launch gets without hipFuncSetAttribute) - beyond ~0.5 M rows the chunk COUNT grows instead of the chunk
+    // (stin_gemm_tn_workspace_bytes sizes the slab from the same function)
+    if (rows > 512) rows = 512;
     return (int)(rows < 128 ? 128 : rows);
 }
 

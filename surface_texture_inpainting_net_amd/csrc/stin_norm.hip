@@ -194,7 +194,8 @@ __global__ __launch_bounds__(BLOCK) void k_colreduce(const T* __restrict__ x, in
 // the last arriver reads the partials with `sc1` loads only (MI355X_MICROARCH.md "Valid forms", row: one lane of each storing
 // workgroup adds to ONE counter / the workgroup whose add came last loads after its add returned, the other waves after a barrier).
 // The ticket words live in a zero-initialised __device__ array of the code object; the folding block resets its word, and every
-// launch takes the next of RED_SLOTS slot rows, so launches in flight on different streams never share a word.
+// launch takes the next slot row of its population (eager launches the lower RED_SLOTS / 2 rows, launches captured into a
+// hipGraph the upper half: stin_ticket_slot), so launches in flight on different streams never share a word.
 constexpr int RED_SLOTS = 256, RED_WORDS = 512;
 __device__ unsigned int g_red_tickets[RED_SLOTS][RED_WORDS];
 
@@ -715,8 +716,8 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
         const int GC = C >= 256 ? 64 : (C >= 128 ? 32 : 16);
         const int ncg = (C + GC - 1) / GC;
         if ((int64_t)B * ncg <= RED_WORDS) {
-            static std::atomic<unsigned> seq{0};
-            const int slot = (int)(seq.fetch_add(1, std::memory_order_relaxed) % RED_SLOTS);
+            static std::atomic<unsigned> seq{0}, seq_cap{0};
+            const int slot = stin_ticket_slot(seq, seq_cap, RED_SLOTS, stream);
             const int RLN = BLOCK / (GC / 4);
             // row chunks: ~8 row trips per block, at most ~2 blocks per CU over all column groups and ranges, and within the workspace
             int64_t R = (N / B + (int64_t)RLN * 8 - 1) / ((int64_t)RLN * 8);

@@ -309,8 +309,8 @@ int linear_tanh_bwd_impl(const float* g, const float* y, const T* x, int64_t ldx
     }
     float* partial = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     const int64_t blocks = tail_bwd_blocks(N);
-    static std::atomic<unsigned> seq{0};
-    const int slot = (int)(seq.fetch_add(1, std::memory_order_relaxed) % TL_SLOTS);
+    static std::atomic<unsigned> seq{0}, seq_cap{0};
+    const int slot = stin_ticket_slot(seq, seq_cap, TL_SLOTS, stream);
     const size_t lds = (size_t)(TL_BWD_BLOCK / 64) * O * sizeof(float);
     const int CH = K <= 64 ? 1 : (K <= 128 ? 2 : 4);
 #define STIN_TL_B(NC_, CH_)                                                                                                          \

@@ -475,15 +475,19 @@ def gemm_tn_wb(G, X, dW, db, precision=GEMM_F32):
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b on the MFMA kernels (the tail Linears and the generic filter paths).  wT: the weight already
     transposed ([K, Nc] fp32, written by the network's PackSet beside the block operands) - without it the backward
-    transposes the weight itself.  Gradients of weight / bias go straight into an accepting TrainStep bucket."""
+    transposes the weight itself.  wT points into a buffer that every PackSet.run() rewrites and is NOT under autograd's version
+    tracking, so wT_guard = (pack set, its run count at this forward) is compared again in backward: after another pack run
+    (a second forward following an in-place weight change) the backward transposes the SAVED, version-checked weight instead.
+    Gradients of weight / bias go straight into an accepting TrainStep bucket."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, out_fp32=False, precision=None, wT=None):
+    def forward(ctx, x, weight, bias, out_fp32=False, precision=None, wT=None, wT_guard=None):
         x, _ = _mat(x)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
         ctx.wT = wT
+        ctx.wT_guard = wT_guard
         return gemm_nt(x, weight, bias, precision=PREC_FWD if precision is None else precision,
                        out_dtype=torch.float32 if out_fp32 else None)
 
@@ -493,21 +497,22 @@ class LinearFn(torch.autograd.Function):
         if g.dtype != x.dtype:                     # fp32 network output on bf16-storage activations
             g = g.to(x.dtype)
         g, _ = _mat(g)
-        wT = ctx.wT if ctx.wT is not None else weight.t().contiguous()
+        fresh = ctx.wT is not None and (ctx.wT_guard is None or getattr(ctx.wT_guard[0], 'runs', None) == ctx.wT_guard[1])
+        wT = ctx.wT if fresh else weight.t().contiguous()
         dx = gemm_nt(g, wT, precision=PREC_BWD) if ctx.needs_input_grad[0] else None
         if not ctx.has_bias:
-            return dx, gemm_tn(g, x, ones_column=False, precision=PREC_BWD), None, None, None, None
+            return dx, gemm_tn(g, x, ones_column=False, precision=PREC_BWD), None, None, None, None, None
         direct = _direct_grad_views(ctx.params) if g.is_cuda else None
         if direct is not None:                     # written where the optimizer reads them: nothing for autograd to copy
             gemm_tn_wb(g, x, direct[0], direct[1], precision=PREC_BWD)
-            return dx, None, None, None, None, None
+            return dx, None, None, None, None, None, None
         if g.is_cuda:
             dW = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
             db = torch.empty(weight.shape[0], dtype=torch.float32, device=g.device)
             gemm_tn_wb(g, x, dW, db, precision=PREC_BWD)
-            return dx, dW, db, None, None, None
+            return dx, dW, db, None, None, None, None
         dwb = gemm_tn(g, x, ones_column=True, precision=PREC_BWD)
-        return dx, dwb[:, :-1].contiguous(), dwb[:, -1].contiguous(), None, None, None
+        return dx, dwb[:, :-1].contiguous(), dwb[:, -1].contiguous(), None, None, None, None
 
 
 def linear_tanh_eligible(x, weight, bias):
@@ -572,10 +577,10 @@ def linear_tanh(x, weight, bias=None, precision=None):
     return torch.tanh(linear(x, weight, bias, out_fp32=True, precision=precision))
 
 
-def linear(x, weight, bias=None, out_fp32=False, precision=None, wT=None):
+def linear(x, weight, bias=None, out_fp32=False, precision=None, wT=None, wT_guard=None):
     """x W^T + b.  out_fp32: fp32 result from bf16-storage activations (the network's final output).
-    precision: forward matrix-core path (None = PREC_FWD); see forward_precision().  wT: see LinearFn."""
-    return LinearFn.apply(x, weight, bias, out_fp32, precision, wT)
+    precision: forward matrix-core path (None = PREC_FWD); see forward_precision().  wT / wT_guard: see LinearFn."""
+    return LinearFn.apply(x, weight, bias, out_fp32, precision, wT, wT_guard)
 
 
 def forward_precision(unbounded_input):
@@ -803,6 +808,7 @@ class PackSet:
         return self.key == self.key_of(specs) + (bool(b16),) + tuple((_ptr(W), tuple(W.shape)) for W in transposes)
 
     def run(self):
+        self.runs = getattr(self, 'runs', 0) + 1       # what a consumer of `transposed` compares (LinearFn's wT guard)
         _call('stin_edgeconv_pack_many_f32', _ptr(self.jobs), self.n, self.max_elems, _stream(self.jobs))
 
 

@@ -77,20 +77,31 @@ _FLAG_POOLS = {}
 
 
 def _flag_word(device):
-    """-> a [1] int32 view of the device's zero-initialised flag pool (round-robin)."""
+    """-> a [1] int32 out-of-range flag for one plan.
+
+    Eager plans take a word of the device's zero-initialised pool (round-robin: no fill kernel per plan).  A plan built
+    while a HIP graph is being captured gets a tensor of its own inside the capture instead: the allocation belongs to the
+    graph's private pool and its zero fill is a memset node, so EVERY replay starts from a clean flag (a pool word would keep
+    the 1 of a bad sample for all later replays, and its address - baked into the graph - would come round again for an eager
+    plan FLAG_POOL plans later)."""
+    if _capturing():
+        return torch.zeros(1, dtype=torch.int32, device=device)
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     ent = _FLAG_POOLS.get(key)
     if ent is None:
-        if _capturing():
-            raise RuntimeError('the first plan of a device must be built outside a HIP-graph capture (flag pool allocation)')
         pool = torch.zeros(FLAG_POOL, dtype=torch.int32, device=device)
         torch.cuda.current_stream(device).synchronize()        # side streams may use a word before the creating stream is joined
         ent = _FLAG_POOLS[key] = [pool, 0]
     ent[1] = (ent[1] + 1) % FLAG_POOL
-    if ent[1] == 0 and not _capturing():
-        # once per FLAG_POOL plans: words dirtied by plans that were never validated (validate=False) come back clean; every
-        # plan old enough to share a word with a new one has long reported
-        ent[0].zero_()
+    half = FLAG_POOL // 2
+    if ent[1] % half == 0:
+        # entering a half of the pool: its words were handed out FLAG_POOL/2 .. FLAG_POOL plans ago, so whatever plan dirtied
+        # one without ever validating (validate=False) has long been dropped.  Builds on the side streams may still be running
+        # for RECENT plans (the other half), so the fill is fenced on both sides by a device-wide wait - once per FLAG_POOL/2
+        # plans - instead of racing them on the current stream.
+        torch.cuda.synchronize(device)
+        ent[0][ent[1]:ent[1] + half].zero_()
+        torch.cuda.current_stream(device).synchronize()
     return ent[0][ent[1]:ent[1] + 1]
 
 

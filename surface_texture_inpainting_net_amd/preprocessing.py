@@ -35,11 +35,12 @@ def coalesce(edge_index, num_nodes, vertex_map=None, drop_loops=False):
     ws_bytes = lib.stin_coalesce_workspace_bytes(E)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     vm = vertex_map.contiguous() if vertex_map is not None else None
-    _lib.check(lib.stin_coalesce_pairs_i64(_ptr(ei[0]), _ptr(ei[1]), _ptr(vm), E, int(num_nodes), int(bool(drop_loops)), _ptr(out[0]),
+    _lib.check(lib.stin_coalesce_pairs_i64(_ptr(ei[0]), _ptr(ei[1]), _ptr(vm), (int(vm.numel()) if vm is not None else 0), E, int(num_nodes), int(bool(drop_loops)), _ptr(out[0]),
                                            _ptr(out[1]), _ptr(state), _ptr(ws), ws_bytes, _stream(ei)), 'stin_coalesce_pairs_i64')
     st = state.cpu()
     if int(st[3]) != 0:
-        raise IndexError('coalesce: an endpoint lies outside [0, %d)' % num_nodes)
+        raise IndexError('coalesce: an endpoint lies outside [0, %d)%s' % (
+            num_nodes, '' if vm is None else ' or a raw endpoint outside the vertex map [0, %d)' % vm.numel()))
     return out[:, :int(st[4])]
 
 

@@ -379,8 +379,10 @@ class SurfaceTextureInpaintingNet(nn.Module):
         else:
             out = self._forward_per_block(out, plan, e0, bn_edges, num_levels)
         tail_prec = SF.forward_precision(not self.using_norm)
+        packed_tail = self._pack_key is not None and self._pack_key[0] and self._tail_wT is not None
         out = SF.linear(out, self.final_linear1.weight, self.final_linear1.bias, precision=tail_prec,
-                        wT=self._tail_wT if self._pack_key is not None and self._pack_key[0] else None)
+                        wT=self._tail_wT if packed_tail else None,
+                        wT_guard=(self._pack_set, self._pack_set.runs) if packed_tail else None)
         if self.norm is M.FastInstanceNorm:                         # per-graph branch even for B = 1 (:465, Q3)
             out = SF.InstanceNormActResFn.apply(out, None, plan.norm_groups(0), True, self.final_norm1.eps)
         else:

@@ -422,8 +422,9 @@ class _CapturedStep:
             self.loss = owner.forward_backward(static, grad_scale)
             self.bad = plan._bad
         self.keep = getattr(model, '_pack_set', None)   # the graph holds raw pointers into the model's packed-operand buffers
-        # index validation: the plan's out-of-range flag is re-zeroed by every replay, so replays add it into a running
-        # total; the total travels to pinned host memory whenever the previous copy has landed (the host never waits)
+        # index validation: the plan's flag lives inside the capture (plan._flag_word: a memset node re-zeroes it at the start
+        # of every replay), so replays add it into a running total; the total travels to pinned host memory whenever the
+        # previous copy has landed (the host never waits)
         self.bad_total = torch.zeros(1, dtype=torch.int32, device=dev)
         self.flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.flag_event = None

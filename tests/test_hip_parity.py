@@ -244,6 +244,23 @@ def test_gemm_nt_and_tn_against_fp64(M, Nc, K):
         assert torch.equal(got_p, SF.gemm_tn(G.to(DEV), A.to(DEV), ones_column=True, precision=prec).cpu().double())
 
 
+@pytest.mark.parametrize('M', [600_000, 1_300_000, 2_800_000])
+def test_skinny_weight_gradient_product_on_long_matrices(M):
+    """k_gemm_tn_skinny (K <= 16: the first block's weight gradient) stages a chunk's X rows in dynamic LDS.  The chunk is
+    capped at 512 rows, so meshes beyond ~1 M vertices get MORE chunks, not a launch that asks for more than 64 KB (which
+    failed the whole backward before the cap).  Exact fp32 products: compared against fp64 sums."""
+    lib = _lib_load()
+    Nc, K = 64, 12
+    assert lib.stin_gemm_tn_workspace_bytes(M, Nc, K, 1) >= ((M + 511) // 512) * Nc * K * 4
+    g = torch.Generator(device=DEV).manual_seed(M % 1000)
+    G = torch.randn(M, Nc, generator=g, device=DEV)
+    X = torch.randn(M, K, generator=g, device=DEV)
+    got = SF.gemm_tn(G, X, ones_column=True, precision=SF.PREC_BWD).double()
+    want = torch.cat([G.double().t() @ X.double(), G.double().sum(0)[:, None]], 1)
+    assert float((got - want).abs().max()) <= 1e-6 * (M ** 0.5) * 8
+    assert torch.equal(got, SF.gemm_tn(G, X, ones_column=True, precision=SF.PREC_BWD).double())
+
+
 @pytest.mark.parametrize('M,Nc,K', [(4097, 320, 64), (2500, 256, 260), (513, 256, 1280), (1000, 128, 10)])
 def test_gemm_nt_precision_modes(M, Nc, K):
     """fp32 MFMA chain vs the split-bf16 paths (fp32 accumulate): error against fp64, relative to the
@@ -681,6 +698,13 @@ def test_linear_backward_separate_weight_and_bias_gradients_and_pretransposed_we
     a = torch.autograd.grad((SF.linear(xs, lin.weight, lin.bias) * w).sum(), [xs, lin.weight, lin.bias])
     b = torch.autograd.grad((SF.linear(xs, lin.weight, lin.bias, wT=ps.transposed[0]) * w).sum(), [xs, lin.weight, lin.bias])
     assert all(torch.equal(p, q) for p, q in zip(a, b))
+    # the pack buffer is rewritten by every run and is not version-tracked: a backward that follows a LATER run must not read
+    # it (wT_guard) - poisoned here to make a stale read visible
+    y = SF.linear(xs, lin.weight, lin.bias, wT=ps.transposed[0], wT_guard=(ps, ps.runs))
+    ps.run()
+    ps.transposed[0].fill_(float('nan'))
+    c = torch.autograd.grad((y * w).sum(), [xs, lin.weight, lin.bias])
+    assert all(torch.equal(p, q) for p, q in zip(a, c))
 
 
 # --------------------------------------------------------- segment sum / pool / unpool

@@ -177,6 +177,14 @@ def test_coalesce_and_vertex_clustering_kernels_edge_cases():
         assert np.array_equal(got[0] * n + got[1], want) and got.shape[1] == want.size
     with pytest.raises(IndexError):
         P.coalesce(torch.tensor([[0, 7], [1, 2]], device=DEV), 5)
+    # with a vertex map the RAW endpoints index the map: outside [0, len(map)) raises before map[] is read (far out of
+    # bounds on purpose: an unchecked read would fault or pick up garbage), inside it the mapped pair is what is coalesced
+    vm = torch.tensor([2, 0, 1, 1], device=DEV)
+    got = P.coalesce(torch.tensor([[0, 3, 2], [1, 0, 0]], device=DEV), 3, vertex_map=vm).cpu().numpy()
+    assert np.array_equal(got, np.array([[1, 2], [2, 0]]))
+    for bad in (4, -1, 1 << 40):
+        with pytest.raises(IndexError):
+            P.coalesce(torch.tensor([[0, bad], [1, 2]], device=DEV), 3, vertex_map=vm)
     for c, v in ((np.array([[0.3, -0.2, 5.0]]), 0.5),
                  (rng.uniform(-50, 50, (3000, 3)), 1.0),
                  (np.round(rng.uniform(-4, 4, (2000, 3)) * 4) / 4, 0.25),          # coordinates exactly on voxel boundaries

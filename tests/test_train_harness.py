@@ -526,6 +526,41 @@ def test_captured_step_reports_out_of_range_indices():
     step(bad)                                           # replay on the bad indices: the kernels leave the pair out
     with pytest.raises(IndexError):
         step.finish()
+    # ... and the flag does not stick: the captured plan's flag is re-zeroed by every replay, so good samples after the bad
+    # one report nothing (a pool word that kept its 1 would raise here for ever)
+    for _ in range(3):
+        step(good)
+    step.finish()
+    with pytest.raises(IndexError):                     # (reported by the next call whose flag copy has landed, finish() at the latest)
+        step(bad)
+        step(good)
+        step.finish()
+    step(good)
+    step.finish()
+
+
+@pytest.mark.gpu
+def test_flag_pool_wraps_without_losing_or_inventing_reports(monkeypatch):
+    """The eager plans' out-of-range flags are words of a round-robin pool: a word dirtied by a plan that never validated comes
+    back clean when its half of the pool is entered again, and a plan built inside a capture does not take a pool word."""
+    from surface_texture_inpainting_net_amd import plan as P
+    monkeypatch.setattr(P, 'FLAG_POOL', 8)
+    P._FLAG_POOLS.clear()
+    dev = torch.device('cuda:0')
+    words = [P._flag_word(dev) for _ in range(3)]
+    words[1].fill_(1)                                    # a plan that saw a bad index and was dropped without validating
+    seen = {w.data_ptr() for w in words}
+    for _ in range(8):
+        w = P._flag_word(dev)
+        assert int(w.item()) == 0, 'a recycled word must be clean'
+        seen.add(w.data_ptr())
+    assert len(seen) == 8
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        inside = P._flag_word(dev)
+    pool = P._FLAG_POOLS[dev.index][0]
+    assert not (pool.data_ptr() <= inside.data_ptr() < pool.data_ptr() + 4 * 8)
+    P._FLAG_POOLS.clear()
 
 
 def test_graph_mode_guards_and_sample_signature():
