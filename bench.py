@@ -95,10 +95,11 @@ def pmc_traffic_bytes(kernel, n, e, h):
 
 
 def measure_fabric_traffic(kernel_prefix='k_edge_fwd_exact<float, 32, 1, 6>'):
-    """LIVE `roofline.traffic` (round 4): two child processes - `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (they do not fit
-    one TCC pass) with `--kernel-trace` only - over profiles/pmc_kernels.py restricted to the level-0 forward edge kernel of the
-    headline mesh; bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB per the gfx950 corrections of MI355X_MICROARCH.md.  Children, not an
-    exec: this process keeps its GPU context.  -> (bytes per launch, note) or (None, reason)."""
+    """LIVE fabric traffic of the level-0 forward edge kernel (round 4: `roofline.traffic`; round 5: also `hbm_honest.traffic`): two
+    child processes - `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (they do not fit one TCC pass) with `--kernel-trace` only -
+    over profiles/pmc_kernels.py in PMC_LIVE mode: 5 launches on the headline mesh, then 4 at the 1 M-vertex / 6 M-edge size, told
+    apart by launch order; bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB per the gfx950 corrections of MI355X_MICROARCH.md.  Children,
+    not an exec: this process keeps its GPU context.  -> ({'headline': bytes per launch, 'n1m': bytes per launch}, note) or (None, reason)."""
     import csv
     import glob
     import re
@@ -111,10 +112,10 @@ def measure_fabric_traffic(kernel_prefix='k_edge_fwd_exact<float, 32, 1, 6>'):
     try:
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             d = os.path.join(tmp, counter)
-            env = dict(os.environ, TMPDIR='/tmp', PMC_ONLY_FWD='1')
+            env = dict(os.environ, TMPDIR='/tmp', PMC_LIVE='1')
             r = subprocess.run(['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'run', '--',
                                 sys.executable, os.path.join(ROOT, 'profiles', 'pmc_kernels.py')], cwd='/tmp', env=env,
-                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
             files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
             if r.returncode != 0 or not files:
                 return None, 'rocprofv3 --pmc %s pass failed (rc %d)' % (counter, r.returncode)
@@ -124,15 +125,20 @@ def measure_fabric_traffic(kernel_prefix='k_edge_fwd_exact<float, 32, 1, 6>'):
                     continue
                 name = re.sub(r'\(anonymous namespace\)::|^void ', '', row['Kernel_Name'])
                 if name.startswith(kernel_prefix):
-                    acc.append(float(row['Counter_Value']))
-            if not acc:
-                return None, 'kernel %s not in the %s pass' % (kernel_prefix, counter)
-            vals[counter] = sum(acc[-3:]) / len(acc[-3:])
+                    acc.append((int(row.get('Dispatch_Id', len(acc))), float(row['Counter_Value'])))
+            acc = [v for _, v in sorted(acc)]
+            if len(acc) < 6:
+                return None, 'expected 5 + 4 launches of %s in the %s pass, found %d' % (kernel_prefix, counter, len(acc))
+            thr = (min(acc) * max(acc)) ** 0.5                               # the 1 M-vertex launches move ~5x the bytes
+            small, large = [v for v in acc if v < thr], [v for v in acc if v >= thr]
+            if len(small) < 3 or len(large) < 3:
+                return None, 'could not separate the two sizes in the %s pass (%d / %d launches)' % (counter, len(small), len(large))
+            vals[counter] = (sum(small[-3:]) / 3.0, sum(large[-3:]) / 3.0)   # mean of the last 3 launches at each size
     except Exception as exc:                                # noqa: BLE001 - a secondary leg must not lose the line
         return None, '%s: %s' % (type(exc).__name__, exc)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, 'measured in this run'
+    return {k: (2.0 * vals['FETCH_SIZE'][i] + vals['WRITE_SIZE'][i]) * 1024.0 for i, k in enumerate(('headline', 'n1m'))}, 'measured in this run'
 
 
 def scatter_add_standalone(device, n=200_000, e=1_200_000, c=64, iters=30):
@@ -158,13 +164,15 @@ def scatter_add_standalone(device, n=200_000, e=1_200_000, c=64, iters=30):
             'GBps': nbytes / dt / 1e9, 'frac_of_hbm_peak': nbytes / dt / 1e9 / HBM_PEAK_GBS}
 
 
-def cpu_baseline(n0_target, levels, seed):
-    """The CPU oracle (op-for-op unfused PyG form) timed on this box's host cores on a BOUNDED sample, SURVEY 8(d) protocol:
-    one warm-up pass AT SIZE, then the median of 3 timed passes.  `value` uses the thread count a short probe over
-    {8, 16, 32, 64} found fastest (torch's CPU index / scatter ops slow down badly when oversubscribed across a
-    256-thread host) - reported as `cores`; `all_cores` is the same protocol with torch.set_num_threads(os.cpu_count())
-    (warm-up + median of up to 3, cut short when a pass exceeds its budget).  The sample is sized so that one pass takes
-    ~5 s at the probe-best thread count: the whole leg stays within about a minute."""
+def cpu_baseline(n0_target, levels, seed, headline_mesh=True):
+    """The CPU oracle (op-for-op unfused PyG form) timed on this box's host cores, SURVEY 8(d) protocol: one warm-up pass AT
+    SIZE, then the median of 3 timed passes.  Round 5: `value` is measured IN THIS RUN on the SAME synthetic mesh the GPU step
+    ran on (200 704 vertices: warm-up + 3 passes of ~20 s each at the probe-best thread count, ~85 s in all - the bounded sample
+    of the contract is three passes of the headline workload itself); the ~40 k-vertex sample of rounds 1-4 (one pass ~4 s)
+    rides along as `quick_sample` and is all that runs with --quick-cpu-baseline.  The thread count is what a short probe over
+    {8, 16, 32, 64} found fastest (torch's CPU index / scatter ops slow down badly when oversubscribed across a 256-thread
+    host) - reported as `cores`; `all_cores` is the same protocol with torch.set_num_threads(os.cpu_count()) (warm-up + median
+    of up to 3, cut short when a pass exceeds its budget)."""
     import statistics
     from oracle import stin_oracle
     from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
@@ -229,22 +237,74 @@ def cpu_baseline(n0_target, levels, seed):
             out['all_cores'] = {'cores': ncpu, 'skipped': 'thread probe: %d threads already run at %.2f of the %d-thread rate on the '
                                 '10 k-vertex probe mesh; %d threads would only thrash the intra-op pool (round 3: 75.8 vertices/s '
                                 'from one 132 s pass)' % (th_max, probe_log[th_max] / probe_log[best_threads], best_threads, ncpu)}
-    import glob
-    committed = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_cpu_baseline_200k.json')))
-    if committed:                       # the same oracle on the HEADLINE mesh (profiles/cpu_baseline_200k.py: ~85 s, not part of the default run)
-        try:
-            c = json.load(open(committed[-1]))
-            out['headline_mesh_committed'] = {k: c.get(k) for k in ('value', 'unit', 'cores', 'cpu_model', 'sample_vertices', 'passes_s', 'warmup_s')}
-            out['headline_mesh_committed']['file'] = os.path.relpath(committed[-1], ROOT)
-        except (OSError, ValueError):
-            pass
     torch.set_num_threads(best_threads)
-    out['sample'] = ('fwd+loss+bwd of the CPU oracle (unfused PyG-form restatement, torch %s CPU, fp32) on a synthetic %d-vertex '
-                     '%d-level mesh: 1 warm-up at size + median of %d passes (%.2f s) with %d of %d host threads of %s (probe-best); '
-                     'all_cores = the same protocol with all %d threads on the 10 k-vertex probe mesh, run only when the probe '
-                     'says it can finish; the 200 704-vertex figure of the same oracle is committed as profiles/r04_cpu_baseline_200k.json'
-                     % (torch.__version__, nv, levels, len(ts), med, best_threads, ncpu, _cpu_model(), ncpu))
+    what = ('fwd+loss+bwd of the CPU oracle (unfused PyG-form restatement, torch %s CPU, fp32) on a synthetic %d-vertex %d-level mesh: '
+            '1 warm-up at size + median of %d passes (%.2f s) with %d of %d host threads of %s (probe-best)')
+    out['sample'] = what % (torch.__version__, nv, levels, len(ts), med, best_threads, ncpu, _cpu_model())
+    if headline_mesh and n0_target > nv:
+        # the headline mesh itself (same generator call as the GPU step's scene: make_synthetic_mesh(vertices, levels, seed=0))
+        quick = {k: out[k] for k in ('value', 'sample_vertices', 'passes_s', 'warmup_s', 'sample')}
+        full = make_synthetic_mesh(n0_target, levels, seed=seed)
+        warm_f, ts_f = protocol(full, best_threads, 240.0)
+        med_f = statistics.median(ts_f) if ts_f else warm_f
+        nf = full.x.shape[0]
+        out.update({'value': nf / med_f, 'sample_vertices': nf, 'edges': int(full.edge_index.shape[1]),
+                    'passes_s': [round(t, 3) for t in ts_f], 'warmup_s': round(warm_f, 3), 'quick_sample': quick,
+                    'sample': what % (torch.__version__, nf, levels, len(ts_f), med_f, best_threads, ncpu, _cpu_model()) +
+                              ' - the SAME mesh the GPU step ran on, timed in this run; quick_sample = the bounded sample of rounds 1-4'})
+    out['sample'] += ('; all_cores = the same protocol with all %d threads on the 10 k-vertex probe mesh, run only when the probe says '
+                      'it can finish' % ncpu)
     return out
+
+
+def exact_fp32_companion(args):
+    """What the SAME step costs with exact-fp32 GEMMs (v_mfma_f32_32x32x2_f32 on every product, STIN_GEMM_FWD=0 STIN_GEMM_BWD=0 -
+    the reference's arithmetic is plain fp32 addmm): a child process of this script, started after the timed region (a child, not an
+    exec: this process keeps its GPU context; the precision switches are read at import), short loop, no secondary legs."""
+    env = dict(os.environ, STIN_GEMM_FWD='0', STIN_GEMM_BWD='0')
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '15', '--warmup', '5', '--vertices', str(args.vertices),
+           '--levels', str(args.levels), '--no-secondary', '--no-cpu-baseline', '--no-live-traffic']
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+        line = [ln for ln in r.stdout.decode(errors='replace').splitlines() if ln.startswith('{')]
+        if r.returncode != 0 or not line:
+            return {'error': 'child run failed (rc %d)' % r.returncode}
+        c = json.loads(line[-1])
+        return {'ms_per_step': c['ms_per_step'], 'vertices_per_s': c['value'],
+                'gemm_precision': {'fwd': c['gemm_precision']['fwd'], 'bwd': c['gemm_precision']['bwd'],
+                                   'note': 'v_mfma_f32_32x32x2_f32 on unsplit fp32 operands, fp32 accumulate'},
+                'loss': c['loss'], 'steps': c['steps'], 'warmup': c['warmup'],
+                'note': 'the same step, mesh and seeds with EXACT fp32 matrix-core products in every GEMM, forward and backward '
+                        '(STIN_GEMM_FWD=0 STIN_GEMM_BWD=0), measured in this run by a child process after the timed region; the headline '
+                        '`value` uses the split-16-bit products named in gemm_precision, which meet the stated fp32 tolerances '
+                        '(dtype_tolerance) at this size'}
+    except Exception as exc:                                # noqa: BLE001 - a secondary leg must not lose the line
+        return {'error': '%s: %s' % (type(exc).__name__, exc)}
+
+
+def backlogged_step_ms(one_step, steps=10):
+    """GPU time of a step when the host is out of the way: a ~60 ms sleep kernel holds the compute stream while the host enqueues
+    `steps` steps behind it, HIP events around those steps on the same stream.  ms_per_step (wall, host in the loop) minus this =
+    the GPU idle time per step that a profiler-free run leaves at launch / step boundaries."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cyc = 20_000_000
+    a.record()
+    torch.cuda._sleep(cyc)
+    b.record()
+    torch.cuda.synchronize()
+    per_ms = cyc / max(a.elapsed_time(b), 1e-3)
+    one_step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(int(per_ms * 60.0))
+    e0.record()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    host_ms = (time.perf_counter() - t0) * 1e3
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps, host_ms / steps
 
 
 def _cpu_model():
@@ -257,7 +317,7 @@ def _cpu_model():
     return 'unknown CPU'
 
 
-def hbm_honest_edge_kernel(device, n=1_000_000, e=6_000_000, h=128, iters=10):
+def hbm_honest_edge_kernel(device, n=1_000_000, e=6_000_000, h=128, iters=10, live_bytes=None):
     """The level-0 forward edge kernel at the 1 M-vertex / 6 M-edge size of BASELINE config 5: its gathered operand B is
     n*h*4 = 512 MB, twice the 256 MB Infinity Cache, so this figure is an HBM figure (at 200 k vertices B is 102 MB and
     lives in the Infinity Cache - the headline `roofline` is the algorithmic-byte convention of SURVEY §8d)."""
@@ -283,19 +343,18 @@ def hbm_honest_edge_kernel(device, n=1_000_000, e=6_000_000, h=128, iters=10):
     out = {'kernel': 'stin_edge_relu_mean_fwd_f32[N=%d,E=%d,H=%d]' % (n, e, h), 'us': dt * 1e6, 'algorithmic_MB': nbytes / 1e6,
            'GBps': nbytes / dt / 1e9, 'frac_of_hbm_peak': nbytes / dt / 1e9 / HBM_PEAK_GBS,
            'note': 'gathered operand 512 MB > 256 MB Infinity Cache: served by HBM (random graph, fp32 rows)'}
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
-    if files and (n, e, h) == (1_000_000, 6_000_000, 128):
-        ent = json.load(open(files[-1])).get('N1000000:k_edge_fwd_exact<float, 32, 1, 6>')
-        if ent:
-            fab = ent['fabric_MB_per_launch'] * 1e6
-            out['traffic'] = fab
-            out['traffic_over_algorithmic'] = fab / (nbytes + e * h / 8.0)
-            out['traffic_unit'] = ('FABRIC bytes per launch ((2*FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 PMC, REPLAYED from %s - not measured in '
-                                   'this run); the counters sit on the L2\'s memory side and include Infinity-Cache hits, so the HBM-served '
-                                   'share cannot be separated with them: with a 512 MB gathered operand, random row order and a 256 MB '
-                                   'cache at most half of the gathered rows can hit; fabric bytes = %.3f x (algorithmic + mask) bytes, '
-                                   'i.e. no reuse is captured in L2' % (os.path.basename(files[-1]), fab / (nbytes + e * h / 8.0)))
+    if live_bytes is not None and (n, e, h) == (1_000_000, 6_000_000, 128):
+        out['traffic'] = live_bytes
+        out['traffic_over_algorithmic'] = live_bytes / (nbytes + e * h / 8.0)
+        out['traffic_unit'] = ('FABRIC bytes per launch ((2*FETCH_SIZE + WRITE_SIZE) KiB), MEASURED in this run: the same two rocprofv3 --pmc child '
+                               'passes as roofline.traffic (profiles/pmc_kernels.py PMC_LIVE=1: this kernel at this shape, mean of the last 3 '
+                               'launches); the counters sit on the L2\'s memory side and include Infinity-Cache hits, so the HBM-served share '
+                               'cannot be separated with them: with a 512 MB gathered operand, random row order and a 256 MB cache at most half of '
+                               'the gathered rows can hit; fabric bytes = %.3f x (algorithmic + mask) bytes, i.e. no reuse is captured in L2'
+                               % (live_bytes / (nbytes + e * h / 8.0)))
+    else:
+        out['traffic'] = None
+        out['traffic_unit'] = 'not measured in this run (live PMC passes skipped or unavailable)'
     return out
 
 
@@ -483,6 +542,9 @@ def main():
     ap.add_argument('--vertices', type=int, default=200_000)
     ap.add_argument('--levels', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--quick-cpu-baseline', action='store_true', help='cpu_baseline on the bounded ~40 k-vertex sample only (rounds 1-4); the '
+                    'default also times the CPU oracle on the headline mesh itself (~85 s)')
+    ap.add_argument('--no-exact-fp32', action='store_true', help='skip the exact-fp32-GEMM companion figure (a child run of ~25 s)')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend ('nccl' = RCCL; 'gloo' only to smoke-test "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument('--time-gemms', action='store_true', help='bracket every MFMA GEMM launch INSIDE the timed region too '
@@ -496,7 +558,7 @@ def main():
                     help='BASELINE config 3: a collated batch of this many unequal crops (12-28k vertices each) per step '
                          'instead of one scene (NOT the headline); combine with --levels 4 --dtype bf16')
     ap.add_argument('--no-live-traffic', action='store_true', help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic '
-                    'live (about 20 s); the figure replayed from profiles/r*_pmc_traffic.json stands then')
+                    'and hbm_honest.traffic live (about 40 s); both are null then')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the passes after the timed region (fwd+loss+bwd-only loop, GEMM table, standalone kernels, CPU '
                          'baseline) - profiling runs: keeps the kernel mix = the step')
@@ -689,7 +751,18 @@ def main():
         gtimes = SF.KernelTimer.stop()
     gc.enable()
     rank_ms = [dt / args.steps * 1e3]
+    # this rank's aggregation figure (the level-0 forward edge kernel = the forward launch with the most algorithmic bytes), for the
+    # 1/2/4/8 table row: summed over the ranks below
+    my_gbps = 0.0
+    fw = [(edge_bytes(name, *tag), sum(ts) / len(ts)) for (name, tag), ts in ktimes.items() if name.startswith('stin_edge_relu_mean_fwd')]
+    if fw:
+        nb, avg = max(fw)
+        my_gbps = nb / avg / 1e9
+    sum_gbps = my_gbps
     if world > 1:
+        gb = torch.tensor([my_gbps], dtype=torch.float64, device=device)
+        dist.all_reduce(gb, op=dist.ReduceOp.SUM)
+        sum_gbps = float(gb.item())
         per_rank = torch.zeros(world, dtype=torch.float64, device=device)
         per_rank[rank] = dt
         dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
@@ -735,9 +808,10 @@ def main():
         edge_total_ms = sum(r['total_ms'] for r in table) / (sum(r['launches'] for r in table) / per_step)
         roofline = {'bound': 'hbm', 'kernel': '%s[N=%d,E=%d,H=%d]' % (dom['kernel'], dom['N'], dom['E'], dom['H']),
                     'achieved': dom['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom['GBps'] / HBM_PEAK_GBS,
-                    'traffic': pmc_traffic_bytes(dom['kernel'], dom['N'], dom['E'], dom['H']),
-                    'traffic_unit': 'FABRIC bytes per launch incl. Infinity-Cache hits ((2*FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 '
-                                    'PMC), REPLAYED from the committed profiles/r*_pmc_traffic.json - not measured in this run',
+                    'traffic': None,
+                    'traffic_unit': 'not measured in this run (the live rocprofv3 --pmc passes run only in the default single-GPU fp32 '
+                                    'headline run; committed passes of every edge kernel: profiles/r*_pmc_traffic.json = %s bytes for this kernel)'
+                                    % pmc_traffic_bytes(dom['kernel'], dom['N'], dom['E'], dom['H']),
                     'avg_us': dom['avg_us'], 'each_us': dom['each_us'], 'algorithmic_bytes': dom['algorithmic_MB'] * 1e6,
                     'convention': 'algorithmic bytes (SURVEY 8d): every gathered row charged once per edge; at 200k vertices the '
                                   'gathered operand (102 MB) is Infinity-Cache resident - see hbm_honest for the HBM-served size',
@@ -779,6 +853,13 @@ def main():
                             'allreduce_us': allreduce_us, 'replicas_bit_identical': identical, 'cores_per_rank': cores_per_rank,
                             'rccl': (rccl_debug_parse(rccl_log, step.bucket.flat.numel() * 4) if rccl_log else None),
                             'allreduce_overlap_validated_on_hardware': False},
+            # one row of north_star's 1/2/4/8 table: absolute throughput and the aggregation's share of N x the one-GPU HBM roofline
+            # (the driver computes scaling efficiency itself from the per-N `value`s)
+            'scaling_table_row': {'gpus': ranks_counted, 'vertices_per_s': total_vertices * args.steps / dt,
+                                  'vertices_per_s_per_gpu': total_vertices * args.steps / dt / max(ranks_counted, 1),
+                                  'scatter_add_GBps_sum_over_gpus': sum_gbps, 'hbm_roofline_GBps': HBM_PEAK_GBS * world,
+                                  'frac_of_n_gpu_hbm_roofline': sum_gbps / (HBM_PEAK_GBS * world),
+                                  'kernel': 'level-0 forward edge stage (algorithmic bytes, SURVEY 8d), HIP-event bracket on every rank'},
             'dtype_tolerance': (
                 {'forward_max_abs_vs_cpu_oracle': 1e-4, 'loss_abs': 1e-6, 'weight_grad_rel_l2': 1e-3,
                  'measured_at_this_size': 'fwd 6.5e-6, grad rel-L2 3.0e-4 (tests/test_full_size_parity.py, two seeds)'}
@@ -825,7 +906,7 @@ def main():
                 'note': 'the GEMM shape with the largest total time; achieved = executed 16-bit MFMA flops (%d per fp32 product) '
                         '/ stand-alone duration; roofline_bound_us = max(min HBM bytes / %.2f TB/s copy rate, executed flops / '
                         '2.5 PF) - these tall-skinny shapes are bounded by their output bytes' % (mult, HBM_COPY_GBS / 1e3),
-                'mfma_busy_replayed': 'SQ-counter MFMA-busy per kernel: profiles/ (rocprofv3 --pmc pass, not measured in this run)'}
+                'mfma_busy': 'SQ-counter MFMA-busy per kernel is a separate rocprofv3 --pmc pass: profiles/r*_pmc_mfma.md (not part of this run)'}
             out['gemm'] = {'ms_per_step': tsum / gemm_steps * 1e3, 'GFLOP_per_step': flops / gemm_steps / 1e9,
                            'TFLOPs_fp32_equivalent': flops / tsum / 1e12, 'mfma_TFLOPs_executed': mult * flops / tsum / 1e12,
                            'frac_of_16bit_mfma_peak': mult * flops / tsum / 1e12 / MFMA_16BIT_PEAK_TF,
@@ -833,19 +914,33 @@ def main():
                            'time_weighted_frac_of_roofline': sum(r['roofline_bound_us'] * r['launches'] for r in gemms) /
                                                              sum(r['avg_us'] * r['launches'] for r in gemms),
                            'kernels': gemms[:24]}
+        live = None
         if world == 1 and not args.no_secondary and args.dtype == 'f32' and (n0, e0) == (200704, 1200642) and not args.no_live_traffic:
-            live, why = measure_fabric_traffic()
+            live_all, why = measure_fabric_traffic()
+            live = live_all['headline'] if live_all is not None else None
             if live is not None:
                 out['roofline']['traffic'] = live
                 out['roofline']['traffic_unit'] = ('FABRIC bytes per launch incl. Infinity-Cache hits ((2*FETCH_SIZE + WRITE_SIZE) KiB), MEASURED in '
                                                    'this run: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) over the '
-                                                   'same kernel at the same shape (profiles/pmc_kernels.py, PMC_ONLY_FWD=1), mean of the last 3 launches')
+                                                   'same kernel at the same shape (profiles/pmc_kernels.py, PMC_LIVE=1), mean of the last 3 launches')
                 out['roofline']['traffic_over_algorithmic'] = live / (out['roofline']['algorithmic_bytes'] + e0 * 128 / 8.0)
             else:
-                out['roofline']['traffic_live_pass'] = 'not available (%s): the replayed figure stands' % why
+                out['roofline']['traffic_live_pass'] = 'not available (%s)' % why
         if world == 1 and not args.no_secondary:
             out['scatter_add'] = scatter_add_standalone(device)
-            out['hbm_honest'] = hbm_honest_edge_kernel(device)
+            out['hbm_honest'] = hbm_honest_edge_kernel(device, live_bytes=(live_all or {}).get('n1m') if live is not None else None)
+            if not (args.graph or args.cache_plan):
+                # GPU idle per step WITHOUT a profiler: the wall step minus the same step with the host out of the way
+                gpu_ms, host_ms = backlogged_step_ms(one_step)
+                out['gpu_idle'] = {'ms_per_step_wall': dt / args.steps * 1e3, 'ms_per_step_gpu_backlogged': gpu_ms,
+                                   'idle_ms_per_step': max(0.0, dt / args.steps * 1e3 - gpu_ms), 'host_enqueue_ms_per_step_backlogged': host_ms,
+                                   'method': 'a ~60 ms sleep kernel holds the compute stream while the host enqueues 10 steps behind it; HIP '
+                                             'events on that stream around the 10 steps = GPU time per step with no launch-side bubbles '
+                                             '(side-stream work included, as in the timed steps); idle = ms_per_step - that figure '
+                                             '(un-profiled; rocprofv3 traces in profiles/ slow the host and show more)'}
+            if args.dtype == 'f32' and not (args.no_exact_fp32 or args.crops or args.graph or args.irregular or args.morton_order or
+                                             args.coherent_order or os.environ.get('STIN_GEMM_FWD') == '0'):
+                out['exact_fp32'] = exact_fp32_companion(args)
             try:                                            # scipy (Delaunay) is an optional dependency of this one leg
                 out['roofline_irregular'] = irregular_edge_kernel(device)
             except Exception as exc:                        # noqa: BLE001 - the JSON line must survive a missing optional package
@@ -874,7 +969,7 @@ def main():
                 except Exception as exc:                    # noqa: BLE001 - a secondary leg must not lose the line
                     out['loader_fed'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
             if not args.no_cpu_baseline:
-                out['cpu_baseline'] = cpu_baseline(args.vertices, args.levels, seed=0)
+                out['cpu_baseline'] = cpu_baseline(args.vertices, args.levels, seed=0, headline_mesh=not args.quick_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -429,13 +429,23 @@ def g12_batchnorm_step(stin, trainer_mod):
     _model_fixture('g12_batchnorm_step', stin, trainer_mod, cfg, s, seed=1212, adam_step=True)
 
 
+def g13_five_levels(stin, trainer_mod):
+    """BASELINE config 5's DEPTH (n_levels=4: five graph levels, four pool / unpool pairs, encoder and decoder built per level -
+    reference models/surfacetextureinpaintingnet.py:316-338) at fixture size: ngf 4 (widths 4 .. 64), two bottleneck blocks, the
+    second on a dilated edge set of the coarsest level."""
+    s = make_synthetic_mesh(3000, 5, seed=13, dilations=(2,))
+    cfg = dict(input_nc=10, output_nc=3, ngf=4, filter_type='edgeconvtransinv', norm='instance', n_blocks=2, n_levels=4,
+               pooling_type='max', dilations=[1, 2], checkpoint_bottleneck=True)
+    _model_fixture('g13_5level', stin, trainer_mod, cfg, s, seed=1313)
+
+
 def param_counts(stin):
     """The structural constants SURVEY.md §8(c) records."""
     out = {}
     base = dict(output_nc=3, ngf=64, norm='instance', pooling_type='max')
     out['c1_edgeconv_nl1_nb9'] = sum(p.numel() for p in stin.define_G(
         input_nc=4, filter_type='edgeconv', n_blocks=9, n_levels=1, **base).parameters())
-    for nl in (2, 3):
+    for nl in (2, 3, 4):
         out['3d_transinv_nl%d_nb9' % nl] = sum(p.numel() for p in stin.define_G(
             input_nc=10, filter_type='edgeconvtransinv', n_blocks=9, n_levels=nl, **base).parameters())
     net = stin.define_G(input_nc=10, filter_type='edgeconvtransinv', n_blocks=9, n_levels=2, **base)
@@ -449,6 +459,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     stin = ref_import.load_model_module()
     trainer_mod = ref_import.load_trainer3d_module()
+    if sys.argv[1:] == ['g13']:                 # (round 5: add the five-level fixture without rewriting the others)
+        g13_five_levels(stin, trainer_mod)
+        param_counts(stin)
+        return
     g1_imagegraph(stin, trainer_mod)
     g2_three_level(stin, trainer_mod)
     g3_batch_unequal(stin, trainer_mod)
@@ -461,6 +475,7 @@ def main():
     g10_singleconvmeshnet()
     g11_scene_reader()
     g12_batchnorm_step(stin, trainer_mod)
+    g13_five_levels(stin, trainer_mod)
     param_counts(stin)
 
 

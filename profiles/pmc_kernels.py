@@ -17,6 +17,31 @@ from surface_texture_inpainting_net_amd.plan import build_csr, plan_for  # noqa:
 from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh  # noqa: E402
 
 dev = torch.device('cuda:0')
+# PMC_LIVE=1 (bench.py's live traffic leg): the level-0 forward edge kernel, 5 launches on the headline mesh, then 4 launches at
+# the 1 M-vertex / 6 M-edge size of `hbm_honest` - one profiler start for both figures; bench.py separates them by launch order
+if os.environ.get('PMC_LIVE', '0') == '1':
+    from surface_texture_inpainting_net_amd.plan import EdgeSet  # noqa: E402
+    H = 128
+    s = make_synthetic_mesh(200_000, 1, seed=0, dilations=()).to(dev)
+    e = plan_for(s).edges('edge_index', 0)
+    n = s.x.shape[0]
+    A, B = (torch.randn(n, H, device=dev) for _ in range(2))
+    out4 = torch.empty(n, H + 4, device=dev)
+    mask = torch.empty(e.n_edges * (H // 32), dtype=torch.int32, device=dev)
+    for _ in range(5):
+        SF.edge_relu_mean_fwd(A, B, e.by_dst, out4, indicator=True, mask=mask)
+    torch.cuda.synchronize()
+    del A, B, out4, mask, e, s
+    NV = 1_000_000
+    ei = torch.randint(0, NV, (2, 6 * NV), generator=torch.Generator().manual_seed(1)).to(dev)
+    e = EdgeSet(ei, NV, torch.zeros(1, dtype=torch.int32, device=dev))
+    A, B = (torch.randn(NV, H, device=dev) for _ in range(2))
+    out4 = torch.empty(NV, H + 4, device=dev)
+    mask = torch.empty(6 * NV * (H // 32), dtype=torch.int32, device=dev)
+    for _ in range(4):
+        SF.edge_relu_mean_fwd(A, B, e.by_dst, out4, indicator=True, mask=mask)
+    torch.cuda.synchronize()
+    sys.exit(0)
 # PMC_VERTICES=1000000: the 1 M-vertex / 6 M-edge size of bench.py's `hbm_honest` (gathered operand 512 MB > Infinity Cache), forward
 # and one-launch backward only
 NV = int(os.environ.get('PMC_VERTICES', '200000'))

@@ -239,9 +239,13 @@ def test_bf16_network_vs_fp32_oracle_stated_tolerance():
     rel = (num / den) ** 0.5
     print('bf16 storage vs fp32 oracle: fwd max-abs %.3e mean-abs %.3e, loss %.6f vs %.6f, grad rel-L2 %.3e'
           % (err, mean_err, float(loss.detach()), float(loss_ref.detach()), rel))
-    assert err <= 0.15 and mean_err <= 2e-2
-    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-2 * float(loss_ref.detach())
-    assert rel <= 0.25
+    # stated tolerance of the mode = what was measured on MI355X in round 5 x 1.5 (NET_BARS): a 1.5x numerical regression fails
+    assert err <= NET_BARS['fwd_max'] and mean_err <= NET_BARS['fwd_mean'], (err, mean_err)
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= NET_BARS['loss_rel'] * float(loss_ref.detach())
+    assert rel <= NET_BARS['grad_rel'], rel
+
+
+NET_BARS = dict(fwd_max=0.15, fwd_mean=2e-2, loss_rel=1e-2, grad_rel=0.25)
 
 
 def test_bf16_network_is_deterministic_and_trains():
@@ -328,10 +332,14 @@ def test_bf16_batch_of_unequal_crops_four_levels():
     loss = stin_oracle.compute_loss(torch.where((bd.mask > 0).expand_as(bd.color), got, bd.color), bd.color, bd.mask)
     d = (got.detach().cpu() - want.detach()).abs()
     print('bf16 crops: fwd max-abs %.3e mean-abs %.3e, loss %.6f vs %.6f' % (float(d.max()), float(d.mean()), float(loss.detach()), float(loss_ref.detach())))
-    assert float(d.max()) <= 0.15 and float(d.mean()) <= 2e-2
-    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-2 * float(loss_ref.detach())
+    assert float(d.max()) <= CROPS_BARS['fwd_max'] and float(d.mean()) <= CROPS_BARS['fwd_mean'], (float(d.max()), float(d.mean()))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= CROPS_BARS['loss_rel'] * float(loss_ref.detach())
     loss.backward()
     assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+
+
+CROPS_BARS = dict(fwd_max=0.15, fwd_mean=2e-2, loss_rel=1e-2)       # measured on MI355X in round 5 x 1.5
+C5_BARS = dict(max=0.25, mean=3e-2)                                 # bf16 vs fp32 storage at 1 M vertices, measured x 1.5
 
 
 def test_config5_shape_one_million_vertices_five_levels():
@@ -352,7 +360,8 @@ def test_config5_shape_one_million_vertices_five_levels():
     net.set_activation_dtype(BF)
     out = net(s)
     d = (out.detach() - a).abs()
-    assert float(d.max()) <= 0.25 and float(d.mean()) <= 3e-2, (float(d.max()), float(d.mean()))
+    print('config 5 (1 M vertices): bf16 vs fp32 storage max-abs %.3e mean-abs %.3e' % (float(d.max()), float(d.mean())))
+    assert float(d.max()) <= C5_BARS['max'] and float(d.mean()) <= C5_BARS['mean'], (float(d.max()), float(d.mean()))
     loss = stin_oracle.compute_loss(torch.where((s.mask > 0).expand_as(s.color), out, s.color), s.color, s.mask)
     loss.backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import MODEL_FIXTURES, ModelFixture, load_npz
+from _golden import MODEL_FIXTURES, ModelFixture, grad_flip_report, load_npz
 from oracle import scatter_ops, stin_oracle
 from surface_texture_inpainting_net_amd import functional as SF
 from surface_texture_inpainting_net_amd import modules as M
@@ -890,9 +890,15 @@ def test_secondary_norms_and_filters_vs_oracle(norm, filter_type):
     got = net(s.to(DEV))
     got.square().sum().backward()
     assert float((got.detach().cpu() - want.detach()).abs().max()) <= FWD_TOL
-    scale = max(float(p.grad.abs().max()) for p in ref.parameters())
-    for (k, p), q in zip(net.named_parameters(), ref.parameters()):
-        assert float((p.grad.cpu() - q.grad).abs().max()) <= 2e-3 * scale, k
+    rep = grad_flip_report(net.named_parameters(), ref.parameters(), 'secondary %s/%s' % (norm, filter_type))
+    bar = SECONDARY_BARS[(norm, filter_type)]
+    assert rep['max_rel'] <= bar[0] and rep['beyond'] <= bar[1] and rep['rel_l2'] <= bar[2], (rep, bar)
+
+
+# (worst entry / gradient scale, entries beyond 1e-3 of scale, relative L2): measured on MI355X in round 5 x 1.5 - a 400-vertex
+# mesh at ngf 8 has ~10 k gradient entries and no averaging, so one flipped decision is visible; the COUNT stays a handful
+SECONDARY_BARS = {('batch', 'edgeconv'): (2e-3, 8, 1e-3), ('none', 'edgeconvtransinv'): (2e-3, 8, 1e-3),
+                  ('instance', 'sageconvtransinv'): (2e-3, 8, 1e-3)}
 
 
 def test_batch_of_unequal_crops_four_levels_vs_oracle():
@@ -915,9 +921,12 @@ def test_batch_of_unequal_crops_four_levels_vs_oracle():
     got = net(bd)
     stin_oracle.compute_loss(torch.where((bd.mask > 0).expand_as(bd.color), got, bd.color), bd.color, bd.mask).backward()
     assert float((got.detach().cpu() - want.detach()).abs().max()) <= FWD_TOL
-    scale = max(float(p.grad.abs().max()) for p in ref.parameters())
-    for (k, p), q in zip(net.named_parameters(), ref.parameters()):
-        assert float((p.grad.cpu() - q.grad).abs().max()) <= 2e-3 * scale, k
+    rep = grad_flip_report(net.named_parameters(), ref.parameters(), 'crops 4 levels')
+    # measured on MI355X in round 5 (x 1.5): see CROPS4_BARS
+    assert rep['max_rel'] <= CROPS4_BARS[0] and rep['beyond'] <= CROPS4_BARS[1] and rep['rel_l2'] <= CROPS4_BARS[2], rep
+
+
+CROPS4_BARS = (2e-3, 8, 1e-3)
 
 
 def test_train_step_against_reference_fixture():
@@ -1107,14 +1116,13 @@ def test_mid_size_full_width_model_vs_oracle():
     # path 6.9e-4 / 7.5e-4 with the shipped split-16-bit GEMMs, 8.1e-4 / 8.2e-4 with exact fp32 GEMMs, identical with
     # bf16x6 backward GEMMs - flip noise, not GEMM precision.  SURVEY 8d's bar (relative 1e-3 on weight gradients) is met
     # at the full 200k size (3.0e-4); at 12k vertices each flip weighs more, hence 1.5e-3 / 3e-3 here.
-    scale = max(float(p.grad.abs().max()) for p in ref.parameters())
-    num = den = 0.0
-    for (k, p), q in zip(net.named_parameters(), ref.parameters()):
-        d = p.grad.cpu() - q.grad
-        assert float(d.abs().max()) <= 3e-3 * scale, k
-        num += float(d.double().pow(2).sum())
-        den += float(q.grad.double().pow(2).sum())
-    assert (num / den) ** 0.5 <= 1.5e-3
+    rep = grad_flip_report(net.named_parameters(), ref.parameters(), 'mid size, full width')
+    assert rep['max_rel'] <= MID_BARS[0] and rep['beyond'] <= MID_BARS[1] and rep['rel_l2'] <= MID_BARS[2], rep
+
+
+# measured on MI355X in round 5 (x 1.5): worst entry / scale, entries beyond 1e-3 of scale (of 4.2 M), relative L2
+MID_BARS = (3e-3, 40, 1.5e-3)
+
 
 
 def test_plan_prefetch_on_side_streams_equals_lazy_build():
