@@ -864,10 +864,11 @@ def main():
                 {'forward_max_abs_vs_cpu_oracle': 1e-4, 'loss_abs': 1e-6, 'weight_grad_rel_l2': 1e-3,
                  'measured_at_this_size': 'fwd 6.5e-6, grad rel-L2 3.0e-4 (tests/test_full_size_parity.py, two seeds)'}
                 if args.dtype == 'f32' else
-                {'forward_max_abs_vs_fp32_oracle': 0.15, 'forward_mean_abs': 2e-2, 'loss_rel': 1e-2, 'weight_grad_rel_l2': 0.25,
-                 'measured': 'fwd max-abs 7.4e-2, mean-abs 9.9e-3, loss 2e-4, grad rel-L2 16 % on the 15-block network '
-                             '(tests/test_hip_bf16.py::test_bf16_network_vs_fp32_oracle_stated_tolerance); 1 M vertices / 5 levels vs the '
-                             'fp32-storage run: max-abs <= 0.25, mean-abs <= 3e-2',
+                {'forward_max_abs_vs_fp32_oracle': 0.115, 'forward_mean_abs': 1.5e-2, 'loss_rel': 5e-4, 'weight_grad_rel_l2': 0.24,
+                 'measured': 'fwd max-abs 7.6e-2, mean-abs 9.9e-3, loss 2.1e-4, grad rel-L2 16.1 % on the 15-block network (bars = 1.5 x: '
+                             'tests/test_hip_bf16.py::test_bf16_network_vs_fp32_oracle_stated_tolerance); five-level network (config 5) vs the '
+                             'fp32 oracle at 30 k vertices: 1.49e-1 / 1.78e-2 / 1.2e-4 / 27.4 % (tests/test_five_level.py, bars 1.5 x); 1 M '
+                             'vertices / 5 levels vs the fp32-storage run: max-abs 0.20 (bar 0.31), mean-abs 1.7e-2 (bar 2.6e-2)',
                  'training_curve_200_steps': {'statement': 'mean loss of the last 50 of 200 Adam steps within `last_50_steps` of the NEARER of two '
                                                            'fp32-storage runs (shipped split GEMMs / exact-fp32 GEMMs), which themselves end up to '
                                                            '`fp32_orders_apart` apart: the trajectories are chaotic',

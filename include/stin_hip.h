@@ -496,6 +496,23 @@ int stin_gemm_nt_colstats_f32(const float* A, int64_t lda, const float* W, int64
                               stin_stream_t stream);
 int stin_moments_final_f32(const double* partial, int64_t groups, int C, const float* inv_cnt, float eps, float* mean,
                            float* rstd, stin_stream_t stream);
+/* Round 5: the fold of per-row-group statistics partials INSIDE the elementwise launch (single graph, fp32 rows, C % 32 == 0,
+ * 16-byte rows): every workgroup folds the partials of its own 32 columns with the arithmetic of stin_moments_final_f32 /
+ * stin_norm_coef_from_partials_f32 and then runs stin_norm_act_res_fwd_f32 / stin_norm_act_bwd_f32's expression on its rows:
+ * bit-identical to the two-launch route, one launch less on the critical path of a block.  Replaces the same reference lines as
+ * those entry points (models/modules/fastinstancenorm.py:44-49 + the ELU / residual of surfacetextureinpaintingnet.py:507-521).
+ * stin_norm_fold_rows: rows per workgroup the form would use for (N, C, groups), or 0 when it does not apply / does not pay (the
+ * grid would read more fold bytes than half its elementwise traffic; STIN_NORM_FOLD=0).  The two launches return
+ * STIN_E_UNSUPPORTED - before anything is enqueued - when the form does not apply: the caller then takes the two-launch route.
+ * fwd: partial [groups][2][C] (sum, sum of squares) -> mean, rstd [C] written; y = ELU((x - mean) rstd) (+ res).
+ * bwd: partial [groups][2][C] (sum of dy xc, sum of dy) with mean, rstd [C] given -> dx = rstd dy + k xc + m. */
+int stin_norm_fold_rows(int64_t N, int C, int64_t groups);
+int stin_norm_act_res_fwd_fold_f32(const double* partial, int64_t groups, const float* x, int64_t ldx, const float* res,
+                                   int64_t ldres, const float* inv_cnt, float eps, int64_t N, int C, float* mean, float* rstd,
+                                   float* y, int64_t ldy, stin_stream_t stream);
+int stin_norm_act_bwd_fold_f32(const double* partial, int64_t groups, const float* x, int64_t ldx, const float* gout, int64_t ldg,
+                               const float* mean, const float* rstd, const float* inv_cnt, int64_t N, int C, float* dx,
+                               int64_t lddx, stin_stream_t stream);
 
 /* --------------------------------------------------- bf16-storage variants of the path --
  * Same semantics, argument order and reference call sites as the *_f32 entry points above, on bf16 rows

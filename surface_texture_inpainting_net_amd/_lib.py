@@ -126,6 +126,11 @@ SIGNATURES['stin_gemm_nt_colstats_groups'] = (c_i64, [c_i64, c_int, c_int, c_int
 SIGNATURES['stin_gemm_nt_colstats_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int,
                                                    c_ptr, c_i64, c_int, c_ptr, c_size, c_ptr])
 SIGNATURES['stin_moments_final_f32'] = (c_int, [c_ptr, c_i64, c_int, c_ptr, c_f32, c_ptr, c_ptr, c_ptr])
+SIGNATURES['stin_norm_fold_rows'] = (c_int, [c_i64, c_int, c_i64])
+SIGNATURES['stin_norm_act_res_fwd_fold_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr,
+                                                        c_ptr, c_i64, c_ptr])
+SIGNATURES['stin_norm_act_bwd_fold_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr,
+                                                    c_i64, c_ptr])
 SIGNATURES['stin_edgeconv_block_fwd_pack_offsets'] = (c_int, [c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr])
 SIGNATURES['stin_edgeconv_pack_many_f32'] = (c_int, [c_ptr, c_int, c_i64, c_ptr])
 SIGNATURES['stin_edgeconv_block_bwd_workspace_bytes'] = (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int, c_int])

@@ -104,11 +104,20 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
         // one graph, all-columns GEMM shape: the column sums of agg come out of GEMM2's epilogue (no pass over agg for them)
         const int64_t stat_groups = (B == 1 && gid == nullptr && !slice_quirk) ? stin_gemm_nt_colstats_groups(N, Cout, H, pf) : 0;
         const bool fused_stats = stat_groups > 0 && (size_t)stat_groups * 2 * Cout * sizeof(double) + 256 <= red_bytes;
+        bool normed = false;
         if (fused_stats) {
             double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(red_ws) + 255) & ~(uintptr_t)255);
             STIN_TRY(stin_gemm_nt_colstats_f32(hf, ldh, w2_op, H, b2, hf + H, ldh, nullptr, 0, N, Cout, H, static_cast<float*>(agg),
                                                Cout, pf, partial, (size_t)stat_groups * 2 * Cout * sizeof(double), stream));
-            STIN_TRY(stin_moments_final_f32(partial, stat_groups, Cout, inv_cnt, eps, mean, rstd, stream));
+            // (round 5) few row groups (the bottleneck level): every workgroup of the normalisation launch folds its own columns'
+            // partials - no separate fold launch on the critical path; same sums, same order: bit-identical (k_norm_fold)
+            int rc_fold = STIN_E_UNSUPPORTED;
+            if (N > 0 && stin_norm_fold_rows(N, Cout, stat_groups) > 0)
+                rc_fold = stin_norm_act_res_fwd_fold_f32(partial, stat_groups, static_cast<const float*>(agg), Cout, static_cast<const float*>(res),
+                                                         ld_res, inv_cnt, eps, N, Cout, mean, rstd, static_cast<float*>(out), ldo, stream);
+            if (rc_fold == STIN_OK) normed = true;
+            else if (rc_fold != STIN_E_UNSUPPORTED) return rc_fold;
+            else STIN_TRY(stin_moments_final_f32(partial, stat_groups, Cout, inv_cnt, eps, mean, rstd, stream));
         } else {
             STIN_TRY(stin_gemm_nt_f32(hf, ldh, w2_op, H, b2, hf + H, ldh, nullptr, 0, N, Cout, H, static_cast<float*>(agg), Cout,
                                       pf, stream));
@@ -126,8 +135,9 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
                                         nullptr, mean, nullptr, nullptr, STIN_POST_RSTD, inv_cnt, eps, rstd, nullptr, red_ws,
                                         red_bytes, stream));
         }
-        STIN_TRY(stin_norm_act_res_fwd_f32(static_cast<const float*>(agg), Cout, mean, rstd, gid, static_cast<const float*>(res),
-                                           ld_res, N, Cout, 1, static_cast<float*>(out), ldo, stream));
+        if (!normed)
+            STIN_TRY(stin_norm_act_res_fwd_f32(static_cast<const float*>(agg), Cout, mean, rstd, gid, static_cast<const float*>(res),
+                                               ld_res, N, Cout, 1, static_cast<float*>(out), ldo, stream));
     } else {
         stin_bf16_t* Yh = static_cast<stin_bf16_t*>(Y);
         stin_bf16_t* hh = static_cast<stin_bf16_t*>(hE);
@@ -267,9 +277,17 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
         const float* hf = static_cast<const float*>(hE);
         float* dYf = static_cast<float*>(dY);
         // instance norm + ELU backward: two column sums finalised straight into the k / m coefficients, one elementwise pass
+        bool dagg_done = false;
         if (link != nullptr && link->pre_partial != nullptr && link->pre_groups > 0 && !sid && B == 1 && gid == nullptr) {
-            // the two column sums came out of the previous block's dx product (BwdLink): fold its partials
-            STIN_TRY(stin_norm_coef_from_partials_f32(link->pre_partial, link->pre_groups, Cout, rstd, inv_cnt, kk, mm, stream));
+            // the two column sums came out of the previous block's dx product (BwdLink): fold its partials - (round 5) inside the
+            // normalisation launch itself where the row groups are few (k_norm_fold: every workgroup folds its own columns)
+            int rc_fold = STIN_E_UNSUPPORTED;
+            if (N > 0 && stin_norm_fold_rows(N, Cout, link->pre_groups) > 0)
+                rc_fold = stin_norm_act_bwd_fold_f32(link->pre_partial, link->pre_groups, static_cast<const float*>(agg), Cout, gf, ldg, mean,
+                                                     rstd, inv_cnt, N, Cout, static_cast<float*>(dagg), Cout, stream);
+            if (rc_fold == STIN_OK) dagg_done = true;
+            else if (rc_fold != STIN_E_UNSUPPORTED) return rc_fold;
+            else STIN_TRY(stin_norm_coef_from_partials_f32(link->pre_partial, link->pre_groups, Cout, rstd, inv_cnt, kk, mm, stream));
         } else if (!sid) {
             STIN_TRY(stin_colreduce_f32(STIN_RED_DOT_ELU, static_cast<const float*>(agg), Cout, gf, ldg, N, Cout, ptr_true, B, gid,
                                         nullptr, mean, rstd, nullptr, STIN_POST_NORM_COEF, inv_cnt, 0.f, kk, mm, red_ws, red_bytes,
@@ -284,8 +302,9 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
                                         stream));
             STIN_TRY(stin_norm_bwd_coef_m_quirk_f32(s0, uu, rstd, inv_cnt, B, Cout, mm, stream));
         }
-        STIN_TRY(stin_norm_act_bwd_f32(static_cast<const float*>(agg), Cout, gf, ldg, mean, rstd, rstd, kk, mm, gid, sid_n, N,
-                                       Cout, 1, static_cast<float*>(dagg), Cout, stream));
+        if (!dagg_done)
+            STIN_TRY(stin_norm_act_bwd_f32(static_cast<const float*>(agg), Cout, gf, ldg, mean, rstd, rstd, kk, mm, gid, sid_n, N,
+                                           Cout, 1, static_cast<float*>(dagg), Cout, stream));
         // second Linear: weight gradient (+ masked bias gradient) and input gradient
         STIN_TRY(stin_gemm_nt_f32(static_cast<const float*>(dagg), Cout, w2T, Cout, nullptr, nullptr, 0, nullptr, 0, N, H, Cout,
                                   static_cast<float*>(dhE), H, pb, stream));

@@ -554,6 +554,172 @@ __global__ __launch_bounds__(BLOCK) void k_norm_bwd(const T* __restrict__ x, int
     o.store(dx + r * lddx + c);
 }
 
+// Round 5: fold + elementwise pass in ONE launch (k_norm_fold<BWD>), for the blocks whose column statistics arrive as per-row-group
+// fp64 partials out of a GEMM epilogue (forward: stin_gemm_nt_colstats_f32 -> k_moments_final -> k_norm_fwd; backward: the hand-off
+// statistics of stin_gemm_nt_dotelu_f32 -> k_colreduce_final -> k_norm_bwd).  The fold is a 5 us launch alone and 18-20 us beside
+// the weight-gradient stream, on the critical path of every bottleneck block in both directions.  Round 4 tried ONE folding
+// workgroup with the others waiting on a flag (three versions, all slower: every poll / atomic on a shared line serialises).  Here
+// nobody waits for anybody: a workgroup owns NF_GC = 32 columns x a chunk of rows and folds ITS columns itself - the [groups][2][C]
+// partials are L2 / Infinity-Cache resident (226 groups at 18 063 rows: 115 KB per workgroup, 29 MB over the grid beside 55 MB of
+// elementwise traffic) - with exactly the per-lane sums, LDS reduction order and final float operations of k_moments_final /
+// k_colreduce_final (16 k-lanes per column, the loops below are theirs), so mean / rstd / k / m and the outputs are BIT-IDENTICAL
+// to the two-launch route.  The row-chunk-0 workgroups write mean / rstd (forward: saved for backward).  Host side: used when
+// the fold traffic stays below half the elementwise traffic (norm_fold_rows()).
+constexpr int NF_GC = 32, NF_BLOCK = 512, NF_RL = NF_BLOCK / (NF_GC / 4);      // 8 lanes per row, 64 rows per trip
+
+// one k-lane's share of k_colreduce_final's sum over the chunk list (same loads, same add order)
+__device__ __forceinline__ double fold_lane_sum(const double* __restrict__ p, int64_t stride, int nch, int ty) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int k = ty; k < nch; k += 32 * FIN_KL) {
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int ku = k + u * FIN_KL;
+            v[u] = p[(int64_t)(ku < nch ? ku : ty) * stride];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k0 = k + 4 * q * FIN_KL;
+            if (k0 + 3 * FIN_KL < nch) {
+                s0 += v[4 * q];
+                s1 += v[4 * q + 1];
+                s2 += v[4 * q + 2];
+                s3 += v[4 * q + 3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k0 + j * FIN_KL < nch) s0 += v[4 * q + j];
+            }
+        }
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+// one k-lane's share of k_moments_final's two sums
+__device__ __forceinline__ void fold_lane_moments(const double* __restrict__ p, int64_t st, int C, int nch, int ty, double& o1, double& o2) {
+    double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int k = ty; k < nch; k += 16 * FIN_KL) {
+        double a[16], q[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int ku = k + u * FIN_KL;
+            const int kc = ku < nch ? ku : ty;
+            a[u] = p[kc * st];
+            q[u] = p[kc * st + C];
+        }
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const int k0 = k + 2 * h * FIN_KL;
+            if (k0 + FIN_KL < nch) {
+                s1 += a[2 * h];
+                s2 += q[2 * h];
+                t1 += a[2 * h + 1];
+                t2 += q[2 * h + 1];
+            } else if (k0 < nch) {
+                s1 += a[2 * h];
+                s2 += q[2 * h];
+            }
+        }
+    }
+    o1 = s1 + t1;
+    o2 = s2 + t2;
+}
+
+// BWD = false: y = ELU((x - mean) rstd) + res with (mean, rstd) folded from moment partials; mean_io / rstd_io are OUTPUTS.
+// BWD = true:  dx = rstd dy + k xc + m, dy = g ELU'((x - mean) rstd), (k, m) folded from the (dy xc, dy) partials; mean_io /
+//              rstd_io are INPUTS.  One graph (B = 1), fp32 rows, C % 32 == 0, 16-byte rows.
+template <bool BWD>
+__global__ __launch_bounds__(NF_BLOCK) void k_norm_fold(const double* __restrict__ partial, int nch, const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ other, int64_t ldo, float* __restrict__ mean_io,
+                                                        float* __restrict__ rstd_io, const float* __restrict__ inv_cnt, float eps,
+                                                        int64_t N, int C, int rows_per_block, float* __restrict__ y, int64_t ldy) {
+    __shared__ double sm[2][FIN_KL][NF_GC + 1];
+    __shared__ __attribute__((aligned(16))) float coef[4][NF_GC];                 // fwd: mean, rstd; bwd: mean, rstd, k, m
+    crit_prio();
+    const int c0 = blockIdx.x * NF_GC;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+    {
+        const int tx = threadIdx.x % NF_GC, ty = threadIdx.x / NF_GC;             // 32 columns x 16 k-lanes
+        const int c = c0 + tx;
+        if (!BWD) {
+            double a, q;
+            fold_lane_moments(partial + c, (int64_t)2 * C, C, nch, ty, a, q);
+            sm[0][ty][tx] = a;
+            sm[1][ty][tx] = q;
+        } else {
+            sm[0][ty][tx] = fold_lane_sum(partial + c, (int64_t)2 * C, nch, ty);
+            sm[1][ty][tx] = fold_lane_sum(partial + C + c, (int64_t)2 * C, nch, ty);
+        }
+        __syncthreads();
+        if (ty == 0) {
+            double a = 0.0, q = 0.0;
+#pragma unroll
+            for (int k = 0; k < FIN_KL; ++k) { a += sm[0][k][tx]; q += sm[1][k][tx]; }
+            if (!BWD) {                                                           // (= k_moments_final)
+                const double ic = (double)inv_cnt[0];
+                const double mu = a * ic;
+                double var = q * ic - mu * mu;
+                if (var < 0.0) var = 0.0;
+                const float mf = (float)mu, rf = (float)(1.0 / sqrt(var + (double)eps));
+                coef[0][tx] = mf;
+                coef[1][tx] = rf;
+                if (blockIdx.y == 0) {
+                    mean_io[c] = mf;
+                    rstd_io[c] = rf;
+                }
+            } else {                                                              // (= k_colreduce_final, STIN_POST_NORM_COEF)
+                const float rs = rstd_io[c], ic = inv_cnt[0];
+                const float t1 = (float)a, s0 = (float)q;
+                coef[0][tx] = mean_io[c];
+                coef[1][tx] = rs;
+                coef[2][tx] = -(rs * rs * rs) * t1 * ic;
+                coef[3][tx] = -(rs * s0) * ic;
+            }
+        }
+        __syncthreads();
+    }
+    const int cl = threadIdx.x % (NF_GC / 4), rl = threadIdx.x / (NF_GC / 4);
+    const int c = c0 + cl * 4;
+    const float4 mu4 = *reinterpret_cast<const float4*>(&coef[0][cl * 4]), rs4 = *reinterpret_cast<const float4*>(&coef[1][cl * 4]);
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+    float kv[4] = {0.f, 0.f, 0.f, 0.f}, mv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (BWD) {
+        const float4 k4 = *reinterpret_cast<const float4*>(&coef[2][cl * 4]), m4 = *reinterpret_cast<const float4*>(&coef[3][cl * 4]);
+        kv[0] = k4.x; kv[1] = k4.y; kv[2] = k4.z; kv[3] = k4.w;
+        mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+    }
+    constexpr int UR = 4;                                                         // rows in flight per thread
+    for (int64_t rb = r0 + rl; rb < r1; rb += UR * NF_RL) {
+        float4 xv[UR], ov[UR];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int64_t r = rb + u * NF_RL < r1 ? rb + u * NF_RL : rb;
+            xv[u] = ld4(x + r * ldx + c);
+            ov[u] = other != nullptr ? ld4(other + r * ldo + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int64_t r = rb + u * NF_RL;
+            if (r >= r1) break;
+            const float xa[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, oa[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!BWD) {                                                       // (= k_norm_fwd, act = 1)
+                    float n = (xa[i] - mu[i]) * rs[i];
+                    n = n > 0.f ? n : expm1f(n);
+                    o[i] = other != nullptr ? n + oa[i] : n;
+                } else {                                                          // (= k_norm_bwd, act = 1, a = rstd)
+                    const float xc = xa[i] - mu[i];
+                    const float dy = oa[i] * elu_grad_from_pre(xc * rs[i]);
+                    o[i] = rs[i] * dy + kv[i] * xc + mv[i];
+                }
+            }
+            st4(y + r * ldy + c, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
 // BatchNorm1d-with-affine over all rows (+ ReLU): forward and backward elementwise passes (fp32, SingleConvMeshNet)
 template <int VW>
 __global__ __launch_bounds__(BLOCK) void k_bn_fwd(const float* __restrict__ x, int64_t ldx, const float* __restrict__ mean,
@@ -840,7 +1006,56 @@ int norm_bwd_impl(const T* x, int64_t ldx, const T* gout, int64_t ldg, const flo
     return stin_launch_status();
 }
 
+// row chunk of a workgroup of k_norm_fold, or 0 when the one-launch form does not pay: the grid is (C / 32) x chunks with ~1
+// workgroup (16 waves) per CU, and all of them together must not read more fold bytes than 3/4 of the elementwise traffic (12
+// bytes per element; 18 063 x 256 with 226 row groups: 256 workgroups x 115 KB = 30 MB beside 55 MB)
+inline int norm_fold_rows(int64_t N, int C, int64_t groups) {
+    static const bool on = !(getenv("STIN_NORM_FOLD") && atoi(getenv("STIN_NORM_FOLD")) == 0);      // A/B switch (read once)
+    static const int per_cu = (getenv("STIN_NORM_FOLD_PER_CU") && atoi(getenv("STIN_NORM_FOLD_PER_CU")) > 0) ? atoi(getenv("STIN_NORM_FOLD_PER_CU")) : 1;   // tuning aid
+    if (!on || C % NF_GC != 0 || N <= 0 || groups <= 0 || groups > INT32_MAX) return 0;
+    const int cg = C / NF_GC;
+    int64_t chunks = (per_cu * (int64_t)norm_cu_count() + cg - 1) / cg;
+    int64_t rows = (N + chunks - 1) / chunks;
+    rows = (rows + NF_RL - 1) / NF_RL * NF_RL;
+    if (rows < 2 * NF_RL) rows = 2 * NF_RL;
+    chunks = (N + rows - 1) / rows;
+    const double fold_bytes = (double)chunks * cg * (double)groups * 2.0 * NF_GC * 8.0, elem_bytes = (double)N * C * 12.0;
+    return (fold_bytes <= 0.75 * elem_bytes && chunks <= 65535 && rows <= INT32_MAX) ? (int)rows : 0;
+}
+
 }  // namespace
+
+// One-launch "fold the GEMM epilogue's statistics partials + elementwise pass" forms of the instance norm (single graph, fp32
+// rows; k_norm_fold).  stin_norm_fold_rows > 0 says the form applies to (N, C, groups) - the caller then checks 16-byte rows itself
+// through the return code (STIN_E_UNSUPPORTED when a pointer / pitch does not allow float4 access).
+extern "C" int stin_norm_fold_rows(int64_t N, int C, int64_t groups) { return norm_fold_rows(N, C, groups); }
+
+extern "C" int stin_norm_act_res_fwd_fold_f32(const double* partial, int64_t groups, const float* x, int64_t ldx, const float* res,
+                                              int64_t ldres, const float* inv_cnt, float eps, int64_t N, int C, float* mean,
+                                              float* rstd, float* y, int64_t ldy, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N > 0 && C > 0 && ldx >= C && ldy >= C && (res == nullptr || ldres >= C), STIN_E_SIZE);
+    STIN_REQUIRE(partial && x && inv_cnt && mean && rstd && y, STIN_E_NULL);
+    const int rows = norm_fold_rows(N, C, groups);
+    if (rows <= 0 || !vec4_ok<float>(C, {x, res, y}, {}, {ldx, ldy, res ? ldres : 0})) return STIN_E_UNSUPPORTED;
+    hipLaunchKernelGGL((k_norm_fold<false>), dim3((unsigned)(C / NF_GC), (unsigned)((N + rows - 1) / rows)), dim3(NF_BLOCK), 0,
+                       (hipStream_t)stream, partial, (int)groups, x, ldx, res, ldres, mean, rstd, inv_cnt, eps, N, C, rows, y, ldy);
+    return stin_launch_status();
+}
+
+extern "C" int stin_norm_act_bwd_fold_f32(const double* partial, int64_t groups, const float* x, int64_t ldx, const float* gout,
+                                          int64_t ldg, const float* mean, const float* rstd, const float* inv_cnt, int64_t N, int C,
+                                          float* dx, int64_t lddx, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N > 0 && C > 0 && ldx >= C && ldg >= C && lddx >= C, STIN_E_SIZE);
+    STIN_REQUIRE(partial && x && gout && inv_cnt && mean && rstd && dx, STIN_E_NULL);
+    const int rows = norm_fold_rows(N, C, groups);
+    if (rows <= 0 || !vec4_ok<float>(C, {x, gout, dx}, {}, {ldx, ldg, lddx})) return STIN_E_UNSUPPORTED;
+    hipLaunchKernelGGL((k_norm_fold<true>), dim3((unsigned)(C / NF_GC), (unsigned)((N + rows - 1) / rows)), dim3(NF_BLOCK), 0,
+                       (hipStream_t)stream, partial, (int)groups, x, ldx, gout, ldg, const_cast<float*>(mean), const_cast<float*>(rstd),
+                       inv_cnt, 0.f, N, C, rows, dx, lddx);
+    return stin_launch_status();
+}
 
 extern "C" size_t stin_colreduce_workspace_bytes(int C, int B) {
     if (C <= 0 || B <= 0) return 0;

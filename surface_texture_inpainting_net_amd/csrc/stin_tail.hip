@@ -190,7 +190,12 @@ __global__ __launch_bounds__(TL_BWD_BLOCK) void k_linear_tanh_bwd(const float* _
     if (!last_s) return;
     // ---- the fold (sc1 loads only): thread (part, o) sums the partials p = part, part + parts, ...; then the parts in order
     const int P = (int)gridDim.x;
-    const int parts = TL_BWD_BLOCK / O > 0 ? TL_BWD_BLOCK / O : 1;
+    // (round 5) at most WAVES parts: the parts' sums go into the [WAVES][O] floats of dynamic LDS this launch was given.  With
+    // O < 64 (K <= 16) the unclamped TL_BWD_BLOCK / O exceeded that, the hardware dropped the out-of-range LDS writes, and on
+    // grids of more than ~17 blocks the partials of the dropped parts were missing from dW (found by the 5-level fixture g13:
+    // K = 4 on 3 025 vertices = 24 blocks; every earlier small-K test ran on fewer blocks than parts)
+    const int parts_fit = TL_BWD_BLOCK / O > 0 ? TL_BWD_BLOCK / O : 1;
+    const int parts = parts_fit < WAVES ? parts_fit : WAVES;
     constexpr int FU = 16;
     for (int t0 = threadIdx.x; t0 < parts * O; t0 += TL_BWD_BLOCK) {       // (one trip: parts * O <= TL_BWD_BLOCK unless O > it)
         const int o = t0 % O, part = t0 / O;

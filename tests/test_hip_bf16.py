@@ -7,8 +7,8 @@ Two layers of checks, all through the C ABI:
     outputs (ReLU masks, pool arg-max) must be identical.
   * GEMMs against fp64 on the bf16-rounded operands (fp32 accumulation: error bound independent of bf16);
   * whole network (shipped 3-D config, 15 blocks) against the fp32 CPU oracle - the STATED tolerance of the bf16
-    mode: tanh output max-abs <= 0.15 and mean-abs <= 2e-2 (measured 7.8e-2 / 9.9e-3), loss within 1 % (measured
-    2e-4), weight gradients within 25 % relative L2 (measured 16 %).
+    mode = 1.5 x what is measured (round 5; NET_BARS): tanh output max-abs <= 0.115 and mean-abs <= 1.5e-2 (measured
+    7.6e-2 / 9.9e-3), loss within 5e-4 (measured 2.1e-4), weight gradients within 24 % relative L2 (measured 16.1 %).
     Why the gradient bar is not tighter, and why no "mixed" variant is shipped (tests/tools/bf16_design_probe.py,
     profiles/r02_bf16_sensitivity.md): this network's gradient responds to a forward perturbation of relative size e like
     sqrt(e), not e - ReLU and arg-max (max pool) decisions flip in proportion to e and each flip moves a gradient entry
@@ -245,7 +245,8 @@ def test_bf16_network_vs_fp32_oracle_stated_tolerance():
     assert rel <= NET_BARS['grad_rel'], rel
 
 
-NET_BARS = dict(fwd_max=0.15, fwd_mean=2e-2, loss_rel=1e-2, grad_rel=0.25)
+# measured on MI355X in round 5: fwd max-abs 7.62e-2, mean-abs 9.87e-3, loss 2.1e-4 relative, gradients 16.1 % relative L2
+NET_BARS = dict(fwd_max=0.115, fwd_mean=1.5e-2, loss_rel=5e-4, grad_rel=0.24)
 
 
 def test_bf16_network_is_deterministic_and_trains():
@@ -338,8 +339,10 @@ def test_bf16_batch_of_unequal_crops_four_levels():
     assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
 
 
-CROPS_BARS = dict(fwd_max=0.15, fwd_mean=2e-2, loss_rel=1e-2)       # measured on MI355X in round 5 x 1.5
-C5_BARS = dict(max=0.25, mean=3e-2)                                 # bf16 vs fp32 storage at 1 M vertices, measured x 1.5
+# measured on MI355X in round 5 (bars = x 1.5): crops fwd max-abs 1.14e-1, mean-abs 1.37e-2, loss 3.8e-4 relative;
+# config 5 (1 M vertices, bf16 vs fp32 storage) max-abs 2.04e-1, mean-abs 1.71e-2
+CROPS_BARS = dict(fwd_max=0.17, fwd_mean=2.1e-2, loss_rel=8e-4)
+C5_BARS = dict(max=0.31, mean=2.6e-2)
 
 
 def test_config5_shape_one_million_vertices_five_levels():

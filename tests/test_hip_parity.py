@@ -648,7 +648,8 @@ def test_gemm_nt_on_strided_views_and_linear_autograd():
     assert float((gb - w.sum(0)).abs().max()) <= 1e-4
 
 
-@pytest.mark.parametrize('N,K,Nc', [(1, 64, 3), (37, 64, 3), (5000, 64, 3), (200_704, 64, 3), (3000, 128, 4), (777, 256, 1), (1234, 20, 2)])
+@pytest.mark.parametrize('N,K,Nc', [(1, 64, 3), (37, 64, 3), (5000, 64, 3), (200_704, 64, 3), (3000, 128, 4), (777, 256, 1), (1234, 20, 2),
+                                    (3025, 4, 3), (40_000, 8, 3), (100_000, 16, 1)])     # (round 5) K <= 16 on grids of > 16 blocks: the fold's LDS parts
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_last_layer_linear_tanh_one_launch_kernels(N, K, Nc, dtype):
     """tanh(x W^T + b) and its backward (stin_linear_tanh_*, csrc/stin_tail.hip) against fp64 on the same inputs:
@@ -705,6 +706,56 @@ def test_linear_backward_separate_weight_and_bias_gradients_and_pretransposed_we
     ps.transposed[0].fill_(float('nan'))
     c = torch.autograd.grad((y * w).sum(), [xs, lin.weight, lin.bias])
     assert all(torch.equal(p, q) for p, q in zip(a, c))
+
+
+@pytest.mark.parametrize('N,C,groups', [(18_063, 256, 226), (18_063, 512, 126), (1806, 256, 58), (5000, 64, 40), (60_211, 128, 942),
+                                        (333, 32, 3), (70, 96, 1)])
+def test_norm_with_the_statistics_fold_inside_the_launch_is_bit_identical(N, C, groups):
+    """k_norm_fold (round 5): the per-row-group statistics partials of a GEMM epilogue folded by every workgroup of the
+    normalisation launch for its own columns - mean / rstd and the outputs must equal the two-launch route (fold launch +
+    elementwise launch) BIT FOR BIT, forward and backward; shapes the host rule declines return STIN_E_UNSUPPORTED untouched."""
+    from surface_texture_inpainting_net_amd.plan import _ptr, _stream
+    lib = _lib_load()
+    g = torch.Generator(device=DEV).manual_seed(N + C)
+    x = torch.randn(N, C, generator=g, device=DEV) * 1.7 + 0.3
+    res = torch.randn(N, C, generator=g, device=DEV)
+    go = torch.randn(N, C, generator=g, device=DEV)
+    inv = torch.full((1,), 1.0 / N, device=DEV)
+    # moment partials of x itself, row groups of unequal size
+    cuts = torch.linspace(0, N, groups + 1).long().tolist()
+    pm = torch.stack([torch.stack([x[a:b].double().sum(0), x[a:b].double().pow(2).sum(0)]) for a, b in zip(cuts, cuts[1:])]).contiguous()
+    mean, rstd = SF.moments_final(pm, inv)
+    y_ref = torch.empty(N, C, device=DEV)
+    SF._call('stin_norm_act_res_fwd_f32', _ptr(x), C, _ptr(mean), _ptr(rstd), None, _ptr(res), C, N, C, 1, _ptr(y_ref), C, _stream(x))
+    rows = lib.stin_norm_fold_rows(N, C, groups)
+    m2, r2, y = torch.zeros(1, C, device=DEV), torch.zeros(1, C, device=DEV), torch.zeros(N, C, device=DEV)
+    rc = lib.stin_norm_act_res_fwd_fold_f32(_ptr(pm), groups, _ptr(x), C, _ptr(res), C, _ptr(inv), float(SF.EPS), N, C, _ptr(m2), _ptr(r2),
+                                            _ptr(y), C, _stream(x))
+    if rows <= 0:
+        assert rc != 0 and float(y.abs().max()) == 0.0       # declined before anything was enqueued
+        return
+    assert rc == 0
+    assert torch.equal(m2, mean) and torch.equal(r2, rstd) and torch.equal(y, y_ref)
+    # backward: partials of (dy xc, dy) as the dx product's epilogue writes them
+    xc = (x - mean).double()
+    n = (x - mean) * rstd
+    dy = (go * torch.where(n > 0, torch.ones_like(n), torch.exp(n))).double()
+    pb = torch.stack([torch.stack([(dy[a:b] * xc[a:b]).sum(0), dy[a:b].sum(0)]) for a, b in zip(cuts, cuts[1:])]).contiguous()
+    kk, mm = SF.norm_coef_from_partials(pb, rstd, inv)
+    d_ref = torch.empty(N, C, device=DEV)
+    SF._call('stin_norm_act_bwd_f32', _ptr(x), C, _ptr(go), C, _ptr(mean), _ptr(rstd), _ptr(rstd), _ptr(kk), _ptr(mm), None, None, N, C, 1,
+             _ptr(d_ref), C, _stream(x))
+    d = torch.zeros(N, C, device=DEV)
+    assert lib.stin_norm_act_bwd_fold_f32(_ptr(pb), groups, _ptr(x), C, _ptr(go), C, _ptr(mean), _ptr(rstd), _ptr(inv), N, C, _ptr(d), C,
+                                          _stream(x)) == 0
+    assert torch.equal(d, d_ref)
+    # strided rows (the residual is a column slice of Y in shortcut blocks)
+    big = torch.randn(N, C + 8, generator=g, device=DEV)
+    y3 = torch.zeros(N, C, device=DEV)
+    assert lib.stin_norm_act_res_fwd_fold_f32(_ptr(pm), groups, _ptr(x), C, _ptr(big[:, 4:]), C + 8, _ptr(inv), float(SF.EPS), N, C, _ptr(m2),
+                                              _ptr(r2), _ptr(y3), C, _stream(x)) == 0
+    SF._call('stin_norm_act_res_fwd_f32', _ptr(x), C, _ptr(mean), _ptr(rstd), None, _ptr(big[:, 4:]), C + 8, N, C, 1, _ptr(y_ref), C, _stream(x))
+    assert torch.equal(y3, y_ref)
 
 
 # --------------------------------------------------------- segment sum / pool / unpool
@@ -865,6 +916,9 @@ def test_model_against_reference_fixture(name):
     assert abs(float(loss.detach()) - float(fx.loss)) <= 1e-6
     loss.backward()
     scale = max(float(g.abs().max()) for g in fx.grads.values())
+    worst = max(float((p.grad.cpu() - fx.grads[k]).abs().max()) for k, p in net.named_parameters()) / scale
+    print('\n[fixture] %s: fwd %.2e, gx %.2e of scale, worst weight-gradient entry %.2e of scale'
+          % (name, float((out.detach().cpu() - fx.out).abs().max()), float((s.x.grad.cpu() - fx.gx).abs().max()) / float(fx.gx.abs().max()), worst))
     assert float((s.x.grad.cpu() - fx.gx).abs().max()) <= 1e-3 * float(fx.gx.abs().max())
     for k, p in net.named_parameters():
         assert float((p.grad.cpu() - fx.grads[k]).abs().max()) <= 1e-3 * scale, k
@@ -895,10 +949,11 @@ def test_secondary_norms_and_filters_vs_oracle(norm, filter_type):
     assert rep['max_rel'] <= bar[0] and rep['beyond'] <= bar[1] and rep['rel_l2'] <= bar[2], (rep, bar)
 
 
-# (worst entry / gradient scale, entries beyond 1e-3 of scale, relative L2): measured on MI355X in round 5 x 1.5 - a 400-vertex
-# mesh at ngf 8 has ~10 k gradient entries and no averaging, so one flipped decision is visible; the COUNT stays a handful
-SECONDARY_BARS = {('batch', 'edgeconv'): (2e-3, 8, 1e-3), ('none', 'edgeconvtransinv'): (2e-3, 8, 1e-3),
-                  ('instance', 'sageconvtransinv'): (2e-3, 8, 1e-3)}
+# (worst entry / gradient scale, entries beyond 1e-3 of scale, relative L2).  Measured on MI355X in round 5: worst 0.9-2.6e-6,
+# none beyond, relative L2 1.8-7.0e-6 - fp32 rounding, no decision flipped on these meshes; the bars leave ~8x for a
+# re-associated sum and are 60-100x below the 2e-3 of rounds 1-4
+SECONDARY_BARS = {('batch', 'edgeconv'): (2e-5, 0, 3e-5), ('none', 'edgeconvtransinv'): (2e-5, 0, 3e-5),
+                  ('instance', 'sageconvtransinv'): (2e-5, 0, 3e-5)}
 
 
 def test_batch_of_unequal_crops_four_levels_vs_oracle():
@@ -922,11 +977,11 @@ def test_batch_of_unequal_crops_four_levels_vs_oracle():
     stin_oracle.compute_loss(torch.where((bd.mask > 0).expand_as(bd.color), got, bd.color), bd.color, bd.mask).backward()
     assert float((got.detach().cpu() - want.detach()).abs().max()) <= FWD_TOL
     rep = grad_flip_report(net.named_parameters(), ref.parameters(), 'crops 4 levels')
-    # measured on MI355X in round 5 (x 1.5): see CROPS4_BARS
+    # measured on MI355X in round 5: worst entry 2.6e-5 of scale, none beyond 1e-3, relative L2 1.7e-5
     assert rep['max_rel'] <= CROPS4_BARS[0] and rep['beyond'] <= CROPS4_BARS[1] and rep['rel_l2'] <= CROPS4_BARS[2], rep
 
 
-CROPS4_BARS = (2e-3, 8, 1e-3)
+CROPS4_BARS = (1e-4, 0, 6e-5)
 
 
 def test_train_step_against_reference_fixture():
@@ -1120,8 +1175,9 @@ def test_mid_size_full_width_model_vs_oracle():
     assert rep['max_rel'] <= MID_BARS[0] and rep['beyond'] <= MID_BARS[1] and rep['rel_l2'] <= MID_BARS[2], rep
 
 
-# measured on MI355X in round 5 (x 1.5): worst entry / scale, entries beyond 1e-3 of scale (of 4.2 M), relative L2
-MID_BARS = (3e-3, 40, 1.5e-3)
+# (worst entry / scale, entries beyond 1e-3 of scale of 4.2 M, relative L2) = 1.5 x the round-5 measurement on MI355X
+# (8.2e-4, 0, 7.3e-4; the flip analysis is in the comment above)
+MID_BARS = (1.3e-3, 10, 1.1e-3)
 
 
 
