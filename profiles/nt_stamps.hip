@@ -1,7 +1,7 @@
 // Profiling harness (not part of the library): the all-columns NT kernel compiled with in-kernel s_memtime stamps.
 //   (add -DSTIN_NT_ABLATE_MASK=<bits> for a compile-time ablation of the panel kernel, see stin_gemm.hip)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DSTIN_NT_STAMPS -I surface_texture_inpainting_net_amd/csrc \
-//       -c profiles/nt_stamps.hip -o /tmp/nt_stamps.o && hipcc --offload-arch=gfx950 /tmp/nt_stamps.o <stin_wgrad.o stin_pack.o stin_api.o> -o profiles/_nt_stamps
+//       -c profiles/nt_stamps.hip -o /tmp/nt_stamps.o && hipcc --offload-arch=gfx950 /tmp/nt_stamps.o <stin_wgrad.o stin_pack.o stin_api.o> -o profiles/probes/nt_stamps
 #include "../surface_texture_inpainting_net_amd/csrc/stin_gemm.hip"
 #include <cstdio>
 #include <vector>

@@ -1,6 +1,6 @@
 // Profiling harness (not part of the library): the producer / consumer TN kernel compiled with in-kernel s_memtime stamps.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -DSTIN_WS_STAMPS -I surface_texture_inpainting_net_amd/csrc \
-//       profiles/tn_stamps.hip surface_texture_inpainting_net_amd/csrc/{stin_gemm,stin_api}.o -o profiles/_tn_stamps
+//       profiles/tn_stamps.hip surface_texture_inpainting_net_amd/csrc/{stin_gemm,stin_api}.o -o profiles/probes/tn_stamps
 // Prints, for a few blocks, the cycle stamps of producer wave 4 and consumer wave 0 (deltas between consecutive stamps).
 #include "../surface_texture_inpainting_net_amd/csrc/stin_wgrad.hip"
 #include <cstdio>

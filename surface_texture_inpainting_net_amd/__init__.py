@@ -6,7 +6,7 @@ import torch as _torch
 # ROCm 7.2 CLR: replaying a LINEAR captured HIP graph through the runtime's pre-built AQL packets ("graph packet capture")
 # faults with "Write access to a read-only page" once eager work (a pinned allocation + a device-to-host copy inside a
 # step) has run between two replays - reproduced with train_step.TrainStep(graph=True) at 20k vertices, gone with the
-# packet path switched off (profiles/_graph_debug.py; host cost of a replay unchanged).  The flag is read when the HIP
+# packet path switched off (profiles/probes/graph_debug.py; host cost of a replay unchanged).  The flag is read when the HIP
 # runtime initialises, i.e. at the first GPU call, so it has to be in the environment before that.  It is an OPT-IN: only
 # a process that asks for graph replay gets its environment changed - enable_graph_replay() before the first GPU call, or
 # STIN_GRAPH_REPLAY=1 exported when the package is imported.  Eager mode never needs it and is left alone.

@@ -281,8 +281,12 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
         if (link != nullptr && link->pre_partial != nullptr && link->pre_groups > 0 && !sid && B == 1 && gid == nullptr) {
             // the two column sums came out of the previous block's dx product (BwdLink): fold its partials - (round 5) inside the
             // normalisation launch itself where the row groups are few (k_norm_fold: every workgroup folds its own columns)
+            // Measured (profiles/r05_norm_fold.md): the forward form is 16 us where norm + fold were 19, the backward form 44 us
+            // where they were 39 (two fp64 folds per workgroup in front of the rows) and the step does not move either way - the
+            // backward form stays behind STIN_NORM_FOLD_BWD=1.
+            static const bool fold_bwd = getenv("STIN_NORM_FOLD_BWD") && atoi(getenv("STIN_NORM_FOLD_BWD")) != 0;
             int rc_fold = STIN_E_UNSUPPORTED;
-            if (N > 0 && stin_norm_fold_rows(N, Cout, link->pre_groups) > 0)
+            if (fold_bwd && N > 0 && stin_norm_fold_rows(N, Cout, link->pre_groups) > 0)
                 rc_fold = stin_norm_act_bwd_fold_f32(link->pre_partial, link->pre_groups, static_cast<const float*>(agg), Cout, gf, ldg, mean,
                                                      rstd, inv_cnt, N, Cout, static_cast<float*>(dagg), Cout, stream);
             if (rc_fold == STIN_OK) dagg_done = true;

@@ -17,7 +17,7 @@
 static inline void stin_clear_stale_error() { (void)hipGetLastError(); }
 
 // Fork without a marker packet (round 4).  hipEventRecord on the compute stream puts a barrier packet behind the kernel and the
-// next kernel waits for the command processor to retire it: ~4 us of idle compute stream per fork (profiles/_fork_bind_probe.hip:
+// next kernel waits for the command processor to retire it: ~4 us of idle compute stream per fork (profiles/probes/fork_bind_probe.hip:
 // record + wait + side kernel 16.1 us per link of an 11.0 us chain, event bound to the kernel's own completion signal 12.0).  A
 // caller that wants "this launch is done" as an event sets stin_tl_stop_event; a launch site that supports it passes the event as
 // hipExtLaunchKernelGGL's stopEvent and clears the variable (= "bound"); the caller records the event the ordinary way if the

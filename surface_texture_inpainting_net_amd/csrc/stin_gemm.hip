@@ -2762,7 +2762,7 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
         int occ = (int)(160 * 1024 / lds);
         // (round 4) at most two resident blocks per CU: with three or four (K chunks of 128: 32-44 KB of LDS per block) the blocks
         // of a CU re-stream the W panels against each other - 200 704 x 320 x 128: 136.6 us at four / three, 126.5 at two, 124 at one
-        // two-quad block (profiles/_nt_probe.py, STIN_STRIP_OCC sweep)
+        // two-quad block (profiles/probes/nt_probe.py, STIN_STRIP_OCC sweep)
         if (occ > 2) occ = 2;
         if (cfg == 22) occ = 1;                                       // eight-wave blocks: one per CU (18 063 x 1280 x 128: 39.2 -> 35.6 us)
         if (occ < 1) occ = 1;

@@ -746,7 +746,7 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_pair8(const stin_bf16* 
 }
 
 // H in {128, 256, 512, 1024, 2048}: G = H/8 capped at 64, VPL = H / (8 G).
-// U (neighbour rows in flight per lane group), MI355X, after the predicate-free rewrite (round 4, profiles/_edge8_sweep.py and
+// U (neighbour rows in flight per lane group), MI355X, after the predicate-free rewrite (round 4, profiles/probes/edge8_sweep.py and
 // _edge8_bwd_sweep.py; regular and Delaunay meshes): forward U = 2 up to H = 1024 (200 704 x 128: 63 us at U = 2, 65 / 68 / 66 at
 // 3 / 4 / 6; the Delaunay mesh 71 / 71 / 73 / 97 - a row whose degree is not a multiple of U re-loads its last neighbour; 1 M
 // vertices would take U = 6: 316 vs 342 us, not worth the irregular-mesh loss), U = 1 at H = 2048 (41 us vs 44 / 59 at 2 / 3);
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(BLOCK) void k_segment_sum(const T* __restrict__ src
 // Round 3 form for rows whose chunks divide evenly over the lanes (C / 4 = G * VPL): no per-chunk predicates, and FEWER
 // lanes per row than chunks - each lane owns VPL = 2 chunks 16 G bytes apart, so a wave covers twice the rows and every
 // load instruction touches twice as many independent rows (memory-level parallelism at the same register cost).  Measured on
-// MI355X (profiles/_seg_tune.py): the standalone scatter-add (E = 1.2 M random 256-byte rows -> N = 200 k) 90.1 us with
+// MI355X (profiles/probes/seg_tune.py): the standalone scatter-add (E = 1.2 M random 256-byte rows -> N = 200 k) 90.1 us with
 // G = 16 / U = 4 -> 72.6 us with G = 8 / VPL = 2 / U = 2 -> 68.9 us with non-temporal loads on top (0.50 -> 0.66 of the HBM
 // peak); the unpool backward of the step 28.5 -> 23.3 us (C = 128), 17.6 -> 15.5 us (C = 256).  NT (non-temporal loads of the
 // gathered rows) only pays when the gathered source cannot stay in the 256 MB Infinity Cache anyway: cache-resident sources
@@ -1296,7 +1296,7 @@ int edge_bwd_mask_pair_impl(const float* G, int64_t ldg, const uint32_t* mask, c
         if (us == 1) STIN_PAIR(64, 2, 2);             // (STIN_U(2, 2) = 1 row: the round-2 choice)
         else if (us == 3) STIN_PAIR_U(3);
         else if (us == 4) STIN_PAIR_U(4);
-        else STIN_PAIR_U(2);                          // 18 063 x 512: 56.8 us at 1, 54.0 at 2, 56.1 / 58.8 at 3 / 4 (profiles/_edge512_sweep.py)
+        else STIN_PAIR_U(2);                          // 18 063 x 512: 56.8 us at 1, 54.0 at 2, 56.1 / 58.8 at 3 / 4 (profiles/probes/edge512_sweep.py)
 #undef STIN_PAIR_U
     }
     else if (vpl <= 4) STIN_PAIR(64, 4, 2);           // 1024
