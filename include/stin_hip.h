@@ -419,6 +419,40 @@ int stin_bn_mean_bwd_f32(const float* m, int64_t ldm, const float* g, int64_t ld
 int stin_bn_running_stats_f32(const float* mean, const float* rstd, int C, float eps, float unbias, float momentum,
                               float* running_mean, float* running_var, stin_stream_t stream);
 
+/* Round 5: the small passes of one fused EdgeConv(BN) layer of SingleConvMeshNet (singleconvmeshnet.EdgeConvBNLayerFn; reference
+ * models/modules/edge_conv_filter.py:34-44 inside models/singleconvmeshnet.py:37-66 `ResBlock`), which were framework kernels:
+ * stin_scmn_pack_f32: W1 [h2, 2 cin] (trans_inv: [h2, cin]), W2 [cout, h2], the two BatchNorm1d affine pairs ->
+ *   wcat [2 h2, cin] = [Wa - Wb ; Wb] (trans_inv: [-W1 ; W1]), wcatT [cin, 2 h2], w2T [h2, cout],
+ *   gb1 [2, h2] = [gamma1 ; beta1], gb2 [2, cout] (the `coef` operand of stin_colreduce_f32(STIN_RED_DOT_BN*)).
+ * stin_scmn_unpack_f32: dwcat [2 h2, cin] -> dW1 in the reference layout (d/dWa = top, d/dWb = bottom - top; trans_inv: bottom - top).
+ * stin_bn_affine_res_fwd_f32: y = [relu](res + [rowptr[r + 1] > rowptr[r]] (gamma ((x - mean) rstd) + beta)) over N rows - the
+ *   BatchNorm affine of the aggregated rows, the "vertex has an in-edge" mask, the ResBlock's `x + f(x)` and its ReLU
+ *   (singleconvmeshnet.py:60-66) in one pass; rowptr / res may be NULL.
+ * stin_relu_mask_bwd_f32: g_eff = g [y > 0] (relu != 0; else g), g_in = g_eff [row has an in-edge]; g_eff may be NULL; both
+ *   outputs are [N, C] with pitch C. */
+/* The per-EDGE Linear of that layer with the BatchNorm1d + ReLU of its input applied while the operand rows are staged
+ * (edge_conv_filter.py:36-40: Lin -> BN -> ReLU -> Lin): the normalised [E, 2 cout] matrix is never written.
+ *   stin_gemm_nt_bn_f32: C [M, Nc] = relu(gamma ((A - mean) rstd) + beta) W^T, W plain fp32 [Nc, K] (no pre-split flags);
+ *   stin_gemm_tn_bn_f32: dW [Nc, K] = G^T relu(gamma ((X - mean) rstd) + beta)  (the weight gradient from the pre-norm rows).
+ * mean / rstd / gamma / beta: [K] fp32.  The transform is evaluated as relu(v s + t) with s = gamma rstd, t = beta - mean s
+ * (3 operations per element on the vector-ALU-bound staging threads; equals stin_bn_act_fwd_f32(act = 1) to fp32 rounding,
+ * ~1e-7 relative; both entry points use the same form).  precision as stin_gemm_nt_f32 / stin_gemm_tn_f32; workspace = stin_gemm_tn_workspace_bytes(M, Nc, K, 0). */
+int stin_gemm_nt_bn_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, int64_t M, int Nc, int K, float* C, int64_t ldc, int precision,
+                        stin_stream_t stream);
+int stin_gemm_tn_bn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, int64_t M, int Nc, int K, float* dW, int64_t lddw, int precision,
+                        void* workspace, size_t workspace_bytes, stin_stream_t stream);
+int stin_scmn_pack_f32(const float* W1, const float* W2, const float* gamma1, const float* beta1, const float* gamma2,
+                       const float* beta2, int cin, int h2, int cout, int trans_inv, float* wcat, float* wcatT, float* w2T,
+                       float* gb1, float* gb2, stin_stream_t stream);
+int stin_scmn_unpack_f32(const float* dwcat, int cin, int h2, int trans_inv, float* dW1, stin_stream_t stream);
+int stin_bn_affine_res_fwd_f32(const float* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, const int32_t* rowptr, const float* res, int64_t ldres, int64_t N, int C,
+                               int relu, float* y, int64_t ldy, stin_stream_t stream);
+int stin_relu_mask_bwd_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, const int32_t* rowptr, int64_t N, int C,
+                           int relu, float* g_eff, float* g_in, stin_stream_t stream);
+
 /* ------------------------------------------------------- parameter-side helpers --
  * pack: the reference-layout EdgeConv parameters (first_filter.nn.0.{weight,bias} = W1 [H, 2Cin]
  * (or [H, Cin] for EdgeConvTransInv), first_filter.nn.2.weight = W2 [Cout, H], shortcut.{weight,bias})

@@ -43,9 +43,40 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / a.steps
-    print(json.dumps({'model': 'SingleConvMeshNet', 'vertices': int(s.x.shape[0]), 'edges': int(s.edge_index.shape[1]),
-                      'ms_per_step': round(ms, 3), 'vertices_per_s': round(s.x.shape[0] / ms * 1e3),
-                      'peak_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2), 'loss': float(loss)}))
+    out = {'model': 'SingleConvMeshNet', 'vertices': int(s.x.shape[0]), 'edges': int(s.edge_index.shape[1]),
+           'ms_per_step': round(ms, 3), 'vertices_per_s': round(s.x.shape[0] / ms * 1e3),
+           'peak_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2), 'loss': float(loss)}
+    # roofline of the level-0 kernels (HIP events around the launches of one more step; algorithmic bytes: every gathered row
+    # charged once per edge, int32 indices) and of the per-edge GEMM (executed 16-bit MFMA flops, 3 per fp32 product)
+    from surface_texture_inpainting_net_amd import functional as SF
+    names = ['stin_gather_add_rows_f32', 'stin_segment_sum_f32', 'stin_gemm_nt_bn_f32', 'stin_gemm_tn_bn_f32']
+    SF.KernelTimer.start(names, max_records=4000)
+    step()
+    times = SF.KernelTimer.stop()
+    n0, e0 = int(s.x.shape[0]), int(s.edge_index.shape[1])
+    roof = {}
+    for (name, tag), ts in times.items():
+        t = sum(ts) / len(ts)
+        if name == 'stin_gather_add_rows_f32' and tag and tag[0] == e0:
+            e, h = tag
+            nbytes = 3 * e * h * 4 + 8 * e
+            roof['gather_add_rows[E=%d,H=%d]' % (e, h)] = {'avg_us': t * 1e6, 'launches': len(ts), 'algorithmic_MB': nbytes / 1e6,
+                                                            'GBps': nbytes / t / 1e9, 'frac_of_hbm_peak': nbytes / t / 1e9 / 8000.0}
+        if name == 'stin_segment_sum_f32' and tag and tag[0] == e0 and tag[1] == n0:
+            e, n, c = tag
+            nbytes = e * c * 4 + n * c * 4 + 4 * e + 4 * (n + 1)
+            roof['segment_mean[E=%d,N=%d,C=%d]' % (e, n, c)] = {'avg_us': t * 1e6, 'launches': len(ts), 'algorithmic_MB': nbytes / 1e6,
+                                                                 'GBps': nbytes / t / 1e9, 'frac_of_hbm_peak': nbytes / t / 1e9 / 8000.0}
+        if name in ('stin_gemm_nt_bn_f32', 'stin_gemm_tn_bn_f32') and tag and tag[0] == e0:
+            m, nc, k = tag
+            flops = 2.0 * m * nc * k * 3
+            minb = 4.0 * (m * k + m * nc)
+            roof['%s[M=%d,Nc=%d,K=%d]' % (name, m, nc, k)] = {
+                'avg_us': t * 1e6, 'launches': len(ts), 'mfma_TFLOPs_executed': flops / t / 1e12, 'frac_of_16bit_mfma_peak': flops / t / 1e12 / 2500.0,
+                'min_bytes_MB': minb / 1e6, 'GBps_min_traffic': minb / t / 1e9, 'frac_of_hbm_peak': minb / t / 1e9 / 8000.0,
+                'bound': 'hbm (operand bytes): the product of an [E, 2 cout] by a [cout, 2 cout] matrix moves 4 (K + Nc) bytes per 6 K Nc flops'}
+    out['roofline'] = roof
+    print(json.dumps(out))
 
 
 if __name__ == '__main__':

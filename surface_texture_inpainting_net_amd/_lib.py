@@ -155,6 +155,14 @@ SIGNATURES['stin_norm_bwd_coef_m_quirk_f32'] = (c_int, [c_ptr, c_ptr, c_ptr, c_p
 SIGNATURES['stin_gather_add_rows_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_bn_mean_bwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64] + [c_ptr] * 7 + [c_f32, c_i64, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_bn_running_stats_f32'] = (c_int, [c_ptr, c_ptr, c_int, c_f32, c_f32, c_f32, c_ptr, c_ptr, c_ptr])
+SIGNATURES['stin_gemm_nt_bn_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_int, c_ptr])
+SIGNATURES['stin_gemm_tn_bn_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_int,
+                                             c_ptr, c_size, c_ptr])
+SIGNATURES['stin_scmn_pack_f32'] = (c_int, [c_ptr] * 6 + [c_int] * 4 + [c_ptr] * 6)
+SIGNATURES['stin_scmn_unpack_f32'] = (c_int, [c_ptr, c_int, c_int, c_int, c_ptr, c_ptr])
+SIGNATURES['stin_bn_affine_res_fwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,
+                                                    c_i64, c_ptr])
+SIGNATURES['stin_relu_mask_bwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr])
 SIGNATURES['stin_bn_act_fwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_bn_act_bwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int,
                                              c_int, c_ptr, c_i64, c_ptr])

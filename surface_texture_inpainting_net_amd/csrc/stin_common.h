@@ -103,7 +103,50 @@ template <typename T> static inline bool stin_aligned_vec4(const void* p) {
 // ---- weight-gradient (TN) products shared between stin_gemm.hip and stin_wgrad.hip ------------------------------------
 // One dW[Nc, K (+1)] = G[M, Nc]^T [X[M, K] | w] product split over row chunks: its geometry and operands as the TN kernels
 // take them.  Pointers are typed float* also for bf16 storage (only the fp32 kernels read them through this struct).
+// Operand transform of the SingleConvMeshNet products (round 5): the operand rows are read as relu(bn(v)) per column - BatchNorm1d
+// + ReLU of the E x 2 cout edge rows applied while the GEMM stages them, so that the normalised matrix never exists in memory
+// (stin_gemm_nt_bn_f32: the A operand; stin_gemm_tn_bn_f32: the X operand).  mean == NULL: off.
+// The staging threads of these kernels are bound by vector-ALU work (the 16-bit split), so the transform is the affine form
+//   relu(v s + t),  s = gamma rstd,  t = beta - mean s        (mul, add, max: 3 operations per element)
+// with (s, t) formed once per thread for its fixed columns - not stin_bn_act_fwd_f32's gamma ((v - mean) rstd) + beta (6
+// operations; measured +80 % on the four-wave TN kernel, +50 % on the producer / consumer kernel).  The two agree to fp32 rounding
+// (~1e-7 relative); forward product and weight gradient use the SAME form, so they stay consistent with each other.
+struct stin_bn_tf {
+    const float *mean, *rstd, *gamma, *beta;
+};
+__device__ __forceinline__ void stin_bn_st(const stin_bn_tf& tf, int c, float& s, float& t) {
+    s = tf.gamma[c] * tf.rstd[c];
+    t = tf.beta[c] - tf.mean[c] * s;
+}
+__device__ __forceinline__ float stin_bn_relu(float v, float s, float t) { return fmaxf(v * s + t, 0.f); }
+// (s, t) of columns [c, c + 4) in registers (a staging thread's columns are fixed: formed once)
+struct stin_bn_coef4 {
+    float4 s, t;
+};
+__device__ __forceinline__ stin_bn_coef4 stin_bn_coef4_load(const stin_bn_tf& tf, int c) {
+    stin_bn_coef4 q;
+    stin_bn_st(tf, c, q.s.x, q.t.x);
+    stin_bn_st(tf, c + 1, q.s.y, q.t.y);
+    stin_bn_st(tf, c + 2, q.s.z, q.t.z);
+    stin_bn_st(tf, c + 3, q.s.w, q.t.w);
+    return q;
+}
+__device__ __forceinline__ float4 stin_bn_relu4(float4 v, const stin_bn_coef4& q) {
+    return make_float4(stin_bn_relu(v.x, q.s.x, q.t.x), stin_bn_relu(v.y, q.s.y, q.t.y), stin_bn_relu(v.z, q.s.z, q.t.z),
+                       stin_bn_relu(v.w, q.s.w, q.t.w));
+}
+// ragged / unaligned form: element e of the float4 is column c + e, valid while c + e < lim
+__device__ __forceinline__ float4 stin_bn_relu4_ragged(float4 v, const stin_bn_tf& tf, int c, int lim) {
+    float s, t;
+    if (c + 0 < lim) { stin_bn_st(tf, c, s, t); v.x = stin_bn_relu(v.x, s, t); }
+    if (c + 1 < lim) { stin_bn_st(tf, c + 1, s, t); v.y = stin_bn_relu(v.y, s, t); }
+    if (c + 2 < lim) { stin_bn_st(tf, c + 2, s, t); v.z = stin_bn_relu(v.z, s, t); }
+    if (c + 3 < lim) { stin_bn_st(tf, c + 3, s, t); v.w = stin_bn_relu(v.w, s, t); }
+    return v;
+}
+
 struct stin_tn_problem {
+    stin_bn_tf xtf;                    // transform of the X operand (mean == NULL: none)
     const float *G, *X, *row_w;
     float* slab;                       // [chunks][Nc * Kq + roundup4(Nc)] partial results
     int64_t ldg, ldx, ld_w, M, chunks;

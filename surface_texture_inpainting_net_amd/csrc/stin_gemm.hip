@@ -56,7 +56,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt(const float* __restrict__ A, 
                                                    const float* __restrict__ bias,
                                                    const float* __restrict__ row_mask, int64_t ld_mask,
                                                    const float* __restrict__ res, int64_t ld_res, int64_t M,
-                                                   int Nc, int K, float* __restrict__ C, int64_t ldc) {
+                                                   int Nc, int K, float* __restrict__ C, int64_t ldc, const stin_bn_tf tf) {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
     constexpr int A_F4 = BM * BK / 4 / BLOCK, W_F4 = BN * BK / 4 / BLOCK;   // float4 per thread per tile
     static_assert(A_F4 >= 1 && W_F4 >= 1, "tile too small for 256 threads");
@@ -80,8 +80,23 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt(const float* __restrict__ A, 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[A_F4], rw[W_F4];
+    // (round 5) optional operand transform relu(bn(.)) of the A columns: applied when the tile is STORED into LDS, not where it is
+    // loaded - the loads must stay in flight during the MFMAs of the previous tile (a use right behind the load drains them:
+    // measured +25 % on this kernel, +70 % on the TN kernels).  Zero padding may pass through it: padded rows are never stored
+    // and padded k-columns meet zero columns of W.
+    stin_bn_coef4 cq;                                                             // (s, t) of this thread's four columns of the tile in `ra`
+    cq.s = cq.t = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_tiles = [&](int k0) {
         const int k = k0 + kq * 4;
+        if (tf.mean != nullptr) {
+            if (VEC) cq = stin_bn_coef4_load(tf, k < K ? k : 0);
+            else {
+                float* sp = reinterpret_cast<float*>(&cq.s);
+                float* tp = reinterpret_cast<float*>(&cq.t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) stin_bn_st(tf, k + e < K ? k + e : 0, sp[e], tp[e]);
+            }
+        }
 #pragma unroll
         for (int s = 0; s < A_F4; ++s) {
             const int64_t row = m0 + r0 + s * RSTEP;
@@ -118,6 +133,10 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt(const float* __restrict__ A, 
         }
     };
     auto store_tiles = [&]() {
+        if (tf.mean != nullptr) {                                                     // block-uniform
+#pragma unroll
+            for (int s = 0; s < A_F4; ++s) ra[s] = stin_bn_relu4(ra[s], cq);
+        }
 #pragma unroll
         for (int s = 0; s < A_F4; ++s) {
             const int row = r0 + s * RSTEP;
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
                                                          const float* __restrict__ row_mask, int64_t ld_mask,
                                                          const float* __restrict__ res, int64_t ld_res,
                                                          int64_t M, int Nc, int K, float* __restrict__ C,
-                                                         int64_t ldc) {
+                                                         int64_t ldc, const stin_bn_tf tf) {
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
     constexpr int A_F4 = BM * BKH / 4 / BLOCK, W_F4 = BN * BKH / 4 / BLOCK;
     static_assert(A_F4 >= 1 && W_F4 >= 1, "tile too small for 256 threads");
@@ -267,8 +286,23 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[A_F4], rw[W_F4];
+    // (round 5) optional operand transform relu(bn(.)) of the A columns: applied when the tile is STORED into LDS, not where it is
+    // loaded - the loads must stay in flight during the MFMAs of the previous tile (a use right behind the load drains them:
+    // measured +25 % on this kernel, +70 % on the TN kernels).  Zero padding may pass through it: padded rows are never stored
+    // and padded k-columns meet zero columns of W.
+    stin_bn_coef4 cq;                                                             // (s, t) of this thread's four columns of the tile in `ra`
+    cq.s = cq.t = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_tiles = [&](int k0) {
         const int k = k0 + kq * 4;
+        if (tf.mean != nullptr) {
+            if (VEC) cq = stin_bn_coef4_load(tf, k < K ? k : 0);
+            else {
+                float* sp = reinterpret_cast<float*>(&cq.s);
+                float* tp = reinterpret_cast<float*>(&cq.t);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) stin_bn_st(tf, k + e < K ? k + e : 0, sp[e], tp[e]);
+            }
+        }
 #pragma unroll
         for (int s = 0; s < A_F4; ++s) {
             const int64_t row = m0 + r0 + s * RSTEP;
@@ -305,6 +339,10 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
         }
     };
     auto store_tiles = [&]() {
+        if (tf.mean != nullptr) {                                                     // block-uniform
+#pragma unroll
+            for (int s = 0; s < A_F4; ++s) ra[s] = stin_bn_relu4(ra[s], cq);
+        }
 #pragma unroll
         for (int s = 0; s < A_F4; ++s) {
             const int row = r0 + s * RSTEP;
@@ -1278,7 +1316,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, 
                                                    const float* __restrict__ X, int64_t ldx, int64_t M, int Nc,
                                                    int K, int Kq, int has_bias, const float* __restrict__ row_w, int64_t ld_w,
                                                    int rows_per_chunk, int tiles_i, int tiles_j, int64_t chunks,
-                                                   float* __restrict__ slab) {
+                                                   float* __restrict__ slab, const stin_bn_tf xtf) {
     constexpr int MT = TI / 64, NT = TJ / 64;                    // 32x32 MFMA tiles per wave
     constexpr int GF4 = TN_R * TI / 4 / BLOCK, XF4 = TN_R * TJ / 4 / BLOCK;   // float4 per thread per slab
     constexpr int GC4 = TI / 4, XC4 = TJ / 4;                    // float4 columns
@@ -1316,6 +1354,14 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, 
     float4 rg[GF4], rx[XF4];
     float rwt[GF4];
 
+    stin_bn_coef4 xq;                                                  // (s, t) of this thread's fixed X columns (transform at STORE time)
+    xq.s = xq.t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xtf.mean != nullptr) {
+        float* sp = reinterpret_cast<float*>(&xq.s);
+        float* tp = reinterpret_cast<float*>(&xq.t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) stin_bn_st(xtf, j0 + xc * 4 + e < K ? j0 + xc * 4 + e : 0, sp[e], tp[e]);
+    }
     auto load_slab = [&](int64_t m0) {
 #pragma unroll
         for (int s = 0; s < GF4; ++s) {
@@ -1367,7 +1413,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn(const float* __restrict__ G, 
             bs.w += rwt[s] * rg[s].w;
         }
 #pragma unroll
-        for (int s = 0; s < XF4; ++s) st4(&Xs[buf][xr + s * (BLOCK / XC4)][xc * 4], rx[s]);
+        for (int s = 0; s < XF4; ++s) st4(&Xs[buf][xr + s * (BLOCK / XC4)][xc * 4], xtf.mean != nullptr ? stin_bn_relu4(rx[s], xq) : rx[s]);
     };
 
     const int kh = lane >> 5, li = lane & 31;
@@ -1435,7 +1481,7 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
                                                          const float* __restrict__ X, int64_t ldx, int64_t M,
                                                          int Nc, int K, int Kq, int has_bias, const float* __restrict__ row_w,
                                                          int64_t ld_w, int rows_per_chunk, int tiles_i, int tiles_j,
-                                                         int64_t chunks, float* __restrict__ slab) {
+                                                         int64_t chunks, float* __restrict__ slab, const stin_bn_tf xtf) {
     constexpr int MT = TI / 64, NT = TJ / 64;
     constexpr int ITEMS = 2 * (TI + TJ);                          // 4x4 patches per slab (G then X)
     constexpr int PASSES = ITEMS / BLOCK;                          // 1, 1.5 -> handled as 2 with a guard, or 2
@@ -1479,6 +1525,18 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
         bool pv[4];
     };
     Slab S0, S1;
+    stin_bn_coef4 xq[NPASS];                                       // (s, t) of the X patches' columns: fixed per thread and pass
+    if (xtf.mean != nullptr) {                                     // (the transform itself runs at STORE time, see k_gemm_nt_bf16s)
+#pragma unroll
+        for (int s = 0; s < NPASS; ++s) {
+            const int item = tid + s * BLOCK;
+            const int c = j0 + ((item >= 2 * TI ? item - 2 * TI : 0) / 8) * 4;
+            float* sp = reinterpret_cast<float*>(&xq[s].s);
+            float* tp = reinterpret_cast<float*>(&xq[s].t);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stin_bn_st(xtf, c + e < K ? c + e : 0, sp[e], tp[e]);
+        }
+    }
     auto load_slab = [&](Slab& P, int64_t m0) {
 #pragma unroll
         for (int s = 0; s < NPASS; ++s) {
@@ -1538,10 +1596,15 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_bf16s(const float* __restrict
             }
             __bf16* dst = isG ? &Gt[0][c4 * 4][rg * 4] : &Xt[0][c4 * 4][rg * 4];
             const int plane = (isG ? TI : TJ) * TNB_PITCH;
-            float col[4][4] = {{P.patch[s][0].x, P.patch[s][1].x, P.patch[s][2].x, P.patch[s][3].x},
-                               {P.patch[s][0].y, P.patch[s][1].y, P.patch[s][2].y, P.patch[s][3].y},
-                               {P.patch[s][0].z, P.patch[s][1].z, P.patch[s][2].z, P.patch[s][3].z},
-                               {P.patch[s][0].w, P.patch[s][1].w, P.patch[s][2].w, P.patch[s][3].w}};
+            float4 pr[4] = {P.patch[s][0], P.patch[s][1], P.patch[s][2], P.patch[s][3]};
+            if (!isG && xtf.mean != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pr[r] = stin_bn_relu4(pr[r], xq[s]);
+            }
+            float col[4][4] = {{pr[0].x, pr[1].x, pr[2].x, pr[3].x},
+                               {pr[0].y, pr[1].y, pr[2].y, pr[3].y},
+                               {pr[0].z, pr[1].z, pr[2].z, pr[3].z},
+                               {pr[0].w, pr[1].w, pr[2].w, pr[3].w}};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -2637,7 +2700,7 @@ inline bool tn_one_per_cu(int storage, int precision, int TI, int TJ, int64_t M)
 static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                             const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
                             int Nc, int K, float* C, int64_t ldc, int precision, double* colstats, stin_stream_t stream_,
-                            const NtDotElu* dotelu = nullptr) {
+                            const NtDotElu* dotelu = nullptr, const stin_bn_tf* tf = nullptr) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
@@ -2649,9 +2712,14 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
                      precision == STIN_GEMM_F16X3,
                  STIN_E_UNSUPPORTED);
     STIN_REQUIRE(!wpre || precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_F16X3, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(tf == nullptr || (!wpre && colstats == nullptr && dotelu == nullptr), STIN_E_UNSUPPORTED);   // (the tiled kernels only)
     if (M == 0) return STIN_OK;
     STIN_REQUIRE(A && W && C, STIN_E_NULL);
-    const bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldw % 4 == 0) && stin_aligned16(A) && stin_aligned16(W);
+    bool vec = (K % 4 == 0) && (lda % 4 == 0) && (ldw % 4 == 0) && stin_aligned16(A) && stin_aligned16(W);
+    if (tf != nullptr) {
+        STIN_REQUIRE(tf->mean && tf->rstd && tf->gamma && tf->beta, STIN_E_NULL);
+        vec = vec && stin_aligned16(tf->mean) && stin_aligned16(tf->rstd) && stin_aligned16(tf->gamma) && stin_aligned16(tf->beta);
+    }
     // Tile choice, from per-shape sweeps on MI355X (profiles/gemm_tiles.py) and whole-step A/B runs: the skinny GEMMs of the
     // shipped 3-level network (K <= 256, or K >= 512 with only 256 output columns) are latency-bound, so the 64x64 tile (4x
     // the blocks in flight) wins there.  Long reductions with enough tiles (the 1024..4096-wide layers of a 5-level network:
@@ -2660,7 +2728,10 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
     static const int64_t min_blocks = getenv("STIN_NT_MINBLOCKS") ? atoi(getenv("STIN_NT_MINBLOCKS")) : 500;   // tuning aid
     const int force_tile = stin_nt_force_tile();   // tuning aid: 0 = rule above, 1 = 128x128, 2 = 128x64, 3 = 64x64
     const bool big_tile = Nc % 128 == 0 && K >= 512 && blocks(128, 128) >= min_blocks;
-#define STIN_NT_ARGS A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc
+    stin_bn_tf tf_arg;
+    tf_arg.mean = tf_arg.rstd = tf_arg.gamma = tf_arg.beta = nullptr;
+    if (tf != nullptr) tf_arg = *tf;
+#define STIN_NT_ARGS A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc, tf_arg
 #define STIN_NT(KERNEL, BM_, BN_, WM_, WN_, ...)                                                                  \
     do {                                                                                                          \
         dim3 grid(nt_grid(M, Nc, BM_, BN_));                                                                      \
@@ -2822,6 +2893,20 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
     return gemm_nt_f32_impl(A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc, precision, nullptr, stream);
 }
 
+// C = relu(gamma ((A - mean) rstd) + beta) W^T: BatchNorm1d + ReLU over the columns of A applied while the rows are staged
+// (SingleConvMeshNet's per-EDGE product: the normalised [E, 2 cout] matrix never exists in memory).  W plain fp32 [Nc, K].
+extern "C" int stin_gemm_nt_bn_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, int64_t M, int Nc, int K, float* C, int64_t ldc,
+                                   int precision, stin_stream_t stream) {
+    STIN_REQUIRE((precision & (STIN_GEMM_W_PRESPLIT | STIN_GEMM_W_FRAG)) == 0, STIN_E_UNSUPPORTED);
+    stin_bn_tf tf;
+    tf.mean = mean;
+    tf.rstd = rstd;
+    tf.gamma = gamma;
+    tf.beta = beta;
+    return gemm_nt_f32_impl(A, lda, W, ldw, nullptr, nullptr, 0, nullptr, 0, M, Nc, K, C, ldc, precision, nullptr, stream, nullptr, &tf);
+}
+
 // The GEMM plus the FIRST stage of the instance-norm statistics of its output: colstats [groups][2][Nc] doubles, groups =
 // ceil(M / 64) (stin_gemm_nt_colstats_groups; 0 = this shape / precision does not support it: only the all-columns kernel's
 // blocks own whole rows).  Second stage: stin_moments_final_f32.
@@ -2905,6 +2990,7 @@ int stin_tn_problem_init(stin_tn_problem* p, int storage, const void* G, int64_t
                          int* ws_eligible) {
     STIN_REQUIRE(M >= 0 && Nc > 0 && K > 0 && ldg >= Nc && ldx >= K, STIN_E_SIZE);
     STIN_REQUIRE(slab && (M == 0 || (G && X)), STIN_E_NULL);
+    p->xtf.mean = p->xtf.rstd = p->xtf.gamma = p->xtf.beta = nullptr;      // (set by the caller after init: stin_gemm_tn_bn_f32)
     p->G = static_cast<const float*>(G);
     p->X = static_cast<const float*>(X);
     p->row_w = static_cast<const float*>(row_w);
@@ -3006,13 +3092,13 @@ int stin_tn_slabs(const stin_tn_problem* p, int storage, int precision, stin_str
     }
 #define STIN_TN(TI_, TJ_)                                                                                            \
     do {                                                                                                             \
-        if (vec) hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
-        else hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
+        if (vec) hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab, p->xtf); \
+        else hipLaunchKernelGGL((k_gemm_tn<TI_, TJ_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab, p->xtf);    \
     } while (0)
 #define STIN_TNB(TI_, TJ_, NS_)                                                                                      \
     do {                                                                                                             \
-        if (vec) hipLaunchKernelGGL((k_gemm_tn_bf16s<TI_, TJ_, NS_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab); \
-        else hipLaunchKernelGGL((k_gemm_tn_bf16s<TI_, TJ_, NS_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab);    \
+        if (vec) hipLaunchKernelGGL((k_gemm_tn_bf16s<TI_, TJ_, NS_, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab, p->xtf); \
+        else hipLaunchKernelGGL((k_gemm_tn_bf16s<TI_, TJ_, NS_, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, stream, G, ldg, X, ldx, M, Nc, K, Kq, has_bias, row_weight, ld_weight, rows, tiles_i, tiles_j, chunks, slab, p->xtf);    \
     } while (0)
 #define STIN_TN_PICK(LAUNCH, ...)                                   \
     do {                                                            \
@@ -3032,7 +3118,8 @@ int stin_tn_slabs(const stin_tn_problem* p, int storage, int precision, stin_str
 
 static int gemm_tn_f32_impl(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int Nc, int K,
                            int ones_column, const float* row_weight, int64_t ld_weight, float* dW, int64_t lddw, float* db,
-                           int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+                           int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream_,
+                           const stin_bn_tf* xtf = nullptr) {
     stin_clear_stale_error();
     hipStream_t stream = (hipStream_t)stream_;
     const int Kp = K + ((ones_column && db == nullptr) ? 1 : 0);
@@ -3045,6 +3132,12 @@ static int gemm_tn_f32_impl(const float* G, int64_t ldg, const float* X, int64_t
     stin_tn_problem p;
     int rc = stin_tn_problem_init(&p, 0, G, ldg, X, ldx, M, Nc, K, ones_column, row_weight, ld_weight, precision, slab, nullptr);
     if (rc != STIN_OK) return rc;
+    if (xtf != nullptr) {                     // X read as relu(bn(X)) per column (the tiled kernels and the producer / consumer kernel)
+        STIN_REQUIRE(xtf->mean && xtf->rstd && xtf->gamma && xtf->beta, STIN_E_NULL);
+        STIN_REQUIRE(p.TI != 0, STIN_E_UNSUPPORTED);                                      // (not the skinny-K kernel)
+        p.xtf = *xtf;
+        if (!(stin_aligned16(xtf->mean) && stin_aligned16(xtf->rstd) && stin_aligned16(xtf->gamma) && stin_aligned16(xtf->beta))) p.vec = 0;
+    }
     rc = stin_tn_slabs(&p, 0, precision, stream_);
     if (rc != STIN_OK) return rc;
     const int64_t n4 = (int64_t)Nc * p.Kq / 4 + (p.has_bias ? (Nc + 3) / 4 : 0);
@@ -3057,6 +3150,18 @@ extern "C" int stin_gemm_tn_f32(const float* G, int64_t ldg, const float* X, int
                                 int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
     return gemm_tn_f32_impl(G, ldg, X, ldx, M, Nc, K, ones_column, row_weight, ld_weight, dW, lddw, nullptr, precision, workspace,
                             workspace_bytes, stream_);
+}
+// dW [Nc, K] = G^T relu(gamma ((X - mean) rstd) + beta): the weight gradient of SingleConvMeshNet's per-edge Linear from the
+// PRE-normalisation rows (the BatchNorm1d + ReLU of stin_gemm_nt_bn_f32 applied to the X operand while it is staged)
+extern "C" int stin_gemm_tn_bn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, int64_t M, int Nc, int K, float* dW, int64_t lddw,
+                                   int precision, void* workspace, size_t workspace_bytes, stin_stream_t stream_) {
+    stin_bn_tf tf;
+    tf.mean = mean;
+    tf.rstd = rstd;
+    tf.gamma = gamma;
+    tf.beta = beta;
+    return gemm_tn_f32_impl(G, ldg, X, ldx, M, Nc, K, 0, nullptr, 0, dW, lddw, nullptr, precision, workspace, workspace_bytes, stream_, &tf);
 }
 // weight gradient dW [Nc, K] (row pitch lddw >= K) and bias gradient db [Nc] as SEPARATE destinations - e.g. the views of an
 // nn.Linear's weight.grad / bias.grad in a flat gradient bucket: no [Nc, K + 1] intermediate and no slicing copies afterwards

@@ -125,7 +125,12 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_tn_ws(const stin_tn_batch b
         // a column group past Nc / K reads column group 0 instead (valid memory): the tile columns it feeds are never stored,
         // so nothing has to be zeroed for them (Nc, K are multiples of 4: a float4 is wholly in or out)
         const float* gp = G + (i0 + c4 * 4 < Nc ? i0 + c4 * 4 : 0) + (mb + rg * 4) * ldg;     // row rg * 4 of the NEXT slab to load
-        const float* xp = X + (j0 + c4 * 4 < K ? j0 + c4 * 4 : 0) + (mb + rg * 4) * ldx;
+        const int xcol = j0 + c4 * 4 < K ? j0 + c4 * 4 : 0;
+        const float* xp = X + xcol + (mb + rg * 4) * ldx;
+        const stin_bn_tf xtf = batch.p[pi].xtf;                   // (round 5) X rows read as relu(bn(.)) per column: block-uniform
+        stin_bn_coef4 xq;                                           // this thread's four X columns are fixed: (s, t) once
+        xq.s = xq.t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (xtf.mean != nullptr) xq = stin_bn_coef4_load(xtf, xcol);
         const float* wp = (want_bias && row_w != nullptr) ? row_w + (mb + rg * 4) * ld_w : nullptr;
         int64_t m_next = mb + rg * 4;                                                          // its row index
         float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -188,7 +193,12 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_tn_ws(const stin_tn_batch b
                 }
             }
             split_store(S.g, &Gt[buf][0][0]);
-            split_store(S.x, &Xt[buf][0][0]);
+            if (xtf.mean != nullptr) {                             // (at STORE time: the loads stay in flight two slabs ahead)
+                const float4 tx[4] = {stin_bn_relu4(S.x[0], xq), stin_bn_relu4(S.x[1], xq), stin_bn_relu4(S.x[2], xq), stin_bn_relu4(S.x[3], xq)};
+                split_store(tx, &Xt[buf][0][0]);
+            } else {
+                split_store(S.x, &Xt[buf][0][0]);
+            }
         };
         WsSlab S0, S1;
         WS_STAMP(0);

@@ -174,7 +174,7 @@ def segment_sum(src, rowptr, col, n_rows, mean=False):
     # (STIN_SEG_NONTEMPORAL = 2: a source that cannot be Infinity-Cache resident is read with non-temporal loads)
     flags = int(mean) | (2 if (src.dtype == torch.float32 and src.shape[0] * ld * 4 > (256 << 20)) else 0)
     _call('stin_segment_sum' + _sfx(src), _ptr(src), ld, _ptr(rowptr), _ptr(col), n_rows, src.shape[1], flags, _ptr(out),
-          out.stride(0) if n_rows > 1 else src.shape[1], _stream(src))
+          out.stride(0) if n_rows > 1 else src.shape[1], _stream(src), tag=(int(src.shape[0]), int(n_rows), int(src.shape[1])))
     return out
 
 

@@ -291,6 +291,125 @@ def batch_norm_rows(x, bn, relu=False, recomputed=False):
     return F.relu(y) if relu else y
 
 
+USE_FUSED_LAYER = __import__('os').environ.get('STIN_SCMN_FUSED', '1') != '0'      # A/B switch: 0 = the per-op autograd path
+# BatchNorm1d + ReLU of the E x 2 cout edge rows applied inside the per-edge GEMMs' operand staging (stin_gemm_nt_bn_f32 /
+# stin_gemm_tn_bn_f32): the normalised matrix h is never written or read (1.2 GB per level-0 layer); 0 = materialise it (A/B)
+BN_IN_GEMM = __import__('os').environ.get('STIN_SCMN_BN_IN_GEMM', '1') != '0'
+
+
+def _gemm_nt_bn(pre, W, mean, rstd, gamma, beta, precision):
+    e, k = pre.shape
+    out = torch.empty(e, W.shape[0], dtype=torch.float32, device=pre.device)
+    SF._call('stin_gemm_nt_bn_f32', SF._ptr(pre), k, SF._ptr(W), k, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gamma), SF._ptr(beta), e,
+             W.shape[0], k, SF._ptr(out), W.shape[0], int(precision), SF._stream(pre), tag=(e, W.shape[0], k))
+    return out
+
+
+def _gemm_tn_bn(G, pre, mean, rstd, gamma, beta, precision):
+    lib = _lib.load()
+    e, nc = G.shape
+    k = pre.shape[1]
+    out = torch.empty(nc, k, dtype=torch.float32, device=G.device)
+    ws_bytes = lib.stin_gemm_tn_workspace_bytes(e, nc, k, 0)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=G.device)
+    SF._call('stin_gemm_tn_bn_f32', SF._ptr(G), nc, SF._ptr(pre), k, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gamma), SF._ptr(beta), e, nc, k,
+             SF._ptr(out), k, int(precision), SF._ptr(ws), ws_bytes, SF._stream(G), tag=(e, nc, k))
+    return out
+
+
+class _EdgeConvBNLayerFn(torch.autograd.Function):
+    """One EdgeConv(BN) layer of SingleConvMeshNet in training mode - Lin1 (per vertex) -> gather-add -> BatchNorm1d + ReLU over
+    the E edge rows -> Lin2 (per edge) -> BatchNorm1d -> mean over the in-edges -> [+ x] -> [ReLU] - as ONE autograd node
+    (round 5; reference models/modules/edge_conv_filter.py:34-44, models/singleconvmeshnet.py:37-66).  The same HIP kernels, in the
+    same order and with the same arithmetic as the per-op path below (stin_bn_affine_res_fwd_f32 repeats the framework
+    expression it replaces), minus the framework's elementwise / copy / stack / accumulate launches: operand packing is one
+    kernel, the residual add and the output ReLU ride on the N-row BatchNorm epilogue, the residual's gradient on the
+    input-gradient GEMM's epilogue, and the BatchNorm backward of the E x 2 cout rows overwrites its own input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, W1, W2, g1, b1, g2, b2, ei, trans_inv, bn1, bn2, residual, relu, recomputed):
+        x, ldx = SF._mat(x)
+        n, cin = x.shape
+        h2, cout, e = W1.shape[0], W2.shape[0], ei.E
+        dev, st = x.device, SF._stream(x)
+        f32 = dict(dtype=torch.float32, device=dev)
+        wcat, wcatT, w2T = torch.empty(2 * h2, cin, **f32), torch.empty(cin, 2 * h2, **f32), torch.empty(h2, cout, **f32)
+        gb1, gb2 = torch.empty(2, h2, **f32), torch.empty(2, cout, **f32)
+        SF._call('stin_scmn_pack_f32', SF._ptr(W1), SF._ptr(W2), SF._ptr(g1), SF._ptr(b1), SF._ptr(g2), SF._ptr(b2), cin, h2, cout,
+                 int(trans_inv), SF._ptr(wcat), SF._ptr(wcatT), SF._ptr(w2T), SF._ptr(gb1), SF._ptr(gb2), st)
+        y = SF.gemm_nt(x, wcat, precision=SF.PREC_FWD)                              # [N, 2 h2] = [A | B]
+        pre = torch.empty(e, h2, **f32)
+        SF._call('stin_gather_add_rows_f32', SF._ptr(y), 2 * h2, SF._ptr(ei.dst32), y.data_ptr() + 4 * h2, 2 * h2, SF._ptr(ei.src32),
+                 e, h2, SF._ptr(pre), h2, st, tag=(e, h2))
+        ge, gn = _all_rows(e, dev), _all_rows(n, dev)
+        mean1, rstd1 = SF.colreduce(SF.RED_MOMENTS, pre, ge, ge.ptr_sum, eps=float(bn1.eps))
+        h = None
+        if BN_IN_GEMM and h2 > 16:
+            m = _gemm_nt_bn(pre, W2, mean1, rstd1, gb1[0], gb1[1], SF.PREC_FWD)     # per-EDGE GEMM on relu(bn(pre)), [E, cout]
+        else:
+            h = torch.empty(e, h2, **f32)
+            SF._call('stin_bn_act_fwd_f32', SF._ptr(pre), h2, SF._ptr(mean1), SF._ptr(rstd1), SF._ptr(gb1[0]), SF._ptr(gb1[1]), e, h2, 1,
+                     SF._ptr(h), h2, st)
+            m = SF.gemm_nt(h, W2, precision=SF.PREC_FWD)                            # per-EDGE GEMM, [E, cout]
+        mean2, rstd2 = SF.colreduce(SF.RED_MOMENTS, m, ge, ge.ptr_sum, eps=float(bn2.eps))
+        agg = SF.segment_sum(m, ei.by_dst.rowptr, ei.by_dst.col, n, mean=True)
+        out = torch.empty(n, cout, **f32)
+        SF._call('stin_bn_affine_res_fwd_f32', SF._ptr(agg), cout, SF._ptr(mean2), SF._ptr(rstd2), SF._ptr(gb2[0]), SF._ptr(gb2[1]),
+                 SF._ptr(ei.by_dst.rowptr), SF._ptr(x) if residual else None, ldx, n, cout, int(relu), SF._ptr(out), cout, st)
+        _update_running(bn1, mean1.view(-1), rstd1.view(-1), e)
+        _update_running(bn2, mean2.view(-1), rstd2.view(-1), e)
+        ctx.save_for_backward(x, W1, out)
+        ctx.bufs = (pre, h, m, agg, mean1, rstd1, mean2, rstd2, wcatT, w2T, gb1, gb2)
+        ctx.meta = (ei, bool(trans_inv), bn1, bn2, bool(residual), bool(relu), bool(recomputed))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W1, out = ctx.saved_tensors
+        pre, h, m, agg, mean1, rstd1, mean2, rstd2, wcatT, w2T, gb1, gb2 = ctx.bufs
+        ei, trans_inv, bn1, bn2, residual, relu, recomputed = ctx.meta
+        ctx.bufs = None
+        x, ldx = SF._mat(x)
+        g, ldg = SF._mat(g)
+        n, cin = x.shape
+        e, h2 = pre.shape
+        cout = m.shape[1]
+        dev, st = x.device, SF._stream(x)
+        f32 = dict(dtype=torch.float32, device=dev)
+        if recomputed:       # the reference recomputes this block's forward here (torch.utils.checkpoint): its BatchNorm running
+            _update_running(bn2, mean2.view(-1), rstd2.view(-1), e)      # statistics take the batch a second time (_second_pass)
+            _update_running(bn1, mean1.view(-1), rstd1.view(-1), e)
+        g_eff = torch.empty(n, cout, **f32) if residual else None
+        g_in = torch.empty(n, cout, **f32)
+        SF._call('stin_relu_mask_bwd_f32', SF._ptr(g), ldg, SF._ptr(out), cout, SF._ptr(ei.by_dst.rowptr), n, cout, int(relu),
+                 SF._ptr(g_eff), SF._ptr(g_in), st)
+        ge, gn = _all_rows(e, dev), _all_rows(n, dev)
+        P2, Q2 = SF.colreduce(SF.RED_DOT_BN, agg, gn, gn.ptr_sum, gout=g_in, mean=mean2, rstd=rstd2, coef=gb2)
+        dm = torch.empty(e, cout, **f32)
+        SF._call('stin_bn_mean_bwd_f32', SF._ptr(m), cout, SF._ptr(g_in), cout, SF._ptr(ei.dst32), SF._ptr(ei.by_dst.inv_deg),
+                 SF._ptr(mean2), SF._ptr(rstd2), SF._ptr(gb2[0]), SF._ptr(P2), SF._ptr(Q2), 1.0 / max(e, 1), e, cout, SF._ptr(dm), cout, st)
+        dh = SF.gemm_nt(dm, w2T, precision=SF.PREC_BWD)                             # [E, h2]
+        if h is None:
+            dW2 = _gemm_tn_bn(dm, pre, mean1, rstd1, gb1[0], gb1[1], SF.PREC_BWD)   # [cout, h2] from the pre-norm rows
+        else:
+            dW2 = SF.gemm_tn(dm, h, ones_column=False, precision=SF.PREC_BWD)       # [cout, h2]
+        del h, m, agg
+        P1, Q1 = SF.colreduce(SF.RED_DOT_BN_RELU, pre, ge, ge.ptr_sum, gout=dh, mean=mean1, rstd=rstd1, coef=gb1)
+        SF._call('stin_bn_act_bwd_f32', SF._ptr(pre), h2, SF._ptr(dh), h2, SF._ptr(mean1), SF._ptr(rstd1), SF._ptr(gb1[0]), SF._ptr(gb1[1]),
+                 SF._ptr(P1), SF._ptr(Q1), 1.0 / e, e, h2, 1, SF._ptr(dh), h2, st)      # (element-wise: in place over dh)
+        dy = torch.empty(n, 2 * h2, **f32)
+        for off, csr in ((0, ei.by_dst), (h2, ei.by_src)):
+            SF._call('stin_segment_sum_f32', SF._ptr(dh), h2, SF._ptr(csr.rowptr), SF._ptr(csr.col), n, h2, 0, dy.data_ptr() + 4 * off,
+                     2 * h2, st)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = SF.gemm_nt(dy, wcatT, precision=SF.PREC_BWD, residual=g_eff)       # (+ the residual branch's gradient)
+        dwcat = SF.gemm_tn(dy, x, ones_column=False, precision=SF.PREC_BWD)         # [2 h2, cin]
+        dW1 = torch.empty(W1.shape, **f32)
+        SF._call('stin_scmn_unpack_f32', SF._ptr(dwcat), cin, h2, int(trans_inv), SF._ptr(dW1), st)
+        return dx, dW1, dW2, P1.view(-1), Q1.view(-1), P2.view(-1), Q2.view(-1), None, None, None, None, None, None, None
+
+
 class EdgeConvBN(nn.Module):
     """EdgeConv(aggr='mean') whose MLP is Lin(no bias) - BatchNorm1d - ReLU - Lin(no bias) - BatchNorm1d
     (edge_conv_filter.py:34-44); `nn` holds the parameters under the reference's names and is never called itself."""
@@ -302,10 +421,22 @@ class EdgeConvBN(nn.Module):
         self.nn = nn.Sequential(nn.Linear(cin if trans_inv else 2 * cin, 2 * cout, bias=False), nn.BatchNorm1d(2 * cout),
                                 nn.ReLU(), nn.Linear(2 * cout, cout, bias=False), nn.BatchNorm1d(cout))
 
-    def forward(self, x, ei):
+    def forward(self, x, ei, residual=False, relu=False):
+        """residual / relu: the enclosing ResBlock's `x + f(x)` and ReLU, applied here so that the fused layer can carry them."""
         ei = _as_edge_index(ei, x.shape[0])
         lin1, bn1, lin2, bn2 = self.nn[0], self.nn[1], self.nn[3], self.nn[4]
         h2, cin = lin1.weight.shape[0], x.shape[1]
+        if (USE_FUSED_LAYER and x.is_cuda and x.dtype == torch.float32 and ei.E > 1 and all(
+                b.training and b.affine and b.track_running_stats for b in (bn1, bn2)) and torch.is_grad_enabled() and
+                (not residual or lin2.weight.shape[0] == cin)):
+            return _EdgeConvBNLayerFn.apply(x, lin1.weight, lin2.weight, bn1.weight, bn1.bias, bn2.weight, bn2.bias, ei, self.trans_inv,
+                                            bn1, bn2, residual, relu, self.recomputed)
+        out = self._forward_per_op(x, ei, lin1, bn1, lin2, bn2, h2, cin)
+        if residual:
+            out = x + out
+        return F.relu(out) if relu else out
+
+    def _forward_per_op(self, x, ei, lin1, bn1, lin2, bn2, h2, cin):
         if self.trans_inv:
             wcat = torch.cat([-lin1.weight, lin1.weight], dim=0)
         else:
@@ -333,9 +464,9 @@ class ResBlock(nn.Module):
         self.filters = nn.ModuleList(filters)
 
     def forward(self, x, ei):
-        x = F.relu(self.filters[0](x, ei))
+        x = self.filters[0](x, ei, relu=True)                         # relu(f0(x))
         for f in list(self.filters)[1:]:
-            x = F.relu(x + f(x, ei))
+            x = f(x, ei, residual=True, relu=True)                    # relu(x + f(x))
         return x
 
 
