@@ -557,6 +557,8 @@ def main():
     ap.add_argument('--crops', type=int, default=0,
                     help='BASELINE config 3: a collated batch of this many unequal crops (12-28k vertices each) per step '
                          'instead of one scene (NOT the headline); combine with --levels 4 --dtype bf16')
+    ap.add_argument('--unequal-scenes', action='store_true', help='config 4 as the reference trains it: rank r gets a scene of '
+                    '150 000 + r * 50 000 / (N - 1) vertices instead of N equal ones (NOT the headline; reports the straggler figure)')
     ap.add_argument('--no-live-traffic', action='store_true', help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic '
                     'and hbm_honest.traffic live (about 40 s); both are null then')
     ap.add_argument('--no-secondary', action='store_true',
@@ -616,7 +618,10 @@ def main():
         sizes = [12_000 + (16_000 * i) // max(args.crops - 1, 1) for i in range(args.crops)]
         sample = collate([make_synthetic_mesh(n, args.levels, seed=100 * rank + i) for i, n in enumerate(sizes)]).to(device)
     else:
-        sample = make_synthetic_mesh(args.vertices, args.levels, seed=rank, irregular=args.irregular,
+        nv_rank = args.vertices
+        if args.unequal_scenes and world > 1:
+            nv_rank = 150_000 + (50_000 * rank) // (world - 1)
+        sample = make_synthetic_mesh(nv_rank, args.levels, seed=rank, irregular=args.irregular,
                                      permute=not args.coherent_order)               # one scene per rank
         if args.morton_order:
             from surface_texture_inpainting_net_amd.synthetic import renumber_by_locality
@@ -759,6 +764,15 @@ def main():
         nb, avg = max(fw)
         my_gbps = nb / avg / 1e9
     sum_gbps = my_gbps
+    ar_wait_us = None
+    if world > 1 and step.bucket.allreduce_log:
+        # every rank's mean time inside the end-of-backward all-reduce bracket: the ranks with the smaller scenes arrive early and
+        # WAIT there for the largest one - the straggler effect made visible (the wall times per rank equalise by construction)
+        mine = sum(a.elapsed_time(b) * 1e3 for a, b in step.bucket.allreduce_log) / len(step.bucket.allreduce_log)
+        w = torch.zeros(world, dtype=torch.float64, device=device)
+        w[rank] = mine
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+        ar_wait_us = [float(v) for v in w.tolist()]
     if world > 1:
         gb = torch.tensor([my_gbps], dtype=torch.float64, device=device)
         dist.all_reduce(gb, op=dist.ReduceOp.SUM)
@@ -855,6 +869,14 @@ def main():
                             'allreduce_overlap_validated_on_hardware': False},
             # one row of north_star's 1/2/4/8 table: absolute throughput and the aggregation's share of N x the one-GPU HBM roofline
             # (the driver computes scaling efficiency itself from the per-N `value`s)
+            # synchronous data parallelism runs at the pace of the slowest rank: per-rank step time over its mean (1.0 = balanced)
+            'straggler': {'vertices_per_rank': 'equal' if not (args.unequal_scenes and world > 1) else
+                          [150_000 + (50_000 * r) // (world - 1) for r in range(world)],
+                          'allreduce_bracket_us_per_rank': ar_wait_us,
+                          'note': 'a synchronous step costs what its largest scene costs (the per-rank wall times equalise); the ranks with '
+                                  'smaller scenes spend the difference waiting inside the gradient all-reduce - allreduce_bracket_us_per_rank '
+                                  '(HIP events around the end-of-backward all-reduce, mean over the timed steps, one entry per rank).  '
+                                  'loader.shard_indices(sizes=...) gives the ranks of one step neighbours in size: profiles/r05_straggler.json'},
             'scaling_table_row': {'gpus': ranks_counted, 'vertices_per_s': total_vertices * args.steps / dt,
                                   'vertices_per_s_per_gpu': total_vertices * args.steps / dt / max(ranks_counted, 1),
                                   'scatter_add_GBps_sum_over_gpus': sum_gbps, 'hbm_roofline_GBps': HBM_PEAK_GBS * world,
