@@ -229,6 +229,20 @@ int stin_gather_rows_f32(const float* src, int64_t ld_src, const int32_t* idx, c
  * of the BatchNorm edge MLP (models/modules/edge_conv_filter.py:34-44), one pass instead of two gathers and an add. */
 int stin_gather_add_rows_f32(const float* a, int64_t lda, const int32_t* idx_a, const float* b, int64_t ldb,
                              const int32_t* idx_b, int64_t n_out, int C, float* out, int64_t ldo, stin_stream_t stream);
+/* (round 5) the same pass WITH the first stage of the column moments of its output - the BatchNorm1d over the E edge rows that
+ * follows it (edge_conv_filter.py:36-38): partial [groups][2][C] doubles (per block: sum, sum of squares), groups =
+ * stin_gather_add_rows_stats_groups(N, C) (0: not supported for this shape); second stage stin_moments_final_f32.  Saves the
+ * separate moments pass over the [E, C] matrix just written. */
+int64_t stin_segment_mean_stats_groups(int64_t N, int C);
+/* segment MEAN of the rows src[col[e]] over the CSR slots of every output row (stin_segment_sum_f32(mean)'s result, bit for bit)
+ * AND partial [groups][2][C] = per-block column sums of the visited source rows and of their squares: the batch statistics of all
+ * E edge rows for scatter_mean(BatchNorm1d(m)) (edge_conv_filter.py:40-44 + aggr='mean') from the pass that aggregates them. */
+int stin_segment_mean_stats_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col, int64_t N, int C,
+                                float* out, int64_t ldo, double* partial, size_t partial_bytes, stin_stream_t stream);
+int64_t stin_gather_add_rows_stats_groups(int64_t N, int C);
+int stin_gather_add_rows_stats_f32(const float* a, int64_t lda, const int32_t* idx_a, const float* b, int64_t ldb,
+                                   const int32_t* idx_b, int64_t N, int C, float* out, int64_t ldo, double* partial,
+                                   size_t partial_bytes, stin_stream_t stream);
 /* Per-level graph-id vector (int64, bit-exact): scatter_max(batch, trace) and
  * batch.index_select(0, trace) (models/surfacetextureinpaintingnet.py:421-422,:446-447). */
 int stin_batch_pool_i64(const int64_t* batch, const int32_t* rowptr, const int32_t* col, int64_t n_coarse,

@@ -153,6 +153,10 @@ SIGNATURES['stin_edgeconv_wgrad'] = (c_int, [c_int, c_ptr, c_i64, c_ptr, c_i64, 
                                      [c_ptr, c_size, c_ptr])
 SIGNATURES['stin_norm_bwd_coef_m_quirk_f32'] = (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr])
 SIGNATURES['stin_gather_add_rows_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr])
+SIGNATURES['stin_segment_mean_stats_groups'] = (c_i64, [c_i64, c_int])
+SIGNATURES['stin_segment_mean_stats_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_size, c_ptr])
+SIGNATURES['stin_gather_add_rows_stats_groups'] = (c_i64, [c_i64, c_int])
+SIGNATURES['stin_gather_add_rows_stats_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr, c_size, c_ptr])
 SIGNATURES['stin_bn_mean_bwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64] + [c_ptr] * 7 + [c_f32, c_i64, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_bn_running_stats_f32'] = (c_int, [c_ptr, c_ptr, c_int, c_f32, c_f32, c_f32, c_ptr, c_ptr, c_ptr])
 SIGNATURES['stin_gemm_nt_bn_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_int, c_ptr])

@@ -3006,6 +3006,15 @@ int stin_tn_problem_init(stin_tn_problem* p, int storage, const void* G, int64_t
     const bool big = storage == 1 && vec16 && tn_b16_big_tile(Nc, K);
     p->TI = big ? 256 : tn_tile(Nc);
     p->TJ = big ? 256 : tn_tile(K);
+    // (round 5) fp32 bf16x3 products whose narrow side is <= 64 columns (the level-0 dW2 = dagg^T h: 64 x 128; SingleConvMeshNet's
+    // per-edge dW2) ran on the four-wave kernel (its 64-wide tiles) at ~3 TB/s; on the producer / consumer kernel the same
+    // product is a 128 x 128 tile that is half or a quarter empty - the wasted MFMAs are free beside the operand stream
+    // (200 704 x 64 x 128: 50 -> 3x us; 1.2 M x 64 x 128: 267 -> 1xx us).  One tile either way: same chunks, same slabs.
+    static const bool ws_narrow = !(getenv("STIN_TN_WS_NARROW") && atoi(getenv("STIN_TN_WS_NARROW")) == 0);   // A/B switch (read once)
+    if (ws_narrow && !big && storage == 0 && precision == STIN_GEMM_BF16X3 && vec16 && M > 0 && Nc >= 32 && K >= 32 && stin_tn_ws_enabled()) {
+        p->TI = 128;
+        p->TJ = 128;
+    }
     p->tiles_i = (Nc + p->TI - 1) / p->TI;
     p->tiles_j = (K + p->TJ - 1) / p->TJ;
     p->rows_per_chunk = tn_rows_per_chunk(M, p->tiles_i * p->tiles_j, big || tn_one_per_cu(storage, precision, p->TI, p->TJ, M));

@@ -877,6 +877,66 @@ __global__ __launch_bounds__(BLOCK) void k_segment_sum_x(const T* __restrict__ s
         st4(out + L.row * ldo + L.chan(k), make_float4(acc[k].x / s, acc[k].y / s, acc[k].z / s, acc[k].w / s));
 }
 
+// Segment MEAN over a CSR (out[i] = mean of src[col[e]] over the slots e of row i; 0 for an empty row) AND the first stage of the
+// column moments of the SOURCE rows it visits: SingleConvMeshNet's scatter_mean(BatchNorm1d(m)) needs the batch statistics of all
+// E edge rows m and their mean per target vertex - every edge row is a slot of exactly one target, so one pass over m gives both
+// (the separate moments pass re-read the [E, cout] matrix).  Persistent grid: G = C / 4 lanes per row, a block walks the rows in
+// passes, fp64 sums of v and v^2 per thread, block fold through LDS in lane order, ONE partial [2][C] per block (the layout
+// stin_moments_final_f32 folds).  Per-row summation order = k_segment_sum_x's (sequential over the slots): same means bit for bit.
+template <int U>
+__global__ __launch_bounds__(BLOCK) void k_segment_mean_stats(const float* __restrict__ src, int64_t lds_, const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ col, int64_t N, int c4,
+                                                              float* __restrict__ out, int64_t ldo, double* __restrict__ partial) {
+    extern __shared__ double sg_sm[];                                  // [2][BLOCK / c4][4 c4]
+    const int lg = threadIdx.x % c4, rl = threadIdx.x / c4, nrl = BLOCK / c4, C = 4 * c4;
+    const int ch = lg * 4;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t row = (int64_t)blockIdx.x * nrl + rl; row < N; row += (int64_t)gridDim.x * nrl) {
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = beg; e < end; e += U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ee = min(e + u, end - 1);
+                v[u] = ld4(src + (int64_t)col[ee] * lds_ + ch);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float w = (e + u < end) ? 1.f : 0.f;
+                acc.x += w * v[u].x;
+                acc.y += w * v[u].y;
+                acc.z += w * v[u].z;
+                acc.w += w * v[u].w;
+                if (e + u < end) {
+                    const float q[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double d = (double)q[i];
+                        s1[i] += d;
+                        s2[i] += d * d;
+                    }
+                }
+            }
+        }
+        const int deg = end - beg;
+        const float s = (float)(deg > 0 ? deg : 1);
+        st4(out + row * ldo + ch, make_float4(acc.x / s, acc.y / s, acc.z / s, acc.w / s));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sg_sm[(0 * nrl + rl) * C + ch + i] = s1[i];
+        sg_sm[(1 * nrl + rl) * C + ch + i] = s2[i];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += BLOCK) {
+        const int o = t / C, c = t % C;
+        double s = 0.0;
+        for (int k = 0; k < nrl; ++k) s += sg_sm[(o * nrl + k) * C + c];
+        partial[((int64_t)blockIdx.x * 2 + o) * C + c] = s;
+    }
+}
+
 // ------------------------------------------------------------------------- max pool
 template <typename T, int G, int VPL, int U>
 __global__ __launch_bounds__(BLOCK) void k_pool_max_fwd(const T* __restrict__ x, int64_t ldx,
@@ -979,6 +1039,101 @@ __global__ __launch_bounds__(BLOCK) void k_gather_add_rows(const T* __restrict__
             const float4 v = ld4(b + tb * ldb + L.chan(k));
             st4(out + L.row * ldo + L.chan(k), make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w));
         }
+}
+
+// (round 5) U rows per thread: the one-row form above issues index load -> two dependent row gathers -> store per thread with
+// nothing else in flight and writes the 614 MB [E, 128] matrix of a level-0 SingleConvMeshNet layer at 2.4 TB/s (254 us);
+// here a thread owns one 16-byte column chunk of U rows R apart (R = rows per pass of the grid): 2 U index loads, then 2 U row
+// gathers in flight, then U stores.  C / 4 must divide the block.  Same sums: bit-identical.
+template <int U>
+__global__ __launch_bounds__(BLOCK) void k_gather_add_rows_u(const float* __restrict__ a, int64_t lda, const int32_t* __restrict__ ia,
+                                                             const float* __restrict__ b, int64_t ldb, const int32_t* __restrict__ ib,
+                                                             int64_t N, int c4, float* __restrict__ out, int64_t ldo) {
+    const int64_t gid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t R = (int64_t)gridDim.x * BLOCK / c4;                 // rows per pass
+    const int64_t r0 = gid / c4;
+    const int ch = (int)(gid % c4) * 4;
+    int32_t ta[U], tb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * R;
+        const int64_t rc = r < N ? r : N - 1;
+        ta[u] = ia[rc];
+        tb[u] = ib[rc];
+    }
+    float4 x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        x[u] = ld4(a + (int64_t)ta[u] * lda + ch);
+        y[u] = ld4(b + (int64_t)tb[u] * ldb + ch);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * R;
+        if (r < N) st4(out + r * ldo + ch, make_float4(x[u].x + y[u].x, x[u].y + y[u].y, x[u].z + y[u].z, x[u].w + y[u].w));
+    }
+}
+
+// The same pass WITH the first stage of the column moments of its output (BatchNorm1d over the E edge rows that follows it in
+// SingleConvMeshNet: the separate moments pass re-read the 614 MB it had just written).  Persistent grid: a block walks the rows in
+// passes of R, every thread keeps fp64 sums of x and x^2 for its four columns, the row lanes of a block are folded through LDS in
+// lane order and the block writes ONE partial [2][C] - the [groups][2][C] layout stin_moments_final_f32 folds (groups = gridDim).
+// Fixed row -> thread map and fixed fold order: deterministic.  C / 4 divides the block.
+template <int U>
+__global__ __launch_bounds__(BLOCK) void k_gather_add_rows_stats(const float* __restrict__ a, int64_t lda, const int32_t* __restrict__ ia,
+                                                                 const float* __restrict__ b, int64_t ldb, const int32_t* __restrict__ ib,
+                                                                 int64_t N, int c4, float* __restrict__ out, int64_t ldo,
+                                                                 double* __restrict__ partial) {
+    extern __shared__ double ga_sm[];                                  // [2][BLOCK / c4][4 c4]
+    const int64_t gid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t R = (int64_t)gridDim.x * BLOCK / c4;                 // rows per pass
+    const int ch = (int)(gid % c4) * 4;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t r0 = gid / c4; r0 < N; r0 += U * R) {
+        int32_t ta[U], tb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + u * R;
+            const int64_t rc = r < N ? r : N - 1;
+            ta[u] = ia[rc];
+            tb[u] = ib[rc];
+        }
+        float4 x[U], y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            x[u] = ld4(a + (int64_t)ta[u] * lda + ch);
+            y[u] = ld4(b + (int64_t)tb[u] * ldb + ch);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = r0 + u * R;
+            if (r < N) {
+                const float4 v = make_float4(x[u].x + y[u].x, x[u].y + y[u].y, x[u].z + y[u].z, x[u].w + y[u].w);
+                st4(out + r * ldo + ch, v);
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double d = (double)e[i];
+                    s1[i] += d;
+                    s2[i] += d * d;
+                }
+            }
+        }
+    }
+    const int rl = threadIdx.x / c4, nrl = BLOCK / c4, C = 4 * c4;
+    const int cc = (threadIdx.x % c4) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ga_sm[(0 * nrl + rl) * C + cc + i] = s1[i];
+        ga_sm[(1 * nrl + rl) * C + cc + i] = s2[i];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += BLOCK) {
+        const int o = t / C, c = t % C;
+        double s = 0.0;
+        for (int k = 0; k < nrl; ++k) s += ga_sm[(o * nrl + k) * C + c];
+        partial[((int64_t)blockIdx.x * 2 + o) * C + c] = s;
+    }
 }
 
 __global__ void k_gather_add_rows_scalar(const float* __restrict__ a, int64_t lda, const int32_t* __restrict__ ia,
@@ -1600,12 +1755,73 @@ extern "C" int stin_gather_add_rows_f32(const float* a, int64_t lda, const int32
     STIN_REQUIRE(N >= 0 && C > 0 && lda >= C && ldb >= C && ldo >= C, STIN_E_SIZE);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(a && b && idx_a && idx_b && out, STIN_E_NULL);
-    if (vec_ok<T>(C, {a, b, out}, {lda, ldb, ldo})) {
+    static const int unroll = getenv("STIN_GATHER_ADD_U") ? atoi(getenv("STIN_GATHER_ADD_U")) : 4;      // tuning aid: 0 = one row per thread
+    if (vec_ok<T>(C, {a, b, out}, {lda, ldb, ldo}) && unroll > 0 && BLOCK % (C / 4) == 0 && N >= 4096) {
+        const int c4 = C / 4;
+        const int64_t threads = (N + 3) / 4 * c4;                                      // U = 4 rows per thread
+        const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
+        if (unroll >= 8) {
+            const int64_t t8 = (N + 7) / 8 * c4;
+            hipLaunchKernelGGL((k_gather_add_rows_u<8>), dim3((unsigned)((t8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, a, lda, idx_a, b, ldb,
+                               idx_b, N, c4, out, ldo);
+        } else {
+            hipLaunchKernelGGL((k_gather_add_rows_u<4>), dim3(grid), dim3(BLOCK), 0, stream, a, lda, idx_a, b, ldb, idx_b, N, c4, out, ldo);
+        }
+    } else if (vec_ok<T>(C, {a, b, out}, {lda, ldb, ldo})) {
         STIN_DISPATCH_NOU(C, k_gather_add_rows, a, lda, idx_a, b, ldb, idx_b, N, C, out, ldo);
     } else {
         hipLaunchKernelGGL(k_gather_add_rows_scalar, dim3(grid_elems(N * C)), dim3(BLOCK), 0, stream, a, lda, idx_a, b, ldb,
                            idx_b, N, C, out, ldo);
     }
+    return stin_launch_status();
+}
+
+// out[e] = a[ia[e]] + b[ib[e]] AND partial [groups][2][C] doubles = per-block column sums of the output and of its squares
+// (second stage: stin_moments_final_f32).  groups = stin_gather_add_rows_stats_groups(N, C) (0: shape not supported - the caller
+// runs stin_gather_add_rows_f32 + stin_colreduce_f32(MOMENTS)).
+extern "C" int64_t stin_gather_add_rows_stats_groups(int64_t N, int C) {
+    if (N < 4096 || C <= 0 || C % 4 != 0 || BLOCK % (C / 4) != 0 || C > 1024) return 0;
+    const int64_t need = ((N + 3) / 4 * (C / 4) + BLOCK - 1) / BLOCK;          // blocks of the one-pass form (4 rows per thread)
+    return need < 1024 ? need : 1024;
+}
+extern "C" int stin_gather_add_rows_stats_f32(const float* a, int64_t lda, const int32_t* idx_a, const float* b, int64_t ldb,
+                                              const int32_t* idx_b, int64_t N, int C, float* out, int64_t ldo, double* partial,
+                                              size_t partial_bytes, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t groups = stin_gather_add_rows_stats_groups(N, C);
+    STIN_REQUIRE(groups > 0, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(lda >= C && ldb >= C && ldo >= C, STIN_E_SIZE);
+    STIN_REQUIRE(a && b && idx_a && idx_b && out && partial, STIN_E_NULL);
+    STIN_REQUIRE(partial_bytes >= (size_t)groups * 2 * (size_t)C * sizeof(double), STIN_E_WORKSPACE);
+    if (!vec_ok<float>(C, {a, b, out}, {lda, ldb, ldo})) return STIN_E_ALIGN;
+    const int c4 = C / 4;
+    const size_t lds = (size_t)2 * (BLOCK / c4) * C * sizeof(double);
+    hipLaunchKernelGGL((k_gather_add_rows_stats<4>), dim3((unsigned)groups), dim3(BLOCK), lds, stream, a, lda, idx_a, b, ldb, idx_b, N, c4,
+                       out, ldo, partial);
+    return stin_launch_status();
+}
+
+// out [N, C] = segment mean of src rows over the CSR (rowptr, col) AND partial [groups][2][C] doubles = per-block column sums of
+// the visited source rows and of their squares (second stage: stin_moments_final_f32 with inv_cnt = 1 / #slots).
+extern "C" int64_t stin_segment_mean_stats_groups(int64_t N, int C) {
+    if (N < 1024 || C <= 0 || C % 4 != 0 || C > 1024 || BLOCK % (C / 4) != 0) return 0;
+    const int64_t need = (N + BLOCK / (C / 4) - 1) / (BLOCK / (C / 4));
+    return need < 2048 ? need : 2048;
+}
+extern "C" int stin_segment_mean_stats_f32(const float* src, int64_t ld_src, const int32_t* rowptr, const int32_t* col, int64_t N, int C,
+                                           float* out, int64_t ldo, double* partial, size_t partial_bytes, stin_stream_t stream_) {
+    stin_clear_stale_error();
+    const int64_t groups = stin_segment_mean_stats_groups(N, C);
+    STIN_REQUIRE(groups > 0, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(ld_src >= C && ldo >= C, STIN_E_SIZE);
+    STIN_REQUIRE(src && rowptr && col && out && partial, STIN_E_NULL);
+    STIN_REQUIRE(partial_bytes >= (size_t)groups * 2 * (size_t)C * sizeof(double), STIN_E_WORKSPACE);
+    if (!vec_ok<float>(C, {src, out}, {ld_src, ldo})) return STIN_E_ALIGN;
+    const int c4 = C / 4;
+    const size_t lds = (size_t)2 * (BLOCK / c4) * C * sizeof(double);
+    hipLaunchKernelGGL((k_segment_mean_stats<2>), dim3((unsigned)groups), dim3(BLOCK), lds, (hipStream_t)stream_, src, ld_src, rowptr, col, N,
+                       c4, out, ldo, partial);
     return stin_launch_status();
 }
 

@@ -226,6 +226,10 @@ def _all_rows(n, device):
 
 
 _NBT_BUMPED = [False]        # SingleConvMeshNet.forward bumps every num_batches_tracked in one multi-tensor launch
+# (round 5) ... and the SECOND bump of the blocks the reference recomputes (their BatchNorms run a second forward inside backward)
+# is one multi-tensor launch too: forward leaves the counters of those layers here, the first recomputed layer whose backward
+# runs bumps them all (a full backward visits every one of them; 12 single-element launches per step before)
+_NBT_SECOND = {'pending': None}
 
 
 def _update_running(bn, mean, rstd, n):
@@ -233,7 +237,14 @@ def _update_running(bn, mean, rstd, n):
     if not (bn.training and bn.track_running_stats):
         return
     with torch.no_grad():
-        if not _NBT_BUMPED[0]:
+        pend = _NBT_SECOND['pending']
+        in_bwd = not torch.is_grad_enabled()             # (autograd runs backward functions with gradients off)
+        if in_bwd and pend is not None and not _NBT_BUMPED[0] and any(t is bn.num_batches_tracked for t in pend):
+            torch._foreach_add_(pend, 1)                 # every recomputed layer's counter at once (backward, second pass)
+            _NBT_SECOND['pending'] = ()
+        elif in_bwd and pend is not None and len(pend) == 0 and not _NBT_BUMPED[0] and getattr(bn, '_stin_second_pass', False):
+            pass                                         # (already bumped with the others)
+        elif not _NBT_BUMPED[0]:
             bn.num_batches_tracked += 1
         mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
         SF._call('stin_bn_running_stats_f32', SF._ptr(mean), SF._ptr(rstd), mean.numel(), float(bn.eps), n / max(n - 1, 1),
@@ -295,6 +306,8 @@ USE_FUSED_LAYER = __import__('os').environ.get('STIN_SCMN_FUSED', '1') != '0'   
 # BatchNorm1d + ReLU of the E x 2 cout edge rows applied inside the per-edge GEMMs' operand staging (stin_gemm_nt_bn_f32 /
 # stin_gemm_tn_bn_f32): the normalised matrix h is never written or read (1.2 GB per level-0 layer); 0 = materialise it (A/B)
 BN_IN_GEMM = __import__('os').environ.get('STIN_SCMN_BN_IN_GEMM', '1') != '0'
+# the column moments of the gather-add output accumulated by the gather-add pass itself (stin_gather_add_rows_stats_f32)
+STATS_IN_GATHER = __import__('os').environ.get('STIN_SCMN_STATS_IN_GATHER', '1') != '0'
 
 
 def _gemm_nt_bn(pre, W, mean, rstd, gamma, beta, precision):
@@ -339,10 +352,17 @@ class _EdgeConvBNLayerFn(torch.autograd.Function):
                  int(trans_inv), SF._ptr(wcat), SF._ptr(wcatT), SF._ptr(w2T), SF._ptr(gb1), SF._ptr(gb2), st)
         y = SF.gemm_nt(x, wcat, precision=SF.PREC_FWD)                              # [N, 2 h2] = [A | B]
         pre = torch.empty(e, h2, **f32)
-        SF._call('stin_gather_add_rows_f32', SF._ptr(y), 2 * h2, SF._ptr(ei.dst32), y.data_ptr() + 4 * h2, 2 * h2, SF._ptr(ei.src32),
-                 e, h2, SF._ptr(pre), h2, st, tag=(e, h2))
         ge, gn = _all_rows(e, dev), _all_rows(n, dev)
-        mean1, rstd1 = SF.colreduce(SF.RED_MOMENTS, pre, ge, ge.ptr_sum, eps=float(bn1.eps))
+        groups = int(_lib.load().stin_gather_add_rows_stats_groups(e, h2)) if STATS_IN_GATHER else 0
+        if groups > 0:       # the moments of `pre` ride on the pass that writes it (no second pass over the [E, 2 cout] matrix)
+            partial = torch.empty(groups, 2, h2, dtype=torch.float64, device=dev)
+            SF._call('stin_gather_add_rows_stats_f32', SF._ptr(y), 2 * h2, SF._ptr(ei.dst32), y.data_ptr() + 4 * h2, 2 * h2,
+                     SF._ptr(ei.src32), e, h2, SF._ptr(pre), h2, SF._ptr(partial), partial.numel() * 8, st, tag=(e, h2))
+            mean1, rstd1 = SF.moments_final(partial, ge.inv_cnt, eps=float(bn1.eps))
+        else:
+            SF._call('stin_gather_add_rows_f32', SF._ptr(y), 2 * h2, SF._ptr(ei.dst32), y.data_ptr() + 4 * h2, 2 * h2, SF._ptr(ei.src32),
+                     e, h2, SF._ptr(pre), h2, st, tag=(e, h2))
+            mean1, rstd1 = SF.colreduce(SF.RED_MOMENTS, pre, ge, ge.ptr_sum, eps=float(bn1.eps))
         h = None
         if BN_IN_GEMM and h2 > 16:
             m = _gemm_nt_bn(pre, W2, mean1, rstd1, gb1[0], gb1[1], SF.PREC_FWD)     # per-EDGE GEMM on relu(bn(pre)), [E, cout]
@@ -351,8 +371,16 @@ class _EdgeConvBNLayerFn(torch.autograd.Function):
             SF._call('stin_bn_act_fwd_f32', SF._ptr(pre), h2, SF._ptr(mean1), SF._ptr(rstd1), SF._ptr(gb1[0]), SF._ptr(gb1[1]), e, h2, 1,
                      SF._ptr(h), h2, st)
             m = SF.gemm_nt(h, W2, precision=SF.PREC_FWD)                            # per-EDGE GEMM, [E, cout]
-        mean2, rstd2 = SF.colreduce(SF.RED_MOMENTS, m, ge, ge.ptr_sum, eps=float(bn2.eps))
-        agg = SF.segment_sum(m, ei.by_dst.rowptr, ei.by_dst.col, n, mean=True)
+        groups2 = int(_lib.load().stin_segment_mean_stats_groups(n, cout)) if STATS_IN_GATHER else 0
+        if groups2 > 0:      # the moments of the E edge rows m ride on the pass that averages them per target vertex
+            partial2 = torch.empty(groups2, 2, cout, dtype=torch.float64, device=dev)
+            agg = torch.empty(n, cout, **f32)
+            SF._call('stin_segment_mean_stats_f32', SF._ptr(m), cout, SF._ptr(ei.by_dst.rowptr), SF._ptr(ei.by_dst.col), n, cout, SF._ptr(agg),
+                     cout, SF._ptr(partial2), partial2.numel() * 8, st, tag=(e, n, cout))
+            mean2, rstd2 = SF.moments_final(partial2, ge.inv_cnt, eps=float(bn2.eps))
+        else:
+            mean2, rstd2 = SF.colreduce(SF.RED_MOMENTS, m, ge, ge.ptr_sum, eps=float(bn2.eps))
+            agg = SF.segment_sum(m, ei.by_dst.rowptr, ei.by_dst.col, n, mean=True)
         out = torch.empty(n, cout, **f32)
         SF._call('stin_bn_affine_res_fwd_f32', SF._ptr(agg), cout, SF._ptr(mean2), SF._ptr(rstd2), SF._ptr(gb2[0]), SF._ptr(gb2[1]),
                  SF._ptr(ei.by_dst.rowptr), SF._ptr(x) if residual else None, ldx, n, cout, int(relu), SF._ptr(out), cout, st)
@@ -545,6 +573,12 @@ class SingleConvMeshNet(nn.Module):
                     torch._foreach_add_(nbt, 1)
                 bumped = True
         _NBT_BUMPED[0] = bumped
+        second = []
+        if bumped and torch.is_grad_enabled():
+            for f in (f for m in self.modules() if isinstance(m, EdgeConvBN) and m.recomputed for f in (m.nn[1], m.nn[4])):
+                f._stin_second_pass = True
+                second.append(f.num_batches_tracked)
+        _NBT_SECOND['pending'] = second if second else None
         try:
             return self._forward(sample)
         finally:
