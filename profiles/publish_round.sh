@@ -2,8 +2,8 @@
 # Copy one collect_round.sh result directory (gpurun_out/<dir>) into the tracked profiles/<round>_* files.
 #   bash profiles/publish_round.sh r03 [r03]        (source directory under gpurun_out/, round prefix)
 set -e
-S=gpurun_out/${1:-r04}
-RN=${2:-r04}
+S=gpurun_out/${1:-r05}
+RN=${2:-r05}
 P=profiles/$RN
 cp $S/bench_default.json ${P}_bench_default.json; cp $S/bench_final.json ${P}_bench_final.json; cp $S/bench_bf16.json ${P}_bench_bf16.json
 cp $S/bench_irregular.json ${P}_bench_irregular.json
@@ -94,7 +94,7 @@ out += ['', '## `roofline.frac`: the bench line\'s bracket against rocprofv3', '
         'the next step\'s plan build - the round-2 artefact that read 0.26 at config 5); the rocprofv3 column is the average of the same '
         'kernel over every profiled step of a separate run (`%s_config_c{2,3,5}_kernel_stats.csv` / `.md`, `%s_bench_final_kernel_stats.csv`), '
         'where prefetch is on: its level-0 launches can overlap the plan build of the next step.' % (RN, RN), ''] + check
-out += ['', 'Round 3 for comparison (r03_configs.md): config 2 6.12 ms, config 3 5.9-6.2 ms, config 5 26.4-27.0 ms (bf16), headline 7.5-7.7 ms, bf16 5.36 ms, 20 k eager 2.8-3.7 ms.',
+out += ['', 'Round 4 for comparison (r04_configs.md): config 2 5.9 ms, config 3 5.46 ms, config 5 23.6 ms (bf16) / 41.1 ms (fp32), headline 7.13-7.3 ms, bf16 4.79 ms, 20 k-vertex crop 2.17 ms as a HIP graph.',
         '', 'JSON lines: `%s_config_{c2,c3,c5_bf16,c5_f32}.json`, `%s_bench_{bf16,irregular}.json`, `%s_small_20k_{eager,graph}.json`.' % (RN, RN, RN)]
 open(P + '_configs.md', 'w').write('\n'.join(out) + '\n')
 # SingleConvMeshNet: the bench line and the kernel table of the same command
@@ -104,9 +104,10 @@ if os.path.exists(S + '/scmn.json') and os.path.exists(S + '/prof_scmn/run_kerne
     open(P + '_scmn.json', 'w').write(json.dumps(sc) + '\n')
     open(P + '_scmn_kernel_stats.csv', 'w').write(open(S + '/prof_scmn/run_kernel_stats.csv').read())
     head = ('# Round %s: SingleConvMeshNet (SURVEY 8f rank 3) training step, %d vertices, filters 64/128/256, 2 propagation steps, fp32, '
-            'Adam: `python profiles/scmn_bench.py` = %.2f ms per step = %.1f M vertices/s, %.2f GB peak (round 1: 22.6 ms; `%s_scmn.json`); '
-            'kernel table of the same command under `rocprofv3 --kernel-trace --stats` (13 steps incl. warm-up)\n\n' % (
+            'Adam: `python profiles/scmn_bench.py` = %.2f ms per step = %.1f M vertices/s, %.2f GB peak (round 4: 21.8 ms, 11.74 GB; round 1: 22.6 ms; '
+            '`%s_scmn.json` incl. the level-0 rooflines); kernel table of the same command under `rocprofv3 --kernel-trace --stats` (14 steps incl. '
+            'warm-up and the bracketed one)\n\n' % (
                 RN[1:], sc['vertices'], sc['ms_per_step'], sc['vertices_per_s'] / 1e6, sc['peak_gb'], RN))
-    open(P + '_scmn.md', 'w').write(head + tool('summarize.py', S + '/prof_scmn/run_kernel_stats.csv', '13'))
+    open(P + '_scmn.md', 'w').write(head + tool('summarize.py', S + '/prof_scmn/run_kernel_stats.csv', '14'))
 print(d['ms_per_step'], dd['ms_per_step'])
 PY

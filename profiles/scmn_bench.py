@@ -49,7 +49,8 @@ def main():
     # roofline of the level-0 kernels (HIP events around the launches of one more step; algorithmic bytes: every gathered row
     # charged once per edge, int32 indices) and of the per-edge GEMM (executed 16-bit MFMA flops, 3 per fp32 product)
     from surface_texture_inpainting_net_amd import functional as SF
-    names = ['stin_gather_add_rows_f32', 'stin_segment_sum_f32', 'stin_gemm_nt_bn_f32', 'stin_gemm_tn_bn_f32']
+    names = ['stin_gather_add_rows_f32', 'stin_gather_add_rows_stats_f32', 'stin_segment_sum_f32', 'stin_segment_mean_stats_f32',
+             'stin_gemm_nt_bn_f32', 'stin_gemm_tn_bn_f32']
     SF.KernelTimer.start(names, max_records=4000)
     step()
     times = SF.KernelTimer.stop()
@@ -57,15 +58,15 @@ def main():
     roof = {}
     for (name, tag), ts in times.items():
         t = sum(ts) / len(ts)
-        if name == 'stin_gather_add_rows_f32' and tag and tag[0] == e0:
+        if name in ('stin_gather_add_rows_f32', 'stin_gather_add_rows_stats_f32') and tag and tag[0] == e0:
             e, h = tag
             nbytes = 3 * e * h * 4 + 8 * e
-            roof['gather_add_rows[E=%d,H=%d]' % (e, h)] = {'avg_us': t * 1e6, 'launches': len(ts), 'algorithmic_MB': nbytes / 1e6,
+            roof['%s[E=%d,H=%d]' % (name, e, h)] = {'avg_us': t * 1e6, 'launches': len(ts), 'algorithmic_MB': nbytes / 1e6,
                                                             'GBps': nbytes / t / 1e9, 'frac_of_hbm_peak': nbytes / t / 1e9 / 8000.0}
-        if name == 'stin_segment_sum_f32' and tag and tag[0] == e0 and tag[1] == n0:
+        if name in ('stin_segment_sum_f32', 'stin_segment_mean_stats_f32') and tag and tag[0] == e0 and tag[1] == n0:
             e, n, c = tag
             nbytes = e * c * 4 + n * c * 4 + 4 * e + 4 * (n + 1)
-            roof['segment_mean[E=%d,N=%d,C=%d]' % (e, n, c)] = {'avg_us': t * 1e6, 'launches': len(ts), 'algorithmic_MB': nbytes / 1e6,
+            roof['%s[E=%d,N=%d,C=%d]' % (name, e, n, c)] = {'avg_us': t * 1e6, 'launches': len(ts), 'algorithmic_MB': nbytes / 1e6,
                                                                  'GBps': nbytes / t / 1e9, 'frac_of_hbm_peak': nbytes / t / 1e9 / 8000.0}
         if name in ('stin_gemm_nt_bn_f32', 'stin_gemm_tn_bn_f32') and tag and tag[0] == e0:
             m, nc, k = tag
