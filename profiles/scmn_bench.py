@@ -17,22 +17,33 @@ def main():
     ap.add_argument('--vertices', type=int, default=200_000)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--torch-adam', action='store_true', help='torch.optim.Adam (multi-tensor framework kernels) instead of the '
+                    "package's TrainStep (flat gradient bucket + one HIP Adam launch) - rounds 1-4 measured this way")
     a = ap.parse_args()
     from surface_texture_inpainting_net_amd.singleconvmeshnet import SingleConvMeshNet
     from surface_texture_inpainting_net_amd.synthetic import make_synthetic_mesh
     torch.manual_seed(0)
     dev = torch.device('cuda:0')
     net = SingleConvMeshNet(10, 2, [64, 128, 256], num_classes=21).to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     s = make_synthetic_mesh(a.vertices, 3, seed=4, dilations=()).to(dev)
     tgt = torch.randn(s.x.shape[0], 21, device=dev)
+    if a.torch_adam:
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = (net(s) - tgt).square().mean()
-        loss.backward()
-        opt.step()
-        return loss
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = (net(s) - tgt).square().mean()
+            loss.backward()
+            opt.step()
+            return loss
+    else:
+        # the package's own step around the model (train_step.TrainStep(loss_fn=...): what the segmentation trainer's loop maps to -
+        # gradients written into one flat bucket, Adam as one HIP launch); same loss as above
+        from surface_texture_inpainting_net_amd.train_step import TrainStep
+        ts = TrainStep(net, lr=1e-3, amsgrad=False, loss_fn=lambda m, smp: (m(smp) - tgt).square().mean())
+
+        def step():
+            return ts(s)
 
     for _ in range(a.warmup):
         step()
@@ -43,7 +54,8 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / a.steps
-    out = {'model': 'SingleConvMeshNet', 'vertices': int(s.x.shape[0]), 'edges': int(s.edge_index.shape[1]),
+    out = {'model': 'SingleConvMeshNet', 'optimizer': 'torch.optim.Adam' if a.torch_adam else 'TrainStep (flat bucket + HIP Adam)',
+           'vertices': int(s.x.shape[0]), 'edges': int(s.edge_index.shape[1]),
            'ms_per_step': round(ms, 3), 'vertices_per_s': round(s.x.shape[0] / ms * 1e3),
            'peak_gb': round(torch.cuda.max_memory_allocated() / 2**30, 2), 'loss': float(loss)}
     # roofline of the level-0 kernels (HIP events around the launches of one more step; algorithmic bytes: every gathered row
