@@ -171,6 +171,25 @@ def test_bench_eight_rank_self_launch_dry_run_on_one_gpu():
     assert abs(out['value'] - 8 * out['config']['vertices_per_gpu'] * out['steps'] / (out['ms_per_step'] * 1e-3 * out['steps'])) < 1e-3 * out['value']
 
 
+@pytest.mark.gpu
+def test_bench_two_rank_unequal_scenes_reports_the_straggler_figures():
+    """`bench.py --gpus N --unequal-scenes` (round 5: BASELINE config 4 as the reference trains it - scenes of 150 k ... 200 k
+    vertices, one per rank) on two gloo ranks sharing one device: the line carries the per-rank scene sizes, every rank's time inside
+    the all-reduce bracket and north_star's 1 / 2 / 4 / 8 table row; replicas stay bit-identical."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
+                        '--unequal-scenes', '--no-cpu-baseline', '--no-secondary'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    s, row = out['straggler'], out['scaling_table_row']
+    assert s['vertices_per_rank'] == [150000, 200000] and len(s['allreduce_bracket_us_per_rank']) == 2
+    assert all(v > 0 for v in s['allreduce_bracket_us_per_rank'])
+    assert row['gpus'] == 2 and row['hbm_roofline_GBps'] == 16000.0 and 0 < row['frac_of_n_gpu_hbm_roofline'] < 1
+    assert abs(row['vertices_per_s'] - out['value']) < 1e-6 * out['value'] and out['distributed']['replicas_bit_identical'] is True
+    # the two ranks' scenes differ: value counts both (150 544 + 200 704 vertices per step)
+    assert abs(out['value'] * out['ms_per_step'] * 1e-3 - (150544 + 200704)) < 1.0
+
+
 def _scmn_xent(model, sample):
     return torch.nn.functional.cross_entropy(model(sample), sample.labels)
 
