@@ -162,6 +162,12 @@ SIGNATURES['stin_bn_running_stats_f32'] = (c_int, [c_ptr, c_ptr, c_int, c_f32, c
 SIGNATURES['stin_gemm_nt_bn_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_int, c_ptr])
 SIGNATURES['stin_gemm_tn_bn_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_int,
                                              c_ptr, c_size, c_ptr])
+SIGNATURES['stin_gemm_nt_stream_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_int, c_ptr])
+SIGNATURES['stin_gemm_nt_bn_bwd_groups'] = (c_i64, [c_i64, c_int, c_int, c_int])
+SIGNATURES['stin_gemm_nt_bn_bwd_stats_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int,
+                                                       c_int, c_ptr, c_size, c_ptr, c_ptr])
+SIGNATURES['stin_gemm_nt_bn_bwd_apply_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_i64,
+                                                       c_int, c_int, c_ptr, c_i64, c_int, c_ptr])
 SIGNATURES['stin_scmn_pack_f32'] = (c_int, [c_ptr] * 6 + [c_int] * 4 + [c_ptr] * 6)
 SIGNATURES['stin_scmn_unpack_f32'] = (c_int, [c_ptr, c_int, c_int, c_int, c_ptr, c_ptr])
 SIGNATURES['stin_bn_affine_res_fwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,

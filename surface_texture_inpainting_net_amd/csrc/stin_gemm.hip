@@ -419,6 +419,269 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_nt_bf16s(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------ NT, split 16-bit, streaming rows through wave-private LDS (round 5)
+// SingleConvMeshNet's per-EDGE products (models/modules/edge_conv_filter.py:34-44: Lin - BN - ReLU - Lin - BN over the E edge rows):
+// M = 1e5..1e6 rows, K and Nc 64..256, plain fp32 weights - a few flops per byte, yet the 64 x 64 tiling above runs them at half the
+// HBM rate: a block lives for K / 32 = 2-4 k-tiles, each a global-load latency + two block barriers, and every block splits the
+// same weight tile again.  Here the loop nest is turned around for rows that only stream:
+//   * persistent blocks of 4 waves; the block's weight slice [BN = 32 NT columns, all K] is split ONCE into LDS (fragment reads as in
+//     the tiling: [piece][32-wide k chunk][row][64 B], XOR-swizzled);
+//   * every wave owns whole 32-row tiles: it loads its tile's KC-wide row chunk with fully coalesced 16-byte loads (8 rows x 128 B
+//     per instruction), splits it into a wave-PRIVATE LDS region and multiplies - no block barrier in the loop, the waves of a block
+//     run free of each other; the next tile's loads are issued right after the registers are stored and stay in flight during the
+//     MFMAs and the epilogue (8-16 KB per wave, 64-128 KB per CU);
+//   * k order, MFMA order and the epilogue expression of k_gemm_nt_bf16s: bit-identical accumulators.
+// Epilogue modes: MODE 0 stores acc (the plain product); MODE 1 / 2 are the two passes of "the product is only the output gradient
+// of BatchNorm1d + ReLU over the pre-norm rows X" (the edge MLP's backward): that backward needs two column sums over ALL rows before
+// any row can be finished (P = sum d nhat, Q = sum d with d = dh [gamma nhat + beta > 0]), so the product runs TWICE instead of
+// being written, re-read by a reduction, and re-read + rewritten by the elementwise pass:
+//   MODE 1: per-lane fp64 sums (a lane owns its columns for the whole loop), nothing stored: partial [gridDim.x][2][Nc] doubles,
+//           folded in a fixed order by k_partial_sums_final;
+//   MODE 2: the product again, stored as dx = rstd gamma (d - Q / n - nhat P / n) - k_bn_bwd's expression on the accumulator.
+// TF: relu(v s + t) (BatchNorm1d + ReLU of the A columns, stin_bn_relu) applied when the tile is stored into LDS - the forward product.
+template <int KC, int NT, int NS, typename PT, int MODE, bool TF>
+__global__ __launch_bounds__(BLOCK, KC == 64 ? 2 : 1) void k_gemm_nt_stream(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                          int64_t ldw, int64_t M, int Nc, int K, const float* __restrict__ X,
+                                                          int64_t ldx, const stin_bn_tf tf, const float* __restrict__ P,
+                                                          const float* __restrict__ Q, float inv_n, double* __restrict__ partial,
+                                                          float* __restrict__ C, int64_t ldc) {
+    constexpr int BN = 32 * NT, CH = KC / 32;                                       // staged k chunks of 32 per tile
+    typedef typename PieceTraits<PT>::vec8 vec8;
+    constexpr float ASCALE = PieceTraits<PT>::ascale, WSCALE = PieceTraits<PT>::wscale;
+    extern __shared__ __attribute__((aligned(16))) unsigned char stream_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = K / 32;                                                          // (K % KC == 0)
+    const int wplane = nch * BN * 32;                                                // elements per weight piece plane
+    constexpr int APLANE = CH * 32 * 32;
+    PT* Wl = reinterpret_cast<PT*>(stream_smem);                                    // [NS][nch][BN][32]
+    PT* Al = Wl + (size_t)NS * wplane + (size_t)wave * NS * APLANE;                 // [NS][CH][32][32], this wave's
+    float* coef = reinterpret_cast<float*>(Wl + (size_t)NS * wplane + (size_t)4 * NS * APLANE);   // TF: s [K] | t [K]
+    const int n0 = blockIdx.y * BN;
+    auto swz = [](int row, int chunk) { return ((chunk ^ ((row >> 2) & 3)) << 3); };
+    const int kh = lane >> 5, li = lane & 31;
+    const int kq = lane & 7, rr = lane >> 3;
+
+    // ---- prologue: the block's weight slice, split once
+    {
+        const int k4n = K / 4;
+        for (int idx = tid; idx < BN * k4n; idx += BLOCK) {
+            const int row = idx / k4n, k4 = idx % k4n;
+            const float4 v = (n0 + row < Nc) ? ld4(W + (int64_t)(n0 + row) * ldw + k4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c = k4 >> 3, q = k4 & 7;
+            split_store<NS, PT>(v, Wl + ((size_t)c * BN + row) * 32 + swz(row, q >> 1) + (q & 1) * 4, wplane, WSCALE);
+        }
+        if (TF) {
+            for (int k = tid; k < K; k += BLOCK) {
+                float s, t;
+                stin_bn_st(tf, k, s, t);
+                coef[k] = s;
+                coef[K + k] = t;
+            }
+        }
+    }
+    __syncthreads();
+
+    // the lane's output columns and their BatchNorm coefficients (MODE 1 / 2; fixed for the whole loop)
+    float mu[NT], rs[NT], ga[NT], be[NT], pn[NT], qn[NT];
+    bool cok[NT];
+    double ps[NT], qs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = n0 + j * 32 + li;
+        cok[j] = col < Nc;
+        const int cc = cok[j] ? col : 0;
+        mu[j] = MODE != 0 ? tf.mean[cc] : 0.f;
+        rs[j] = MODE != 0 ? tf.rstd[cc] : 0.f;
+        ga[j] = MODE != 0 ? tf.gamma[cc] : 0.f;
+        be[j] = MODE != 0 ? tf.beta[cc] : 0.f;
+        pn[j] = MODE == 2 ? P[cc] * inv_n : 0.f;
+        qn[j] = MODE == 2 ? Q[cc] * inv_n : 0.f;
+        ps[j] = 0.0;
+        qs[j] = 0.0;
+    }
+
+    const int64_t tiles = (M + 31) / 32;
+    const int64_t wstride = (int64_t)gridDim.x * 4;
+    const int kcn = K / KC;
+    float4 ra[CH][4];
+    auto load_chunk = [&](int64_t tile, int kc) {                                   // rows [32 tile, +32), columns [KC kc, +KC)
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t row = tile * 32 + g * 8 + rr;
+                ra[c][g] = row < M ? ld4(A + row * lda + kc * KC + c * 32 + kq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    };
+    auto store_chunk = [&](int kc) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            stin_bn_coef4 cq;
+            if (TF) {
+                cq.s = *reinterpret_cast<const float4*>(coef + kc * KC + c * 32 + kq * 4);
+                cq.t = *reinterpret_cast<const float4*>(coef + K + kc * KC + c * 32 + kq * 4);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = g * 8 + rr;
+                const float4 v = TF ? stin_bn_relu4(ra[c][g], cq) : ra[c][g];
+                split_store<NS, PT>(v, Al + (c * 32 + row) * 32 + swz(row, kq >> 1) + (kq & 1) * 4, APLANE, ASCALE);
+            }
+        }
+    };
+
+    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t < tiles) load_chunk(t, 0);
+    for (; t < tiles; t += wstride) {
+        const int64_t m0 = t * 32;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        float4 xq[MODE != 0 ? NT : 1][4];                                           // X rows 8 u + rr, columns 32 j + 4 kq .. + 3
+        for (int kc = 0; kc < kcn; ++kc) {
+            __builtin_amdgcn_wave_barrier();                                        // (the previous chunk's fragment reads precede these stores)
+            store_chunk(kc);
+            if (MODE != 0 && kc + 1 == kcn) {                                       // the epilogue's X rows: requested before the MFMAs
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t row = m0 + u * 8 + rr;
+                        const int col = n0 + j * 32 + kq * 4;
+                        xq[j][u] = (row < M && col < Nc) ? ld4(X + row * ldx + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+            }
+            if (kc + 1 < kcn) load_chunk(t, kc + 1);
+            else if (t + wstride < tiles) load_chunk(t + wstride, 0);               // in flight during the MFMAs and the epilogue
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const PT* wb = Wl + (size_t)(kc * CH + c) * BN * 32;
+#pragma unroll
+                for (int ks = 0; ks < 32; ks += 16) {
+                    vec8 a[NS];
+#pragma unroll
+                    for (int p = 0; p < NS; ++p)
+                        a[p] = *reinterpret_cast<const vec8*>(Al + p * APLANE + (c * 32 + li) * 32 + swz(li, (ks >> 3) + kh));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        vec8 b[NS];
+#pragma unroll
+                        for (int p = 0; p < NS; ++p)
+                            b[p] = *reinterpret_cast<const vec8*>(wb + (size_t)p * wplane + (j * 32 + li) * 32 + swz(li, (ks >> 3) + kh));
+                        if (NS == 3) {
+                            acc[j] = mfma_k16(a[1], b[1], acc[j]);
+                            acc[j] = mfma_k16(a[0], b[2], acc[j]);
+                            acc[j] = mfma_k16(a[2], b[0], acc[j]);
+                        }
+                        acc[j] = mfma_k16(a[0], b[1], acc[j]);
+                        acc[j] = mfma_k16(a[1], b[0], acc[j]);
+                        acc[j] = mfma_k16(a[0], b[0], acc[j]);
+                    }
+                }
+            }
+        }
+        // ---- epilogue: the accumulator layout (lane = column, 16 rows) meets row-major memory (16-byte accesses, 8 rows x 128 B per
+        // instruction) through a 4 KB [32][32] tile of the wave's staging region - X comes in through it, the result goes out through it
+        float* stg = reinterpret_cast<float*>(Al);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[j][r] * (1.f / (ASCALE * WSCALE));
+            if (MODE != 0) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(stg + (u * 8 + rr) * 32 + kq * 4) = xq[j][u];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const float n = (stg[tr * 32 + li] - mu[j]) * rs[j];
+                    const float d = !(ga[j] * n + be[j] > 0.f) ? 0.f : v[r];
+                    if (MODE == 1) {
+                        if (cok[j] && m0 + tr < M) {
+                            ps[j] += (double)(d * n);
+                            qs[j] += (double)d;
+                        }
+                    } else {
+                        v[r] = rs[j] * ga[j] * (d - qn[j] - n * pn[j]);
+                    }
+                }
+            }
+            if (MODE != 1) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + li] = v[r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t row = m0 + u * 8 + rr;
+                    const int col = n0 + j * 32 + kq * 4;
+                    const float4 o = *reinterpret_cast<const float4*>(stg + (u * 8 + rr) * 32 + kq * 4);
+                    if (row < M && col < Nc) st4(C + row * ldc + col, o);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (MODE == 1) {
+        // fold: the two row halves of a wave (same column), then the four waves of the block in wave order
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            ps[j] += __shfl_xor(ps[j], 32);
+            qs[j] += __shfl_xor(qs[j], 32);
+        }
+        __syncthreads();                                                            // (every wave is done with its LDS region)
+        double* red = reinterpret_cast<double*>(stream_smem);                        // [4 waves][2][BN]
+        if (kh == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                red[(wave * 2 + 0) * BN + j * 32 + li] = ps[j];
+                red[(wave * 2 + 1) * BN + j * 32 + li] = qs[j];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += BLOCK) {
+            const int o = i / BN, lc = i % BN;
+            if (n0 + lc < Nc)
+                partial[((int64_t)blockIdx.x * 2 + o) * Nc + n0 + lc] =
+                    ((red[(0 * 2 + o) * BN + lc] + red[(1 * 2 + o) * BN + lc]) + red[(2 * 2 + o) * BN + lc]) + red[(3 * 2 + o) * BN + lc];
+        }
+    }
+}
+
+// out[i] = (float) sum over the groups of partial[g][i], i < n: 64 columns x 16 group lanes per block, each lane a fixed
+// interleaved chain over g, the lanes combined in lane order - deterministic
+__global__ __launch_bounds__(1024) void k_partial_sums_final(const double* __restrict__ partial, int64_t groups, int n,
+                                                               float* __restrict__ out) {
+    __shared__ double sm[16][65];
+    const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cl;
+    double s0 = 0.0, s1 = 0.0;
+    if (i < n) {
+        int64_t g = gl;
+        for (; g + 16 < groups; g += 32) {
+            s0 += partial[g * n + i];
+            s1 += partial[(g + 16) * n + i];
+        }
+        if (g < groups) s0 += partial[g * n + i];
+    }
+    sm[gl][cl] = s0 + s1;
+    __syncthreads();
+    if (gl == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][cl];
+        out[i] = (float)t;
+    }
+}
+
 // ------------------------------------------------------------ NT, split 16-bit, resident row strip
 // The tall-skinny shapes of this network (M = 1e4..1e6 rows, K <= 1280, Nc <= 1280) spend their time moving operands, not
 // multiplying: with 64x64 output tiles every A tile is fetched from L2 and split into its 16-bit pieces once per COLUMN
@@ -2887,9 +3150,24 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
     return stin_launch_status();
 }
 
+extern "C" int stin_gemm_nt_stream_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta, int64_t M, int Nc, int K, float* C, int64_t ldc,
+                                       int precision, stin_stream_t stream);
+namespace {
+constexpr int64_t STREAM_MIN_ROWS = 65536;      // below this the tiling's many short blocks fill the chip better than 32-row wave tiles
+inline bool stream_enabled() {
+    const char* e = getenv("STIN_NT_STREAM");                                  // A/B switch, re-read per call (tests flip it)
+    return e == nullptr || atoi(e) != 0;
+}
+}  // namespace
+
 extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                                 const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
                                 int Nc, int K, float* C, int64_t ldc, int precision, stin_stream_t stream) {
+    if (M >= STREAM_MIN_ROWS && bias == nullptr && row_mask == nullptr && residual == nullptr && stream_enabled()) {
+        const int rc = stin_gemm_nt_stream_f32(A, lda, W, ldw, nullptr, nullptr, nullptr, nullptr, M, Nc, K, C, ldc, precision, stream);
+        if (rc != STIN_E_UNSUPPORTED) return rc;                               // (plain fp32 weights, K = 64 / 128 / 256: the streaming kernel)
+    }
     return gemm_nt_f32_impl(A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc, precision, nullptr, stream);
 }
 
@@ -2899,12 +3177,160 @@ extern "C" int stin_gemm_nt_bn_f32(const float* A, int64_t lda, const float* W, 
                                    const float* gamma, const float* beta, int64_t M, int Nc, int K, float* C, int64_t ldc,
                                    int precision, stin_stream_t stream) {
     STIN_REQUIRE((precision & (STIN_GEMM_W_PRESPLIT | STIN_GEMM_W_FRAG)) == 0, STIN_E_UNSUPPORTED);
+    if (M >= STREAM_MIN_ROWS && mean != nullptr && stream_enabled()) {
+        const int rc = stin_gemm_nt_stream_f32(A, lda, W, ldw, mean, rstd, gamma, beta, M, Nc, K, C, ldc, precision, stream);
+        if (rc != STIN_E_UNSUPPORTED) return rc;
+    }
     stin_bn_tf tf;
     tf.mean = mean;
     tf.rstd = rstd;
     tf.gamma = gamma;
     tf.beta = beta;
     return gemm_nt_f32_impl(A, lda, W, ldw, nullptr, nullptr, 0, nullptr, 0, M, Nc, K, C, ldc, precision, nullptr, stream, nullptr, &tf);
+}
+
+// dh = A W^T used ONLY as the output gradient of BatchNorm1d + ReLU over the rows X (k_gemm_nt_stream MODE 1 / 2; SingleConvMeshNet's
+// per-edge backward, edge_conv_filter.py:34-44): `stats` = the product with the two column sums on its epilogue (nothing stored:
+// partial [groups][2][Nc] doubles, then sums [2][Nc] floats = P | Q, the gradients of gamma | beta); `apply` = the product again,
+// stored as dx = rstd gamma (d - Q / n - nhat P / n).  groups = stin_gemm_nt_bn_bwd_groups (0: shape / precision not served -
+// the caller keeps stin_gemm_nt_f32 + stin_colreduce_f32(DOT_BN_RELU) + stin_bn_act_bwd_f32).  W plain fp32 [Nc, K].
+namespace {
+// geometry of the streaming kernel for a shape: KC (staged k chunk), NT (32-column tiles per block), LDS bytes, blocks per CU
+struct StreamGeo {
+    int kc, nt, ncb, bpc;
+    size_t lds;
+    int64_t gx;
+};
+inline bool stream_geo(int64_t M, int Nc, int K, bool tf, StreamGeo* g, int mode = 0) {
+    if (M <= 0 || Nc <= 0 || Nc % 4 != 0 || K < 64 || K > 256 || K % 64 != 0 || (K > 64 && K % 128 != 0)) return false;
+    g->kc = K == 64 ? 64 : 128;
+    const char* e = getenv("STIN_NT_STREAM_NT");
+    int nt = e != nullptr ? atoi(e) : 0;
+    // (four column tiles + the statistics pass's X rows and fp64 sums do not fit 256 registers: two blocks per CU need them to)
+    if (nt != 2 && nt != 4) nt = (Nc <= 64 || (mode == 1 && K == 64)) ? 2 : 4;
+    auto lds_of = [&](int nt_) { return (size_t)4 * ((size_t)K * 32 * nt_ + (size_t)128 * g->kc) + (tf ? (size_t)8 * K : 0); };
+    if (lds_of(nt) > 160 * 1024) nt = 2;
+    if (lds_of(nt) > 160 * 1024) return false;
+    g->nt = nt;
+    g->lds = lds_of(nt);
+    if (g->lds < 4 * 2 * 32 * nt * sizeof(double)) g->lds = 4 * 2 * 32 * nt * sizeof(double);
+    g->ncb = (Nc + 32 * nt - 1) / (32 * nt);
+    g->bpc = (int)((160 * 1024) / g->lds);
+    if (g->bpc > 2) g->bpc = 2;
+    e = getenv("STIN_NT_STREAM_BPC");
+    if (e != nullptr && atoi(e) > 0 && atoi(e) < g->bpc) g->bpc = atoi(e);
+    int64_t gx = (int64_t)stin_cu_count() * g->bpc / g->ncb;
+    if (gx < 1) gx = 1;
+    const int64_t need = ((M + 31) / 32 + 3) / 4;                                 // blocks that have a tile for every wave
+    g->gx = need < gx ? need : gx;
+    return true;
+}
+inline bool stream_ok(const float* A, int64_t lda, const float* W, int64_t ldw, const float* X, int64_t ldx, const float* C, int64_t ldc,
+                      int precision) {
+    return lda % 4 == 0 && ldw % 4 == 0 && stin_aligned16(A) && stin_aligned16(W) && ldx % 4 == 0 && ldc % 4 == 0 && stin_aligned16(X) &&
+           stin_aligned16(C) &&
+           (precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6 || precision == STIN_GEMM_F16X3);
+}
+template <int MODE, bool TF>
+int stream_launch(const float* A, int64_t lda, const float* W, int64_t ldw, const float* X, int64_t ldx, const stin_bn_tf& tf,
+                  const float* P, const float* Q, float inv_n, int64_t M, int Nc, int K, double* partial, float* C, int64_t ldc,
+                  int precision, hipStream_t stream) {
+    StreamGeo g;
+    if (!stream_geo(M, Nc, K, TF, &g, MODE)) return STIN_E_UNSUPPORTED;
+    const dim3 grid((unsigned)g.gx, (unsigned)g.ncb);
+#define STIN_STREAM(KC_, NT_, NS_, PT_)                                                                                              \
+    do {                                                                                                                             \
+        static bool attr_set = false;                                                                                                \
+        if (!attr_set) {                                                                                                             \
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_stream<KC_, NT_, NS_, PT_, MODE, TF>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024);                                                                                   \
+            attr_set = true;                                                                                                         \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((k_gemm_nt_stream<KC_, NT_, NS_, PT_, MODE, TF>), grid, dim3(BLOCK), g.lds, stream, A, lda, W, ldw, M, Nc, K, X, \
+                           ldx, tf, P, Q, inv_n, partial, C, ldc);                                                                   \
+    } while (0)
+#define STIN_STREAM_P(KC_, NT_)                                                  \
+    do {                                                                         \
+        if (precision == STIN_GEMM_BF16X3) STIN_STREAM(KC_, NT_, 2, __bf16);     \
+        else if (precision == STIN_GEMM_BF16X6) STIN_STREAM(KC_, NT_, 3, __bf16); \
+        else STIN_STREAM(KC_, NT_, 2, _Float16);                                 \
+    } while (0)
+    if (g.kc == 64 && g.nt == 2) STIN_STREAM_P(64, 2);
+    else if (g.kc == 64) STIN_STREAM_P(64, 4);
+    else if (g.nt == 2) STIN_STREAM_P(128, 2);
+    else STIN_STREAM_P(128, 4);
+#undef STIN_STREAM_P
+#undef STIN_STREAM
+    return stin_launch_status();
+}
+}  // namespace
+extern "C" int64_t stin_gemm_nt_bn_bwd_groups(int64_t M, int Nc, int K, int precision) {
+    if (!(precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6 || precision == STIN_GEMM_F16X3)) return 0;
+    const char* e = getenv("STIN_NT_BNBWD");                                   // A/B switch, re-read per call (tests flip it)
+    if (e != nullptr && atoi(e) == 0) return 0;
+    StreamGeo g;
+    return stream_geo(M, Nc, K, false, &g, 1) ? g.gx : 0;
+}
+extern "C" int stin_gemm_nt_bn_bwd_stats_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* X, int64_t ldx,
+                                             const float* mean, const float* rstd, const float* gamma, const float* beta, int64_t M,
+                                             int Nc, int K, int precision, double* partial, size_t partial_bytes, float* sums,
+                                             stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(lda >= K && ldw >= K && ldx >= Nc, STIN_E_SIZE);
+    StreamGeo g;
+    STIN_REQUIRE(stream_geo(M, Nc, K, false, &g, 1) && stream_ok(A, lda, W, ldw, X, ldx, nullptr, 0, precision), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(A && W && X && mean && rstd && gamma && beta && partial && sums, STIN_E_NULL);
+    STIN_REQUIRE(partial_bytes >= (size_t)g.gx * 2 * (size_t)Nc * sizeof(double), STIN_E_WORKSPACE);
+    stin_bn_tf tf;
+    tf.mean = mean;
+    tf.rstd = rstd;
+    tf.gamma = gamma;
+    tf.beta = beta;
+    const int rc = stream_launch<1, false>(A, lda, W, ldw, X, ldx, tf, nullptr, nullptr, 0.f, M, Nc, K, partial, nullptr, 0, precision,
+                                           (hipStream_t)stream);
+    if (rc != STIN_OK) return rc;
+    hipLaunchKernelGGL(k_partial_sums_final, dim3((unsigned)((2 * Nc + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, partial, g.gx, 2 * Nc,
+                       sums);
+    return stin_launch_status();
+}
+extern "C" int stin_gemm_nt_bn_bwd_apply_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* X, int64_t ldx,
+                                             const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                             const float* sums, float inv_n, int64_t M, int Nc, int K, float* dx, int64_t lddx,
+                                             int precision, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(lda >= K && ldw >= K && ldx >= Nc && lddx >= Nc, STIN_E_SIZE);
+    StreamGeo g;
+    STIN_REQUIRE(stream_geo(M, Nc, K, false, &g) && stream_ok(A, lda, W, ldw, X, ldx, dx, lddx, precision), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(A && W && X && mean && rstd && gamma && beta && sums && dx, STIN_E_NULL);
+    stin_bn_tf tf;
+    tf.mean = mean;
+    tf.rstd = rstd;
+    tf.gamma = gamma;
+    tf.beta = beta;
+    return stream_launch<2, false>(A, lda, W, ldw, X, ldx, tf, sums, sums + Nc, inv_n, M, Nc, K, nullptr, dx, lddx, precision,
+                                   (hipStream_t)stream);
+}
+// The plain product C = A W^T (mean == NULL) or C = relu(gamma ((A - mean) rstd) + beta) W^T on the streaming kernel; returns
+// STIN_E_UNSUPPORTED for the shapes it does not serve (K not 64 / 128 / 256, rows not 16-byte aligned, a pre-split precision flag):
+// stin_gemm_nt_f32 / stin_gemm_nt_bn_f32 try it first for M >= 65 536 rows (STIN_NT_STREAM=0: never).
+extern "C" int stin_gemm_nt_stream_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta, int64_t M, int Nc, int K, float* C, int64_t ldc,
+                                       int precision, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
+    StreamGeo g;
+    STIN_REQUIRE(stream_geo(M, Nc, K, mean != nullptr, &g) && stream_ok(A, lda, W, ldw, nullptr, 0, C, ldc, precision), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(A && W && C && (mean == nullptr || (rstd && gamma && beta)), STIN_E_NULL);
+    stin_bn_tf tf;
+    tf.mean = mean;
+    tf.rstd = rstd;
+    tf.gamma = gamma;
+    tf.beta = beta;
+    if (mean != nullptr)
+        return stream_launch<0, true>(A, lda, W, ldw, nullptr, 0, tf, nullptr, nullptr, 0.f, M, Nc, K, nullptr, C, ldc, precision,
+                                      (hipStream_t)stream);
+    return stream_launch<0, false>(A, lda, W, ldw, nullptr, 0, tf, nullptr, nullptr, 0.f, M, Nc, K, nullptr, C, ldc, precision,
+                                   (hipStream_t)stream);
 }
 
 // The GEMM plus the FIRST stage of the instance-norm statistics of its output: colstats [groups][2][Nc] doubles, groups =

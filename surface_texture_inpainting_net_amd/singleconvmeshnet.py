@@ -308,6 +308,9 @@ USE_FUSED_LAYER = __import__('os').environ.get('STIN_SCMN_FUSED', '1') != '0'   
 BN_IN_GEMM = __import__('os').environ.get('STIN_SCMN_BN_IN_GEMM', '1') != '0'
 # the column moments of the gather-add output accumulated by the gather-add pass itself (stin_gather_add_rows_stats_f32)
 STATS_IN_GATHER = __import__('os').environ.get('STIN_SCMN_STATS_IN_GATHER', '1') != '0'
+# backward: the per-edge input-gradient product with BatchNorm1d + ReLU's backward on its epilogue, run twice (statistics, then the
+# finished gradient: stin_gemm_nt_bn_bwd_{stats,apply}_f32) instead of GEMM + column reduction + elementwise pass
+BN_BWD_IN_GEMM = __import__('os').environ.get('STIN_SCMN_BN_BWD_IN_GEMM', '1') != '0'
 
 
 def _gemm_nt_bn(pre, W, mean, rstd, gamma, beta, precision):
@@ -416,15 +419,31 @@ class _EdgeConvBNLayerFn(torch.autograd.Function):
         dm = torch.empty(e, cout, **f32)
         SF._call('stin_bn_mean_bwd_f32', SF._ptr(m), cout, SF._ptr(g_in), cout, SF._ptr(ei.dst32), SF._ptr(ei.by_dst.inv_deg),
                  SF._ptr(mean2), SF._ptr(rstd2), SF._ptr(gb2[0]), SF._ptr(P2), SF._ptr(Q2), 1.0 / max(e, 1), e, cout, SF._ptr(dm), cout, st)
-        dh = SF.gemm_nt(dm, w2T, precision=SF.PREC_BWD)                             # [E, h2]
+        lib = _lib.load()
+        two_pass = int(lib.stin_gemm_nt_bn_bwd_groups(e, h2, cout, int(SF.PREC_BWD))) if BN_BWD_IN_GEMM else 0
+        if two_pass > 0:
+            # dh = dm W2 is only the output gradient of BN1 + ReLU: the product runs twice (column sums on its epilogue, then the
+            # finished edge-row gradient) instead of being stored, reduced and rewritten - 3.1 of 4 GB per level-0 layer
+            partial = torch.empty(two_pass, 2, h2, dtype=torch.float64, device=dev)
+            pq1 = torch.empty(2, h2, **f32)
+            bn_args = (SF._ptr(dm), cout, SF._ptr(w2T), cout, SF._ptr(pre), h2, SF._ptr(mean1), SF._ptr(rstd1), SF._ptr(gb1[0]), SF._ptr(gb1[1]))
+            SF._call('stin_gemm_nt_bn_bwd_stats_f32', *bn_args, e, h2, cout, int(SF.PREC_BWD), SF._ptr(partial), partial.numel() * 8,
+                     SF._ptr(pq1), st, tag=(e, h2, cout))
+            P1, Q1 = pq1[0], pq1[1]
+            dh = torch.empty(e, h2, **f32)
+            SF._call('stin_gemm_nt_bn_bwd_apply_f32', *bn_args, SF._ptr(pq1), 1.0 / e, e, h2, cout, SF._ptr(dh), h2, int(SF.PREC_BWD), st,
+                     tag=(e, h2, cout))
+        else:
+            dh = SF.gemm_nt(dm, w2T, precision=SF.PREC_BWD)                         # [E, h2]
         if h is None:
             dW2 = _gemm_tn_bn(dm, pre, mean1, rstd1, gb1[0], gb1[1], SF.PREC_BWD)   # [cout, h2] from the pre-norm rows
         else:
             dW2 = SF.gemm_tn(dm, h, ones_column=False, precision=SF.PREC_BWD)       # [cout, h2]
         del h, m, agg
-        P1, Q1 = SF.colreduce(SF.RED_DOT_BN_RELU, pre, ge, ge.ptr_sum, gout=dh, mean=mean1, rstd=rstd1, coef=gb1)
-        SF._call('stin_bn_act_bwd_f32', SF._ptr(pre), h2, SF._ptr(dh), h2, SF._ptr(mean1), SF._ptr(rstd1), SF._ptr(gb1[0]), SF._ptr(gb1[1]),
-                 SF._ptr(P1), SF._ptr(Q1), 1.0 / e, e, h2, 1, SF._ptr(dh), h2, st)      # (element-wise: in place over dh)
+        if two_pass <= 0:
+            P1, Q1 = SF.colreduce(SF.RED_DOT_BN_RELU, pre, ge, ge.ptr_sum, gout=dh, mean=mean1, rstd=rstd1, coef=gb1)
+            SF._call('stin_bn_act_bwd_f32', SF._ptr(pre), h2, SF._ptr(dh), h2, SF._ptr(mean1), SF._ptr(rstd1), SF._ptr(gb1[0]),
+                     SF._ptr(gb1[1]), SF._ptr(P1), SF._ptr(Q1), 1.0 / e, e, h2, 1, SF._ptr(dh), h2, st)   # (element-wise: in place over dh)
         dy = torch.empty(n, 2 * h2, **f32)
         for off, csr in ((0, ei.by_dst), (h2, ei.by_src)):
             SF._call('stin_segment_sum_f32', SF._ptr(dh), h2, SF._ptr(csr.rowptr), SF._ptr(csr.col), n, h2, 0, dy.data_ptr() + 4 * off,

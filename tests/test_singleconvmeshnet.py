@@ -216,6 +216,7 @@ def test_hip_fused_layer_equals_the_per_op_path(pooling, monkeypatch):
         monkeypatch.setattr(M, 'USE_FUSED_LAYER', fused)
         monkeypatch.setattr(M, 'BN_IN_GEMM', in_gemm)
         monkeypatch.setattr(M, 'STATS_IN_GATHER', in_gemm)    # (fp64 sums in another order: mean / rstd equal to fp32 rounding)
+        monkeypatch.setattr(M, 'BN_BWD_IN_GEMM', in_gemm)     # (likewise: the two column sums of the BatchNorm backward)
         torch.manual_seed(3)
         net = M.SingleConvMeshNet(10, 2, [16, 32, 64], num_classes=5, pooling_method=pooling).to('cuda:0')
         outs = []
@@ -307,3 +308,86 @@ def test_hip_segment_mean_with_moments_equals_the_two_passes(C, n, e):
     mean, rstd = SF.moments_final(partial, ge.inv_cnt, eps=1e-5)
     m0, r0 = SF.colreduce(SF.RED_MOMENTS, m, ge, ge.ptr_sum, eps=1e-5)
     assert float((mean - m0).abs().max()) <= 1e-6 and float((rstd / r0 - 1).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('e,h2,cout', [(70_001, 128, 64), (33_333, 256, 128), (9000, 512, 256), (5000, 96, 64), (3001, 32, 64), (1_200_642, 128, 64)])
+def test_hip_gemm_with_batchnorm_backward_on_its_epilogue_equals_the_three_launches(e, h2, cout, monkeypatch):
+    """stin_gemm_nt_bn_bwd_{stats,apply}_f32 (the per-edge input-gradient product run twice, BatchNorm1d + ReLU's backward on its
+    epilogue) against stin_gemm_nt_f32 + stin_colreduce_f32(DOT_BN_RELU) + stin_bn_act_bwd_f32: the accumulators are the same
+    numbers, so the two column sums agree to fp64-summation-order rounding and the finished gradient to a few fp32 ulps of
+    its scale; both tile widths (two or four 32-column tiles per block); deterministic."""
+    from surface_texture_inpainting_net_amd import _lib
+    from surface_texture_inpainting_net_amd import functional as SF
+    from surface_texture_inpainting_net_amd.singleconvmeshnet import _all_rows
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(e + h2)
+    dm = (torch.randn(e, cout, generator=g) * 0.3).to('cuda:0')
+    w2T = (torch.randn(h2, cout, generator=g) * 0.1).to('cuda:0')
+    pre = (torch.randn(e, h2, generator=g) * 1.1 + 0.2).to('cuda:0')
+    gb = torch.stack([torch.rand(h2, generator=g) + 0.5, torch.randn(h2, generator=g) * 0.3]).to('cuda:0')
+    ge = _all_rows(e, pre.device)
+    mean, rstd = SF.colreduce(SF.RED_MOMENTS, pre, ge, ge.ptr_sum, eps=1e-5)
+    st = SF._stream(pre)
+    # the three-launch route
+    dh = SF.gemm_nt(dm, w2T, precision=SF.PREC_BWD)
+    P0, Q0 = SF.colreduce(SF.RED_DOT_BN_RELU, pre, ge, ge.ptr_sum, gout=dh, mean=mean, rstd=rstd, coef=gb)
+    ref = torch.empty_like(dh)
+    SF._call('stin_bn_act_bwd_f32', SF._ptr(pre), h2, SF._ptr(dh), h2, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gb[0]), SF._ptr(gb[1]),
+             SF._ptr(P0), SF._ptr(Q0), 1.0 / e, e, h2, 1, SF._ptr(ref), h2, st)
+    for bn in ['2', '4']:
+        monkeypatch.setenv('STIN_NT_STREAM_NT', bn)
+        groups = int(lib.stin_gemm_nt_bn_bwd_groups(e, h2, cout, int(SF.PREC_BWD)))
+        assert 0 < groups <= 2048
+        args = (SF._ptr(dm), cout, SF._ptr(w2T), cout, SF._ptr(pre), h2, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gb[0]), SF._ptr(gb[1]))
+        res = []
+        for _ in range(2):
+            partial = torch.full((groups, 2, h2), float('nan'), dtype=torch.float64, device='cuda:0')
+            pq = torch.empty(2, h2, device='cuda:0')
+            SF._call('stin_gemm_nt_bn_bwd_stats_f32', *args, e, h2, cout, int(SF.PREC_BWD), SF._ptr(partial), partial.numel() * 8, SF._ptr(pq), st)
+            out = torch.full((e, h2), float('nan'), device='cuda:0')
+            SF._call('stin_gemm_nt_bn_bwd_apply_f32', *args, SF._ptr(pq), 1.0 / e, e, h2, cout, SF._ptr(out), h2, int(SF.PREC_BWD), st)
+            res.append((pq, out))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), 'deterministic'
+        pq, out = res[0]
+        sp, sq = float(P0.abs().max()), float(Q0.abs().max())
+        ep, eq = float((pq[0] - P0.view(-1)).abs().max()) / sp, float((pq[1] - Q0.view(-1)).abs().max()) / sq
+        eo = float((out - ref).abs().max()) / float(ref.abs().max())
+        print('\n[%d x %d x %d, tile width %s] P %.1e, Q %.1e, dx %.1e of scale' % (e, h2, cout, bn, ep, eq, eo))
+        assert ep <= 2e-7 and eq <= 2e-7 and eo <= 1e-6
+    monkeypatch.setenv('STIN_NT_BNBWD', '0')
+    assert int(lib.stin_gemm_nt_bn_bwd_groups(e, h2, cout, int(SF.PREC_BWD))) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('m,nc,k', [(70_001, 128, 64), (70_001, 64, 128), (33_333, 256, 128), (20_000, 128, 256), (5000, 96, 64), (66_000, 64, 128)])
+def test_hip_streaming_rows_gemm_is_bit_identical_to_the_tiled_kernels(m, nc, k, monkeypatch):
+    """stin_gemm_nt_stream_f32 (persistent blocks, wave-owned 32-row tiles through wave-private LDS, the weight slice split once per
+    block) multiplies in the tiled kernels' k and MFMA order: the plain product and the product with BatchNorm1d + ReLU applied to
+    the staged operand equal stin_gemm_nt_f32 / stin_gemm_nt_bn_f32 on the 64 x 64 tiling bit for bit, for every precision the
+    edge MLP uses; the public entry points route M >= 65 536 rows to it."""
+    from surface_texture_inpainting_net_amd import functional as SF
+    g = torch.Generator().manual_seed(m + nc)
+    A = (torch.randn(m, k, generator=g) * 0.7 + 0.1).to('cuda:0')
+    W = (torch.randn(nc, k, generator=g) * 0.1).to('cuda:0')
+    mean, rstd = (torch.randn(k, generator=g) * 0.1).to('cuda:0'), (torch.rand(k, generator=g) + 0.5).to('cuda:0')
+    gamma, beta = (torch.rand(k, generator=g) + 0.5).to('cuda:0'), (torch.randn(k, generator=g) * 0.2).to('cuda:0')
+    st = SF._stream(A)
+    monkeypatch.setenv('STIN_NT_STREAM', '0')
+    for prec in (SF.PREC_FWD, SF.PREC_BWD):
+        ref = SF.gemm_nt(A, W, precision=prec)
+        ref_bn = torch.empty(m, nc, device='cuda:0')
+        SF._call('stin_gemm_nt_bn_f32', SF._ptr(A), k, SF._ptr(W), k, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gamma), SF._ptr(beta), m, nc, k,
+                 SF._ptr(ref_bn), nc, int(prec), st)
+        for nt in ('2', '4'):
+            monkeypatch.setenv('STIN_NT_STREAM_NT', nt)
+            out = torch.full((m, nc), float('nan'), device='cuda:0')
+            SF._call('stin_gemm_nt_stream_f32', SF._ptr(A), k, SF._ptr(W), k, None, None, None, None, m, nc, k, SF._ptr(out), nc, int(prec), st)
+            assert torch.equal(out, ref), (prec, nt)
+            out.fill_(float('nan'))
+            SF._call('stin_gemm_nt_stream_f32', SF._ptr(A), k, SF._ptr(W), k, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gamma), SF._ptr(beta), m, nc,
+                     k, SF._ptr(out), nc, int(prec), st)
+            assert torch.equal(out, ref_bn), (prec, nt, 'bn')
+    monkeypatch.delenv('STIN_NT_STREAM_NT')
+    monkeypatch.setenv('STIN_NT_STREAM', '1')
+    assert torch.equal(SF.gemm_nt(A, W, precision=SF.PREC_BWD), ref)               # (routed by size; same numbers either way)
