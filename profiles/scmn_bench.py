@@ -62,7 +62,7 @@ def main():
     # charged once per edge, int32 indices) and of the per-edge GEMM (executed 16-bit MFMA flops, 3 per fp32 product)
     from surface_texture_inpainting_net_amd import functional as SF
     names = ['stin_gather_add_rows_f32', 'stin_gather_add_rows_stats_f32', 'stin_segment_sum_f32', 'stin_segment_mean_stats_f32',
-             'stin_gemm_nt_bn_f32', 'stin_gemm_tn_bn_f32']
+             'stin_gemm_nt_bn_f32', 'stin_gemm_tn_bn_f32', 'stin_gemm_nt_bn_bwd_stats_f32', 'stin_gemm_nt_bn_bwd_apply_f32']
     SF.KernelTimer.start(names, max_records=4000)
     step()
     times = SF.KernelTimer.stop()
@@ -88,6 +88,13 @@ def main():
                 'avg_us': t * 1e6, 'launches': len(ts), 'mfma_TFLOPs_executed': flops / t / 1e12, 'frac_of_16bit_mfma_peak': flops / t / 1e12 / 2500.0,
                 'min_bytes_MB': minb / 1e6, 'GBps_min_traffic': minb / t / 1e9, 'frac_of_hbm_peak': minb / t / 1e9 / 8000.0,
                 'bound': 'hbm (operand bytes): the product of an [E, 2 cout] by a [cout, 2 cout] matrix moves 4 (K + Nc) bytes per 6 K Nc flops'}
+        if name in ('stin_gemm_nt_bn_bwd_stats_f32', 'stin_gemm_nt_bn_bwd_apply_f32') and tag and tag[0] == e0:
+            m, nc, k = tag                       # A [M, K] and X [M, Nc] read (+ dx [M, Nc] written by `apply`); the statistics fold rides in `stats`
+            flops = 2.0 * m * nc * k * 3
+            minb = 4.0 * (m * k + m * nc * (2 if name.endswith('apply_f32') else 1))
+            roof['%s[M=%d,Nc=%d,K=%d]' % (name, m, nc, k)] = {
+                'avg_us': t * 1e6, 'launches': len(ts), 'mfma_TFLOPs_executed': flops / t / 1e12, 'min_bytes_MB': minb / 1e6,
+                'GBps_min_traffic': minb / t / 1e9, 'frac_of_hbm_peak': minb / t / 1e9 / 8000.0, 'bound': 'hbm (operand bytes)'}
     out['roofline'] = roof
     print(json.dumps(out))
 

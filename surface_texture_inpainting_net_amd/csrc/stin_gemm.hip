@@ -444,7 +444,9 @@ __global__ __launch_bounds__(BLOCK, KC == 64 ? 2 : 1) void k_gemm_nt_stream(cons
                                                           int64_t ldw, int64_t M, int Nc, int K, const float* __restrict__ X,
                                                           int64_t ldx, const stin_bn_tf tf, const float* __restrict__ P,
                                                           const float* __restrict__ Q, float inv_n, double* __restrict__ partial,
-                                                          float* __restrict__ C, int64_t ldc) {
+                                                          float* __restrict__ C, int64_t ldc, const float* __restrict__ bias,
+                                                          const float* __restrict__ row_mask, int64_t ld_mask,
+                                                          const float* __restrict__ res, int64_t ld_res, int wpre) {
     constexpr int BN = 32 * NT, CH = KC / 32;                                       // staged k chunks of 32 per tile
     typedef typename PieceTraits<PT>::vec8 vec8;
     constexpr float ASCALE = PieceTraits<PT>::ascale, WSCALE = PieceTraits<PT>::wscale;
@@ -468,7 +470,13 @@ __global__ __launch_bounds__(BLOCK, KC == 64 ? 2 : 1) void k_gemm_nt_stream(cons
             const int row = idx / k4n, k4 = idx % k4n;
             const float4 v = (n0 + row < Nc) ? ld4(W + (int64_t)(n0 + row) * ldw + k4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             const int c = k4 >> 3, q = k4 & 7;
-            split_store<NS, PT>(v, Wl + ((size_t)c * BN + row) * 32 + swz(row, q >> 1) + (q & 1) * 4, wplane, WSCALE);
+            PT* dst = Wl + ((size_t)c * BN + row) * 32 + swz(row, q >> 1) + (q & 1) * 4;
+            if (wpre) {          // pre-split weights (stin_pack.hip put_weight): [hi x 4 | lo x 4] per k-group, scaled already
+                *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(dst + wplane) = make_float2(v.z, v.w);
+            } else {
+                split_store<NS, PT>(v, dst, wplane, WSCALE);
+            }
         }
         if (TF) {
             for (int k = tid; k < K; k += BLOCK) {
@@ -539,19 +547,23 @@ __global__ __launch_bounds__(BLOCK, KC == 64 ? 2 : 1) void k_gemm_nt_stream(cons
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        float4 xq[MODE != 0 ? NT : 1][4];                                           // X rows 8 u + rr, columns 32 j + 4 kq .. + 3
+        // X rows 8 u + rr, columns 32 j + 4 kq .. + 3 of column tile j in slot j & 1: two tiles requested before the MFMAs, tile
+        // j + 2 when tile j has gone into LDS (all NT at once do not fit 256 registers beside the accumulators)
+        float4 xq[2][4];
+        auto load_x = [&](int j) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t row = m0 + u * 8 + rr;
+                const int col = n0 + j * 32 + kq * 4;
+                xq[j & 1][u] = (row < M && col < Nc) ? ld4(X + row * ldx + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
         for (int kc = 0; kc < kcn; ++kc) {
             __builtin_amdgcn_wave_barrier();                                        // (the previous chunk's fragment reads precede these stores)
             store_chunk(kc);
             if (MODE != 0 && kc + 1 == kcn) {                                       // the epilogue's X rows: requested before the MFMAs
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int64_t row = m0 + u * 8 + rr;
-                        const int col = n0 + j * 32 + kq * 4;
-                        xq[j][u] = (row < M && col < Nc) ? ld4(X + row * ldx + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                load_x(0);
+                if (NT > 1) load_x(1);
             }
             if (kc + 1 < kcn) load_chunk(t, kc + 1);
             else if (t + wstride < tiles) load_chunk(t + wstride, 0);               // in flight during the MFMAs and the epilogue
@@ -595,7 +607,8 @@ __global__ __launch_bounds__(BLOCK, KC == 64 ? 2 : 1) void k_gemm_nt_stream(cons
             if (MODE != 0) {
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(stg + (u * 8 + rr) * 32 + kq * 4) = xq[j][u];
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(stg + (u * 8 + rr) * 32 + kq * 4) = xq[j & 1][u];
+                if (j + 2 < NT) load_x(j + 2);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -623,8 +636,19 @@ __global__ __launch_bounds__(BLOCK, KC == 64 ? 2 : 1) void k_gemm_nt_stream(cons
                 for (int u = 0; u < 4; ++u) {
                     const int64_t row = m0 + u * 8 + rr;
                     const int col = n0 + j * 32 + kq * 4;
-                    const float4 o = *reinterpret_cast<const float4*>(stg + (u * 8 + rr) * 32 + kq * 4);
-                    if (row < M && col < Nc) st4(C + row * ldc + col, o);
+                    float4 o = *reinterpret_cast<const float4*>(stg + (u * 8 + rr) * 32 + kq * 4);
+                    if (row < M && col < Nc) {
+                        if (MODE == 0 && (bias != nullptr || res != nullptr)) {      // k_gemm_nt_bf16s's expression: (v + bias [* mask]) + res
+                            const float4 bq = bias != nullptr ? ld4(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            const float mk = row_mask != nullptr ? row_mask[row * ld_mask] : 1.f;
+                            const float4 rv = res != nullptr ? ld4(res + row * ld_res + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            o.x = o.x + (row_mask != nullptr ? bq.x * mk : bq.x) + rv.x;
+                            o.y = o.y + (row_mask != nullptr ? bq.y * mk : bq.y) + rv.y;
+                            o.z = o.z + (row_mask != nullptr ? bq.z * mk : bq.z) + rv.z;
+                            o.w = o.w + (row_mask != nullptr ? bq.w * mk : bq.w) + rv.w;
+                        }
+                        st4(C + row * ldc + col, o);
+                    }
                 }
             }
         }
@@ -2960,6 +2984,11 @@ inline bool tn_one_per_cu(int storage, int precision, int TI, int TJ, int64_t M)
 }  // namespace
 
 // colstats != NULL: the launch must be the all-columns kernel (its blocks own whole rows) - STIN_E_UNSUPPORTED otherwise
+// the streaming-rows kernel for a pre-split (not fragment-ordered) weight operand with the tiled kernels' epilogue; defined below
+static int stream_nt_presplit_try(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* row_mask,
+                                  int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M, int Nc, int K, float* C,
+                                  int64_t ldc, int precision, hipStream_t stream);
+
 static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                             const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
                             int Nc, int K, float* C, int64_t ldc, int precision, double* colstats, stin_stream_t stream_,
@@ -3127,6 +3156,10 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
     } else if (wpre) {
         // pre-split W: the 16-byte vector path only (K % 4 == 0, aligned rows) - one tile shape, the data is per-network
         STIN_REQUIRE(vec, STIN_E_ALIGN);
+        if (tf == nullptr && colstats == nullptr) {       // (round 5) very tall products: the streaming-rows kernel, bit-identical
+            const int rc = stream_nt_presplit_try(A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc, precision, stream);
+            if (rc != STIN_E_UNSUPPORTED) return rc;
+        }
         if (force_tile == 1 || (force_tile == 0 && big_tile)) {
             dim3 grid(nt_grid(M, Nc, 128, 128));
             if (precision == STIN_GEMM_BF16X3)
@@ -3202,12 +3235,16 @@ struct StreamGeo {
     int64_t gx;
 };
 inline bool stream_geo(int64_t M, int Nc, int K, bool tf, StreamGeo* g, int mode = 0) {
-    if (M <= 0 || Nc <= 0 || Nc % 4 != 0 || K < 64 || K > 256 || K % 64 != 0 || (K > 64 && K % 128 != 0)) return false;
-    g->kc = K == 64 ? 64 : 128;
-    const char* e = getenv("STIN_NT_STREAM_NT");
+    if (M <= 0 || Nc <= 0 || Nc % 4 != 0 || K < 64 || K > 512 || K % 64 != 0) return false;
+    // staged chunk: 64 columns (8 KB per wave in flight, 32 KB of staging per block: two blocks per CU up to K = 128 -
+    // 1 200 642 x 64 x 128 with the BatchNorm transform: 184 us against 212 with 128-column chunks, profiles/probes/kc_probe.sh)
+    g->kc = 64;
+    const char* e = getenv("STIN_NT_STREAM_KC");
+    if (e != nullptr && atoi(e) == 128 && K % 128 == 0) g->kc = 128;
+    e = getenv("STIN_NT_STREAM_NT");
     int nt = e != nullptr ? atoi(e) : 0;
-    // (four column tiles + the statistics pass's X rows and fp64 sums do not fit 256 registers: two blocks per CU need them to)
-    if (nt != 2 && nt != 4) nt = (Nc <= 64 || (mode == 1 && K == 64)) ? 2 : 4;
+    // (the statistics pass with four column tiles spills ~40 registers at two blocks per CU: two tiles, the A rows come from L2 again)
+    if (nt != 2 && nt != 4) nt = (Nc <= 64 || mode == 1) ? 2 : 4;
     auto lds_of = [&](int nt_) { return (size_t)4 * ((size_t)K * 32 * nt_ + (size_t)128 * g->kc) + (tf ? (size_t)8 * K : 0); };
     if (lds_of(nt) > 160 * 1024) nt = 2;
     if (lds_of(nt) > 160 * 1024) return false;
@@ -3231,10 +3268,15 @@ inline bool stream_ok(const float* A, int64_t lda, const float* W, int64_t ldw, 
            stin_aligned16(C) &&
            (precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6 || precision == STIN_GEMM_F16X3);
 }
+struct StreamEpi {                     // MODE 0 only: C = (acc + bias [* row_mask]) + res; wpre: W pre-split (not in fragment order)
+    const float *bias = nullptr, *row_mask = nullptr, *res = nullptr;
+    int64_t ld_mask = 0, ld_res = 0;
+    int wpre = 0;
+};
 template <int MODE, bool TF>
 int stream_launch(const float* A, int64_t lda, const float* W, int64_t ldw, const float* X, int64_t ldx, const stin_bn_tf& tf,
                   const float* P, const float* Q, float inv_n, int64_t M, int Nc, int K, double* partial, float* C, int64_t ldc,
-                  int precision, hipStream_t stream) {
+                  int precision, hipStream_t stream, const StreamEpi epi = StreamEpi()) {
     StreamGeo g;
     if (!stream_geo(M, Nc, K, TF, &g, MODE)) return STIN_E_UNSUPPORTED;
     const dim3 grid((unsigned)g.gx, (unsigned)g.ncb);
@@ -3247,7 +3289,7 @@ int stream_launch(const float* A, int64_t lda, const float* W, int64_t ldw, cons
             attr_set = true;                                                                                                         \
         }                                                                                                                            \
         hipLaunchKernelGGL((k_gemm_nt_stream<KC_, NT_, NS_, PT_, MODE, TF>), grid, dim3(BLOCK), g.lds, stream, A, lda, W, ldw, M, Nc, K, X, \
-                           ldx, tf, P, Q, inv_n, partial, C, ldc);                                                                   \
+                           ldx, tf, P, Q, inv_n, partial, C, ldc, epi.bias, epi.row_mask, epi.ld_mask, epi.res, epi.ld_res, epi.wpre);       \
     } while (0)
 #define STIN_STREAM_P(KC_, NT_)                                                  \
     do {                                                                         \
@@ -3264,6 +3306,31 @@ int stream_launch(const float* A, int64_t lda, const float* W, int64_t ldw, cons
     return stin_launch_status();
 }
 }  // namespace
+static int stream_nt_presplit_try(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* row_mask,
+                                  int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M, int Nc, int K, float* C,
+                                  int64_t ldc, int precision, hipStream_t stream) {
+    // in-step A/B (profiles/r05_experiments_not_shipped.md): at 200 704 rows the headline step is 0.03 ms SLOWER with it (7.36-7.39
+    // against 7.34 ms), at 1 M rows (config 5 in fp32) 0.35 ms faster (41.45 against 41.81 ms) - the default sits between
+    const char* er = getenv("STIN_NT_STREAM_PRE_ROWS");                        // (re-read per call: tests flip it)
+    const int64_t min_rows = er != nullptr ? atoll(er) : 500000;
+    const char* e = getenv("STIN_NT_STREAM");
+    if (M < min_rows || (e != nullptr && atoi(e) == 0)) return STIN_E_UNSUPPORTED;
+    StreamGeo g;
+    if (!(precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_F16X3) || !stream_geo(M, Nc, K, false, &g) ||
+        !stream_ok(A, lda, W, ldw, nullptr, 0, C, ldc, precision) || (bias != nullptr && !stin_aligned16(bias)) ||
+        (residual != nullptr && (ld_res % 4 != 0 || !stin_aligned16(residual))))
+        return STIN_E_UNSUPPORTED;
+    StreamEpi epi;
+    epi.bias = bias;
+    epi.row_mask = row_mask;
+    epi.ld_mask = ld_mask;
+    epi.res = residual;
+    epi.ld_res = ld_res;
+    epi.wpre = 1;
+    stin_bn_tf tf;
+    tf.mean = tf.rstd = tf.gamma = tf.beta = nullptr;
+    return stream_launch<0, false>(A, lda, W, ldw, nullptr, 0, tf, nullptr, nullptr, 0.f, M, Nc, K, nullptr, C, ldc, precision, stream, epi);
+}
 extern "C" int64_t stin_gemm_nt_bn_bwd_groups(int64_t M, int Nc, int K, int precision) {
     if (!(precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6 || precision == STIN_GEMM_F16X3)) return 0;
     const char* e = getenv("STIN_NT_BNBWD");                                   // A/B switch, re-read per call (tests flip it)

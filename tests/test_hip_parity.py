@@ -619,6 +619,32 @@ def test_gemm_nt_panel_kernel_equals_tiled_kernel(M, Nc, K, monkeypatch):
         assert float((SF.gemm_nt(A, Wf, b, row_mask=mask, precision=prec | SF.GEMM_W_PRESPLIT | FR).double() - ref).abs().max()) <= tol * scale
 
 
+@pytest.mark.parametrize('M,Nc,K', [(40_001, 64, 128), (40_001, 128, 64), (9000, 64, 256), (20_000, 256, 64), (5003, 64, 320), (3000, 96, 192)])
+def test_gemm_nt_streaming_rows_kernel_with_presplit_weights_equals_tiled_kernel(M, Nc, K, monkeypatch):
+    """Round 5: the streaming-rows NT kernel (k_gemm_nt_stream: persistent blocks, wave-owned 32-row tiles through wave-private
+    LDS, the pre-split weight slice copied once per block) on the k-group layout of the block launches' tall products
+    (agg = hE W2^T, dhE = g W2: >= 500 000 rows by default, STIN_NT_STREAM_PRE_ROWS) against the tiled kernel: same k order,
+    MFMA order and epilogue expression (bias [* row mask], residual) -> bit-identical; ragged last tile, strided views,
+    two and four column tiles per block."""
+    g = torch.Generator().manual_seed(M + Nc + K)
+    A = torch.randn(M + 3, K + 4, generator=g).to(DEV)[1:M + 1, :K]
+    W = (torch.randn(Nc, K, generator=g) * 0.1).to(DEV)
+    b = torch.randn(Nc, generator=g).to(DEV)
+    mask = (torch.rand(M, 3, generator=g) < 0.7).float().to(DEV)[:, 1]
+    res = torch.randn(M, Nc + 4, generator=g).to(DEV)[:, :Nc]
+    for prec in (SF.GEMM_F16X3, SF.GEMM_BF16X3):
+        Wk = SF.split_weights(W, prec)
+        for kw in (dict(), dict(bias=b, row_mask=mask), dict(bias=b, residual=res), dict(residual=res)):
+            monkeypatch.setenv('STIN_NT_STREAM_PRE_ROWS', '999999999')
+            tiled = SF.gemm_nt(A, Wk, precision=prec | SF.GEMM_W_PRESPLIT, **kw)
+            monkeypatch.setenv('STIN_NT_STREAM_PRE_ROWS', '1')
+            for nt in ('2', '4'):
+                monkeypatch.setenv('STIN_NT_STREAM_NT', nt)
+                new = SF.gemm_nt(A, Wk, precision=prec | SF.GEMM_W_PRESPLIT, **kw)
+                assert torch.equal(new, tiled), (prec, sorted(kw), nt)
+            monkeypatch.delenv('STIN_NT_STREAM_NT')
+
+
 def _lib_load():
     from surface_texture_inpainting_net_amd import _lib
     return _lib.load()
