@@ -3234,7 +3234,7 @@ struct StreamGeo {
     size_t lds;
     int64_t gx;
 };
-inline bool stream_geo(int64_t M, int Nc, int K, bool tf, StreamGeo* g, int mode = 0) {
+inline bool stream_geo(int64_t M, int Nc, int K, bool tf, StreamGeo* g, int mode = 0, int precision = STIN_GEMM_BF16X3) {
     if (M <= 0 || Nc <= 0 || Nc % 4 != 0 || K < 64 || K > 512 || K % 64 != 0) return false;
     // staged chunk: 64 columns (8 KB per wave in flight, 32 KB of staging per block: two blocks per CU up to K = 128 -
     // 1 200 642 x 64 x 128 with the BatchNorm transform: 184 us against 212 with 128-column chunks, profiles/probes/kc_probe.sh)
@@ -3245,7 +3245,8 @@ inline bool stream_geo(int64_t M, int Nc, int K, bool tf, StreamGeo* g, int mode
     int nt = e != nullptr ? atoi(e) : 0;
     // (the statistics pass with four column tiles spills ~40 registers at two blocks per CU: two tiles, the A rows come from L2 again)
     if (nt != 2 && nt != 4) nt = (Nc <= 64 || mode == 1) ? 2 : 4;
-    auto lds_of = [&](int nt_) { return (size_t)4 * ((size_t)K * 32 * nt_ + (size_t)128 * g->kc) + (tf ? (size_t)8 * K : 0); };
+    const size_t esz = precision == STIN_GEMM_BF16X6 ? 6 : 4;                   // bytes per operand element in LDS: 2 or 3 pieces of 16 bits
+    auto lds_of = [&](int nt_) { return esz * ((size_t)K * 32 * nt_ + (size_t)128 * g->kc) + (tf ? (size_t)8 * K : 0); };
     if (lds_of(nt) > 160 * 1024) nt = 2;
     if (lds_of(nt) > 160 * 1024) return false;
     g->nt = nt;
@@ -3278,7 +3279,7 @@ int stream_launch(const float* A, int64_t lda, const float* W, int64_t ldw, cons
                   const float* P, const float* Q, float inv_n, int64_t M, int Nc, int K, double* partial, float* C, int64_t ldc,
                   int precision, hipStream_t stream, const StreamEpi epi = StreamEpi()) {
     StreamGeo g;
-    if (!stream_geo(M, Nc, K, TF, &g, MODE)) return STIN_E_UNSUPPORTED;
+    if (!stream_geo(M, Nc, K, TF, &g, MODE, precision)) return STIN_E_UNSUPPORTED;
     const dim3 grid((unsigned)g.gx, (unsigned)g.ncb);
 #define STIN_STREAM(KC_, NT_, NS_, PT_)                                                                                              \
     do {                                                                                                                             \
@@ -3316,7 +3317,7 @@ static int stream_nt_presplit_try(const float* A, int64_t lda, const float* W, i
     const char* e = getenv("STIN_NT_STREAM");
     if (M < min_rows || (e != nullptr && atoi(e) == 0)) return STIN_E_UNSUPPORTED;
     StreamGeo g;
-    if (!(precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_F16X3) || !stream_geo(M, Nc, K, false, &g) ||
+    if (!(precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_F16X3) || !stream_geo(M, Nc, K, false, &g, 0, precision) ||
         !stream_ok(A, lda, W, ldw, nullptr, 0, C, ldc, precision) || (bias != nullptr && !stin_aligned16(bias)) ||
         (residual != nullptr && (ld_res % 4 != 0 || !stin_aligned16(residual))))
         return STIN_E_UNSUPPORTED;
@@ -3336,7 +3337,7 @@ extern "C" int64_t stin_gemm_nt_bn_bwd_groups(int64_t M, int Nc, int K, int prec
     const char* e = getenv("STIN_NT_BNBWD");                                   // A/B switch, re-read per call (tests flip it)
     if (e != nullptr && atoi(e) == 0) return 0;
     StreamGeo g;
-    return stream_geo(M, Nc, K, false, &g, 1) ? g.gx : 0;
+    return stream_geo(M, Nc, K, false, &g, 1, precision) ? g.gx : 0;
 }
 extern "C" int stin_gemm_nt_bn_bwd_stats_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* X, int64_t ldx,
                                              const float* mean, const float* rstd, const float* gamma, const float* beta, int64_t M,
@@ -3345,7 +3346,7 @@ extern "C" int stin_gemm_nt_bn_bwd_stats_f32(const float* A, int64_t lda, const 
     stin_clear_stale_error();
     STIN_REQUIRE(lda >= K && ldw >= K && ldx >= Nc, STIN_E_SIZE);
     StreamGeo g;
-    STIN_REQUIRE(stream_geo(M, Nc, K, false, &g, 1) && stream_ok(A, lda, W, ldw, X, ldx, nullptr, 0, precision), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(stream_geo(M, Nc, K, false, &g, 1, precision) && stream_ok(A, lda, W, ldw, X, ldx, nullptr, 0, precision), STIN_E_UNSUPPORTED);
     STIN_REQUIRE(A && W && X && mean && rstd && gamma && beta && partial && sums, STIN_E_NULL);
     STIN_REQUIRE(partial_bytes >= (size_t)g.gx * 2 * (size_t)Nc * sizeof(double), STIN_E_WORKSPACE);
     stin_bn_tf tf;
@@ -3367,7 +3368,7 @@ extern "C" int stin_gemm_nt_bn_bwd_apply_f32(const float* A, int64_t lda, const 
     stin_clear_stale_error();
     STIN_REQUIRE(lda >= K && ldw >= K && ldx >= Nc && lddx >= Nc, STIN_E_SIZE);
     StreamGeo g;
-    STIN_REQUIRE(stream_geo(M, Nc, K, false, &g) && stream_ok(A, lda, W, ldw, X, ldx, dx, lddx, precision), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(stream_geo(M, Nc, K, false, &g, 2, precision) && stream_ok(A, lda, W, ldw, X, ldx, dx, lddx, precision), STIN_E_UNSUPPORTED);
     STIN_REQUIRE(A && W && X && mean && rstd && gamma && beta && sums && dx, STIN_E_NULL);
     stin_bn_tf tf;
     tf.mean = mean;
@@ -3386,7 +3387,7 @@ extern "C" int stin_gemm_nt_stream_f32(const float* A, int64_t lda, const float*
     stin_clear_stale_error();
     STIN_REQUIRE(lda >= K && ldw >= K && ldc >= Nc, STIN_E_SIZE);
     StreamGeo g;
-    STIN_REQUIRE(stream_geo(M, Nc, K, mean != nullptr, &g) && stream_ok(A, lda, W, ldw, nullptr, 0, C, ldc, precision), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(stream_geo(M, Nc, K, mean != nullptr, &g, 0, precision) && stream_ok(A, lda, W, ldw, nullptr, 0, C, ldc, precision), STIN_E_UNSUPPORTED);
     STIN_REQUIRE(A && W && C && (mean == nullptr || (rstd && gamma && beta)), STIN_E_NULL);
     stin_bn_tf tf;
     tf.mean = mean;

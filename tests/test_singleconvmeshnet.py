@@ -374,7 +374,7 @@ def test_hip_streaming_rows_gemm_is_bit_identical_to_the_tiled_kernels(m, nc, k,
     gamma, beta = (torch.rand(k, generator=g) + 0.5).to('cuda:0'), (torch.randn(k, generator=g) * 0.2).to('cuda:0')
     st = SF._stream(A)
     monkeypatch.setenv('STIN_NT_STREAM', '0')
-    for prec in (SF.PREC_FWD, SF.PREC_BWD):
+    for prec in (SF.PREC_FWD, SF.PREC_BWD, SF.GEMM_BF16X6):                      # (three 16-bit pieces: 6 bytes per element of LDS)
         ref = SF.gemm_nt(A, W, precision=prec)
         ref_bn = torch.empty(m, nc, device='cuda:0')
         SF._call('stin_gemm_nt_bn_f32', SF._ptr(A), k, SF._ptr(W), k, SF._ptr(mean), SF._ptr(rstd), SF._ptr(gamma), SF._ptr(beta), m, nc, k,
