@@ -390,4 +390,4 @@ def test_hip_streaming_rows_gemm_is_bit_identical_to_the_tiled_kernels(m, nc, k,
             assert torch.equal(out, ref_bn), (prec, nt, 'bn')
     monkeypatch.delenv('STIN_NT_STREAM_NT')
     monkeypatch.setenv('STIN_NT_STREAM', '1')
-    assert torch.equal(SF.gemm_nt(A, W, precision=SF.PREC_BWD), ref)               # (routed by size; same numbers either way)
+    assert torch.equal(SF.gemm_nt(A, W, precision=SF.GEMM_BF16X6), ref)            # (routed by size; same numbers either way)
