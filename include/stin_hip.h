@@ -463,12 +463,12 @@ int stin_gemm_tn_bn_f32(const float* G, int64_t ldg, const float* X, int64_t ldx
  *   stin_gemm_nt_bn_bwd_stats_f32: nothing stored; sums [2][Nc] floats = P | Q (P = sum d nhat, Q = sum d, d = dh [gamma nhat + beta > 0],
  *     nhat = (X - mean) rstd: the gradients of gamma | beta) through partial [groups][2][Nc] doubles (fixed-order fp64 fold);
  *   stin_gemm_nt_bn_bwd_apply_f32: dx [M, Nc] = rstd gamma (d - Q inv_n - nhat P inv_n) - stin_bn_act_bwd_f32's expression.
- * groups = stin_gemm_nt_bn_bwd_groups(M, Nc, K, precision); 0: not served (K not 64 / 128 / 256, a pre-split precision flag,
+ * groups = stin_gemm_nt_bn_bwd_groups(M, Nc, K, precision); 0: not served (K not 64 or 128, a pre-split precision flag,
  * STIN_NT_BNBWD=0) - keep the three-launch route.  Rows of A / W 16-byte aligned.  The accumulators equal stin_gemm_nt_f32's
  * bit for bit (same tiles, k order, MFMA order); the sums differ from the reduction kernel's only by fp64 summation order. */
 /* The streaming-rows kernel behind them, as the plain product (mean == NULL) or with stin_gemm_nt_bn_f32's operand transform:
  * persistent blocks whose waves own 32-row tiles staged through wave-private LDS, the weight slice split once per block - for
- * M >> 1e5 rows with K = 64 / 128 / 256 and plain fp32 weights; STIN_E_UNSUPPORTED otherwise.  Bit-identical to the tiled
+ * M >> 1e5 rows with K = 64 .. 512 (a multiple of 64) and plain fp32 weights; STIN_E_UNSUPPORTED otherwise.  Bit-identical to the tiled
  * kernels (same k and MFMA order).  stin_gemm_nt_f32 (no bias / mask / residual) and stin_gemm_nt_bn_f32 route M >= 65 536 rows
  * here (STIN_NT_STREAM=0: never). */
 int stin_gemm_nt_stream_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* mean, const float* rstd,

@@ -3336,8 +3336,10 @@ extern "C" int64_t stin_gemm_nt_bn_bwd_groups(int64_t M, int Nc, int K, int prec
     if (!(precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_BF16X6 || precision == STIN_GEMM_F16X3)) return 0;
     const char* e = getenv("STIN_NT_BNBWD");                                   // A/B switch, re-read per call (tests flip it)
     if (e != nullptr && atoi(e) == 0) return 0;
+    // K = 256 (Nc = 512, the 18 063-vertex level of SingleConvMeshNet): the weight slice leaves room for two column tiles per block, so the
+    // A rows are re-read by 8 column blocks and the two passes (436 us) lose to the three launches (377 us, profiles/probes/bnbwd_probe.py)
     StreamGeo g;
-    return stream_geo(M, Nc, K, false, &g, 1, precision) ? g.gx : 0;
+    return (K <= 128 && stream_geo(M, Nc, K, false, &g, 1, precision)) ? g.gx : 0;
 }
 extern "C" int stin_gemm_nt_bn_bwd_stats_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* X, int64_t ldx,
                                              const float* mean, const float* rstd, const float* gamma, const float* beta, int64_t M,
@@ -3346,7 +3348,7 @@ extern "C" int stin_gemm_nt_bn_bwd_stats_f32(const float* A, int64_t lda, const 
     stin_clear_stale_error();
     STIN_REQUIRE(lda >= K && ldw >= K && ldx >= Nc, STIN_E_SIZE);
     StreamGeo g;
-    STIN_REQUIRE(stream_geo(M, Nc, K, false, &g, 1, precision) && stream_ok(A, lda, W, ldw, X, ldx, nullptr, 0, precision), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(K <= 128 && stream_geo(M, Nc, K, false, &g, 1, precision) && stream_ok(A, lda, W, ldw, X, ldx, nullptr, 0, precision), STIN_E_UNSUPPORTED);
     STIN_REQUIRE(A && W && X && mean && rstd && gamma && beta && partial && sums, STIN_E_NULL);
     STIN_REQUIRE(partial_bytes >= (size_t)g.gx * 2 * (size_t)Nc * sizeof(double), STIN_E_WORKSPACE);
     stin_bn_tf tf;
@@ -3368,7 +3370,7 @@ extern "C" int stin_gemm_nt_bn_bwd_apply_f32(const float* A, int64_t lda, const 
     stin_clear_stale_error();
     STIN_REQUIRE(lda >= K && ldw >= K && ldx >= Nc && lddx >= Nc, STIN_E_SIZE);
     StreamGeo g;
-    STIN_REQUIRE(stream_geo(M, Nc, K, false, &g, 2, precision) && stream_ok(A, lda, W, ldw, X, ldx, dx, lddx, precision), STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(K <= 128 && stream_geo(M, Nc, K, false, &g, 2, precision) && stream_ok(A, lda, W, ldw, X, ldx, dx, lddx, precision), STIN_E_UNSUPPORTED);
     STIN_REQUIRE(A && W && X && mean && rstd && gamma && beta && sums && dx, STIN_E_NULL);
     stin_bn_tf tf;
     tf.mean = mean;

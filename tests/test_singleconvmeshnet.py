@@ -311,7 +311,7 @@ def test_hip_segment_mean_with_moments_equals_the_two_passes(C, n, e):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('e,h2,cout', [(70_001, 128, 64), (33_333, 256, 128), (9000, 512, 256), (5000, 96, 64), (3001, 32, 64), (1_200_642, 128, 64)])
+@pytest.mark.parametrize('e,h2,cout', [(70_001, 128, 64), (33_333, 256, 128), (9000, 512, 128), (5000, 96, 64), (3001, 32, 64), (1_200_642, 128, 64)])
 def test_hip_gemm_with_batchnorm_backward_on_its_epilogue_equals_the_three_launches(e, h2, cout, monkeypatch):
     """stin_gemm_nt_bn_bwd_{stats,apply}_f32 (the per-edge input-gradient product run twice, BatchNorm1d + ReLU's backward on its
     epilogue) against stin_gemm_nt_f32 + stin_colreduce_f32(DOT_BN_RELU) + stin_bn_act_bwd_f32: the accumulators are the same
@@ -357,6 +357,8 @@ def test_hip_gemm_with_batchnorm_backward_on_its_epilogue_equals_the_three_launc
         assert ep <= 2e-7 and eq <= 2e-7 and eo <= 1e-6
     monkeypatch.setenv('STIN_NT_BNBWD', '0')
     assert int(lib.stin_gemm_nt_bn_bwd_groups(e, h2, cout, int(SF.PREC_BWD))) == 0
+    monkeypatch.delenv('STIN_NT_BNBWD')
+    assert int(lib.stin_gemm_nt_bn_bwd_groups(e, 512, 256, int(SF.PREC_BWD))) == 0      # (K = 256: the three launches are faster)
 
 
 @pytest.mark.gpu
