@@ -486,24 +486,27 @@ __global__ __launch_bounds__(BLOCK, KC == 64 ? 2 : 1) void k_gemm_nt_stream(cons
                 coef[K + k] = t;
             }
         }
+        if (MODE != 0) {
+            for (int i = tid; i < BN; i += BLOCK) {
+                const int cc = n0 + i < Nc ? n0 + i : 0;
+                coef[i] = tf.mean[cc];
+                coef[BN + i] = tf.rstd[cc];
+                coef[2 * BN + i] = tf.gamma[cc];
+                coef[3 * BN + i] = tf.beta[cc];
+                coef[4 * BN + i] = MODE == 2 ? P[cc] * inv_n : 0.f;
+                coef[5 * BN + i] = MODE == 2 ? Q[cc] * inv_n : 0.f;
+            }
+        }
     }
     __syncthreads();
 
-    // the lane's output columns and their BatchNorm coefficients (MODE 1 / 2; fixed for the whole loop)
-    float mu[NT], rs[NT], ga[NT], be[NT], pn[NT], qn[NT];
+    // the lane's output columns; their BatchNorm coefficients (MODE 1 / 2) live in LDS - [mean | rstd | gamma | beta | P / n | Q / n][BN],
+    // read per column tile in the epilogue: six registers per tile across the MFMA loop are what pushes four tiles over 256
     bool cok[NT];
     double ps[NT], qs[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int col = n0 + j * 32 + li;
-        cok[j] = col < Nc;
-        const int cc = cok[j] ? col : 0;
-        mu[j] = MODE != 0 ? tf.mean[cc] : 0.f;
-        rs[j] = MODE != 0 ? tf.rstd[cc] : 0.f;
-        ga[j] = MODE != 0 ? tf.gamma[cc] : 0.f;
-        be[j] = MODE != 0 ? tf.beta[cc] : 0.f;
-        pn[j] = MODE == 2 ? P[cc] * inv_n : 0.f;
-        qn[j] = MODE == 2 ? Q[cc] * inv_n : 0.f;
+        cok[j] = n0 + j * 32 + li < Nc;
         ps[j] = 0.0;
         qs[j] = 0.0;
     }
@@ -611,18 +614,20 @@ __global__ __launch_bounds__(BLOCK, KC == 64 ? 2 : 1) void k_gemm_nt_stream(cons
                 if (j + 2 < NT) load_x(j + 2);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                const float mu = coef[j * 32 + li], rs = coef[BN + j * 32 + li], ga = coef[2 * BN + j * 32 + li], be = coef[3 * BN + j * 32 + li];
+                const float pn = MODE == 2 ? coef[4 * BN + j * 32 + li] : 0.f, qn = MODE == 2 ? coef[5 * BN + j * 32 + li] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int tr = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    const float n = (stg[tr * 32 + li] - mu[j]) * rs[j];
-                    const float d = !(ga[j] * n + be[j] > 0.f) ? 0.f : v[r];
+                    const float n = (stg[tr * 32 + li] - mu) * rs;
+                    const float d = !(ga * n + be > 0.f) ? 0.f : v[r];
                     if (MODE == 1) {
                         if (cok[j] && m0 + tr < M) {
                             ps[j] += (double)(d * n);
                             qs[j] += (double)d;
                         }
                     } else {
-                        v[r] = rs[j] * ga[j] * (d - qn[j] - n * pn[j]);
+                        v[r] = rs * ga * (d - qn - n * pn);
                     }
                 }
             }
@@ -3243,10 +3248,11 @@ inline bool stream_geo(int64_t M, int Nc, int K, bool tf, StreamGeo* g, int mode
     if (e != nullptr && atoi(e) == 128 && K % 128 == 0) g->kc = 128;
     e = getenv("STIN_NT_STREAM_NT");
     int nt = e != nullptr ? atoi(e) : 0;
-    // (the statistics pass with four column tiles spills ~40 registers at two blocks per CU: two tiles, the A rows come from L2 again)
-    if (nt != 2 && nt != 4) nt = (Nc <= 64 || mode == 1) ? 2 : 4;
+    // (the statistics pass is faster with two column tiles although the A rows then come from L2 a second time: 207 against 232 us at
+    // 1 200 642 x 128 x 64, 178 against 277 at 361 000 x 256 x 128 - STIN_NT_STREAM_STATS4=1 is the four-tile form, a tuning aid)
+    if (nt != 2 && nt != 4) nt = (Nc <= 64 || (mode == 1 && getenv("STIN_NT_STREAM_STATS4") == nullptr)) ? 2 : 4;
     const size_t esz = precision == STIN_GEMM_BF16X6 ? 6 : 4;                   // bytes per operand element in LDS: 2 or 3 pieces of 16 bits
-    auto lds_of = [&](int nt_) { return esz * ((size_t)K * 32 * nt_ + (size_t)128 * g->kc) + (tf ? (size_t)8 * K : 0); };
+    auto lds_of = [&](int nt_) { return esz * ((size_t)K * 32 * nt_ + (size_t)128 * g->kc) + (tf ? (size_t)8 * K : 0) + (mode != 0 ? (size_t)24 * 32 * nt_ : 0); };
     if (lds_of(nt) > 160 * 1024) nt = 2;
     if (lds_of(nt) > 160 * 1024) return false;
     g->nt = nt;
