@@ -2993,6 +2993,9 @@ inline bool tn_one_per_cu(int storage, int precision, int TI, int TJ, int64_t M)
 static int stream_nt_presplit_try(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* row_mask,
                                   int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M, int Nc, int K, float* C,
                                   int64_t ldc, int precision, hipStream_t stream);
+static int stream_nt_epi_try(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* row_mask,
+                             int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M, int Nc, int K, float* C, int64_t ldc,
+                             int precision, hipStream_t stream, int wpre);
 
 static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                             const float* row_mask, int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M,
@@ -3204,7 +3207,10 @@ extern "C" int stin_gemm_nt_f32(const float* A, int64_t lda, const float* W, int
                                 int Nc, int K, float* C, int64_t ldc, int precision, stin_stream_t stream) {
     if (M >= STREAM_MIN_ROWS && bias == nullptr && row_mask == nullptr && residual == nullptr && stream_enabled()) {
         const int rc = stin_gemm_nt_stream_f32(A, lda, W, ldw, nullptr, nullptr, nullptr, nullptr, M, Nc, K, C, ldc, precision, stream);
-        if (rc != STIN_E_UNSUPPORTED) return rc;                               // (plain fp32 weights, K = 64 / 128 / 256: the streaming kernel)
+        if (rc != STIN_E_UNSUPPORTED) return rc;                               // (plain fp32 weights, K = 64 .. 512: the streaming kernel)
+    } else if (M >= STREAM_MIN_ROWS && stream_enabled()) {                      // ... with the tiled kernels' epilogue (bias [* mask], residual)
+        const int rc = stream_nt_epi_try(A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc, precision, (hipStream_t)stream, 0);
+        if (rc != STIN_E_UNSUPPORTED) return rc;
     }
     return gemm_nt_f32_impl(A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc, precision, nullptr, stream);
 }
@@ -3322,6 +3328,11 @@ static int stream_nt_presplit_try(const float* A, int64_t lda, const float* W, i
     const int64_t min_rows = er != nullptr ? atoll(er) : 500000;
     const char* e = getenv("STIN_NT_STREAM");
     if (M < min_rows || (e != nullptr && atoi(e) == 0)) return STIN_E_UNSUPPORTED;
+    return stream_nt_epi_try(A, lda, W, ldw, bias, row_mask, ld_mask, residual, ld_res, M, Nc, K, C, ldc, precision, stream, 1);
+}
+static int stream_nt_epi_try(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* row_mask,
+                             int64_t ld_mask, const float* residual, int64_t ld_res, int64_t M, int Nc, int K, float* C, int64_t ldc,
+                             int precision, hipStream_t stream, int wpre) {
     StreamGeo g;
     if (!(precision == STIN_GEMM_BF16X3 || precision == STIN_GEMM_F16X3) || !stream_geo(M, Nc, K, false, &g, 0, precision) ||
         !stream_ok(A, lda, W, ldw, nullptr, 0, C, ldc, precision) || (bias != nullptr && !stin_aligned16(bias)) ||
@@ -3333,7 +3344,7 @@ static int stream_nt_presplit_try(const float* A, int64_t lda, const float* W, i
     epi.ld_mask = ld_mask;
     epi.res = residual;
     epi.ld_res = ld_res;
-    epi.wpre = 1;
+    epi.wpre = wpre;
     stin_bn_tf tf;
     tf.mean = tf.rstd = tf.gamma = tf.beta = nullptr;
     return stream_launch<0, false>(A, lda, W, ldw, nullptr, 0, tf, nullptr, nullptr, 0.f, M, Nc, K, nullptr, C, ldc, precision, stream, epi);

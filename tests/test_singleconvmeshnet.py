@@ -393,3 +393,12 @@ def test_hip_streaming_rows_gemm_is_bit_identical_to_the_tiled_kernels(m, nc, k,
     monkeypatch.delenv('STIN_NT_STREAM_NT')
     monkeypatch.setenv('STIN_NT_STREAM', '1')
     assert torch.equal(SF.gemm_nt(A, W, precision=SF.GEMM_BF16X6), ref)            # (routed by size; same numbers either way)
+    if m >= 65536:                                                                   # the epilogue forms the public entry point routes as well
+        b = torch.randn(nc, generator=g).to('cuda:0')
+        mask = (torch.rand(m, generator=g) < 0.7).float().to('cuda:0')
+        res = torch.randn(m, nc, generator=g).to('cuda:0')
+        for kw in (dict(bias=b, row_mask=mask), dict(bias=b, residual=res), dict(residual=res)):
+            monkeypatch.setenv('STIN_NT_STREAM', '0')
+            want = SF.gemm_nt(A, W, precision=SF.PREC_BWD, **kw)
+            monkeypatch.setenv('STIN_NT_STREAM', '1')
+            assert torch.equal(SF.gemm_nt(A, W, precision=SF.PREC_BWD, **kw), want), sorted(kw)
