@@ -491,6 +491,12 @@ int stin_bn_affine_res_fwd_f32(const float* x, int64_t ldx, const float* mean, c
                                int relu, float* y, int64_t ldy, stin_stream_t stream);
 int stin_relu_mask_bwd_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, const int32_t* rowptr, int64_t N, int C,
                            int relu, float* g_eff, float* g_in, stin_stream_t stream);
+/* out[r] = [ skip[r, :cs] | coarse[trace[r], :cu] ], r < N: the decoder's torch.cat((skip, x[trace]), -1) with the unpool gather writing
+ * straight into its half (models/singleconvmeshnet.py:146-150); trace values must lie in [0, rows of coarse) (validated when the
+ * pooling map is built).  Backward needs no kernel of its own: the skip gradient is the left column block of the incoming gradient,
+ * the coarse gradient stin_segment_sum_f32 over the right one. */
+int stin_concat_unpool_f32(const float* skip, int64_t ld_skip, const float* coarse, int64_t ld_coarse, const int32_t* trace, int64_t N,
+                           int cs, int cu, float* out, int64_t ldo, stin_stream_t stream);
 
 /* ------------------------------------------------------- parameter-side helpers --
  * pack: the reference-layout EdgeConv parameters (first_filter.nn.0.{weight,bias} = W1 [H, 2Cin]

@@ -173,6 +173,7 @@ SIGNATURES['stin_scmn_unpack_f32'] = (c_int, [c_ptr, c_int, c_int, c_int, c_ptr,
 SIGNATURES['stin_bn_affine_res_fwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr,
                                                     c_i64, c_ptr])
 SIGNATURES['stin_relu_mask_bwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr])
+SIGNATURES['stin_concat_unpool_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_bn_act_fwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_bn_act_bwd_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int,
                                              c_int, c_ptr, c_i64, c_ptr])

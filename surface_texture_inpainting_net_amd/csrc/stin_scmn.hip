@@ -128,6 +128,23 @@ __global__ __launch_bounds__(BLOCK) void k_relu_mask_bwd(const float* __restrict
     stv<VW>(g_in + r * (int64_t)C + c, b);
 }
 
+// out[r] = [ skip[r, :cs] | coarse[trace[r], :cu] ]: the decoder's `torch.cat((skip, unpooled), -1)` with the unpool gather writing
+// straight into its half (one thread per 4 (VW) output columns)
+template <int VW>
+__global__ __launch_bounds__(BLOCK) void k_concat_unpool(const float* __restrict__ skip, int64_t ld_skip, const float* __restrict__ coarse,
+                                                         int64_t ld_c, const int32_t* __restrict__ trace, int64_t N, int cs, int cu,
+                                                         float* __restrict__ out, int64_t ldo) {
+    const int CV = (cs + cu) / VW;
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= N * CV) return;
+    const int64_t r = t / CV;
+    const int c = (int)(t % CV) * VW;
+    float v[VW];
+    if (c < cs) ldv<VW>(skip + r * ld_skip + c, v);
+    else ldv<VW>(coarse + (int64_t)trace[r] * ld_c + (c - cs), v);
+    stv<VW>(out + r * ldo + c, v);
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
 
 }  // namespace
@@ -186,5 +203,21 @@ extern "C" int stin_relu_mask_bwd_f32(const float* g, int64_t ldg, const float* 
     else
         hipLaunchKernelGGL((k_relu_mask_bwd<1>), dim3(grid_for(N * C)), dim3(BLOCK), 0, (hipStream_t)stream, g, ldg, y, ldy, rowptr, N, C, relu,
                            g_eff, g_in);
+    return stin_launch_status();
+}
+
+extern "C" int stin_concat_unpool_f32(const float* skip, int64_t ld_skip, const float* coarse, int64_t ld_coarse, const int32_t* trace,
+                                      int64_t N, int cs, int cu, float* out, int64_t ldo, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(N >= 0 && cs > 0 && cu > 0 && ld_skip >= cs && ld_coarse >= cu && ldo >= cs + cu, STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(skip && coarse && trace && out, STIN_E_NULL);
+    if (cs % 4 == 0 && cu % 4 == 0 && ld_skip % 4 == 0 && ld_coarse % 4 == 0 && ldo % 4 == 0 && stin_aligned16(skip) && stin_aligned16(coarse) &&
+        stin_aligned16(out))
+        hipLaunchKernelGGL((k_concat_unpool<4>), dim3(grid_for(N * ((cs + cu) / 4))), dim3(BLOCK), 0, (hipStream_t)stream, skip, ld_skip, coarse,
+                           ld_coarse, trace, N, cs, cu, out, ldo);
+    else
+        hipLaunchKernelGGL((k_concat_unpool<1>), dim3(grid_for(N * (int64_t)(cs + cu))), dim3(BLOCK), 0, (hipStream_t)stream, skip, ld_skip, coarse,
+                           ld_coarse, trace, N, cs, cu, out, ldo);
     return stin_launch_status();
 }

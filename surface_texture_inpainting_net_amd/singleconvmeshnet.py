@@ -107,6 +107,28 @@ class _ScatterMeanFn(torch.autograd.Function):
         return SF.gather_rows(g, ei.dst32, ei.by_dst.inv_deg), None
 
 
+class _SkipUnpoolConcatFn(torch.autograd.Function):
+    """torch.cat((skip, coarse[trace]), -1) in one launch (stin_concat_unpool_f32: the unpool gather writes straight into its half of
+    the concatenated rows); backward: the skip gradient is the left column block of the incoming gradient (a view), the coarse
+    gradient the segment sum of the right block over each coarse vertex's children - UnpoolFn's backward on a strided view."""
+
+    @staticmethod
+    def forward(ctx, skip, coarse, pool):
+        skip, lds = SF._mat(skip)
+        coarse, ldc = SF._mat(coarse)
+        n, cs, cu = skip.shape[0], skip.shape[1], coarse.shape[1]
+        out = torch.empty(n, cs + cu, dtype=skip.dtype, device=skip.device)
+        SF._call('stin_concat_unpool_f32', SF._ptr(skip), lds, SF._ptr(coarse), ldc, SF._ptr(pool.trace), n, cs, cu, SF._ptr(out), cs + cu,
+                 SF._stream(skip))
+        ctx.pool, ctx.cs = pool, cs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, cs = ctx.pool, ctx.cs
+        return g[:, :cs], SF.segment_sum(g[:, cs:], p.children.rowptr, p.children.col, p.n_coarse, mean=False), None
+
+
 class _RowStatsNormFn(torch.autograd.Function):
     """y = (x - mean) * rstd over ALL rows (biased variance, eps inside the root), plus the batch mean / biased variance
     as non-differentiable outputs for the running statistics: BatchNorm1d's training-mode normalisation."""
@@ -611,8 +633,11 @@ class SingleConvMeshNet(nn.Module):
             levels.append(self.left_geo_cnns[level](self._pooling(levels[-1], pools[level]), edges[level]))
         current = levels[-1]
         for level in range(1, L):
-            back = SF.UnpoolFn.apply(current, pools[L - level])
-            fused = torch.cat((levels[-(level + 1)], back), -1)
+            skip, pool = levels[-(level + 1)], pools[L - level]
+            if USE_FUSED_LAYER and skip.is_cuda and skip.dtype == torch.float32 and current.dtype == torch.float32:
+                fused = _SkipUnpoolConcatFn.apply(skip, current, pool)              # cat((skip, current[trace]), -1), one launch
+            else:
+                fused = torch.cat((skip, SF.UnpoolFn.apply(current, pool)), -1)
             current = self.right_geo_cnns[-level](fused, edges[L - level - 1])
         lin1, bn, lin2 = self.final_convs[0][0], self.final_convs[0][1], self.final_convs[0][3]
         out = batch_norm_rows(SF.linear(current, lin1.weight, lin1.bias), bn, relu=True)

@@ -402,3 +402,32 @@ def test_hip_streaming_rows_gemm_is_bit_identical_to_the_tiled_kernels(m, nc, k,
             want = SF.gemm_nt(A, W, precision=SF.PREC_BWD, **kw)
             monkeypatch.setenv('STIN_NT_STREAM', '1')
             assert torch.equal(SF.gemm_nt(A, W, precision=SF.PREC_BWD, **kw), want), sorted(kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cs,cu', [(64, 128), (6, 10), (128, 256)])
+def test_hip_skip_unpool_concat_equals_cat_of_the_gather(cs, cu):
+    """stin_concat_unpool_f32 / _SkipUnpoolConcatFn: torch.cat((skip, coarse[trace]), -1) in one launch - forward bit for bit, and
+    both gradients (the left column block as a view; the segment sum of the right one over each coarse vertex's children) equal
+    to the cat + UnpoolFn composition bit for bit."""
+    from surface_texture_inpainting_net_amd import functional as SF
+    from surface_texture_inpainting_net_amd.plan import PoolMap
+    from surface_texture_inpainting_net_amd.singleconvmeshnet import _SkipUnpoolConcatFn
+    g = torch.Generator().manual_seed(cs + cu)
+    n_fine, n_coarse = 20_011, 3000
+    trace = torch.randint(0, n_coarse, (n_fine,), generator=g)
+    trace[:n_coarse] = torch.arange(n_coarse)                                      # every coarse vertex has a child
+    bad = torch.zeros(1, dtype=torch.int32, device='cuda:0')
+    pool = PoolMap(trace.to('cuda:0'), n_fine, n_coarse, bad)
+    assert int(bad.item()) == 0
+    skip = torch.randn(n_fine, cs, generator=g).to('cuda:0').requires_grad_(True)
+    coarse = torch.randn(n_coarse, cu, generator=g).to('cuda:0').requires_grad_(True)
+    w = torch.randn(n_fine, cs + cu, generator=g).to('cuda:0')
+    ref = torch.cat((skip, SF.UnpoolFn.apply(coarse, pool)), -1)
+    (ref * w).sum().backward()
+    gs, gc = skip.grad.clone(), coarse.grad.clone()
+    skip.grad = coarse.grad = None
+    out = _SkipUnpoolConcatFn.apply(skip, coarse, pool)
+    assert torch.equal(out, ref)
+    (out * w).sum().backward()
+    assert torch.equal(skip.grad, gs) and torch.equal(coarse.grad, gc)
