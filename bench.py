@@ -11,7 +11,9 @@ the shipped 3-D config), one scene per GPU, pure data parallel with one RCCL gra
 
 A "step" = GraphPlan (CSR) build from the int64 index tensors + forward + masked weighted L1 loss +
 backward + flat-bucket gradient all-reduce + Adam(amsgrad) update, on inputs already resident in HBM.
-Rank 0 prints ONE JSON line; see DESIGN.md §Measurement for the roofline / cpu_baseline definitions.
+Rank 0 prints ONE JSON line of < 4 KB (`compact_line`: the contract keys, `roofline`, `cpu_baseline`, a few scalars - no prose) and
+writes the full detail object (every secondary leg, per-kernel tables, notes) to `--detail` (default gpurun_out/bench_detail.json);
+see DESIGN.md §Measurement for the roofline / cpu_baseline definitions.
 """
 import argparse
 import json
@@ -39,6 +41,81 @@ HBM_COPY_GBS = 6290.0          # achievable HBM copy rate measured in the guide 
 CONFIG_3D = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=9,
                  n_levels=2, pooling_type='max', dilations=[1, 1, 1, 2, 4, 8, 16, 1, 1], checkpoint_bottleneck=True,
                  num_blocks_per_uncheckpointed_block=1)
+
+COMPACT_LIMIT = 4096           # the driver keeps a bounded tail of stdout: the final line must fit in it with room to spare
+
+
+def _num(v, digits=6):
+    """Round floats for the compact line (6 significant digits); pass None / ints / strings through."""
+    if isinstance(v, float):
+        return float('%.*g' % (digits, v))
+    return v
+
+
+def compact_line(out, detail_path=None):
+    """The ONE stdout line: the bench contract's keys + `roofline` + `cpu_baseline` + a few scalars of the secondary legs, all
+    numbers or short identifiers (round 5's line carried paragraphs of notes, grew to 20 KB and the driver's 8 KB tail lost its
+    head).  `out` is the full detail object, which goes to a file instead."""
+    cfg = out.get('config', {})
+    line = {k: _num(out.get(k)) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                                          'scaling', 'vs_baseline', 'dtype', 'data')}
+    line['config'] = {'workload': 'STINet 3-D config, synthetic mesh %s vertices / %s directed edges / %s levels per GPU, step = plan build + '
+                                  'fwd + L1 + bwd + all-reduce + Adam' % (cfg.get('vertices_per_gpu'), cfg.get('edges_per_gpu'), cfg.get('levels')),
+                      **{k: cfg.get(k) for k in ('vertices_per_gpu', 'edges_per_gpu', 'levels', 'parallelism', 'hip_graph', 'crops_per_step')}}
+    r = out.get('roofline') or {}
+    line['roofline'] = {k: _num(r.get(k)) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_us', 'algorithmic_bytes',
+                                                    'traffic', 'traffic_over_algorithmic')}
+    c = out.get('cpu_baseline')
+    if c:
+        line['cpu_baseline'] = {k: _num(c.get(k)) for k in ('value', 'unit', 'cores', 'kind', 'cpu_model', 'sample_vertices')}
+        line['cpu_baseline']['sample'] = 'CPU oracle fwd+loss+bwd, %s-vertex mesh, warm-up + median of %d passes' % (
+            c.get('sample_vertices'), len(c.get('passes_s') or []))
+    else:
+        line['cpu_baseline'] = None
+
+    def leaf(key, sub):
+        v = out.get(key)
+        return _num(v.get(sub)) if isinstance(v, dict) else None
+    line['gemm_precision'] = '%s/%s' % ((out.get('gemm_precision') or {}).get('fwd'), (out.get('gemm_precision') or {}).get('bwd'))
+    line['exact_fp32_ms_per_step'] = leaf('exact_fp32', 'ms_per_step')
+    line['hbm_honest_frac'] = leaf('hbm_honest', 'frac_of_hbm_peak')
+    line['hbm_honest_traffic_over_algorithmic'] = leaf('hbm_honest', 'traffic_over_algorithmic')
+    line['scatter_add_frac'] = leaf('scatter_add', 'frac_of_hbm_peak')
+    line['roofline_irregular_frac'] = leaf('roofline_irregular', 'frac')
+    line['gpu_idle_ms'] = leaf('gpu_idle', 'idle_ms_per_step')
+    line['fwd_loss_bwd_only_ms'] = leaf('fwd_loss_bwd_only', 'ms_per_step')
+    line['inference_ms'] = leaf('inference', 'ms')
+    line['vertex_locality_ms'] = leaf('vertex_locality', 'ms_per_step')
+    lf = (out.get('loader_fed') or {}).get('graph_and_plan_resident')
+    line['loader_fed_ms'] = _num(lf.get('ms_per_step')) if isinstance(lf, dict) else None
+    line['gemm_ms_per_step_standalone'] = leaf('gemm', 'ms_per_step')
+    line['gemm_frac_of_roofline'] = leaf('gemm', 'time_weighted_frac_of_roofline')
+    line['edge_stage_ms_per_step'] = _num(out.get('edge_stage_ms_per_step'))
+    line['host_enqueue_ms_per_step'] = _num(out.get('host_enqueue_ms_per_step'))
+    line['loss'] = _num(out.get('loss'))
+    d = out.get('distributed') or {}
+    line['replicas_bit_identical'] = d.get('replicas_bit_identical')
+    line['ms_per_step_per_rank'] = [_num(v, 5) for v in (d.get('ms_per_step_per_rank') or [])][:16]
+    line['allreduce_us_mean'] = _num((d.get('allreduce_us') or {}).get('mean')) if d.get('allreduce_us') else None
+    line['detail'] = detail_path
+    text = json.dumps(line)
+    assert len(text) < COMPACT_LIMIT, 'compact bench line grew to %d bytes' % len(text)
+    return text
+
+
+def write_detail(out, path):
+    """The full detail object -> `path` (JSON, one object).  Falls back to the temp dir when the target cannot be written."""
+    import tempfile
+    for cand in (path, os.path.join(tempfile.gettempdir(), 'stin_bench_detail_%d.json' % os.getpid())):
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(cand)), exist_ok=True)
+            with open(cand, 'w') as f:
+                json.dump(out, f)
+                f.write('\n')
+            return cand
+        except OSError:
+            continue
+    return None
 
 
 def edge_bytes(kernel, n, e, h):
@@ -263,7 +340,8 @@ def exact_fp32_companion(args):
     exec: this process keeps its GPU context; the precision switches are read at import), short loop, no secondary legs."""
     env = dict(os.environ, STIN_GEMM_FWD='0', STIN_GEMM_BWD='0')
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '15', '--warmup', '5', '--vertices', str(args.vertices),
-           '--levels', str(args.levels), '--no-secondary', '--no-cpu-baseline', '--no-live-traffic']
+           '--levels', str(args.levels), '--no-secondary', '--no-cpu-baseline', '--no-live-traffic',
+           '--detail', os.path.splitext(args.detail)[0] + '_exact_fp32.json']
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
         line = [ln for ln in r.stdout.decode(errors='replace').splitlines() if ln.startswith('{')]
@@ -271,7 +349,7 @@ def exact_fp32_companion(args):
             return {'error': 'child run failed (rc %d)' % r.returncode}
         c = json.loads(line[-1])
         return {'ms_per_step': c['ms_per_step'], 'vertices_per_s': c['value'],
-                'gemm_precision': {'fwd': c['gemm_precision']['fwd'], 'bwd': c['gemm_precision']['bwd'],
+                'gemm_precision': {'fwd/bwd': c['gemm_precision'],
                                    'note': 'v_mfma_f32_32x32x2_f32 on unsplit fp32 operands, fp32 accumulate'},
                 'loss': c['loss'], 'steps': c['steps'], 'warmup': c['warmup'],
                 'note': 'the same step, mesh and seeds with EXACT fp32 matrix-core products in every GEMM, forward and backward '
@@ -573,6 +651,8 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="activation storage: f32 = the headline (reference numerics); bf16 = the build's "
                          "mixed-precision mode of BASELINE configs 3/5 (NOT the headline, stated tolerance)")
+    ap.add_argument('--detail', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'),
+                    help='file the FULL detail object goes to (stdout carries only the compact line)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -993,7 +1073,7 @@ def main():
                     out['loader_fed'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(args.vertices, args.levels, seed=0, headline_mesh=not args.quick_cpu_baseline)
-        print(json.dumps(out), flush=True)
+        print(compact_line(out, write_detail(out, args.detail)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -2,11 +2,12 @@
 # Copy one collect_round.sh result directory (gpurun_out/<dir>) into the tracked profiles/<round>_* files.
 #   bash profiles/publish_round.sh r03 [r03]        (source directory under gpurun_out/, round prefix)
 set -e
-S=gpurun_out/${1:-r05}
-RN=${2:-r05}
+S=gpurun_out/${1:-r06}
+RN=${2:-r06}
 P=profiles/$RN
 cp $S/bench_default.json ${P}_bench_default.json; cp $S/bench_final.json ${P}_bench_final.json; cp $S/bench_bf16.json ${P}_bench_bf16.json
 cp $S/bench_irregular.json ${P}_bench_irregular.json
+cp $S/bench_default_line.json ${P}_bench_default_line.json; cp $S/bench_final_line.json ${P}_bench_final_line.json   # the compact stdout lines (what the driver parses)
 for c in c2 c3 c5_bf16 c5_f32; do cp $S/config_$c.json ${P}_config_$c.json; done
 cp $S/small_20k_eager.json ${P}_small_20k_eager.json; cp $S/small_20k_graph.json ${P}_small_20k_graph.json
 cp $S/gemm_shapes.md ${P}_gemm_shapes.md; cp $S/tn_ws.md ${P}_tn_ws.md

@@ -121,6 +121,59 @@ def test_bench_refuses_a_world_size_mismatch_and_too_few_gpus():
     assert r.returncode == 2 and 'RCCL needs one device per rank' in r.stderr
 
 
+def _bench_outputs(stdout):
+    """-> (compact line, detail object): rank 0 prints ONE compact JSON line whose `detail` key names the file with the full object."""
+    lines = [ln for ln in stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, 'rank 0 prints ONE json line'
+    assert len(lines[0]) < 4096
+    line = json.loads(lines[0])
+    return line, json.load(open(line['detail']))
+
+
+def test_bench_compact_line_is_short_and_carries_the_contract_keys():
+    """Round 5's line grew to 20 KB and the driver's bounded stdout tail lost its head (BENCH_r05.parsed null): the final line is built
+    by bench.compact_line from the detail object, stays under 4 KB whatever the detail holds and carries the graded keys."""
+    sys.path.insert(0, ROOT)
+    import bench
+    prose = 'x' * 5000
+    detail = {'metric': 'vertices/sec forward+backward on 200k-vert ScanNet mesh; scatter-add GB/s vs HBM roofline', 'value': 27.7e6,
+              'unit': 'vertices/s', 'n_gpus': 1, 'steps': 20, 'warmup': 3, 'ms_per_step': 7.2512345678, 'higher_is_better': True,
+              'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+              'config': {'workload': prose, 'vertices_per_gpu': 200704, 'edges_per_gpu': 1200642, 'levels': 3, 'parallelism': 'dp1',
+                         'hip_graph': False, 'crops_per_step': None, 'params': 1},
+              'roofline': {'bound': 'hbm', 'kernel': 'stin_edge_relu_mean_fwd_f32[N=200704,E=1200642,H=128]', 'achieved': 6900.123456789,
+                           'peak': 8000.0, 'unit': 'GB/s', 'frac': 0.8625, 'avg_us': 119.4, 'algorithmic_bytes': 825.85e6, 'traffic': 841e6,
+                           'traffic_over_algorithmic': 0.996, 'traffic_unit': prose, 'convention': prose, 'selection': prose, 'each_us': [1.0] * 8},
+              'cpu_baseline': {'value': 10274.0, 'unit': 'vertices/s', 'cores': 16, 'kind': 'port', 'cpu_model': 'AMD EPYC 9575F 64-Core Processor',
+                               'sample_vertices': 200704, 'passes_s': [20.5, 19.5, 16.9], 'sample': prose, 'quick_sample': {'sample': prose}},
+              'gemm_precision': {'fwd': 'fp16x3', 'bwd': 'bf16x3', 'note': prose},
+              'exact_fp32': {'ms_per_step': 10.59, 'note': prose}, 'hbm_honest': {'frac_of_hbm_peak': 0.776, 'traffic_over_algorithmic': 1.015},
+              'scatter_add': {'frac_of_hbm_peak': 0.616}, 'gpu_idle': {'idle_ms_per_step': 0.17, 'method': prose},
+              'gemm': {'ms_per_step': 3.6, 'time_weighted_frac_of_roofline': 0.43, 'kernels': [{'note': prose}] * 24},
+              'distributed': {'replicas_bit_identical': True, 'ms_per_step_per_rank': [7.25], 'allreduce_us': None},
+              'edge_kernels': [{'note': prose}] * 6, 'dtype_tolerance': {'note': prose}, 'loss': 0.1234567891}
+    text = bench.compact_line(detail, '/tmp/x.json')
+    assert len(text) < 4096 and '\n' not in text
+    line = json.loads(text)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in line, k
+    assert line['metric'] == detail['metric'] and line['value'] == 27.7e6 and abs(line['ms_per_step'] - 7.25123) < 1e-9
+    assert set(line['config']) >= {'workload', 'vertices_per_gpu', 'edges_per_gpu', 'levels', 'parallelism'} and 'model' not in line['config']
+    assert set(line['roofline']) == {'bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_us', 'algorithmic_bytes', 'traffic',
+                                     'traffic_over_algorithmic'}
+    assert line['roofline']['bound'] == 'hbm' and abs(line['roofline']['frac'] - 0.8625) < 1e-9
+    assert set(line['cpu_baseline']) == {'value', 'unit', 'cores', 'kind', 'cpu_model', 'sample_vertices', 'sample'}
+    assert line['cpu_baseline']['kind'] == 'port' and len(line['cpu_baseline']['sample']) < 120
+    assert line['exact_fp32_ms_per_step'] == 10.59 and line['hbm_honest_frac'] == 0.776 and line['scatter_add_frac'] == 0.616
+    assert line['gpu_idle_ms'] == 0.17 and line['gemm_precision'] == 'fp16x3/bf16x3' and line['detail'] == '/tmp/x.json'
+    assert all(len(v) < 200 for v in line.values() if isinstance(v, str))
+    # a run without the secondary legs / the CPU leg: the keys stay, as nulls
+    bare = {k: detail[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'config', 'roofline')}
+    line = json.loads(bench.compact_line(bare))
+    assert line['cpu_baseline'] is None and line['exact_fp32_ms_per_step'] is None and line['roofline']['frac'] == 0.8625
+
+
 # ------------------------------------------------------------------------------------------------- GPU
 def _free_port():
     s = socket.socket()
@@ -131,17 +184,17 @@ def _free_port():
 
 
 @pytest.mark.gpu
-def test_bench_self_launches_two_ranks_from_a_plain_python_invocation():
+def test_bench_self_launches_two_ranks_from_a_plain_python_invocation(tmp_path):
     """`python bench.py --gpus 2 --backend gloo` on a 1-GPU box: the parent starts two ranks itself, the line reports the
     all-reduced rank count, per-rank times, the all-reduce bracket and bit-identical replicas."""
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '3',
-                        '--warmup', '1', '--vertices', '20000', '--no-cpu-baseline'], env=env, capture_output=True, text=True,
-                       timeout=600)
+                        '--warmup', '1', '--vertices', '20000', '--no-cpu-baseline', '--detail', str(tmp_path / 'd.json')], env=env,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, 'rank 0 prints ONE json line'
-    out = json.loads(lines[0])
+    line, out = _bench_outputs(r.stdout)
+    assert line['n_gpus'] == 2 and line['replicas_bit_identical'] is True and len(line['ms_per_step_per_rank']) == 2
+    assert line['value'] == pytest.approx(out['value'], rel=1e-5) and line['config']['parallelism'] == 'dp2'
     assert out['n_gpus'] == 2 and out['distributed']['world_size'] == 2 and out['distributed']['backend'] == 'gloo'
     assert len(out['distributed']['ms_per_step_per_rank']) == 2 and out['distributed']['replicas_bit_identical'] is True
     assert out['distributed']['allreduce_us']['bytes'] == 4 * out['config']['params']
@@ -149,18 +202,17 @@ def test_bench_self_launches_two_ranks_from_a_plain_python_invocation():
 
 
 @pytest.mark.gpu
-def test_bench_eight_rank_self_launch_dry_run_on_one_gpu():
+def test_bench_eight_rank_self_launch_dry_run_on_one_gpu(tmp_path):
     """The 8-rank path the driver's scaling run takes (`python bench.py --gpus 8`), dry-run on ONE device with gloo: the
     self-launch (free port, 127.0.0.1 rendezvous), the core-affinity shares (cores // 8 per rank), OMP_NUM_THREADS, the
     all-reduced rank count, per-rank times and bit-identical replicas - everything but RCCL itself."""
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--steps', '2',
-                        '--warmup', '1', '--vertices', '3000', '--no-cpu-baseline'], env=env, capture_output=True, text=True,
-                       timeout=900)
+                        '--warmup', '1', '--vertices', '3000', '--no-cpu-baseline', '--detail', str(tmp_path / 'd.json')], env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, 'rank 0 prints ONE json line'
-    out = json.loads(lines[0])
+    line, out = _bench_outputs(r.stdout)
+    assert line['n_gpus'] == 8 and line['scaling'] == 'weak' and len(line['ms_per_step_per_rank']) == 8
     d = out['distributed']
     assert out['n_gpus'] == 8 and d['world_size'] == 8 and d['ranks_counted_by_allreduce'] == 8
     assert len(d['ms_per_step_per_rank']) == 8 and d['replicas_bit_identical'] is True
@@ -172,15 +224,16 @@ def test_bench_eight_rank_self_launch_dry_run_on_one_gpu():
 
 
 @pytest.mark.gpu
-def test_bench_two_rank_unequal_scenes_reports_the_straggler_figures():
+def test_bench_two_rank_unequal_scenes_reports_the_straggler_figures(tmp_path):
     """`bench.py --gpus N --unequal-scenes` (round 5: BASELINE config 4 as the reference trains it - scenes of 150 k ... 200 k
     vertices, one per rank) on two gloo ranks sharing one device: the line carries the per-rank scene sizes, every rank's time inside
     the all-reduce bracket and north_star's 1 / 2 / 4 / 8 table row; replicas stay bit-identical."""
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
-                        '--unequal-scenes', '--no-cpu-baseline', '--no-secondary'], env=env, capture_output=True, text=True, timeout=900)
+                        '--unequal-scenes', '--no-cpu-baseline', '--no-secondary', '--detail', str(tmp_path / 'd.json')], env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    _, out = _bench_outputs(r.stdout)
     s, row = out['straggler'], out['scaling_table_row']
     assert s['vertices_per_rank'] == [150000, 200000] and len(s['allreduce_bracket_us_per_rank']) == 2
     assert all(v > 0 for v in s['allreduce_bracket_us_per_rank'])
