@@ -822,6 +822,23 @@ def main():
         step.forward_backward(sample)
     fence()
     dt_fb = time.perf_counter() - t1
+    # forward only, as the reference's validation loop runs it (trainers/inpainting3d_trainer.py:204-263: model.eval(), model(data)
+    # under torch.no_grad()): CSR plan resident, no ReLU mask stored, block temporaries shared (functional.NetFn, need_grad False)
+    inference = None
+    if not args.no_secondary:
+        net.eval()
+        with torch.no_grad():
+            for _ in range(3):
+                net(sample)
+            fence()
+            t_inf = time.perf_counter()
+            for _ in range(args.steps):
+                net(sample)
+            fence()
+            dt_inf = time.perf_counter() - t_inf
+        net.train()
+        inference = {'ms': dt_inf / args.steps * 1e3, 'vertices_per_s': n0 * args.steps / dt_inf,
+                     'note': 'eval mode, torch.no_grad(), plan resident, rank 0; no ReLU mask store, shared block temporaries'}
     # GEMM pass (after the timed region): every MFMA GEMM launch of two more steps bracketed with HIP events; the
     # per-kernel path runs the weight-gradient GEMMs on the compute stream, so these are stand-alone durations
     gtimes = {}
@@ -990,6 +1007,7 @@ def main():
             'fwd_loss_bwd_only': None if args.no_secondary else {
                 'ms_per_step': dt_fb / args.steps * 1e3, 'vertices_per_s_per_gpu': n0 * args.steps / dt_fb,
                 'note': 'same scene, CSR plan reused, no gradient all-reduce, no optimizer step (rank 0)'},
+            'inference': inference,
             'roofline': roofline,
             'contention': contention,
             'edge_stage_ms_per_step': edge_total_ms,

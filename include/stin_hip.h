@@ -671,6 +671,9 @@ int stin_linear_tanh_bwd_bf16(const float* g, const float* y, const stin_bf16_t*
  *        (ptr_sum/gid may be NULL for one graph; inv_cnt [B]); writes what backward needs - wcatT [Cp, Yw], w2T [H, Cout]
  *        (fp32 or pre-split per bwd_split), Y [N, Yw], hE [N, H + pad] (column H = [deg > 0]), mask [E * H / 32],
  *        agg [N, Cout], mean / rstd [B, Cout] - and out [N, Cout].  Yw = 2 H (+ Cout with a shortcut).
+ *        mask may be NULL for a forward nobody differentiates (the reference's validation loop,
+ *        trainers/inpainting3d_trainer.py:204-263: model(data) under torch.no_grad()): same kernels, same rows bit for
+ *        bit, the E * H / 8 mask bytes per block are not written.
  *   bwd: g = dL/dout; dx [N, Cp] may be NULL; parameter gradients in the reference layout (NULL where the parameter
  *        does not exist).  All temporaries live in the caller's workspace.
  *        wgrad_stream (optional, NULL = everything on `stream`): the two weight-gradient GEMMs, their slab reductions

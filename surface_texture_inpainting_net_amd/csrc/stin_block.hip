@@ -71,7 +71,8 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
                                        size_t workspace_bytes, stin_stream_t stream) {
     STIN_REQUIRE(storage == 0 || storage == 1, STIN_E_UNSUPPORTED);
     STIN_REQUIRE(N >= 0 && Cin > 0 && Cp >= Cin && H > 0 && Cout > 0 && B > 0, STIN_E_SIZE);
-    STIN_REQUIRE(x && W1 && W2 && rowptr_dst && wcatT && w2T && Y && hE && mask && agg && mean && rstd && out && workspace,
+    // mask == NULL (round 6): a forward nobody differentiates (torch.no_grad() / evaluation) - the ReLU mask is not stored
+    STIN_REQUIRE(x && W1 && W2 && rowptr_dst && wcatT && w2T && Y && hE && agg && mean && rstd && out && workspace,
                  STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_edgeconv_block_fwd_workspace_bytes(Cin, Cp, H, Cout, has_shortcut, B), STIN_E_WORKSPACE);
     const int Yw = 2 * H + (has_shortcut ? Cout : 0);

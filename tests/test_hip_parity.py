@@ -1964,3 +1964,46 @@ def test_vertex_order_hip_path_equals_the_torch_formulation(monkeypatch):
         pa, pb = a._pools[lvl], b._pools[lvl]
         assert torch.equal(pa.trace, pb.trace) and torch.equal(pa.children.rowptr, pb.children.rowptr)
         assert torch.equal(pa.children.col, pb.children.col) and torch.equal(pa.inv_count, pb.inv_count)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_no_grad_forward_is_bit_identical_to_the_training_forward_and_keeps_no_mask(dtype):
+    """Round 6: the reference's validation loop runs model(data) under torch.no_grad() (trainers/inpainting3d_trainer.py:204-263).
+    There the whole-network call stores no ReLU mask (stin_edgeconv_block_fwd: mask NULL), shares one temporaries region between
+    all blocks and ping-pongs the op outputs - same kernels otherwise: the colours equal the differentiable forward's bit for bit,
+    no autograd graph is built, and the pass allocates a fraction of the training forward's arena."""
+    cfg = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', norm='instance', n_blocks=3, n_levels=2,
+               pooling_type='max', dilations=[1, 2, 4])
+    torch.manual_seed(3)
+    net = S.define_G(**cfg).to(DEV)
+    if dtype == torch.bfloat16:
+        net.set_activation_dtype(torch.bfloat16)
+    s = make_synthetic_mesh(20000, 3, seed=5, dilations=(2, 4)).to(DEV)
+    calls = SF.NetFn.calls
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    want = net(s)
+    torch.cuda.synchronize()
+    peak_train = torch.cuda.max_memory_allocated() - base
+    assert SF.NetFn.calls == calls + 1 and want.requires_grad
+    want = want.detach().clone()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        got = net(s)
+    torch.cuda.synchronize()
+    peak_eval = torch.cuda.max_memory_allocated() - base
+    assert SF.NetFn.calls == calls + 2 and not got.requires_grad and got.grad_fn is None
+    assert torch.equal(got, want)
+    assert peak_eval < 0.5 * peak_train, (peak_eval, peak_train)
+    net.eval()                                                # eval mode changes nothing for instance norm: still the same bits
+    with torch.no_grad():
+        again = net(s)
+    assert torch.equal(again, want)
+    for p in net.parameters():                                # frozen parameters + a plain input: no gradient needed either
+        p.requires_grad_(False)
+    net.train()
+    frozen = net(s)
+    assert not frozen.requires_grad and torch.equal(frozen, want)
