@@ -488,8 +488,9 @@ def loader_fed_step(device, net, step, vertices, levels, scenes=3, epochs=3):
     items = [make_synthetic_mesh(vertices, levels, seed=1000 + i) for i in range(scenes)]
     nv = sum(int(it.x.shape[0]) for it in items)
     out = {}
-    for name, cache_bytes in (('fresh_scene_every_step', 0), ('graph_and_plan_resident', 32 << 30)):
-        ld = SceneLoader(items, device, shuffle=False, cache_bytes=cache_bytes, model=net, end_level=levels)
+    for name, cache_bytes, loc in (('fresh_scene_every_step', 0, True), ('graph_and_plan_resident', 32 << 30, True),
+                                   ('graph_and_plan_resident_file_order', 32 << 30, False)):
+        ld = SceneLoader(items, device, shuffle=False, cache_bytes=cache_bytes, model=net, end_level=levels, locality_order=loc)
         for smp in ld.epoch(0):                                 # untimed: pinned ring, allocator pools (and the resident cache)
             step(smp)
         torch.cuda.synchronize()
@@ -503,7 +504,9 @@ def loader_fed_step(device, net, step, vertices, levels, scenes=3, epochs=3):
     step.finish()
     out['note'] = ('%d host-resident synthetic scenes of the headline size through loader.SceneLoader (worker threads, pinned '
                    'staging ring, copy stream), %d epochs after one untimed epoch; fresh = upload + plan build every step, '
-                   'resident = graph tensors + plan cached in HBM, features uploaded' % (scenes, epochs))
+                   'resident = graph tensors + plan cached in HBM, features uploaded; the resident plan is built with the vertices '
+                   'renumbered by locality (the loader default, paid once per scene; colours come back in the scene\'s vertex order), '
+                   '_file_order = the same with locality_order=False' % (scenes, epochs))
     return out
 
 

@@ -331,7 +331,10 @@ class NormGroups:
 class GraphPlan:
     """All CSR structures of one (possibly batched) hierarchical sample."""
 
-    def __init__(self, sample, linspace_quirk=True, validate=True, validation=None, positions=None):
+    def __init__(self, sample, linspace_quirk=True, validate=True, validation=None, positions=None, reorder=None):
+        """reorder: None = the module default (REORDER, off); True / False = renumber the vertices by locality inside THIS plan
+        (see _ensure_order) - what a caller that builds a plan ONCE and keeps it resident asks for (loader.SceneLoader's graph
+        cache: the renumbering is paid once per scene, every later step gathers L2-resident neighbour rows)."""
         x = sample.x
         assert x.is_cuda, 'the HIP path needs the sample on the GPU (sample.to("cuda"))'
         self.device = x.device
@@ -367,7 +370,8 @@ class GraphPlan:
         self._pos_cols = positions
         self._ranks = None                 # per level: int64 [n_l + 1], old id -> new id (last entry = n_l: the out-of-range sentinel)
         self.order0 = self.rank0 = None    # int32: new -> old / old -> new at level 0, for the gathers at the model's boundary
-        self._reorder = bool(positions is not None and REORDER and self.num_graphs == 1 and self.level_sizes[0] >= REORDER_MIN
+        self._reorder = bool(positions is not None and (REORDER if reorder is None else reorder) and self.num_graphs == 1
+                             and self.level_sizes[0] >= (REORDER_MIN if reorder is None else 2)
                              and x.dim() == 2 and x.shape[1] >= positions[1] and not _capturing())
 
     # ---- vertex renumbering -------------------------------------------------------------

@@ -278,26 +278,26 @@ class SurfaceTextureInpaintingNet(nn.Module):
                 uniq.append(it)
         return uniq, list(range(1, num_levels))
 
-    def prefetch_plan(self, sample, inputs_ready=False):
+    def prefetch_plan(self, sample, inputs_ready=False, reorder=None):
         """Build the sample's CSR plan now, its independent pieces side by side on side streams (plan.GraphPlan.prefetch).
         Optional: forward() builds whatever is missing at first use on the compute stream.  A data pipeline that hands
         over GPU-resident index tensors can call this with inputs_ready=True as soon as the sample exists, so that the
         build overlaps with the step still running (measured on the 200k-vertex step: no net gain while the step is
         launch-bound on the host)."""
         plan = plan_for(sample, linspace_quirk=self.compat_linspace_norm, validation=self.plan_validation,
-                        positions=self.position_channels)
+                        positions=self.position_channels, reorder=reorder)
         edges, pools = self._plan_items()
         plan.prefetch(edges, pools, inputs_ready=inputs_ready)
         return plan
 
-    def build_plan(self, sample, inputs_ready=True, after=None):
+    def build_plan(self, sample, inputs_ready=True, after=None, reorder=None):
         """A NEW, complete GraphPlan of `sample`, built on the side streams WITHOUT making the compute stream wait (it
         waits when the plan is first used) and without touching the sample's cached plan: the data pipeline's way to
         prepare step k+1 while step k runs.  Hand it over with `sample._plan_cache = plan` (TrainStep.prefetch and
         loader.SceneLoader do).  after = event of the stream that uploads the sample's index tensors, if one does."""
         from .plan import GraphPlan
         plan = GraphPlan(sample, linspace_quirk=self.compat_linspace_norm, validation=self.plan_validation,
-                         positions=self.position_channels)
+                         positions=self.position_channels, reorder=reorder)
         edges, pools = self._plan_items()
         return plan.prefetch(edges, pools, inputs_ready=inputs_ready, join=False, after=after)
 
