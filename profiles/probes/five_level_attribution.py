@@ -7,7 +7,8 @@ oracle where the fp32 CPU oracle is 0.93e-3.  This probe runs the same network /
 
     shipped   STIN_GEMM_FWD=4 (fp16x3)  STIN_GEMM_BWD=2 (bf16x3)
     bwd_exact STIN_GEMM_FWD=4           STIN_GEMM_BWD=0 (v_mfma_f32_32x32x2_f32 on unsplit operands)
-    bwd_f16x3 STIN_GEMM_FWD=4           STIN_GEMM_BWD=4 (fp16x3 in the backward products too)
+    fwd_x6    STIN_GEMM_FWD=3 (bf16x6)  STIN_GEMM_BWD=2
+    fwd_exact STIN_GEMM_FWD=0           STIN_GEMM_BWD=2
     bwd_x6    STIN_GEMM_FWD=4           STIN_GEMM_BWD=3 (bf16x6: 24-bit products)
     exact     STIN_GEMM_FWD=0           STIN_GEMM_BWD=0
 
@@ -26,8 +27,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SETTINGS = [('shipped (fp16x3 fwd, bf16x3 bwd)', {}),
             ('bwd exact fp32', {'STIN_GEMM_BWD': '0'}),
-            ('bwd fp16x3', {'STIN_GEMM_BWD': '4'}),
             ('bwd bf16x6', {'STIN_GEMM_BWD': '3'}),
+            ('fwd bf16x6 (24-bit products)', {'STIN_GEMM_FWD': '3'}),
+            ('fwd exact fp32 only', {'STIN_GEMM_FWD': '0'}),
             ('fwd + bwd exact fp32', {'STIN_GEMM_FWD': '0', 'STIN_GEMM_BWD': '0'})]
 
 
