@@ -825,23 +825,6 @@ def main():
         step.forward_backward(sample)
     fence()
     dt_fb = time.perf_counter() - t1
-    # forward only, as the reference's validation loop runs it (trainers/inpainting3d_trainer.py:204-263: model.eval(), model(data)
-    # under torch.no_grad()): CSR plan resident, no ReLU mask stored, block temporaries shared (functional.NetFn, need_grad False)
-    inference = None
-    if not args.no_secondary:
-        net.eval()
-        with torch.no_grad():
-            for _ in range(3):
-                net(sample)
-            fence()
-            t_inf = time.perf_counter()
-            for _ in range(args.steps):
-                net(sample)
-            fence()
-            dt_inf = time.perf_counter() - t_inf
-        net.train()
-        inference = {'ms': dt_inf / args.steps * 1e3, 'vertices_per_s': n0 * args.steps / dt_inf,
-                     'note': 'eval mode, torch.no_grad(), plan resident, rank 0; no ReLU mask store, shared block temporaries'}
     # GEMM pass (after the timed region): every MFMA GEMM launch of two more steps bracketed with HIP events; the
     # per-kernel path runs the weight-gradient GEMMs on the compute stream, so these are stand-alone durations
     gtimes = {}
@@ -1010,7 +993,7 @@ def main():
             'fwd_loss_bwd_only': None if args.no_secondary else {
                 'ms_per_step': dt_fb / args.steps * 1e3, 'vertices_per_s_per_gpu': n0 * args.steps / dt_fb,
                 'note': 'same scene, CSR plan reused, no gradient all-reduce, no optimizer step (rank 0)'},
-            'inference': inference,
+            'inference': None,
             'roofline': roofline,
             'contention': contention,
             'edge_stage_ms_per_step': edge_total_ms,
@@ -1092,6 +1075,24 @@ def main():
                     out['loader_fed'] = loader_fed_step(device, net, step, args.vertices, args.levels)
                 except Exception as exc:                    # noqa: BLE001 - a secondary leg must not lose the line
                     out['loader_fed'] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+            # forward only, as the reference's validation loop runs it (trainers/inpainting3d_trainer.py:204-263: model.eval(),
+            # model(data) under torch.no_grad()): CSR plan resident, no ReLU mask stored, block temporaries shared (functional.NetFn,
+            # need_grad False).  Runs AFTER every training leg: its differently sized arenas re-cut the caching allocator's blocks
+            # (a training leg measured right behind it paid hipMalloc / hipFree in every step: 20 ms instead of 7).
+            net.eval()
+            with torch.no_grad():
+                for _ in range(3):
+                    net(sample)
+                fence()
+                t_inf = time.perf_counter()
+                for _ in range(args.steps):
+                    net(sample)
+                fence()
+                dt_inf = time.perf_counter() - t_inf
+            net.train()
+            torch.cuda.empty_cache()
+            out['inference'] = {'ms': dt_inf / args.steps * 1e3, 'vertices_per_s': n0 * args.steps / dt_inf,
+                                'note': 'eval mode, torch.no_grad(), plan resident, rank 0; no ReLU mask store, shared block temporaries'}
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline(args.vertices, args.levels, seed=0, headline_mesh=not args.quick_cpu_baseline)
         print(compact_line(out, write_detail(out, args.detail)), flush=True)
