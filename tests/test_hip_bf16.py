@@ -264,7 +264,7 @@ def test_bf16_network_is_deterministic_and_trains():
 
 
 @pytest.mark.parametrize('seed', [3, 4, 5])
-@pytest.mark.parametrize('shape', ['scene', 'crops'])
+@pytest.mark.parametrize('shape', ['scene', 'crops', 'scene5'])
 def test_bf16_training_curve_tracks_fp32(shape, seed):
     """(round 4: three initialisation seeds, and BASELINE config 3's shape - batches of 8 unequal crops, 4 graph levels, per-graph
     instance norm with the linspace slices - beside the single scene.)
@@ -282,6 +282,10 @@ def test_bf16_training_curve_tracks_fp32(shape, seed):
     spec.loader.exec_module(tool)
     if shape == 'scene':
         samples, cfg = [s.to(DEV) for s in tool.learnable_samples(20_000)], None
+    elif shape == 'scene5':
+        # (round 6) BASELINE config 5's network: five graph levels, 67 M parameters, the 2048-wide bottleneck - the depth at which one
+        # bf16 forward/backward is 27 % (relative L2) from the fp32 gradients (tests/test_five_level.py); what certifies the mode is this curve
+        samples, cfg = [s.to(DEV) for s in tool.learnable_samples(30_000, levels=5)], dict(tool.CFG, n_levels=4)
     else:
         samples, cfg = [s.to(DEV) for s in tool.learnable_crop_batches()], dict(tool.CFG, n_levels=3)
     curves = {m: tool.curve(samples, 200, m, seed=seed, lr=5e-5, cfg=cfg) for m in ('f32', 'f32-exact-gemm', 'bf16')}
@@ -298,12 +302,17 @@ def test_bf16_training_curve_tracks_fp32(shape, seed):
     #   crops  seeds 3 / 4 / 5: -6.4 .. -2.2 % / -2.6 .. -0.6 % / +2.1 .. +2.7 %              | -8.1 .. +0.7 %
     # (the crop batches change every step and hold 8 small graphs: a noisier loss, and it falls to 0.32 of its start in 200 steps
     #  where the single scene reaches 0.17).  Stated bars = bench.py's `dtype_tolerance`.
-    trains, head_bar, tail_bar, ctrl_bar = (0.25, 1e-2, 5e-2, 8e-2) if shape == 'scene' else (0.40, 2e-2, 8e-2, 12e-2)
+    trains, head_bar, tail_bar, ctrl_bar = {'scene': (0.25, 1e-2, 5e-2, 8e-2), 'crops': (0.40, 2e-2, 8e-2, 12e-2),
+                                            'scene5': SCENE5_BARS}[shape]
     assert tail['f32'] < trains * head['f32'], 'the task must actually train'
     assert abs(head['bf16'] - head['f32']) <= head_bar * head['f32']
     near = min(abs(tail['bf16'] - tail['f32']), abs(tail['bf16'] - tail['f32-exact-gemm']))
     assert near <= tail_bar * tail['f32'], (tail, near / tail['f32'])
     assert abs(tail['f32-exact-gemm'] - tail['f32']) <= ctrl_bar * tail['f32'], 'the two fp32 evaluation orders drifted further apart than ever measured'
+
+
+# five-level scene (round 6): provisional bars until the first MI355X measurement is in (then 1.5 x measured, as everywhere)
+SCENE5_BARS = (0.60, 3e-2, 15e-2, 20e-2)
 
 
 def test_bf16_mode_is_refused_for_unsupported_variants():

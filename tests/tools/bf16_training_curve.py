@@ -21,9 +21,9 @@ CFG = dict(input_nc=10, output_nc=3, ngf=64, filter_type='edgeconvtransinv', nor
            n_levels=2, pooling_type='max', dilations=[1, 1, 1, 2, 4, 8, 16, 1, 1], checkpoint_bottleneck=True)
 
 
-def learnable_samples(vertices, n_masks=4, seed=11):
+def learnable_samples(vertices, n_masks=4, seed=11, levels=3):
     """One mesh, a SMOOTH colour field over it (a texture a network can actually inpaint) and n_masks different hole masks."""
-    base = make_synthetic_mesh(vertices, 3, seed=seed, dilations=(2, 4, 8, 16))
+    base = make_synthetic_mesh(vertices, levels, seed=seed, dilations=(2, 4, 8, 16))
     p = base.x[:, 6:9] * 1.5
     rgb = torch.stack([torch.sin(6.0 * p[:, 0] + 2.0 * p[:, 1]), torch.cos(5.0 * p[:, 1] - 3.0 * p[:, 2]),
                        torch.sin(4.0 * (p[:, 0] + p[:, 2]))], 1) * 0.8
