@@ -138,6 +138,10 @@ def edge_bytes(kernel, n, e, h):
         sfx = '_bf16' if s == 2 else '_f32'
         return (edge_bytes('stin_edge_relu_mean_bwd_dst_mask' + sfx, n, e, h) +
                 edge_bytes('stin_edge_relu_mean_bwd_src_mask' + sfx, n, e, h))
+    if kernel == 'stin_edge_relu_mean_fwd_ti_f32':        # compact trans-inv: the row's own B row instead of its A row - same bytes
+        return edge_bytes('stin_edge_relu_mean_fwd_f32', n, e, h)
+    if kernel == 'stin_edge_relu_mean_bwd_mask_ti_f32':   # both halves per row, ONE output row D = dB - dA (+ the tiny column partials)
+        return edge_bytes('stin_edge_relu_mean_bwd_mask_f32', n, e, h) - n * h * s
     raise KeyError(kernel)
 
 
@@ -153,7 +157,8 @@ def pmc_traffic_bytes(kernel, n, e, h):
              'stin_edge_relu_mean_bwd_src_f32': 'k_edge_bwd_src',
              'stin_edge_relu_mean_bwd_dst_mask_f32': 'k_edge_bwd_dst_mask',
              'stin_edge_relu_mean_bwd_src_mask_f32': 'k_edge_bwd_src_mask',
-             'stin_edge_relu_mean_bwd_mask_f32': 'k_edge_bwd_mask_pair'}[kernel]
+             'stin_edge_relu_mean_bwd_mask_f32': 'k_edge_bwd_mask_pair', 'stin_edge_relu_mean_fwd_ti_f32': 'k_edge_fwd_ti',
+             'stin_edge_relu_mean_bwd_mask_ti_f32': 'k_edge_bwd_mask_ti'}[kernel]
     if elem == 'float':                                     # Lane<G, VPL>: 4 channels per lane
         c4 = h // 4
         g = 1
@@ -750,7 +755,7 @@ def main():
     sfx = '_' + args.dtype
     edge_names = ['stin_edge_relu_mean_fwd' + sfx, 'stin_edge_relu_mean_bwd_dst_f32', 'stin_edge_relu_mean_bwd_src_f32',
                   'stin_edge_relu_mean_bwd_dst_mask' + sfx, 'stin_edge_relu_mean_bwd_src_mask' + sfx,
-                  'stin_edge_relu_mean_bwd_mask' + sfx]
+                  'stin_edge_relu_mean_bwd_mask' + sfx, 'stin_edge_relu_mean_fwd_ti_f32', 'stin_edge_relu_mean_bwd_mask_ti_f32']
     gemm_names = ['stin_gemm_nt' + sfx, 'stin_gemm_tn' + sfx]
     timed = edge_names + (gemm_names if args.time_gemms else [])
     # HIP-event brackets need the per-kernel host path (the whole-block C calls enqueue their kernels natively) and event

@@ -201,6 +201,25 @@ int stin_edge_relu_mean_bwd_mask_f32(const float* G, int64_t ldg, const uint32_t
                                      const int32_t* xslot, int64_t N, int H, float* dA, int64_t ldda, float* dB,
                                      int64_t lddb, const float* copy_src, int64_t ld_copy_src, float* copy_dst,
                                      int64_t ld_copy_dst, int C_copy, stin_stream_t stream);
+/* Translation-invariant blocks in the COMPACT layout (round 6; STIN_TI_COMPACT below).  The reference's message is
+ * nn(x_j - x_i) (models/modules/edge_conv_translation_invariance.py:20-22): W1 (x_j - x_i) + b1 = A_i + B_j with B = x W1^T and
+ * A_i = b1 - B_i.  A is therefore not a GEMM output at all:
+ *   fwd_ti:      out / mask exactly as stin_edge_relu_mean_fwd_f32 with A_i = b1 - B_i formed per row (b1 [H] or NULL = zeros) - bit
+ *                for bit the rows that call produces from A = x (-W1)^T + b1 (rounding is symmetric under negation);
+ *   bwd_mask_ti: D [N, H] = dB - dA (both halves of stin_edge_relu_mean_bwd_mask_f32 for the same row, one rounding for the
+ *                difference) - the gradient w.r.t. B in the compact layout - plus colsum [colsum_rows][H]: per-workgroup column sums
+ *                of dA in a fixed order (db1 = their sum; sum_i D_i itself is ~ 0).  colsum_rows >= stin_edge_bwd_ti_colsum_rows(N, H).
+ *                Same optional row-copy rider as the pair launch.  fp32 rows, H in {128, 256, 512, 1024, 2048}. */
+int stin_edge_relu_mean_fwd_ti_f32(const float* b1, const float* B, int64_t ldb, const int32_t* rowptr, const int32_t* col,
+                                   int64_t N, int H, float* out, int64_t ldo, int indicator, uint32_t* mask, stin_stream_t stream);
+int64_t stin_edge_bwd_ti_colsum_rows(int64_t N, int H);
+/* db1 [H] = the sum of the `rows` rows of colsum, in the order stin_edgeconv_wgrad_ti's finalize launch folds them (same bits) */
+int stin_edge_bwd_ti_colsum_fold_f32(const float* colsum, int64_t rows, int H, float* db1, stin_stream_t stream);
+int stin_edge_relu_mean_bwd_mask_ti_f32(const float* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst,
+                                        const float* w_src, const int32_t* rowptr_src, const int32_t* col_src,
+                                        const int32_t* xslot, int64_t N, int H, float* D, int64_t ldd, const float* copy_src,
+                                        int64_t ld_copy_src, float* copy_dst, int64_t ld_copy_dst, int C_copy, float* colsum,
+                                        int64_t colsum_rows, stin_stream_t stream);
 int stin_edge_relu_mean_bwd_dst_f32(const float* A, int64_t lda, const float* B, int64_t ldb,
                                     const float* G, int64_t ldg, const int32_t* rowptr,
                                     const int32_t* col, int64_t N, int H, float* dA, int64_t ldda,
@@ -504,6 +523,11 @@ int stin_concat_unpool_f32(const float* skip, int64_t ld_skip, const float* coar
  * -> the per-vertex GEMM operands  wcat [Yw, Cin] = [Wa-Wb ; Wb ; Ws] (trans_inv: [-W1 ; W1 ; Ws]),
  * bcat [Yw] = [b1 ; 0 ; bs], wcatT = wcat^T, w2T = W2^T; Yw = 2H (+ Cout).  The inner dimension may be zero-padded
  * from Cin to Cp (a multiple of 4) so that a 10-channel network input still takes the 16-byte GEMM paths.
+ * trans_inv = STIN_TI_COMPACT (2, round 6; every entry point that takes trans_inv): the translation-invariant filter with ONLY
+ * B = x W1^T materialised - wcat = [W1 ; Ws], bcat = [0 ; bs], Yw = H (+ Cout); A_i = b1 - B_i is formed by the edge stage
+ * (stin_edge_relu_mean_fwd_ti_f32: same bits as mode 1) and the backward pass carries D = dB - dA in H columns
+ * (stin_edge_relu_mean_bwd_mask_ti_f32) - half the first Linear's GEMM work in every direction.  fp32 rows with a saved-mask
+ * width H; unpack then takes dW1 = rows [0, H) as they are and leaves db1 to the caller (the column sums of dA).
  * unpack: dwb [Yw, Cin+1] (gemm_tn output: weight grad | bias grad) -> dW1, db1, dWs, dbs; and
  *   dw2b [Cout, H+1] (optional) -> contiguous dW2 [Cout, H], db2 [Cout].
  * (models/modules/edge_conv_filter.py:46-52, models/surfacetextureinpaintingnet.py:505-506)
@@ -683,6 +707,7 @@ int stin_linear_tanh_bwd_bf16(const float* g, const float* y, const stin_bf16_t*
  *        caller's next enqueue; with join == 0 the CALLER must order any reader of dW1..dbs after ev_done and keep the
  *        workspace (and x, hE, g) alive until then.  The three events are caller-owned hipEvent_t.
  */
+#define STIN_TI_COMPACT 2         /* value of `trans_inv`: translation-invariant, compact layout (see the pack documentation above) */
 #define STIN_BLOCK_PACKED 0x800   /* OR-ed into stin_edgeconv_block_fwd's fwd_split: the caller has already run the pack (e.g.
                                      stin_edgeconv_pack_many_f32) with the same modes into wcatT / w2T and into THIS workspace
                                      at the offsets stin_edgeconv_block_fwd_pack_offsets reports - the call then skips it    */
@@ -809,6 +834,14 @@ int stin_edgeconv_wgrad(int storage, const void* dagg, int64_t ld_dagg, const vo
                         int64_t ldy, const void* x, int64_t ldx, int64_t N, int Cin, int Cp, int H, int Cout,
                         int has_shortcut, int trans_inv, int precision, float* dW1, float* db1, float* dW2, float* db2,
                         float* dWs, float* dbs, void* workspace, size_t workspace_bytes, stin_stream_t stream);
+/* ... for every trans_inv mode.  trans_inv == STIN_TI_COMPACT: dY = [D | g] is [N, H (+ Cout)], dW1 = the first H rows of the packed
+ * product as they are, and db1 = the sum of the ti_rows rows of ti_colsum [ti_rows][H] (stin_edge_relu_mean_bwd_mask_ti_f32's column
+ * partials of dA), folded by the same finalize launch; other modes ignore the two arguments. */
+int stin_edgeconv_wgrad_ti(int storage, const void* dagg, int64_t ld_dagg, const void* hE, int64_t ldh, const void* dY,
+                           int64_t ldy, const void* x, int64_t ldx, int64_t N, int Cin, int Cp, int H, int Cout,
+                           int has_shortcut, int trans_inv, int precision, float* dW1, float* db1, float* dW2, float* db2,
+                           float* dWs, float* dbs, const float* ti_colsum, int64_t ti_rows, void* workspace,
+                           size_t workspace_bytes, stin_stream_t stream);
 
 /* ------------------------------------------------- offline preprocessing on the GPU --
  * The dilated-edge walk of preprocessing/graph_dilation.py:85-137 (`compute_dilated_edges`), one thread per

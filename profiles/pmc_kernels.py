@@ -58,6 +58,14 @@ if NV != 200_000:
         SF.edge_relu_mean_fwd(A, B, e.by_dst, out, indicator=True, mask=mask)
         SF.edge_relu_mean_bwd_mask(G, mask, e, out[:, :H], out2)
     torch.cuda.synchronize()
+    # (round 6) the bf16-storage twins at the same size (BASELINE config 5's level 0: k_edge_fwd8 / k_edge_bwd_mask_pair8)
+    A16, B16, G16 = A.bfloat16(), B.bfloat16(), G.bfloat16()
+    del A, B, G, out, out2
+    out16, out16b = torch.empty(NV, H + 8, dtype=torch.bfloat16, device=dev), torch.empty(NV, H, dtype=torch.bfloat16, device=dev)
+    for _ in range(4):
+        SF.edge_relu_mean_fwd(A16, B16, e.by_dst, out16, indicator=True, mask=mask)
+        SF.edge_relu_mean_bwd_mask(G16, mask, e, out16[:, :H], out16b)
+    torch.cuda.synchronize()
     sys.exit(0)
 # PMC_ONLY_FWD=1: the level-0 forward edge kernel of the headline mesh only (what bench.py's live `roofline.traffic` leg profiles)
 ONLY_FWD = os.environ.get('PMC_ONLY_FWD', '0') == '1'

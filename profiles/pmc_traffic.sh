@@ -2,7 +2,7 @@
 # rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: they do not fit one TCC pass) over profiles/pmc_kernels.py at the headline size and
 # at the 1 M-vertex size of bench.py's `hbm_honest` -> gpurun_out/<tag>/pmc_traffic.json (keys of the 1 M pass prefixed "N1000000:")
 #   gpurun --timeout 1200 -- 'bash profiles/pmc_traffic.sh r04'
-TAG=${1:-r04}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O

@@ -65,6 +65,11 @@ SIGNATURES = {
                                           c_i64, c_ptr]),
     'stin_norm_act_bwd_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                       c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
+    'stin_edge_relu_mean_fwd_ti_f32': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    'stin_edge_bwd_ti_colsum_rows': (c_i64, [c_i64, c_int]),
+    'stin_edge_bwd_ti_colsum_fold_f32': (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    'stin_edge_relu_mean_bwd_mask_ti_f32': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr, c_i64,
+                                                    c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
     'stin_gemm_nt_f32': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int,
                                  c_ptr, c_i64, c_int, c_ptr]),
     'stin_gemm_tn_workspace_bytes': (c_size, [c_i64, c_int, c_int, c_int]),
@@ -151,6 +156,8 @@ SIGNATURES['stin_plan_build_many'] = (c_int, [c_ptr, c_int, c_ptr, c_ptr, c_size
 SIGNATURES['stin_edgeconv_wgrad_workspace_bytes'] = (c_size, [c_i64, c_int, c_int, c_int, c_int])
 SIGNATURES['stin_edgeconv_wgrad'] = (c_int, [c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64] + [c_int] * 7 + [c_ptr] * 6 +
                                      [c_ptr, c_size, c_ptr])
+SIGNATURES['stin_edgeconv_wgrad_ti'] = (c_int, [c_int, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64] + [c_int] * 7 + [c_ptr] * 6 +
+                                        [c_ptr, c_i64, c_ptr, c_size, c_ptr])
 SIGNATURES['stin_norm_bwd_coef_m_quirk_f32'] = (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr])
 SIGNATURES['stin_gather_add_rows_f32'] = (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr])
 SIGNATURES['stin_segment_mean_stats_groups'] = (c_i64, [c_i64, c_int])

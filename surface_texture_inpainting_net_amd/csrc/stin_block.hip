@@ -75,11 +75,16 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
     STIN_REQUIRE(x && W1 && W2 && rowptr_dst && wcatT && w2T && Y && hE && agg && mean && rstd && out && workspace,
                  STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_edgeconv_block_fwd_workspace_bytes(Cin, Cp, H, Cout, has_shortcut, B), STIN_E_WORKSPACE);
-    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+    // trans_inv == STIN_TI_COMPACT (round 6, fp32 rows): Y = [B | S], the edge stage forms A_i = b1 - B_i (stin_common.h: stin_yw)
+    const bool compact = trans_inv == STIN_TI_COMPACT;
+    STIN_REQUIRE(!compact || storage == 0, STIN_E_UNSUPPORTED);
+    const int Yw = stin_yw(H, Cout, has_shortcut, trans_inv);
+    const int Yw_max = 2 * H + (has_shortcut ? Cout : 0);          // the carve keeps the offsets of stin_edgeconv_block_fwd_pack_offsets
+    STIN_REQUIRE(ldy >= Yw, STIN_E_SIZE);
     char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    float* wcat = reinterpret_cast<float*>(carve(p, (size_t)Yw * Cp * 4));
+    float* wcat = reinterpret_cast<float*>(carve(p, (size_t)Yw_max * Cp * 4));
     float* w2s = reinterpret_cast<float*>(carve(p, (size_t)Cout * H * 4));
-    float* bcat = reinterpret_cast<float*>(carve(p, (size_t)Yw * 4));
+    float* bcat = reinterpret_cast<float*>(carve(p, (size_t)Yw_max * 4));
     void* red_ws = p;
     const size_t red_bytes = stin_colreduce_workspace_bytes(Cout, B);
 
@@ -94,14 +99,17 @@ extern "C" int stin_edgeconv_block_fwd(int storage, const void* x, int64_t ldx, 
     const float* w2_op = fwd_split ? w2s : W2;
     const int wbf = (storage == 1 && fwd_split) ? STIN_GEMM_W_BF16 : 0;
     const int pf = fwd_split ? (prec_fwd | STIN_GEMM_W_PRESPLIT | (fwd_split & STIN_GEMM_W_FRAG)) : prec_fwd;
-    const void* res = has_shortcut ? col_off(static_cast<const void*>(Y), 2 * (int64_t)H, storage) : x;
+    const void* res = has_shortcut ? col_off(static_cast<const void*>(Y), (int64_t)(Yw - Cout), storage) : x;
     const int64_t ld_res = has_shortcut ? ldy : ldx;
     if (storage == 0) {
         float* Yf = static_cast<float*>(Y);
         float* hf = static_cast<float*>(hE);
         STIN_TRY(stin_gemm_nt_f32(static_cast<const float*>(x), ldx, wcat, Cp, bcat, nullptr, 0, nullptr, 0, N, Yw, Cp, Yf, ldy,
                                   pf, stream));
-        STIN_EDGE_BRACKET(stin_edge_relu_mean_fwd_f32(Yf, ldy, Yf + H, ldy, rowptr_dst, col_dst, N, H, hf, ldh, 1, mask, stream));
+        if (compact)
+            STIN_EDGE_BRACKET(stin_edge_relu_mean_fwd_ti_f32(b1, Yf, ldy, rowptr_dst, col_dst, N, H, hf, ldh, 1, mask, stream));
+        else
+            STIN_EDGE_BRACKET(stin_edge_relu_mean_fwd_f32(Yf, ldy, Yf + H, ldy, rowptr_dst, col_dst, N, H, hf, ldh, 1, mask, stream));
         // one graph, all-columns GEMM shape: the column sums of agg come out of GEMM2's epilogue (no pass over agg for them)
         const int64_t stat_groups = (B == 1 && gid == nullptr && !slice_quirk) ? stin_gemm_nt_colstats_groups(N, Cout, H, pf) : 0;
         const bool fused_stats = stat_groups > 0 && (size_t)stat_groups * 2 * Cout * sizeof(double) + 256 <= red_bytes;
@@ -171,6 +179,7 @@ extern "C" size_t stin_edgeconv_block_bwd_workspace_bytes(int64_t N, int Cp, int
     const size_t Yw = 2 * (size_t)H + (has_shortcut ? Cout : 0);
     const size_t es = storage ? 2 : 4;
     const size_t tn = stin_edgeconv_wgrad_workspace_bytes(N, Cp, H, Cout, has_shortcut);   // the slabs of both products
+    // (sized for the wide layout; the compact trans-inv layout uses H of dY's 2 H columns and the slack pays for its dA column partials)
     return up256((size_t)N * Cout * es)      /* dagg */
            + up256((size_t)N * H * es)       /* dhE  */
            + up256((size_t)N * Yw * es)      /* dY   */
@@ -232,12 +241,24 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
                  STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_edgeconv_block_bwd_workspace_bytes(N, Cp, H, Cout, has_shortcut, B, storage),
                  STIN_E_WORKSPACE);
-    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+    const bool compact = trans_inv == STIN_TI_COMPACT;
+    STIN_REQUIRE(!compact || storage == 0, STIN_E_UNSUPPORTED);
+    const int Yw = stin_yw(H, Cout, has_shortcut, trans_inv);
+    const int Yw_max = 2 * H + (has_shortcut ? Cout : 0);
     const size_t es = storage ? 2 : 4;
     char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     void* dagg = carve(p, (size_t)N * Cout * es);
     void* dhE = carve(p, (size_t)N * H * es);
-    void* dY = carve(p, (size_t)N * Yw * es);
+    void* dY = carve(p, (size_t)N * Yw_max * es);
+    // compact layout: dY is [N, Yw] inside that region; the column partials of dA ([rows][H] floats, rows ~ N / 16..32) live behind it
+    // in the H unused columns' worth of space (N * H * 4 bytes >= rows * H * 4)
+    float* ti_colsum = nullptr;
+    int64_t ti_rows = 0;
+    if (compact) {
+        ti_rows = stin_edge_bwd_ti_colsum_rows(N, H);
+        ti_colsum = reinterpret_cast<float*>(static_cast<char*>(dY) + up256((size_t)N * Yw * 4));
+        STIN_REQUIRE(up256((size_t)N * Yw * 4) + (size_t)ti_rows * H * 4 <= up256((size_t)N * Yw_max * 4), STIN_E_WORKSPACE);
+    }
     float* kk = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
     float* mm = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
     float* t1 = reinterpret_cast<float*>(carve(p, (size_t)B * Cout * 4));
@@ -315,14 +336,20 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
                                   static_cast<float*>(dhE), H, pb, stream));
         // edge stage backward from the saved ReLU mask -> dY = [dA | dB | g]
         // (a shortcut block's dY[:, 2H:] = g rides on the same launch when the rows allow 16-byte copies, else one 2-D memcpy)
+        float* dYs = dYf + (Yw - Cout);                             // the shortcut columns of dY (has_shortcut)
         const bool ride = has_shortcut && N > 0 && Cout % 4 == 0 && ldg % 4 == 0 && Yw % 4 == 0 && stin_aligned16(gf) &&
-                          stin_aligned16(dYf + 2 * H);
+                          stin_aligned16(dYs) && Cout <= H;
         if (side && bind_on && N > 0 && (!has_shortcut || ride) && t_edge_ev1 == nullptr) stin_tl_stop_event = (hipEvent_t)ev_dy;
-        STIN_EDGE_BRACKET(stin_edge_relu_mean_bwd_mask_f32(static_cast<const float*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src, col_src,
-                                                          xslot, N, H, dYf, Yw, dYf + H, Yw, ride ? gf : nullptr, ldg,
-                                                          ride ? dYf + 2 * H : nullptr, Yw, ride ? Cout : 0, stream));
+        if (compact)     // D = dB - dA in ONE row of H columns, + the column partials of dA for db1 (stin_graph.hip: k_edge_bwd_mask_ti)
+            STIN_EDGE_BRACKET(stin_edge_relu_mean_bwd_mask_ti_f32(static_cast<const float*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src,
+                                                                 col_src, xslot, N, H, dYf, Yw, ride ? gf : nullptr, ldg,
+                                                                 ride ? dYs : nullptr, Yw, ride ? Cout : 0, ti_colsum, ti_rows, stream));
+        else
+            STIN_EDGE_BRACKET(stin_edge_relu_mean_bwd_mask_f32(static_cast<const float*>(dhE), H, mask, rowptr_dst, w_src, rowptr_src, col_src,
+                                                              xslot, N, H, dYf, Yw, dYf + H, Yw, ride ? gf : nullptr, ldg,
+                                                              ride ? dYs : nullptr, Yw, ride ? Cout : 0, stream));
         if (has_shortcut && N > 0 && !ride) {
-            hipError_t e = hipMemcpy2DAsync(dYf + 2 * H, (size_t)Yw * 4, gf, (size_t)ldg * 4, (size_t)Cout * 4, (size_t)N,
+            hipError_t e = hipMemcpy2DAsync(dYs, (size_t)Yw * 4, gf, (size_t)ldg * 4, (size_t)Cout * 4, (size_t)N,
                                             hipMemcpyDeviceToDevice, hs);
             if (e != hipSuccess) return (int)e;
         }
@@ -332,8 +359,8 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
         bound = side && bind_on && N > 0 && (!has_shortcut || ride) && t_edge_ev1 == nullptr && stin_tl_stop_event == nullptr;
         stin_tl_stop_event = nullptr;
         STIN_TRY(fork(ev_dy));
-        STIN_TRY(stin_edgeconv_wgrad(0, dagg, Cout, hf, ldh, dYf, Yw, x, ldx, N, Cin, Cp, H, Cout, has_shortcut, trans_inv, prec_bwd,
-                                     dW1, db1, dW2, db2, dWs, dbs, tn_ws, tn_bytes, ws_));
+        STIN_TRY(stin_edgeconv_wgrad_ti(0, dagg, Cout, hf, ldh, dYf, Yw, x, ldx, N, Cin, Cp, H, Cout, has_shortcut, trans_inv, prec_bwd,
+                                        dW1, db1, dW2, db2, dWs, dbs, ti_colsum, ti_rows, tn_ws, tn_bytes, ws_));
         if (dx != nullptr) {
             const bool link_ok = link != nullptr && link->next_agg != nullptr && link->next_ld % 4 == 0 && stin_aligned16(link->next_agg) &&
                                  stin_aligned16(link->next_mean) && stin_aligned16(link->next_rstd) && link->next_partial != nullptr;

@@ -51,6 +51,14 @@ __host__ __device__ static inline bool stin_w_frag_shape(int Nc, int K) {
     return Nc % 32 == 0 && K >= 128 && K <= 256 && Nc >= 320;
 }
 
+// Width of the packed first-Linear operand / of Y and dY of a fused block.  trans_inv: 0 = EdgeConv ([Wa - Wb ; Wb ; Ws], A and B
+// materialised), 1 = translation-invariant, both halves materialised ([-W1 ; W1 ; Ws]), 2 = translation-invariant COMPACT (round 6):
+// the operand is [W1 ; Ws], only B = x W1^T exists - A_i = b1 - B_i is formed by the edge stage, bit for bit the value the GEMM
+// wrote for mode 1 - and the backward pass carries D = dB - dA (stin_hip.h, STIN_TI_COMPACT).
+__host__ __device__ static inline int stin_yw(int H, int Cout, int has_shortcut, int trans_inv) {
+    return (trans_inv == STIN_TI_COMPACT ? H : 2 * H) + (has_shortcut ? Cout : 0);
+}
+
 // Ticket words of the one-launch reductions (stin_norm.hip k_colreduce_t, stin_tail.hip k_linear_tanh_bwd) live in a global
 // array of `slots` rows and every launch takes the next row, so launches in flight never share a word.  A launch that is being
 // CAPTURED into a hipGraph bakes its row into the graph and will run at every replay - possibly beside eager launches whose

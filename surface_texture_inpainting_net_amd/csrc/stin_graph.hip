@@ -79,7 +79,10 @@ struct Lane {
 
 // ------------------------------------------------------------------ edge stage, forward
 // EXACT: H == 4 * G * VPL (every width the saved-mask path supports): no per-chunk predicates on the gathers
-template <typename T, int G, int VPL, int U, bool EXACT>
+// TI (round 6, translation-invariant blocks in the compact layout): the row's own operand is not read from memory but formed
+// as a = b1 - B_i (A points at the bias vector b1 [H], or is NULL for a filter without bias) - bit for bit the value the Y
+// product wrote into its A columns when it multiplied by [-W1 ; W1] (round-to-nearest is symmetric under negation).
+template <typename T, int G, int VPL, int U, bool EXACT, bool TI = false>
 __device__ __forceinline__ void edge_fwd_body(const T* __restrict__ A, int64_t lda,
                                               const T* __restrict__ B, int64_t ldb,
                                               const int32_t* __restrict__ rowptr,
@@ -95,7 +98,13 @@ __device__ __forceinline__ void edge_fwd_body(const T* __restrict__ A, int64_t l
 #pragma unroll
     for (int k = 0; k < VPL; ++k) {
         on[k] = EXACT || L.chan(k) < H;
-        a[k] = on[k] ? ld4_stream(A + L.row * lda + L.chan(k)) : f4zero();
+        if (TI) {
+            const float4 bo = ld4(B + L.row * ldb + L.chan(k));
+            const float4 bi = A != nullptr ? ld4(A + L.chan(k)) : f4zero();
+            a[k] = make_float4(bi.x - bo.x, bi.y - bo.y, bi.z - bo.z, bi.w - bo.w);
+        } else {
+            a[k] = on[k] ? ld4_stream(A + L.row * lda + L.chan(k)) : f4zero();
+        }
         acc[k] = f4zero();
     }
     const int mwords = H >> 5;                            // mask words per edge slot
@@ -169,6 +178,14 @@ __global__ __launch_bounds__(BLOCK) void k_edge_fwd_exact(const T* __restrict__ 
                                                           int64_t N, int H, T* __restrict__ out, int64_t ldo, int indicator,
                                                           uint32_t* __restrict__ mask) {
     edge_fwd_body<T, G, VPL, U, true>(A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+}
+
+template <typename T, int G, int VPL, int U>
+__global__ __launch_bounds__(BLOCK) void k_edge_fwd_ti(const T* __restrict__ b1, int64_t, const T* __restrict__ B, int64_t ldb,
+                                                       const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       int64_t N, int H, T* __restrict__ out, int64_t ldo, int indicator,
+                                                       uint32_t* __restrict__ mask) {
+    edge_fwd_body<T, G, VPL, U, true, true>(b1, 0, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
 }
 
 // ------------------------------------------ edge stage, backward w.r.t. A (destination CSR)
@@ -446,6 +463,141 @@ __global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_pair(const T* __restric
             }
         }
         edge_bwd_dst_mask_body<T, G, VPL, UD>(vb, Gr, ldg, mask, rowptr_dst, N, H, dA, ldda);
+    }
+}
+
+// ---- translation-invariant blocks in the compact layout (round 6): A_i = b1 - B_i, so dL/dB_i collects BOTH roles of vertex i:
+//   D_i = dB_i - dA_i,   dB_i = sum over out-edges (the gathering half above),  dA_i = G_i / deg_i * popcount of the in-edge masks
+// (the streaming half).  One block computes both halves of its rows - same arithmetic per half as the two bodies above - and writes
+// ONE row of H channels where the pair kernel wrote two; the first Linear's backward products (dx = D W1, dW1 = D^T x) then run
+// over H columns instead of 2 H.  db1 = sum_i dA_i no longer falls out of the transposed product's ones column (sum_i D_i is ~ 0):
+// every lane adds up dA over the TI_ITER rows it visits (a lane keeps its channels from row to row), the block folds its row slots
+// in a fixed order through LDS and writes colsum[blockIdx][H]; stin_wgrad.hip's finalize adds the block rows in a fixed order.
+constexpr int TI_ITER = 4;                                 // row groups per block (fixes the number of partial rows: see ti_colsum_rows)
+template <typename T, int G, int VPL, int UD, int US>
+__global__ __launch_bounds__(BLOCK) void k_edge_bwd_mask_ti(const T* __restrict__ Gr, int64_t ldg, const uint32_t* __restrict__ mask,
+                                                            const int32_t* __restrict__ rowptr_dst, const float* __restrict__ w_slot,
+                                                            const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ col_src,
+                                                            const int32_t* __restrict__ xslot, int64_t N, int H, T* __restrict__ D,
+                                                            int64_t ldd, const T* __restrict__ cp_src, int64_t ld_cps,
+                                                            T* __restrict__ cp_dst, int64_t ld_cpd, int Ccp, float* __restrict__ colsum) {
+    constexpr int RPB = BLOCK / G;                          // rows per block and iteration
+    __shared__ float4 red[RPB][G * VPL];
+    const int mwords = H >> 5;
+    constexpr int WPC = G / 32;
+    float4 csum[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) csum[k] = f4zero();
+    for (int it = 0; it < TI_ITER; ++it) {
+        Lane<G, VPL> L(blockIdx.x * TI_ITER + it);
+        if (L.row >= N) break;                              // (rows ascend with `it`: nothing further for this row slot)
+        const int wsel = L.lg >> 5, bit = L.lg & 31;
+        // ---- gathering half: dB (edge_bwd_src_mask_body)
+        float4 acc[VPL];
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) acc[k] = f4zero();
+        {
+            const int beg = rowptr_src[L.row], end = rowptr_src[L.row + 1];
+            for (int e = beg; e < end; e += US) {
+                float4 g[US][VPL];
+                uint32_t wv[US][VPL][4];
+                float w[US];
+#pragma unroll
+                for (int u = 0; u < US; ++u) {
+                    const int ee = min(e + u, end - 1);
+                    const int64_t i = col_src[ee];
+                    const int64_t xs = xslot[ee];
+                    const float ws = w_slot[ee];
+                    w[u] = (e + u < end) ? ws : 0.f;
+#pragma unroll
+                    for (int k = 0; k < VPL; ++k) {
+                        g[u][k] = ld4(Gr + i * ldg + L.chan(k));
+                        const uint32_t* m = mask + xs * mwords + k * (G / 8);
+                        if (WPC == 1) {
+                            const uint4 q = *reinterpret_cast<const uint4*>(m);
+                            wv[u][k][0] = q.x; wv[u][k][1] = q.y; wv[u][k][2] = q.z; wv[u][k][3] = q.w;
+                        } else {
+                            const uint4 q0 = reinterpret_cast<const uint4*>(m)[0], q1 = reinterpret_cast<const uint4*>(m)[1];
+                            wv[u][k][0] = wsel ? q0.y : q0.x; wv[u][k][1] = wsel ? q0.w : q0.z;
+                            wv[u][k][2] = wsel ? q1.y : q1.x; wv[u][k][3] = wsel ? q1.w : q1.z;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < US; ++u) {
+#pragma unroll
+                    for (int k = 0; k < VPL; ++k) {
+                        acc[k].x += ((wv[u][k][0] >> bit) & 1u) ? w[u] * g[u][k].x : 0.f;
+                        acc[k].y += ((wv[u][k][1] >> bit) & 1u) ? w[u] * g[u][k].y : 0.f;
+                        acc[k].z += ((wv[u][k][2] >> bit) & 1u) ? w[u] * g[u][k].z : 0.f;
+                        acc[k].w += ((wv[u][k][3] >> bit) & 1u) ? w[u] * g[u][k].w : 0.f;
+                    }
+                }
+            }
+        }
+        // ---- streaming half: dA (edge_bwd_dst_mask_body)
+        int cnt[VPL][4];
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) cnt[k][0] = cnt[k][1] = cnt[k][2] = cnt[k][3] = 0;
+        const int beg = rowptr_dst[L.row], end = rowptr_dst[L.row + 1];
+        for (int e = beg; e < end; e += UD) {
+            uint32_t wv[UD][VPL][4];
+#pragma unroll
+            for (int u = 0; u < UD; ++u) {
+                const int ee = min(e + u, end - 1);
+#pragma unroll
+                for (int k = 0; k < VPL; ++k) {
+                    const uint32_t* m = mask + (int64_t)ee * mwords + k * (G / 8);
+                    if (WPC == 1) {
+                        const uint4 q = *reinterpret_cast<const uint4*>(m);
+                        wv[u][k][0] = q.x; wv[u][k][1] = q.y; wv[u][k][2] = q.z; wv[u][k][3] = q.w;
+                    } else {
+                        const uint4 q0 = reinterpret_cast<const uint4*>(m)[0], q1 = reinterpret_cast<const uint4*>(m)[1];
+                        wv[u][k][0] = wsel ? q0.y : q0.x; wv[u][k][1] = wsel ? q0.w : q0.z;
+                        wv[u][k][2] = wsel ? q1.y : q1.x; wv[u][k][3] = wsel ? q1.w : q1.z;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UD; ++u) {
+                if (e + u < end) {
+#pragma unroll
+                    for (int k = 0; k < VPL; ++k) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) cnt[k][c] += (wv[u][k][c] >> bit) & 1u;
+                    }
+                }
+            }
+        }
+        const int deg = end - beg;
+        const float s = 1.0f / (float)(deg > 0 ? deg : 1);
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const float4 g = ld4(Gr + L.row * ldg + L.chan(k));
+            const float4 dA = make_float4(g.x * s * (float)cnt[k][0], g.y * s * (float)cnt[k][1], g.z * s * (float)cnt[k][2],
+                                          g.w * s * (float)cnt[k][3]);
+            st4(D + L.row * ldd + L.chan(k), make_float4(acc[k].x - dA.x, acc[k].y - dA.y, acc[k].z - dA.z, acc[k].w - dA.w));
+            csum[k].x += dA.x; csum[k].y += dA.y; csum[k].z += dA.z; csum[k].w += dA.w;
+            // optional row copy (the block backward's dY[:, H:] = g of a shortcut block)
+            if (cp_src != nullptr && L.chan(k) < Ccp) st4(cp_dst + L.row * ld_cpd + L.chan(k), ld4(cp_src + L.row * ld_cps + L.chan(k)));
+        }
+    }
+    // ---- column sums of dA over this block's rows: row slots folded in ascending order
+    const int slot = threadIdx.x / G, lg = threadIdx.x % G;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) red[slot][k * G + lg] = csum[k];
+    __syncthreads();
+    if (slot == 0) {
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            float4 t = red[0][k * G + lg];
+#pragma unroll
+            for (int r = 1; r < RPB; ++r) {
+                const float4 v = red[r][k * G + lg];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            *reinterpret_cast<float4*>(colsum + (int64_t)blockIdx.x * H + (k * G + lg) * 4) = t;
+        }
     }
 }
 
@@ -1462,6 +1614,54 @@ int edge_bwd_mask_pair_impl(const float* G, int64_t ldg, const uint32_t* mask, c
     return stin_launch_status();
 }
 
+// translation-invariant compact layout, fp32 rows (see k_edge_bwd_mask_ti): D [N, H] = dB - dA, colsum [ti_colsum_rows(N, H)][H]
+inline int64_t ti_colsum_rows(int64_t N, int H) {
+    const int c4 = H / 4, g = stin_group_lanes(c4);
+    const int64_t nb = (N + (BLOCK / g) - 1) / (BLOCK / g);
+    return (nb + TI_ITER - 1) / TI_ITER;
+}
+int edge_bwd_mask_ti_impl(const float* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst, const float* w_src,
+                          const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot, int64_t N, int H, float* D,
+                          int64_t ldd, const float* cp_src, int64_t ld_cps, float* cp_dst, int64_t ld_cpd, int Ccp, float* colsum,
+                          int64_t colsum_rows, hipStream_t stream) {
+    using T = float;
+    STIN_REQUIRE(N >= 0 && H > 0 && ldg >= H && ldd >= H, STIN_E_SIZE);
+    if (cp_src != nullptr) {
+        STIN_REQUIRE(cp_dst != nullptr && Ccp > 0 && Ccp <= H && Ccp % 4 == 0 && ld_cps >= Ccp && ld_cpd >= Ccp, STIN_E_SIZE);
+        STIN_REQUIRE(stin_aligned16(cp_src) && stin_aligned16(cp_dst) && ld_cps % 4 == 0 && ld_cpd % 4 == 0, STIN_E_ALIGN);
+    }
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(G && mask && rowptr_dst && w_src && rowptr_src && col_src && xslot && D && colsum, STIN_E_NULL);
+    STIN_REQUIRE(mask_shape_ok(H) && vec_ok<T>(H, {G, D}, {ldg, ldd}) && stin_aligned16(colsum), STIN_E_UNSUPPORTED);
+    const int64_t nblk = ti_colsum_rows(N, H);
+    STIN_REQUIRE(colsum_rows >= nblk, STIN_E_WORKSPACE);
+    const int c4 = H / 4, g = stin_group_lanes(c4), vpl = (c4 + g - 1) / g;
+    // rows in flight per role: the pair kernel's choices (UD = STIN_U(base, 1), US = STIN_U(base, 2))
+#define STIN_TI(G_, VPL_, UD_, US_)                                                                                      \
+    STIN_LAUNCH_STOP((k_edge_bwd_mask_ti<T, G_, VPL_, UD_, US_>), dim3((unsigned)nblk), dim3(BLOCK), stream, G, ldg, mask,  \
+                     rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, D, ldd, cp_src, ld_cps, cp_dst, ld_cpd, Ccp, colsum)
+    if (g == 32) STIN_TI(32, 1, STIN_U(6, 1), STIN_U(6, 2));          // H = 128
+    else if (vpl == 1) STIN_TI(64, 1, STIN_U(4, 1), STIN_U(4, 2));    // 256
+    else if (vpl == 2) STIN_TI(64, 2, 2, 2);                          // 512
+    else if (vpl <= 4) STIN_TI(64, 4, STIN_U(2, 1), STIN_U(2, 2));    // 1024
+    else STIN_TI(64, 8, 1, 1);                                        // 2048
+#undef STIN_TI
+    return stin_launch_status();
+}
+
+int edge_fwd_ti_impl(const float* b1, const float* B, int64_t ldb, const int32_t* rowptr, const int32_t* col, int64_t N, int H,
+                     float* out, int64_t ldo, int indicator, uint32_t* mask, hipStream_t stream) {
+    using T = float;
+    STIN_REQUIRE(N >= 0 && H > 0 && ldb >= H && ldo >= H + (indicator ? 4 : 0), STIN_E_SIZE);
+    if (N == 0) return STIN_OK;
+    STIN_REQUIRE(B && rowptr && out, STIN_E_NULL);
+    STIN_REQUIRE(mask_shape_ok(H) && vec_ok<T>(H, {B, out}, {ldb, ldo}) && (b1 == nullptr || stin_aligned16(b1)), STIN_E_UNSUPPORTED);
+    const float* A = b1;
+    const int64_t lda = 0;
+    STIN_DISPATCH(H, k_edge_fwd_ti, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
+    return stin_launch_status();
+}
+
 int edge_bwd_mask_pair8_impl(const stin_bf16* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst,
                              const float* w_src, const int32_t* rowptr_src, const int32_t* col_src, const int32_t* xslot,
                              int64_t N, int H, stin_bf16* dA, int64_t ldda, stin_bf16* dB, int64_t lddb, const stin_bf16* cp_src,
@@ -1623,6 +1823,26 @@ extern "C" int stin_edge_relu_mean_fwd_bf16(const stin_bf16_t* A, int64_t lda, c
     stin_clear_stale_error();
     return edge_fwd_impl<stin_bf16>(b16(A), lda, b16(B), ldb, rowptr, col, N, H, b16(out), ldo, indicator, mask,
                                     (hipStream_t)stream);
+}
+
+extern "C" int stin_edge_relu_mean_fwd_ti_f32(const float* b1, const float* B, int64_t ldb, const int32_t* rowptr, const int32_t* col,
+                                              int64_t N, int H, float* out, int64_t ldo, int indicator, uint32_t* mask,
+                                              stin_stream_t stream) {
+    stin_clear_stale_error();
+    return edge_fwd_ti_impl(b1, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask, (hipStream_t)stream);
+}
+extern "C" int64_t stin_edge_bwd_ti_colsum_rows(int64_t N, int H) {
+    if (N <= 0 || H <= 0 || !mask_shape_ok(H)) return 0;
+    return ti_colsum_rows(N, H);
+}
+extern "C" int stin_edge_relu_mean_bwd_mask_ti_f32(const float* G, int64_t ldg, const uint32_t* mask, const int32_t* rowptr_dst,
+                                                   const float* w_src, const int32_t* rowptr_src, const int32_t* col_src,
+                                                   const int32_t* xslot, int64_t N, int H, float* D, int64_t ldd,
+                                                   const float* cp_src, int64_t ld_cps, float* cp_dst, int64_t ld_cpd, int Ccp,
+                                                   float* colsum, int64_t colsum_rows, stin_stream_t stream) {
+    stin_clear_stale_error();
+    return edge_bwd_mask_ti_impl(G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, D, ldd, cp_src, ld_cps, cp_dst,
+                                 ld_cpd, Ccp, colsum, colsum_rows, (hipStream_t)stream);
 }
 
 extern "C" int stin_edge_relu_mean_bwd_dst_f32(const float* A, int64_t lda, const float* B, int64_t ldb, const float* G,

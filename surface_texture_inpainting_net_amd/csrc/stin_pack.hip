@@ -69,26 +69,36 @@ __global__ void k_split_weights(const float* __restrict__ W, int64_t ldw, int Nc
 // wcatT [Cin, Yw] = wcat^T,  w2T [H, Cout] = W2^T,  w2s [Cout, H] = W2 (only when pre-split).  Yw = 2H (+ Cout with a
 // shortcut).  fwd_mode / bwd_mode: the storage form (put_weight) of the forward operands (wcat, w2s) and of the
 // backward operands (wcatT, w2T).
+// element (r, c) of the packed operand wcat, c < Cin; and entry r of its bias bcat (compact trans-inv: b1 is NOT in bcat - the
+// edge stage adds it when it forms A_i = b1 - B_i)
+__device__ __forceinline__ float pack_value(const float* __restrict__ W1, const float* __restrict__ Ws, int Cin, int H, int ld1,
+                                            int trans_inv, int r, int c) {
+    if (trans_inv == STIN_TI_COMPACT) return r < H ? W1[(int64_t)r * ld1 + c] : Ws[(int64_t)(r - H) * Cin + c];
+    if (r < H) return trans_inv ? -W1[(int64_t)r * ld1 + c] : W1[(int64_t)r * ld1 + c] - W1[(int64_t)r * ld1 + Cin + c];
+    if (r < 2 * H) return trans_inv ? W1[(int64_t)(r - H) * ld1 + c] : W1[(int64_t)(r - H) * ld1 + Cin + c];
+    return Ws[(int64_t)(r - 2 * H) * Cin + c];
+}
+__device__ __forceinline__ float pack_bias(const float* __restrict__ b1, const float* __restrict__ bs, int H, int trans_inv, int r) {
+    if (trans_inv == STIN_TI_COMPACT) return r < H ? 0.f : (bs != nullptr ? bs[r - H] : 0.f);
+    return r < H ? (b1 != nullptr ? b1[r] : 0.f) : (r < 2 * H ? 0.f : (bs != nullptr ? bs[r - 2 * H] : 0.f));
+}
+
 __device__ __forceinline__ void pack_body(int64_t t, const float* __restrict__ W1, const float* __restrict__ b1,
                                           const float* __restrict__ Ws, const float* __restrict__ bs,
                                           const float* __restrict__ W2, int Cin, int Cp, int H, int Cout, int has_shortcut,
                                           int trans_inv, float* __restrict__ wcat, float* __restrict__ bcat,
                                           float* __restrict__ wcatT, float* __restrict__ w2T, float* __restrict__ w2s,
                                           int fwd_mode, int bwd_mode) {
-    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+    const int Yw = stin_yw(H, Cout, has_shortcut, trans_inv);
     const int ld1 = trans_inv ? Cin : 2 * Cin;
     const int64_t n_w = (int64_t)Yw * Cp, n_2 = (int64_t)H * Cout;
     if (t < n_w) {
         const int r = (int)(t / Cp), c = (int)(t % Cp);
         float v = 0.f;                                   // zero padding columns c >= Cin (inner dimension padded to Cp)
-        if (c < Cin) {
-            if (r < H) v = trans_inv ? -W1[(int64_t)r * ld1 + c] : W1[(int64_t)r * ld1 + c] - W1[(int64_t)r * ld1 + Cin + c];
-            else if (r < 2 * H) v = trans_inv ? W1[(int64_t)(r - H) * ld1 + c] : W1[(int64_t)(r - H) * ld1 + Cin + c];
-            else v = Ws[(int64_t)(r - 2 * H) * Cin + c];
-        }
+        if (c < Cin) v = pack_value(W1, Ws, Cin, H, ld1, trans_inv, r, c);
         put_weight(wcat, (int64_t)r * Cp, c, v, fwd_mode, r, Yw, Cp);
         put_weight(wcatT, (int64_t)c * Yw, r, v, bwd_mode, c, Cp, Yw);
-        if (c == 0) bcat[r] = r < H ? (b1 != nullptr ? b1[r] : 0.f) : (r < 2 * H ? 0.f : (bs != nullptr ? bs[r - 2 * H] : 0.f));
+        if (c == 0) bcat[r] = pack_bias(b1, bs, H, trans_inv, r);
     } else if (t < n_w + n_2) {
         const int64_t u = t - n_w;
         const int k = (int)(u / Cout), o = (int)(u % Cout);      // w2T[k][o] = W2[o][k]
@@ -161,8 +171,8 @@ __device__ __forceinline__ void put_weight8(float* __restrict__ base, int64_t ro
     }
 }
 
-__device__ __forceinline__ bool pack8_shape(int Cp, int H, int Cout, int has_shortcut) {
-    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+__device__ __forceinline__ bool pack8_shape(int Cp, int H, int Cout, int has_shortcut, int trans_inv) {
+    const int Yw = stin_yw(H, Cout, has_shortcut, trans_inv);
     return Cp % 8 == 0 && Yw % 8 == 0 && H % 8 == 0 && Cout % 8 == 0;
 }
 
@@ -172,13 +182,11 @@ __device__ __forceinline__ void pack_body8(int64_t t, const float* __restrict__ 
                                            int trans_inv, float* __restrict__ wcat, float* __restrict__ bcat,
                                            float* __restrict__ wcatT, float* __restrict__ w2T, float* __restrict__ w2s,
                                            int fwd_mode, int bwd_mode) {
-    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+    const int Yw = stin_yw(H, Cout, has_shortcut, trans_inv);
     const int ld1 = trans_inv ? Cin : 2 * Cin;
     auto val = [&](int r, int c) -> float {                        // wcat[r][c] (pack_body's expression)
         if (c >= Cin) return 0.f;
-        if (r < H) return trans_inv ? -W1[(int64_t)r * ld1 + c] : W1[(int64_t)r * ld1 + c] - W1[(int64_t)r * ld1 + Cin + c];
-        if (r < 2 * H) return trans_inv ? W1[(int64_t)(r - H) * ld1 + c] : W1[(int64_t)(r - H) * ld1 + Cin + c];
-        return Ws[(int64_t)(r - 2 * H) * Cin + c];
+        return pack_value(W1, Ws, Cin, H, ld1, trans_inv, r, c);
     };
     const int64_t nA = (int64_t)Yw * (Cp / 8), nB = (int64_t)Cp * (Yw / 8), nC = (int64_t)H * (Cout / 8),
                   nD = w2s != nullptr ? (int64_t)Cout * (H / 8) : 0;
@@ -188,7 +196,7 @@ __device__ __forceinline__ void pack_body8(int64_t t, const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = val(r, c0 + e);
         put_weight8(wcat, (int64_t)r * Cp, c0, v, fwd_mode, r, Yw, Cp);
-        if (c0 == 0) bcat[r] = r < H ? (b1 != nullptr ? b1[r] : 0.f) : (r < 2 * H ? 0.f : (bs != nullptr ? bs[r - 2 * H] : 0.f));
+        if (c0 == 0) bcat[r] = pack_bias(b1, bs, H, trans_inv, r);
     } else if ((t -= nA) < nB) {                                   // wcatT rows (= input channel c): 8 consecutive output rows; c fastest
         const int c = (int)(t % Cp), r0 = (int)(t / Cp) * 8;
 #pragma unroll
@@ -213,7 +221,7 @@ __global__ void k_pack(const float* __restrict__ W1, const float* __restrict__ b
                        float* __restrict__ wcatT, float* __restrict__ w2T, float* __restrict__ w2s, int fwd_mode,
                        int bwd_mode, int pack8) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pack8 && pack8_shape(Cp, H, Cout, has_shortcut))
+    if (pack8 && pack8_shape(Cp, H, Cout, has_shortcut, trans_inv))
         pack_body8(t, W1, b1, Ws, bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T, w2s, fwd_mode, bwd_mode);
     else
         pack_body(t, W1, b1, Ws, bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T, w2s, fwd_mode, bwd_mode);
@@ -223,7 +231,7 @@ __global__ void k_pack(const float* __restrict__ W1, const float* __restrict__ b
 __global__ void k_pack_many(const stin_pack_job_t* __restrict__ jobs, int pack8) {
     const stin_pack_job_t j = jobs[blockIdx.y];
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pack8 && pack8_shape(j.Cp, j.H, j.Cout, j.has_shortcut))       // (block-uniform: one job per blockIdx.y)
+    if (pack8 && pack8_shape(j.Cp, j.H, j.Cout, j.has_shortcut, j.trans_inv))       // (block-uniform: one job per blockIdx.y)
         pack_body8(t, j.W1, j.b1, j.Ws, j.bs, j.W2, j.Cin, j.Cp, j.H, j.Cout, j.has_shortcut, j.trans_inv, j.wcat, j.bcat, j.wcatT, j.w2T,
                    j.w2s, j.fwd_split, j.bwd_split);
     else
@@ -249,9 +257,14 @@ __global__ void k_unpack(const float* __restrict__ dwb, const float* __restrict_
         if (c == 0 && db2 != nullptr) db2[r] = dw2b[(int64_t)r * (H + 1) + H];
         return;
     }
+    const int s0 = trans_inv == STIN_TI_COMPACT ? H : 2 * H;   // first shortcut row of dwb
     if (t < n1) {
         const int r = (int)(t / ld1), c = (int)(t % ld1);
         float v;
+        if (trans_inv == STIN_TI_COMPACT) {                    // the operand IS W1: its gradient rows as they are; db1 comes from the
+            dW1[t] = dwb[(int64_t)r * ld + c];                 // edge stage's column sums of dA (not from this product)
+            return;
+        }
         if (trans_inv) v = dwb[(int64_t)(H + r) * ld + c] - dwb[(int64_t)r * ld + c];              // d/dW1 of (-W1, W1)
         else if (c < Cin) v = dwb[(int64_t)r * ld + c];                                            // Wa
         else v = dwb[(int64_t)(H + r) * ld + (c - Cin)] - dwb[(int64_t)r * ld + (c - Cin)];        // Wb
@@ -260,8 +273,8 @@ __global__ void k_unpack(const float* __restrict__ dwb, const float* __restrict_
     } else if (t < n1 + ns) {
         const int64_t u = t - n1;
         const int r = (int)(u / Cin), c = (int)(u % Cin);
-        dWs[u] = dwb[(int64_t)(2 * H + r) * ld + c];
-        if (c == 0 && dbs != nullptr) dbs[r] = dwb[(int64_t)(2 * H + r) * ld + Cp];
+        dWs[u] = dwb[(int64_t)(s0 + r) * ld + c];
+        if (c == 0 && dbs != nullptr) dbs[r] = dwb[(int64_t)(s0 + r) * ld + Cp];
     }
 }
 
@@ -322,8 +335,9 @@ extern "C" int stin_edgeconv_pack_f32(const float* W1, const float* b1, const fl
     STIN_REQUIRE((split_mode_ok(fwd_split) || fwd_split == STIN_GEMM_W_BF16) && (split_mode_ok(bwd_split) || bwd_split == STIN_GEMM_W_BF16),
                  STIN_E_UNSUPPORTED);
     STIN_REQUIRE(fwd_split == 0 || (w2s != nullptr && Cp % 4 == 0 && H % 4 == 0), STIN_E_ALIGN);
-    STIN_REQUIRE(bwd_split == 0 || (Cout % 4 == 0 && H % 2 == 0), STIN_E_ALIGN);     // Yw = 2H (+ Cout) must be a multiple of 4
-    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+    STIN_REQUIRE(trans_inv >= 0 && trans_inv <= STIN_TI_COMPACT, STIN_E_UNSUPPORTED);
+    STIN_REQUIRE(bwd_split == 0 || (Cout % 4 == 0 && H % (trans_inv == STIN_TI_COMPACT ? 4 : 2) == 0), STIN_E_ALIGN);   // Yw a multiple of 4
+    const int Yw = stin_yw(H, Cout, has_shortcut, trans_inv);
     const int64_t n = (int64_t)Yw * Cp + (int64_t)H * Cout;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, (hipStream_t)stream_, W1, b1, Ws,
                        bs, W2, Cin, Cp, H, Cout, has_shortcut, trans_inv, wcat, bcat, wcatT, w2T, w2s, fwd_split, bwd_split, pack8_on());

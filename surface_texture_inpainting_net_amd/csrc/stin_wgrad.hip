@@ -328,27 +328,14 @@ struct WgFinal {
     int64_t chunksA, chunksB;
     int KqA, KqB, Cin, Cp, H, Cout, has_shortcut, trans_inv;
     float *dW1, *db1, *dWs, *dbs, *dW2, *db2;
+    const float* ti_colsum;  // compact trans-inv layout: [ti_rows][H] column partials of dA (stin_graph.hip k_edge_bwd_mask_ti) -> db1
+    int64_t ti_rows;
 };
 __device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
-__global__ __launch_bounds__(FN_BLOCK) void k_wgrad_finalize(const WgFinal f) {
-    __shared__ float4 sm[2][FN_KL][FN_COLS + 1];
-    const int tx = threadIdx.x % FN_COLS, ty = threadIdx.x / FN_COLS;
-    const int Yw = 2 * f.H + (f.has_shortcut ? f.Cout : 0);
-    const int64_t csA = (int64_t)f.Cout * f.KqA + ((f.Cout + 3) & ~3), csB = (int64_t)Yw * f.KqB + ((Yw + 3) & ~3);
-    // sections of float4 groups: A weights | A bias | B rows [0, H) (paired with rows [H, 2H)) | B shortcut rows | B bias
-    const int64_t nAw = (int64_t)f.Cout * f.KqA / 4, nAb = (f.Cout + 3) / 4;
-    const int64_t nB1 = (int64_t)f.H * f.KqB / 4, nB2 = f.has_shortcut ? (int64_t)f.Cout * f.KqB / 4 : 0, nBb = (Yw + 3) / 4;
-    int64_t g = (int64_t)blockIdx.x * FN_COLS + tx;
-    const float *p0 = nullptr, *p1 = nullptr;
-    int64_t cs = 0, chunks = 0;
-    int section = -1;
-    if (g < nAw) section = 0, p0 = f.slabA + 4 * g, cs = csA, chunks = f.chunksA;
-    else if ((g -= nAw) < nAb) section = 1, p0 = f.slabA + (int64_t)f.Cout * f.KqA + 4 * g, cs = csA, chunks = f.chunksA;
-    else if ((g -= nAb) < nB1) section = 2, p0 = f.slabB + 4 * g, p1 = p0 + (int64_t)f.H * f.KqB, cs = csB, chunks = f.chunksB;
-    else if ((g -= nB1) < nB2) section = 3, p0 = f.slabB + 2 * (int64_t)f.H * f.KqB + 4 * g, cs = csB, chunks = f.chunksB;
-    else if ((g -= nB2) < nBb) section = 4, p0 = f.slabB + (int64_t)Yw * f.KqB + 4 * g, cs = csB, chunks = f.chunksB;
-    auto partial = [&](const float* p) {
+// One chunk-lane's share of a fixed-order fold over `chunks` rows of stride `cs` floats (lane ty of FN_KL walks rows ty, ty + FN_KL, ...;
+// four running sums, merged (s0 + s1) + (s2 + s3)): shared by k_wgrad_finalize and k_colsum_fold so that both give the same bits.
+__device__ __forceinline__ float4 fn_partial(const float* __restrict__ p, int64_t cs, int64_t chunks, int ty) {
         float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
         if (p != nullptr) {
             int64_t c = ty;
@@ -379,7 +366,47 @@ __global__ __launch_bounds__(FN_BLOCK) void k_wgrad_finalize(const WgFinal f) {
         add4(s2, s3);
         add4(s0, s2);
         return s0;
-    };
+}
+
+// db1 of a compact trans-inv block from the edge stage's column partials [rows][H] alone (the per-op path; the whole-block path folds
+// them inside k_wgrad_finalize): same lanes, same order -> the same bits
+__global__ __launch_bounds__(FN_BLOCK) void k_colsum_fold(const float* __restrict__ colsum, int64_t rows, int H, float* __restrict__ out) {
+    __shared__ float4 sm[FN_KL][FN_COLS + 1];
+    const int tx = threadIdx.x % FN_COLS, ty = threadIdx.x / FN_COLS;
+    const int64_t g = (int64_t)blockIdx.x * FN_COLS + tx;
+    const bool on = g < H / 4;
+    sm[ty][tx] = fn_partial(on ? colsum + 4 * g : nullptr, H, rows, ty);
+    __syncthreads();
+    if (ty != 0 || !on) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < FN_KL; ++k) add4(a, sm[k][tx]);
+    st4(out + 4 * g, a);
+}
+
+__global__ __launch_bounds__(FN_BLOCK) void k_wgrad_finalize(const WgFinal f) {
+    __shared__ float4 sm[2][FN_KL][FN_COLS + 1];
+    const int tx = threadIdx.x % FN_COLS, ty = threadIdx.x / FN_COLS;
+    const bool compact = f.trans_inv == STIN_TI_COMPACT;
+    const int Yw = stin_yw(f.H, f.Cout, f.has_shortcut, f.trans_inv);
+    const int s0 = Yw - (f.has_shortcut ? f.Cout : 0);          // first shortcut row of the packed product (2 H, compact: H)
+    const int64_t csA = (int64_t)f.Cout * f.KqA + ((f.Cout + 3) & ~3), csB = (int64_t)Yw * f.KqB + ((Yw + 3) & ~3);
+    // sections of float4 groups: A weights | A bias | B rows [0, H) (paired with rows [H, 2H); compact: alone) | B shortcut rows |
+    // B bias | (compact) db1 from the edge stage's column partials of dA
+    const int64_t nAw = (int64_t)f.Cout * f.KqA / 4, nAb = (f.Cout + 3) / 4;
+    const int64_t nB1 = (int64_t)f.H * f.KqB / 4, nB2 = f.has_shortcut ? (int64_t)f.Cout * f.KqB / 4 : 0, nBb = (Yw + 3) / 4;
+    const int64_t nT = (compact && f.db1 != nullptr) ? f.H / 4 : 0;
+    int64_t g = (int64_t)blockIdx.x * FN_COLS + tx;
+    const float *p0 = nullptr, *p1 = nullptr;
+    int64_t cs = 0, chunks = 0;
+    int section = -1;
+    if (g < nAw) section = 0, p0 = f.slabA + 4 * g, cs = csA, chunks = f.chunksA;
+    else if ((g -= nAw) < nAb) section = 1, p0 = f.slabA + (int64_t)f.Cout * f.KqA + 4 * g, cs = csA, chunks = f.chunksA;
+    else if ((g -= nAb) < nB1) section = 2, p0 = f.slabB + 4 * g, p1 = compact ? nullptr : p0 + (int64_t)f.H * f.KqB, cs = csB, chunks = f.chunksB;
+    else if ((g -= nB1) < nB2) section = 3, p0 = f.slabB + (int64_t)s0 * f.KqB + 4 * g, cs = csB, chunks = f.chunksB;
+    else if ((g -= nB2) < nBb) section = 4, p0 = f.slabB + (int64_t)Yw * f.KqB + 4 * g, cs = csB, chunks = f.chunksB;
+    else if ((g -= nBb) < nT) section = 5, p0 = f.ti_colsum + 4 * g, cs = f.H, chunks = f.ti_rows;
+    auto partial = [&](const float* p) { return fn_partial(p, cs, chunks, ty); };
     sm[0][ty][tx] = partial(p0);
     sm[1][ty][tx] = partial(p1);
     __syncthreads();
@@ -408,7 +435,8 @@ __global__ __launch_bounds__(FN_BLOCK) void k_wgrad_finalize(const WgFinal f) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (col + e >= f.Cin) continue;
-            if (f.trans_inv) f.dW1[row * f.Cin + col + e] = vb[e] - va[e];
+            if (compact) f.dW1[row * f.Cin + col + e] = va[e];                  // the operand is W1 itself
+            else if (f.trans_inv) f.dW1[row * f.Cin + col + e] = vb[e] - va[e];
             else {
                 f.dW1[row * 2 * f.Cin + col + e] = va[e];
                 f.dW1[row * 2 * f.Cin + f.Cin + col + e] = vb[e] - va[e];
@@ -420,14 +448,17 @@ __global__ __launch_bounds__(FN_BLOCK) void k_wgrad_finalize(const WgFinal f) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (col + e < f.Cin) f.dWs[row * f.Cin + col + e] = va[e];
-    } else {                                              // bias gradients of the packed operand: db1 = rows [0, H), dbs = rows [2H, ..)
+    } else if (section == 4) {                            // bias gradients of the packed operand: db1 = rows [0, H), dbs = rows [s0, ..)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int64_t i = 4 * g + e;
-            if (i < f.H) {
+            if (i < f.H && !compact) {
                 if (f.db1 != nullptr) f.db1[i] = va[e];
-            } else if (i >= 2 * f.H && i < Yw && f.dbs != nullptr) f.dbs[i - 2 * f.H] = va[e];
+            } else if (i >= s0 && i < Yw && f.dbs != nullptr) f.dbs[i - s0] = va[e];
         }
+    } else {                                              // compact trans-inv: db1 = sum_i dA_i, the block rows of the edge stage's partials
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f.db1[4 * g + e] = va[e];
     }
 }
 
@@ -469,10 +500,23 @@ extern "C" int stin_edgeconv_wgrad(int storage, const void* dagg, int64_t ld_dag
                                    int64_t ldy, const void* x, int64_t ldx, int64_t N, int Cin, int Cp, int H, int Cout,
                                    int has_shortcut, int trans_inv, int precision, float* dW1, float* db1, float* dW2, float* db2,
                                    float* dWs, float* dbs, void* workspace, size_t workspace_bytes, stin_stream_t stream) {
+    STIN_REQUIRE(trans_inv != STIN_TI_COMPACT, STIN_E_UNSUPPORTED);        // (the compact layout needs the dA partials: _ti below)
+    return stin_edgeconv_wgrad_ti(storage, dagg, ld_dagg, hE, ldh, dY, ldy, x, ldx, N, Cin, Cp, H, Cout, has_shortcut, trans_inv, precision,
+                                  dW1, db1, dW2, db2, dWs, dbs, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int stin_edgeconv_wgrad_ti(int storage, const void* dagg, int64_t ld_dagg, const void* hE, int64_t ldh, const void* dY,
+                                      int64_t ldy, const void* x, int64_t ldx, int64_t N, int Cin, int Cp, int H, int Cout,
+                                      int has_shortcut, int trans_inv, int precision, float* dW1, float* db1, float* dW2, float* db2,
+                                      float* dWs, float* dbs, const float* ti_colsum, int64_t ti_rows, void* workspace,
+                                      size_t workspace_bytes, stin_stream_t stream) {
     stin_clear_stale_error();
     STIN_REQUIRE(storage == 0 || storage == 1, STIN_E_UNSUPPORTED);
     STIN_REQUIRE(N >= 0 && Cin > 0 && Cp >= Cin && H > 0 && Cout > 0, STIN_E_SIZE);
-    const int Yw = 2 * H + (has_shortcut ? Cout : 0);
+    STIN_REQUIRE(trans_inv >= 0 && trans_inv <= STIN_TI_COMPACT, STIN_E_UNSUPPORTED);
+    const bool compact = trans_inv == STIN_TI_COMPACT;
+    STIN_REQUIRE(!compact || (storage == 0 && H % 4 == 0 && (db1 == nullptr || N == 0 || (ti_colsum != nullptr && ti_rows > 0))), STIN_E_UNSUPPORTED);
+    const int Yw = stin_yw(H, Cout, has_shortcut, trans_inv);
     STIN_REQUIRE(ld_dagg >= Cout && ldh >= H + 1 && ldy >= Yw && ldx >= Cp, STIN_E_SIZE);
     STIN_REQUIRE(dW1 && dW2 && workspace && (!has_shortcut || dWs) && (N == 0 || (dagg && hE && dY && x)), STIN_E_NULL);
     STIN_REQUIRE(workspace_bytes >= stin_edgeconv_wgrad_workspace_bytes(N, Cp, H, Cout, has_shortcut), STIN_E_WORKSPACE);
@@ -517,8 +561,19 @@ extern "C" int stin_edgeconv_wgrad(int storage, const void* dagg, int64_t ld_dag
     f.dbs = dbs;
     f.dW2 = dW2;
     f.db2 = db2;
+    f.ti_colsum = ti_colsum;
+    f.ti_rows = ti_rows;
     const int64_t groups = (int64_t)Cout * pa.Kq / 4 + (Cout + 3) / 4 + (int64_t)H * pb.Kq / 4 +
-                           (has_shortcut ? (int64_t)Cout * pb.Kq / 4 : 0) + (Yw + 3) / 4;
+                           (has_shortcut ? (int64_t)Cout * pb.Kq / 4 : 0) + (Yw + 3) / 4 + ((compact && db1 != nullptr) ? H / 4 : 0);
     hipLaunchKernelGGL(k_wgrad_finalize, dim3((unsigned)((groups + FN_COLS - 1) / FN_COLS)), dim3(FN_BLOCK), 0, (hipStream_t)stream, f);
+    return stin_launch_status();
+}
+
+extern "C" int stin_edge_bwd_ti_colsum_fold_f32(const float* colsum, int64_t rows, int H, float* db1, stin_stream_t stream) {
+    stin_clear_stale_error();
+    STIN_REQUIRE(rows >= 0 && H > 0 && H % 4 == 0, STIN_E_SIZE);
+    STIN_REQUIRE(db1 && (rows == 0 || colsum) && stin_aligned16(db1) && stin_aligned16(colsum), STIN_E_NULL);
+    const unsigned grid = (unsigned)((H / 4 + FN_COLS - 1) / FN_COLS);
+    hipLaunchKernelGGL(k_colsum_fold, dim3(grid), dim3(FN_BLOCK), 0, (hipStream_t)stream, colsum, rows, H, db1);
     return stin_launch_status();
 }

@@ -149,6 +149,38 @@ def edge_relu_mean_bwd_mask(G, mask, edges, dA, dB, copy_src=None, copy_dst=None
     return dA, dB
 
 
+def edge_relu_mean_fwd_ti(b1, B, csr, out, indicator=False, mask=None):
+    """h = mean_j ReLU(A_i + B_j) with A_i = b1 - B_i formed per row (translation-invariant filter, compact layout): the same
+    bits as edge_relu_mean_fwd on A = x (-W1)^T + b1.  b1 [H] or None.  fp32 rows, saved-mask widths."""
+    B, ldb = _mat(B)
+    _same(B, out)
+    H = B.shape[1]
+    _call('stin_edge_relu_mean_fwd_ti_f32', _ptr(b1), _ptr(B), ldb, _ptr(csr.rowptr), _ptr(csr.col), B.shape[0], H,
+          _ptr(out), out.stride(0), int(indicator), _ptr(mask), _stream(B), tag=(B.shape[0], csr.n_entries, H))
+    return out
+
+
+def edge_relu_mean_bwd_mask_ti(G, mask, edges, D, copy_src=None, copy_dst=None):
+    """D = dB - dA of the mask backward in one row of H columns (compact trans-inv layout) -> db1 = sum_i dA_i [H] (the kernel's
+    per-workgroup column partials, folded in a fixed order)."""
+    G, ldg = _mat(G)
+    cs = edges.by_src
+    _same(G, D)
+    N, H = G.shape
+    rows = int(_lib.load().stin_edge_bwd_ti_colsum_rows(N, H))
+    colsum = torch.empty(max(rows, 1), H, dtype=torch.float32, device=G.device)
+    cp = (None, 0, None, 0, 0)
+    if copy_src is not None:
+        _same(G, copy_src, copy_dst)
+        cp = (_ptr(copy_src), copy_src.stride(0), _ptr(copy_dst), copy_dst.stride(0), copy_src.shape[1])
+    _call('stin_edge_relu_mean_bwd_mask_ti_f32', _ptr(G), ldg, _ptr(mask), _ptr(edges.by_dst.rowptr), _ptr(edges.w_src),
+          _ptr(cs.rowptr), _ptr(cs.col), _ptr(edges.xslot), N, H, _ptr(D), D.stride(0), *cp, _ptr(colsum), rows, _stream(G),
+          tag=(N, cs.n_entries, H))
+    db1 = torch.empty(H, dtype=torch.float32, device=G.device)
+    _call('stin_edge_bwd_ti_colsum_fold_f32', _ptr(colsum), rows if N > 0 else 0, H, _ptr(db1), _stream(G))
+    return db1
+
+
 def edge_relu_mean_bwd_dst(A, B, G, csr, dA):
     A, lda = _mat(A)
     B, ldb = _mat(B)
@@ -743,6 +775,27 @@ def block_split_modes(prec_fwd, b16, Cout):
     return fsp, bsp
 
 
+# Translation-invariant blocks in the COMPACT layout (round 6; include/stin_hip.h STIN_TI_COMPACT): the reference's message is
+# nn(x_j - x_i) (models/modules/edge_conv_translation_invariance.py:20-22), so W1 (x_j - x_i) + b1 = A_i + B_j with B = x W1^T and
+# A_i = b1 - B_i: only B is a GEMM output (Yw = H (+ Cout) instead of 2 H (+ Cout)), the edge stage forms A_i per row - the same bits
+# the [-W1 ; W1] product wrote - and the backward pass carries D = dB - dA in H columns.  Half the first Linear's GEMM work in
+# every direction.  fp32 storage with a saved-mask hidden width; STIN_TI_COMPACT=0 keeps both halves materialised (A/B switch).
+TI_COMPACT = os.environ.get('STIN_TI_COMPACT', '1') != '0'
+TI_MODE_COMPACT = 2
+
+
+def trans_inv_mode(trans_inv, b16, H):
+    """The `trans_inv` value the C entry points take: 0 = EdgeConv, 1 = translation-invariant (A and B materialised), 2 = compact."""
+    if not trans_inv:
+        return 0
+    return TI_MODE_COMPACT if (TI_COMPACT and not b16 and USE_EDGE_MASK and edge_mask_supported(H)) else 1
+
+
+def block_yw(H, Cout, has_shortcut, ti_mode):
+    """Width of Y / dY / the packed first-Linear operand (csrc/stin_common.h: stin_yw)."""
+    return (H if ti_mode == TI_MODE_COMPACT else 2 * H) + (Cout if has_shortcut else 0)
+
+
 BLOCK_PACKED = 0x800
 USE_PACK_MANY = os.environ.get('STIN_PACK_MANY', '1') != '0'
 
@@ -767,7 +820,8 @@ class PackSet:
             Cin = W1.shape[1] if trans_inv else W1.shape[1] // 2
             Cp = (Cin + pad - 1) // pad * pad
             has_sc = Ws is not None
-            Yw = 2 * H + (Cout if has_sc else 0)
+            ti = trans_inv_mode(trans_inv, b16, H)
+            Yw = block_yw(H, Cout, has_sc, ti)
             fsp, bsp = block_split_modes(prec_fwd, b16, Cout)       # what the block call is handed (bf16 rows: 0, 0)
             # what the pack writes: bf16 rows -> plain bf16 operands where every reduction length is a multiple of 8
             # (the rule of stin_edgeconv_block_fwd), else the fp32 / split form of the fp32-storage path
@@ -782,7 +836,7 @@ class PackSet:
             W1c, W2c = W1.contiguous(), W2.contiguous()
             assert W1c.data_ptr() == W1.data_ptr() and W2c.data_ptr() == W2.data_ptr(), 'pack_many needs contiguous weights'
             blob += struct.pack('<10Q8i', _ptr(W1), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2), wcat, bcat, _ptr(wts),
-                                _ptr(wts) + 4 * Yw * Cp, w2s if jf else 0, Cin, Cp, H, Cout, int(has_sc), int(trans_inv), jf, jb)
+                                _ptr(wts) + 4 * Yw * Cp, w2s if jf else 0, Cin, Cp, H, Cout, int(has_sc), ti, jf, jb)
             self.max_elems = max(self.max_elems, Yw * Cp + H * Cout)
             # (the two backward operands as ready-made views: no tensor views are created inside autograd.Function.forward)
             self.buffers.append((ws, wts, fsp, bsp, wts[:Yw * Cp].view(Cp, Yw), wts[Yw * Cp:].view(H, Cout), bool(b16)))
@@ -802,7 +856,7 @@ class PackSet:
     @staticmethod
     def key_of(specs):
         return tuple((_ptr(W1), _ptr(b1), _ptr(W2), _ptr(Ws), _ptr(bs), tuple(W1.shape), tuple(W2.shape), bool(t), int(pf), int(B),
-                      PREC_BWD, WEIGHT_PRESPLIT, GEMM_W_FRAG) for (W1, b1, W2, b2, Ws, bs, t, pf, B) in specs)
+                      PREC_BWD, WEIGHT_PRESPLIT, GEMM_W_FRAG, TI_COMPACT, USE_EDGE_MASK) for (W1, b1, W2, b2, Ws, bs, t, pf, B) in specs)
 
     def matches(self, specs, b16=False, transposes=()):
         return self.key == self.key_of(specs) + (bool(b16),) + tuple((_ptr(W), tuple(W.shape)) for W in transposes)
@@ -832,9 +886,11 @@ class EdgeConvBlockFn(torch.autograd.Function):
         N, Cin = x.shape
         H, Cout = W1.shape[0], W2.shape[0]
         has_shortcut = Ws is not None
-        Yw = 2 * H + (Cout if has_shortcut else 0)
         dev = x.device
         b16 = x.dtype == torch.bfloat16
+        ti = trans_inv_mode(trans_inv, b16, H)                    # 2 = compact: Y = [B | S], A_i = b1 - B_i formed by the edge stage
+        Yw = block_yw(H, Cout, has_shortcut, ti)
+        oB, oS = (0 if ti == TI_MODE_COMPACT else H), Yw - (Cout if has_shortcut else 0)   # columns of B and of the shortcut in Y / dY
         pad = 8 if b16 else 4
         Cp = (Cin + pad - 1) // pad * pad                         # inner dimension padded for the 16-byte GEMM paths
         if Cp != Cin:                                             # (the 10-channel network input -> 12; bf16: 16)
@@ -873,7 +929,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
             W1c, W2c = W1.contiguous(), W2.contiguous()
             cd = edges.by_dst
             _call('stin_edgeconv_block_fwd', int(b16), _ptr(xp), xp.stride(0), N, Cin, Cp, H, Cout, int(has_shortcut),
-                  int(trans_inv), _ptr(W1c), _ptr(b1), _ptr(W2c), _ptr(b2), _ptr(Ws), _ptr(bs), _ptr(cd.rowptr), _ptr(cd.col),
+                  ti, _ptr(W1c), _ptr(b1), _ptr(W2c), _ptr(b2), _ptr(Ws), _ptr(bs), _ptr(cd.rowptr), _ptr(cd.col),
                   _ptr(groups.ptr_sum), B, _ptr(groups.gid), _ptr(groups.inv_cnt), int(groups.quirk), float(eps), prec_fwd,
                   fsp | packed, bsp,
                   _ptr(wcatT), _ptr(w2T), _ptr(Y), Yw, _ptr(hE), H + pad, _ptr(mask), _ptr(agg), _ptr(mean), _ptr(rstd),
@@ -881,7 +937,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
             ctx.save_for_backward(xp, Y, hE, agg, mean, rstd, wcatT, w2T)
             ctx.mask = mask
             ctx.cin = Cin
-            ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut, ctx.trans_inv = edges, groups, H, has_shortcut, trans_inv
+            ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut, ctx.trans_inv = edges, groups, H, has_shortcut, ti
             ctx.has_b1, ctx.has_b2, ctx.has_bs = b1 is not None, b2 is not None, bs is not None
             ctx.w1_shape = tuple(W1.shape)
             ctx.bsp = bsp
@@ -895,7 +951,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
         bcat = pack[2 * Yw * Cp + 2 * H * Cout:]
         W1c, W2c = W1.contiguous(), W2.contiguous()
         _call('stin_edgeconv_pack_f32', _ptr(W1c), _ptr(b1), _ptr(Ws), _ptr(bs), _ptr(W2c), Cin, Cp, H, Cout,
-              int(has_shortcut), int(trans_inv), _ptr(wcat), _ptr(bcat), _ptr(wcatT), _ptr(w2T), _ptr(w2s) if fsp else None,
+              int(has_shortcut), ti, _ptr(wcat), _ptr(bcat), _ptr(wcatT), _ptr(w2T), _ptr(w2s) if fsp else None,
               fsp, bsp, _stream(x))
         pf = (prec_fwd | GEMM_W_PRESPLIT | GEMM_W_FRAG) if fsp else prec_fwd
         Y = gemm_nt(xp, wcat, bcat, precision=pf)
@@ -906,7 +962,12 @@ class EdgeConvBlockFn(torch.autograd.Function):
             raise NotImplementedError('bf16 storage needs the saved ReLU mask: hidden width %d not in '
                                       '{128, 256, 512, 1024, 2048} (or STIN_EDGE_MASK=0)' % H)
         mask = torch.empty(max(edges.n_edges, 1) * (H // 32), dtype=torch.int32, device=dev) if use_mask else None
-        edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True, mask=mask)
+        if ti == TI_MODE_COMPACT:
+            if not use_mask:
+                raise RuntimeError('compact trans-inv layout needs the saved ReLU mask (16-byte aligned rows)')
+            edge_relu_mean_fwd_ti(b1, Y[:, :H], edges.by_dst, hE, indicator=True, mask=mask)
+        else:
+            edge_relu_mean_fwd(Y[:, :H], Y[:, H:2 * H], edges.by_dst, hE, indicator=True, mask=mask)
         fused = None
         if fsp and groups.B == 1 and groups.gid is None and not groups.quirk and N > 1:
             fused = gemm_nt_colstats(hE[:, :H], w2s, b2, hE[:, H], pf, Cout)       # GEMM2 + column sums in one launch
@@ -916,12 +977,12 @@ class EdgeConvBlockFn(torch.autograd.Function):
         else:
             agg = gemm_nt(hE[:, :H], w2s if fsp else W2c, b2, row_mask=hE[:, H], precision=pf)
             mean, rstd = instance_stats(agg, groups, eps)
-        res = Y[:, 2 * H:] if has_shortcut else x
+        res = Y[:, oS:] if has_shortcut else x
         out = norm_act_res_fwd(agg, mean, rstd, groups, res=res, act=True)
         ctx.save_for_backward(xp, Y, hE, agg, mean, rstd, wcatT, w2T)
         ctx.mask = mask
         ctx.cin = Cin
-        ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut, ctx.trans_inv = edges, groups, H, has_shortcut, trans_inv
+        ctx.edges, ctx.groups, ctx.H, ctx.has_shortcut, ctx.trans_inv = edges, groups, H, has_shortcut, ti
         ctx.has_b1, ctx.has_b2, ctx.has_bs = b1 is not None, b2 is not None, bs is not None
         ctx.w1_shape = tuple(W1.shape)
         ctx.prec_bwd_nt = (PREC_BWD | GEMM_W_PRESPLIT | GEMM_W_FRAG) if bsp else PREC_BWD
@@ -988,7 +1049,13 @@ class EdgeConvBlockFn(torch.autograd.Function):
         dw2b = gemm_tn(dagg, hE[:, :H], ones_column=True, row_weight=hE[:, H], precision=PREC_BWD)   # [Cout, H + 1] = dW2 | db2
         dhE = gemm_nt(dagg, w2T, precision=ctx.prec_bwd_nt)                                             # [N, H] = dagg W2
         dY = torch.empty_like(Y)
-        if ctx.mask is not None:
+        compact = ctx.trans_inv == TI_MODE_COMPACT
+        oS = Y.shape[1] - (Cout if ctx.has_shortcut else 0)
+        db1_ti = None
+        if compact:                                     # D = dB - dA in one row of H columns (+ the column sums of dA = db1)
+            db1_ti = edge_relu_mean_bwd_mask_ti(dhE, ctx.mask, edges, dY[:, :H])
+            ctx.mask = None
+        elif ctx.mask is not None:
             edge_relu_mean_bwd_mask(dhE, ctx.mask, edges, dY[:, :H], dY[:, H:2 * H])
             ctx.mask = None
         else:
@@ -996,7 +1063,7 @@ class EdgeConvBlockFn(torch.autograd.Function):
             edge_relu_mean_bwd_dst(A, B, dhE, edges.by_dst, dY[:, :H])
             edge_relu_mean_bwd_src(A, B, dhE, edges.inv_deg, edges.by_src, dY[:, H:2 * H])
         if ctx.has_shortcut:
-            dY[:, 2 * H:].copy_(g)                  # (the whole-block C call lets this ride on the edge launch)
+            dY[:, oS:].copy_(g)                     # (the whole-block C call lets this ride on the edge launch)
         dwb = gemm_tn(dY, x, ones_column=True, precision=PREC_BWD)           # [Yw, Cin + 1]: packed weight grad | bias grad
         # dx = dY Wcat (+ g: the identity-residual path, added in the GEMM epilogue); skipped when the block input
         # needs no gradient (the network input of the first block)
@@ -1014,6 +1081,8 @@ class EdgeConvBlockFn(torch.autograd.Function):
         db2 = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b2 else None
         _call('stin_edgeconv_unpack_grads_f32', _ptr(dwb), _ptr(dw2b), Cin, Cp, H, Cout, int(ctx.has_shortcut),
               int(ctx.trans_inv), _ptr(dW1), _ptr(db1), _ptr(dWs), _ptr(dbs), _ptr(dW2), _ptr(db2), _stream(x))
+        if compact and db1 is not None:
+            db1 = db1_ti                            # (the packed product's ones column holds sum_i D_i ~ 0, not db1)
         return dx, dW1, db1, dW2, db2, dWs, dbs, None, None, None, None, None, None
 
 
@@ -1223,8 +1292,9 @@ def edgeconv_chain(x, blocks, edges_list, groups, eps, prec_fwd):
     for b in blocks:
         lin1, lin2 = b.first_filter.nn[0], b.first_filter.nn[2]
         params += [lin1.weight, lin1.bias, lin2.weight, lin2.bias]
+    b16 = x.dtype == torch.bfloat16
     meta = (list(edges_list), groups, float(eps), int(prec_fwd), [b._prepacked for b in blocks],
-            [bool(b.first_filter.trans_inv) for b in blocks])
+            [trans_inv_mode(b.first_filter.trans_inv, b16, b.first_filter.nn[0].weight.shape[0]) for b in blocks])
     return EdgeConvChainFn.apply(x, meta, *params)
 
 
@@ -1332,14 +1402,15 @@ class NetFn(torch.autograd.Function):
                 Cin = width
                 Cp = (Cin + pad - 1) // pad * pad
                 sc = Ws is not None
-                Yw = 2 * H + (Cout if sc else 0)
+                ti = trans_inv_mode(blk.first_filter.trans_inv, b16, H)
+                Yw = block_yw(H, Cout, sc, ti)
                 B = groups.B
                 prec = forward_precision(blk.unbounded_input)
                 fsp, bsp = block_split_modes(prec, b16, Cout)
                 pp = blk._prepacked
                 ws_bytes = lib.stin_edgeconv_block_fwd_workspace_bytes(Cin, Cp, H, Cout, int(sc), B)
                 d = dict(kind=OP_BLOCK, N=n_rows, Cin=Cin, Cp=Cp, H=H, Cout=Cout, sc=sc, Yw=Yw, B=B, prec=prec, fsp=fsp, bsp=bsp, pp=pp,
-                         ws_bytes=ws_bytes, edges=edges, groups=groups, ti=bool(blk.first_filter.trans_inv), eps=float(blk.first_norm.eps),
+                         ws_bytes=ws_bytes, edges=edges, groups=groups, ti=ti, eps=float(blk.first_norm.eps),
                          params=(W1, b1, W2, b2, Ws, bs))
                 d['oY'] = take(n_rows * Yw * es, 'tmp')
                 d['oH'] = take(n_rows * (H + pad) * es, 'tmp')
@@ -1550,7 +1621,8 @@ class NetFn(torch.autograd.Function):
                                      base + d['oS'] + B * Cout * 4, 0, 0,
                                      _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gs[3]), _ptr(gs[4]), _ptr(gs[5]),
                                      p_ws + ws_off[bi], ev_dy, ev_done,
-                                     *KernelTimer.edge_events('stin_edge_relu_mean_bwd_mask' + sfx, (d['N'], e.n_edges, H))))
+                                     *KernelTimer.edge_events('stin_edge_relu_mean_bwd_mask' + ('_ti' if d['ti'] == TI_MODE_COMPACT else '') + sfx,
+                                                              (d['N'], e.n_edges, H))))
                 bi += 1
             else:
                 pool, C = d['pool'], d['C']

@@ -2007,3 +2007,81 @@ def test_no_grad_forward_is_bit_identical_to_the_training_forward_and_keeps_no_m
     net.train()
     frozen = net(s)
     assert not frozen.requires_grad and torch.equal(frozen, want)
+
+
+# ----------------------------------------------------------------- translation-invariant blocks, compact layout (round 6)
+@pytest.mark.parametrize('H', [128, 256, 512, 1024, 2048])
+def test_trans_inv_compact_edge_kernels_equal_the_materialised_form(H):
+    """EdgeConvTransInv's message is nn(x_j - x_i) (models/modules/edge_conv_translation_invariance.py:20-22): A_i = b1 - B_i.  The
+    compact forward forms A per row instead of reading a GEMM output - same rows and same mask bit for bit - and the compact backward
+    writes D = dB - dA (one rounding of the difference of the pair launch's two outputs) plus the column sums of dA (= db1)."""
+    n, e = 1500, 9000
+    ei = _random_graph(n, e, seed=H + 3)
+    es = EdgeSet(ei.to(DEV), n, _bad())
+    g = torch.Generator().manual_seed(H)
+    Bm = torch.randn(n, H + 8, generator=g).to(DEV)[:, :H]         # a column slice of a wider matrix, as B is of Y
+    b1 = torch.randn(H, generator=g).to(DEV)
+    for bias in (b1, None):
+        A = (-Bm + bias) if bias is not None else (-Bm + 0.0)        # what the [-W1 ; W1] product's A columns hold: fl(b1 - B_i)
+        out0, out1 = torch.empty(n, H + 4, device=DEV), torch.full((n, H + 4), 3.0, device=DEV)
+        m0 = torch.zeros(e * (H // 32), dtype=torch.int32, device=DEV)
+        m1 = torch.zeros_like(m0)
+        SF.edge_relu_mean_fwd(A.contiguous(), Bm, es.by_dst, out0, indicator=True, mask=m0)
+        SF.edge_relu_mean_fwd_ti(bias, Bm, es.by_dst, out1, indicator=True, mask=m1)
+        assert torch.equal(out0, out1) and torch.equal(m0, m1)
+        out2 = torch.empty(n, H + 4, device=DEV)
+        SF.edge_relu_mean_fwd_ti(bias, Bm, es.by_dst, out2, indicator=True, mask=None)      # the no-grad forward: no mask store
+        assert torch.equal(out0, out2)
+    Gr = torch.randn(n, H, generator=g).to(DEV)
+    dA, dB = torch.empty(n, H, device=DEV), torch.empty(n, H, device=DEV)
+    SF.edge_relu_mean_bwd_mask(Gr, m0, es, dA, dB)
+    dY = torch.full((n, H + H // 2 + 4), 7.0, device=DEV)
+    src = torch.randn(n, H, device=DEV)[:, :H // 2]
+    db1 = SF.edge_relu_mean_bwd_mask_ti(Gr, m0, es, dY[:, :H], copy_src=src, copy_dst=dY[:, H:H + H // 2])
+    assert torch.equal(dY[:, :H], dB - dA) and torch.equal(dY[:, H:H + H // 2], src)
+    assert float((dY[:, H + H // 2:] - 7.0).abs().max()) == 0.0
+    want = dA.double().sum(0)
+    assert float((db1.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    db1_again = SF.edge_relu_mean_bwd_mask_ti(Gr, m0, es, torch.empty(n, H, device=DEV))
+    assert torch.equal(db1, db1_again), 'fixed-order partial sums: bit-reproducible'
+
+
+@pytest.mark.parametrize('shortcut', [False, True])
+def test_trans_inv_compact_block_equals_the_materialised_block(shortcut, monkeypatch):
+    """One GraphResnetBlock, EdgeConvTransInv, compact layout (Y = [B | S], H (+ Cout) columns) against both halves materialised
+    (STIN_TI_COMPACT=0: Y = [A | B | S]): the forward is bit-identical (same products, A_i = b1 - B_i has the bits of the [-W1]
+    product), the backward agrees to fp32 rounding (dx = (dB - dA) W1 with one rounding of the difference instead of a product over
+    2 H columns; dW1 = D^T x instead of dB^T x - dA^T x; db1 from the column partials of dA) - on the whole-block C path, the per-op
+    path and the whole-network node."""
+    from surface_texture_inpainting_net_amd.surfacetextureinpaintingnet import GraphResnetBlock
+    n = 6000
+    s = make_synthetic_mesh(n, 1, seed=9, dilations=()).to(DEV)
+    es = plan_for(s).edges('edge_index', 0)
+    cin, cout = (64, 128) if shortcut else (128, 128)
+    torch.manual_seed(1)
+    blk = GraphResnetBlock(cin, cout, norm_layer=M.FastInstanceNorm, conv_type=M.EdgeConvTransInv).to(DEV)
+    with torch.no_grad():
+        blk.first_filter.nn[0].bias.normal_(0, 0.3)            # (zero at init in the reference: make b1 matter)
+    x0 = torch.randn(n, cin, device=DEV)
+    w = torch.randn(n, cout, device=DEV)
+
+    def run(compact, per_op):
+        monkeypatch.setattr(SF, 'TI_COMPACT', compact)
+        monkeypatch.setattr(SF, 'USE_BLOCK_CALL', not per_op)
+        blk.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = blk(x, es)
+        (y * w).sum().backward()
+        return [y.detach(), x.grad] + [p.grad.clone() for p in blk.parameters()]
+
+    base = run(False, False)
+    names = ['out', 'dx'] + [k for k, _ in blk.named_parameters()]
+    for compact, per_op in ((True, False), (True, True)):
+        got = run(compact, per_op)
+        assert torch.equal(got[0], base[0]), 'forward bits'
+        for k, a, b in zip(names[1:], got[1:], base[1:]):
+            scale = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= 2e-5 * scale, (k, compact, per_op, float((a - b).abs().max()), scale)
+    c_fast, c_op = run(True, False), run(True, True)
+    for k, a, b in zip(names, c_fast, c_op):                   # same kernels, same fold order on both paths
+        assert torch.equal(a, b), k
