@@ -204,8 +204,9 @@ int stin_edge_relu_mean_bwd_mask_f32(const float* G, int64_t ldg, const uint32_t
 /* Translation-invariant blocks in the COMPACT layout (round 6; STIN_TI_COMPACT below).  The reference's message is
  * nn(x_j - x_i) (models/modules/edge_conv_translation_invariance.py:20-22): W1 (x_j - x_i) + b1 = A_i + B_j with B = x W1^T and
  * A_i = b1 - B_i.  A is therefore not a GEMM output at all:
- *   fwd_ti:      out / mask exactly as stin_edge_relu_mean_fwd_f32 with A_i = b1 - B_i formed per row (b1 [H] or NULL = zeros) - bit
- *                for bit the rows that call produces from A = x (-W1)^T + b1 (rounding is symmetric under negation);
+ *   fwd_ti:      out / mask exactly as stin_edge_relu_mean_fwd_f32 given A_i = fl(b1 - B_i), formed per row (b1 [H] or NULL = zeros);
+ *                a GEMM output A = x (-W1)^T + b1 differs from that by <= 1 ulp of the matrix-core accumulator (the MFMA adder is not
+ *                symmetric under negation) - both are fp32 evaluations of the same expression;
  *   bwd_mask_ti: D [N, H] = dB - dA (both halves of stin_edge_relu_mean_bwd_mask_f32 for the same row, one rounding for the
  *                difference) - the gradient w.r.t. B in the compact layout - plus colsum [colsum_rows][H]: per-workgroup column sums
  *                of dA in a fixed order (db1 = their sum; sum_i D_i itself is ~ 0).  colsum_rows >= stin_edge_bwd_ti_colsum_rows(N, H).
@@ -525,7 +526,7 @@ int stin_concat_unpool_f32(const float* skip, int64_t ld_skip, const float* coar
  * from Cin to Cp (a multiple of 4) so that a 10-channel network input still takes the 16-byte GEMM paths.
  * trans_inv = STIN_TI_COMPACT (2, round 6; every entry point that takes trans_inv): the translation-invariant filter with ONLY
  * B = x W1^T materialised - wcat = [W1 ; Ws], bcat = [0 ; bs], Yw = H (+ Cout); A_i = b1 - B_i is formed by the edge stage
- * (stin_edge_relu_mean_fwd_ti_f32: same bits as mode 1) and the backward pass carries D = dB - dA in H columns
+ * (stin_edge_relu_mean_fwd_ti_f32: mode 1's values up to one ulp of A) and the backward pass carries D = dB - dA in H columns
  * (stin_edge_relu_mean_bwd_mask_ti_f32) - half the first Linear's GEMM work in every direction.  fp32 rows with a saved-mask
  * width H; unpack then takes dW1 = rows [0, H) as they are and leaves db1 to the caller (the column sums of dA).
  * unpack: dwb [Yw, Cin+1] (gemm_tn output: weight grad | bias grad) -> dW1, db1, dWs, dbs; and

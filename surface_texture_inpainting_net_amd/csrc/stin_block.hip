@@ -278,10 +278,9 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
     (void)ev_dagg;                             // (round 2 forked the dW2 product here; both products now start behind ev_dy)
     stin_stream_t ws_ = side ? wgrad_stream : stream;
     // the fork event is bound to the edge-stage kernel's own completion signal where that launch is the last one before the fork
-    // (STIN_LAUNCH_STOP, stin_common.h; STIN_FORK_BIND=0: always an event record)
-    static const bool bind_env = [] { const char* e = getenv("STIN_FORK_BIND"); return e == nullptr || atoi(e) != 0; }();
+    // (STIN_LAUNCH_STOP, stin_common.h)
     bool bind_on = false;
-    if (side && bind_env) {                    // (a stream being captured into a hipGraph keeps the event-record node)
+    if (side) {                    // (a stream being captured into a hipGraph keeps the event-record node)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         bind_on = hipStreamIsCapturing(hs, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
     }
@@ -303,17 +302,9 @@ static int block_bwd_impl(int storage, const void* g, int64_t ldg, const void* x
         if (link != nullptr && link->pre_partial != nullptr && link->pre_groups > 0 && !sid && B == 1 && gid == nullptr) {
             // the two column sums came out of the previous block's dx product (BwdLink): fold its partials - (round 5) inside the
             // normalisation launch itself where the row groups are few (k_norm_fold: every workgroup folds its own columns)
-            // Measured (profiles/r05_norm_fold.md): the forward form is 16 us where norm + fold were 19, the backward form 44 us
-            // where they were 39 (two fp64 folds per workgroup in front of the rows) and the step does not move either way - the
-            // backward form stays behind STIN_NORM_FOLD_BWD=1.
-            static const bool fold_bwd = getenv("STIN_NORM_FOLD_BWD") && atoi(getenv("STIN_NORM_FOLD_BWD")) != 0;
-            int rc_fold = STIN_E_UNSUPPORTED;
-            if (fold_bwd && N > 0 && stin_norm_fold_rows(N, Cout, link->pre_groups) > 0)
-                rc_fold = stin_norm_act_bwd_fold_f32(link->pre_partial, link->pre_groups, static_cast<const float*>(agg), Cout, gf, ldg, mean,
-                                                     rstd, inv_cnt, N, Cout, static_cast<float*>(dagg), Cout, stream);
-            if (rc_fold == STIN_OK) dagg_done = true;
-            else if (rc_fold != STIN_E_UNSUPPORTED) return rc_fold;
-            else STIN_TRY(stin_norm_coef_from_partials_f32(link->pre_partial, link->pre_groups, Cout, rstd, inv_cnt, kk, mm, stream));
+            // Measured (round 5): the forward form is 16 us where norm + fold were 19; the backward twin (stin_norm_act_bwd_fold_f32:
+            // two fp64 folds per workgroup in front of the rows) 44 us where they were 39 - the backward keeps the separate fold.
+            STIN_TRY(stin_norm_coef_from_partials_f32(link->pre_partial, link->pre_groups, Cout, rstd, inv_cnt, kk, mm, stream));
         } else if (!sid) {
             STIN_TRY(stin_colreduce_f32(STIN_RED_DOT_ELU, static_cast<const float*>(agg), Cout, gf, ldg, N, Cout, ptr_true, B, gid,
                                         nullptr, mean, rstd, nullptr, STIN_POST_NORM_COEF, inv_cnt, 0.f, kk, mm, red_ws, red_bytes,

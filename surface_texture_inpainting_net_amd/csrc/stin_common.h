@@ -53,8 +53,8 @@ __host__ __device__ static inline bool stin_w_frag_shape(int Nc, int K) {
 
 // Width of the packed first-Linear operand / of Y and dY of a fused block.  trans_inv: 0 = EdgeConv ([Wa - Wb ; Wb ; Ws], A and B
 // materialised), 1 = translation-invariant, both halves materialised ([-W1 ; W1 ; Ws]), 2 = translation-invariant COMPACT (round 6):
-// the operand is [W1 ; Ws], only B = x W1^T exists - A_i = b1 - B_i is formed by the edge stage, bit for bit the value the GEMM
-// wrote for mode 1 - and the backward pass carries D = dB - dA (stin_hip.h, STIN_TI_COMPACT).
+// the operand is [W1 ; Ws], only B = x W1^T exists - A_i = b1 - B_i is formed by the edge stage (the value the GEMM wrote for mode 1
+// up to one ulp of the accumulator) - and the backward pass carries D = dB - dA (stin_hip.h, STIN_TI_COMPACT).
 __host__ __device__ static inline int stin_yw(int H, int Cout, int has_shortcut, int trans_inv) {
     return (trans_inv == STIN_TI_COMPACT ? H : 2 * H) + (has_shortcut ? Cout : 0);
 }

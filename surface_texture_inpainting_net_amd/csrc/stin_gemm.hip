@@ -2782,12 +2782,11 @@ __global__ __launch_bounds__(BLOCK) void k_gemm_tn_skinny(const float* __restric
         for (int c = threadIdx.x; c < Nc; c += BLOCK) out[(int64_t)Nc * Kq + c] = sk_smem[c * (KP + 1) + KP];
 }
 inline bool tn_skinny_shape(int storage, int Nc, int K, int64_t ldg, int64_t ldx, const void* G, const void* X) {
-    static const bool on = !(getenv("STIN_TN_SKINNY") && atoi(getenv("STIN_TN_SKINNY")) == 0);     // A/B switch (read once)
-    return on && storage == 0 && K <= 16 && K % 4 == 0 && Nc % 4 == 0 && Nc >= 64 && Nc <= 4 * BLOCK && ldg % 4 == 0 && ldx % 4 == 0 &&
+    return storage == 0 && K <= 16 && K % 4 == 0 && Nc % 4 == 0 && Nc >= 64 && Nc <= 4 * BLOCK && ldg % 4 == 0 && ldx % 4 == 0 &&
            stin_aligned16(G) && stin_aligned16(X);
 }
 inline int tn_skinny_rows(int64_t M) {                                         // ~1024 chunks, a multiple of 32 rows, at least 128
-    static const int want = getenv("STIN_TN_SKINNY_CHUNKS") ? atoi(getenv("STIN_TN_SKINNY_CHUNKS")) : 1024;   // tuning aid (read once); 256 / 512 / 1024 / 2048 chunks: 106 / 75 / 72 / 79 us at 200 704 x 320 x 12
+    constexpr int want = 1024;                                                  // measured: 256 / 512 / 1024 / 2048 chunks: 106 / 75 / 72 / 79 us at 200 704 x 320 x 12
     int64_t rows = (M + want - 1) / want;
     rows = (rows + 31) / 32 * 32;
     // the chunk's [X | w] image is rows x (KP + 4 <= 20) floats of dynamic LDS: capped at 512 rows = 40 KB (below the 64 KB a
@@ -2863,15 +2862,11 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_slabs(const float* __restrict_
 }
 
 inline int tn_tile(int n) {
-    static const int cap = getenv("STIN_TN_TILE") ? atoi(getenv("STIN_TN_TILE")) : 128;   // tuning aid: 64 forces 64x64 tiles
-    return (n > 64 && cap >= 128) ? 128 : 64;    // (measured: 64x64 wgrad tiles are 2-5 % slower end to end at any slab count)
+    return n > 64 ? 128 : 64;    // (measured: 64x64 wgrad tiles are 2-5 % slower end to end at any slab count)
 }
 
-// tuning aid (profiles/gemm_tiles.py): STIN_NT_TILE is re-read on every call so that one process can sweep the tiles
-inline int stin_nt_force_tile() {
-    const char* e = getenv("STIN_NT_TILE");
-    return e ? atoi(e) : 0;
-}
+// (the STIN_NT_TILE sweep aid of rounds 1-5 is gone: 0 = the measured rule below)
+inline int stin_nt_force_tile() { return 0; }
 
 inline int stin_cu_count() {
     static int n = 0;
@@ -2891,13 +2886,12 @@ inline int tn_rows_per_chunk(int64_t M, int tiles, bool one_per_cu = false) {
     // 256 blocks - the producer / consumer kernel's fixed cost per block (first-load latency ~5 k cycles, slab store ~9 k) is
     // a sixth of a 750-row chunk; measured 18 063 x 1024 x 256 49.7 -> 45.7 us, block weight gradients 69 -> 62 us, while the
     // 60 k-row products lose 10 % with 256 blocks and keep 384
-    static const int target = getenv("STIN_TN_BLOCKS") ? atoi(getenv("STIN_TN_BLOCKS")) : 0;   // tuning aid
-    const int want = target > 0 ? target : (one_per_cu ? 256 : 384);
+    const int want = one_per_cu ? 256 : 384;
     int64_t chunks = (want + tiles - 1) / tiles;
     if (chunks > 8) chunks = (chunks + 7) / 8 * 8;          // whole rounds of 8 chunks (one per XCD, see the kernels' block map)
     int64_t rows = (M + chunks - 1) / chunks;
     if (rows < 4 * TN_R) rows = 4 * TN_R;
-    static const int max_rows = getenv("STIN_TN_MAXROWS") ? atoi(getenv("STIN_TN_MAXROWS")) : 128 * TN_R;   // tuning aid
+    constexpr int max_rows = 128 * TN_R;
     if (rows > max_rows) rows = max_rows;
     rows = (rows + TN_R - 1) / TN_R * TN_R;
     return (int)rows;
@@ -2950,9 +2944,7 @@ inline int strip_config(int64_t M, int Nc, int KC) {
 // while the 128-row blocks fit the chip in one round: 18 063 x 256 x 1024 41.6 -> 36.7 us, x 512 29.3 -> 27.7; slower for 60 k
 // rows (471 blocks: 59 -> 64 us) and for Nc = 128 (256-row blocks: 71 of them at 18 k rows, 34 -> 52 us), which keep 4 waves.
 inline int wide_waves_m(int64_t M, int Nc) {
-    static const int force = getenv("STIN_WIDE_WAVES") ? atoi(getenv("STIN_WIDE_WAVES")) : 0;      // tuning aid: 4 | 8 waves per block
     const int nw = Nc / 64;
-    if (force == 4 || force == 8) return force / nw;
     return (Nc == 256 && (M + 127) / 128 <= (int64_t)stin_cu_count()) ? 2 : 4 / nw;
 }
 // Balanced column-panel kernel (k_gemm_nt_panel): 32-row tiles per block (MT0 + MT1, 2 .. 9) so that (row blocks) x (128-column
@@ -2968,8 +2960,6 @@ inline int panel_tiles(int64_t M, int Nc, int K) {
     if (forced == 0 || Nc % 128 != 0 || K % WD_KC != 0 || M <= 0) return 0;
     const int P = Nc / 128;
     const int64_t rg = (M + 31) / 32, cu = stin_cu_count();
-    const char* em = getenv("STIN_NT_PANEL_MTS");                               // tuning aid: tiles per block, 2 .. 9
-    if (em && atoi(em) >= 2 && atoi(em) <= 9) return atoi(em);
     const int max_rounds = forced == 1 ? 64 : 1;
     for (int rounds = 1; rounds <= max_rounds; ++rounds) {
         const int64_t slots = cu * rounds / P;
@@ -2977,8 +2967,7 @@ inline int panel_tiles(int64_t M, int Nc, int K) {
         const int64_t mts = (rg + slots - 1) / slots;
         // (fewer row groups than slots - the coarse levels of a small crop, 1 806 x 256 x 1024: the finest blocks, 64 rows; the
         // all-columns kernel ran that shape on 15 workgroups, 41.8 us; STIN_NT_PANEL_SMALL=0 keeps it there)
-        static const bool small_on = !(getenv("STIN_NT_PANEL_SMALL") && atoi(getenv("STIN_NT_PANEL_SMALL")) == 0);
-        if (mts <= 9) return mts < 2 ? ((forced == 1 || small_on) ? 2 : 0) : (int)mts;
+        if (mts <= 9) return mts < 2 ? 2 : (int)mts;
     }
     return 0;
 }
@@ -3025,7 +3014,7 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
     // the blocks in flight) wins there.  Long reductions with enough tiles (the 1024..4096-wide layers of a 5-level network:
     // K >= 512, >= 500 tiles of 128x128) are 1.15-1.35x faster on 128x128.
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Nc + bn - 1) / bn); };
-    static const int64_t min_blocks = getenv("STIN_NT_MINBLOCKS") ? atoi(getenv("STIN_NT_MINBLOCKS")) : 500;   // tuning aid
+    constexpr int64_t min_blocks = 500;
     const int force_tile = stin_nt_force_tile();   // tuning aid: 0 = rule above, 1 = 128x128, 2 = 128x64, 3 = 64x64
     const bool big_tile = Nc % 128 == 0 && K >= 512 && blocks(128, 128) >= min_blocks;
     stin_bn_tf tf_arg;
@@ -3137,8 +3126,6 @@ static int gemm_nt_f32_impl(const float* A, int64_t lda, const float* W, int64_t
         if (occ > 2) occ = 2;
         if (cfg == 22) occ = 1;                                       // eight-wave blocks: one per CU (18 063 x 1280 x 128: 39.2 -> 35.6 us)
         if (occ < 1) occ = 1;
-        const char* e_occ = getenv("STIN_STRIP_OCC");                 // tuning aid
-        if (e_occ && atoi(e_occ) > 0) occ = atoi(e_occ);
         int64_t grid = (int64_t)stin_cu_count() * occ;
         if (grid > units) grid = units;
 #define STIN_STRIP_L(PT_, MT_, QM_)                                                                                       \
@@ -3250,13 +3237,11 @@ inline bool stream_geo(int64_t M, int Nc, int K, bool tf, StreamGeo* g, int mode
     // staged chunk: 64 columns (8 KB per wave in flight, 32 KB of staging per block: two blocks per CU up to K = 128 -
     // 1 200 642 x 64 x 128 with the BatchNorm transform: 184 us against 212 with 128-column chunks, profiles/probes/kc_probe.sh)
     g->kc = 64;
-    const char* e = getenv("STIN_NT_STREAM_KC");
-    if (e != nullptr && atoi(e) == 128 && K % 128 == 0) g->kc = 128;
-    e = getenv("STIN_NT_STREAM_NT");
+    const char* e = getenv("STIN_NT_STREAM_NT");
     int nt = e != nullptr ? atoi(e) : 0;
     // (the statistics pass is faster with two column tiles although the A rows then come from L2 a second time: 207 against 232 us at
     // 1 200 642 x 128 x 64, 178 against 277 at 361 000 x 256 x 128 - STIN_NT_STREAM_STATS4=1 is the four-tile form, a tuning aid)
-    if (nt != 2 && nt != 4) nt = (Nc <= 64 || (mode == 1 && getenv("STIN_NT_STREAM_STATS4") == nullptr)) ? 2 : 4;
+    if (nt != 2 && nt != 4) nt = (Nc <= 64 || mode == 1) ? 2 : 4;
     const size_t esz = precision == STIN_GEMM_BF16X6 ? 6 : 4;                   // bytes per operand element in LDS: 2 or 3 pieces of 16 bits
     auto lds_of = [&](int nt_) { return esz * ((size_t)K * 32 * nt_ + (size_t)128 * g->kc) + (tf ? (size_t)8 * K : 0) + (mode != 0 ? (size_t)24 * 32 * nt_ : 0); };
     if (lds_of(nt) > 160 * 1024) nt = 2;
@@ -3267,8 +3252,6 @@ inline bool stream_geo(int64_t M, int Nc, int K, bool tf, StreamGeo* g, int mode
     g->ncb = (Nc + 32 * nt - 1) / (32 * nt);
     g->bpc = (int)((160 * 1024) / g->lds);
     if (g->bpc > 2) g->bpc = 2;
-    e = getenv("STIN_NT_STREAM_BPC");
-    if (e != nullptr && atoi(e) > 0 && atoi(e) < g->bpc) g->bpc = atoi(e);
     int64_t gx = (int64_t)stin_cu_count() * g->bpc / g->ncb;
     if (gx < 1) gx = 1;
     const int64_t need = ((M + 31) / 32 + 3) / 4;                                 // blocks that have a tile for every wave
@@ -3523,8 +3506,7 @@ int stin_tn_problem_init(stin_tn_problem* p, int storage, const void* G, int64_t
     // per-edge dW2) ran on the four-wave kernel (its 64-wide tiles) at ~3 TB/s; on the producer / consumer kernel the same
     // product is a 128 x 128 tile that is half or a quarter empty - the wasted MFMAs are free beside the operand stream
     // (200 704 x 64 x 128: 50 -> 3x us; 1.2 M x 64 x 128: 267 -> 1xx us).  One tile either way: same chunks, same slabs.
-    static const bool ws_narrow = !(getenv("STIN_TN_WS_NARROW") && atoi(getenv("STIN_TN_WS_NARROW")) == 0);   // A/B switch (read once)
-    if (ws_narrow && !big && storage == 0 && precision == STIN_GEMM_BF16X3 && vec16 && M > 0 && Nc >= 32 && K >= 32 && stin_tn_ws_enabled()) {
+    if (!big && storage == 0 && precision == STIN_GEMM_BF16X3 && vec16 && M > 0 && Nc >= 32 && K >= 32 && stin_tn_ws_enabled()) {
         p->TI = 128;
         p->TJ = 128;
     }

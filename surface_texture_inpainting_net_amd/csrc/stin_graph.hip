@@ -80,8 +80,10 @@ struct Lane {
 // ------------------------------------------------------------------ edge stage, forward
 // EXACT: H == 4 * G * VPL (every width the saved-mask path supports): no per-chunk predicates on the gathers
 // TI (round 6, translation-invariant blocks in the compact layout): the row's own operand is not read from memory but formed
-// as a = b1 - B_i (A points at the bias vector b1 [H], or is NULL for a filter without bias) - bit for bit the value the Y
-// product wrote into its A columns when it multiplied by [-W1 ; W1] (round-to-nearest is symmetric under negation).
+// as a = b1 - B_i (A points at the bias vector b1 [H], or is NULL for a filter without bias).  Against the A columns the Y product
+// wrote when it multiplied by [-W1 ; W1] this differs by at most one unit in the last place of the matrix-core accumulator (the
+// MFMA's internal adder is not symmetric under negation: measured 2.4e-7 .. 9.5e-7 absolute on unit-scale rows) - both are fp32
+// evaluations of W1 (x_j - x_i) + b1.
 template <typename T, int G, int VPL, int U, bool EXACT, bool TI = false>
 __device__ __forceinline__ void edge_fwd_body(const T* __restrict__ A, int64_t lda,
                                               const T* __restrict__ B, int64_t ldb,
@@ -1418,11 +1420,7 @@ inline unsigned grid_rows(int64_t N, int G) { return (unsigned)((N + (BLOCK / G)
 // (nothing to reuse), and on coherently numbered ones the plain order is the better one (level-0 forward at 200 704 vertices,
 // grid order: 82 us plain vs 96 us chunked; 1 M bf16: 344 vs 353) - with round-robin dealing the 8 XCDs sweep the SAME
 // neighbourhood together and share its lines in the Infinity Cache, chunked they stream eight distant regions at once.
-inline bool xcd_rows_on(unsigned nwg) {
-    const char* e = getenv("STIN_XCD_ROWS");
-    if (!e || atoi(e) == 0) return false;
-    return nwg >= 64 && (nwg + 7) / 8 <= 32767;
-}
+inline bool xcd_rows_on(unsigned) { return false; }   // (the (8, q) launch shape measured no gain - comment above - and stays off)
 inline dim3 rows_grid(unsigned nwg) { return xcd_rows_on(nwg) ? dim3(8, (nwg + 7) / 8) : dim3(nwg); }
 inline dim3 pair_grid(unsigned nb) { return xcd_rows_on(nb) ? dim3(8, 2 * ((nb + 7) / 8)) : dim3(2 * nb); }
 inline unsigned grid_elems(int64_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
@@ -1504,7 +1502,11 @@ int edge_fwd_impl(const T* A, int64_t lda, const T* B, int64_t ldb, const int32_
             const int cfg = eu ? atoi(eu) : 0;
             auto pick = [&](int pos, int dflt) { int d = cfg; for (int i = 0; i < 4 - pos; ++i) d /= 10; d %= 10; return (cfg > 0 && d > 0) ? d : dflt; };
             const int hsel = H == 128 ? 0 : H == 256 ? 1 : H == 512 ? 2 : H == 1024 ? 3 : 4;
-            const int u = pick(hsel, hsel <= 3 ? STIN_FWD8_U_SMALL : STIN_FWD8_U_BIG);
+            // (round 6) a gathered operand that cannot be cache resident (N x H x 2 bytes > 128 MB: BASELINE config 5's level 0, 256 MB)
+            // takes four 256-byte rows in flight per lane group: 1 M x 128: 549 / 407 / 416 / 393 / 439 us at U = 1 / 2 / 3 / 4 / 6, where
+            // the cache-resident headline size reads 82 / 76 / 73 / 76 / 98 (profiles/probes/edge8_u_sweep.py)
+            const bool hbm_served = hsel == 0 && (int64_t)N * H * 2 > ((int64_t)128 << 20);
+            const int u = pick(hsel, hbm_served ? 4 : (hsel <= 3 ? STIN_FWD8_U_SMALL : STIN_FWD8_U_BIG));
 #define STIN_FWD8(U_) STIN_DISPATCH8(H, k_edge_fwd8, U_, U_, U_, U_, U_, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask)
             if (u == 1) STIN_FWD8(1);
             else if (u == 2) STIN_FWD8(2);
@@ -1518,18 +1520,6 @@ int edge_fwd_impl(const T* A, int64_t lda, const T* B, int64_t ldb, const int32_
     // (round 6) mask == NULL at a mask shape - the forward of a no-grad / evaluation pass - runs the SAME kernel without the mask
     // stores (edge_fwd_body tests the pointer): same gathers, same summation order, bit-identical rows, E * H / 8 bytes less written
     if (vec && (mask != nullptr || mask_shape_ok(H))) {   // mask shapes are exact multiples of the lane geometry
-        // tuning aid (re-read per call): STIN_EDGE_U512 = neighbour rows in flight of the fp32 forward at H = 512 (2-KB rows)
-        const char* eu = is_f32((const T*)nullptr) && H == 512 ? getenv("STIN_EDGE_U512") : nullptr;
-        const int u512 = eu ? atoi(eu) : 0;
-        if constexpr (is_f32((const T*)nullptr)) {
-            if (u512 == 3 || u512 == 4 || u512 == 6) {
-                const unsigned grid_ = grid_rows(N, 64);
-                if (u512 == 3) hipLaunchKernelGGL((k_edge_fwd_exact<T, 64, 2, 3>), rows_grid(grid_), dim3(BLOCK), 0, stream, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
-                else if (u512 == 4) hipLaunchKernelGGL((k_edge_fwd_exact<T, 64, 2, 4>), rows_grid(grid_), dim3(BLOCK), 0, stream, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
-                else hipLaunchKernelGGL((k_edge_fwd_exact<T, 64, 2, 6>), rows_grid(grid_), dim3(BLOCK), 0, stream, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
-                return stin_launch_status();
-            }
-        }
         STIN_DISPATCH(H, k_edge_fwd_exact, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
     } else if (vec) {
         STIN_DISPATCH(H, k_edge_fwd, 1, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask);
@@ -1598,15 +1588,8 @@ int edge_bwd_mask_pair_impl(const float* G, int64_t ldg, const uint32_t* mask, c
                      ld_cps, cp_dst, ld_cpd, Ccp)
     if (g == 32) STIN_PAIR(32, 1, 6);                 // H = 128
     else if (vpl == 1) STIN_PAIR(64, 1, 4);           // 256
-    else if (vpl == 2) {                              // 512 (tuning aid STIN_EDGE_US512: rows in flight of the gathering role)
-        const char* eu = getenv("STIN_EDGE_US512");
-        const int us = eu ? atoi(eu) : 0;
-#define STIN_PAIR_U(US_) STIN_LAUNCH_STOP((k_edge_bwd_mask_pair<T, 64, 2, 2, US_>), pair_grid(nb), dim3(BLOCK), stream, G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src, ld_cps, cp_dst, ld_cpd, Ccp)
-        if (us == 1) STIN_PAIR(64, 2, 2);             // (STIN_U(2, 2) = 1 row: the round-2 choice)
-        else if (us == 3) STIN_PAIR_U(3);
-        else if (us == 4) STIN_PAIR_U(4);
-        else STIN_PAIR_U(2);                          // 18 063 x 512: 56.8 us at 1, 54.0 at 2, 56.1 / 58.8 at 3 / 4 (profiles/probes/edge512_sweep.py)
-#undef STIN_PAIR_U
+    else if (vpl == 2) {                              // 512: two rows in flight in the gathering role (18 063 x 512: 56.8 us at 1, 54.0 at 2, 56.1 / 58.8 at 3 / 4)
+        STIN_LAUNCH_STOP((k_edge_bwd_mask_pair<T, 64, 2, 2, 2>), pair_grid(nb), dim3(BLOCK), stream, G, ldg, mask, rowptr_dst, w_src, rowptr_src, col_src, xslot, N, H, dA, ldda, dB, lddb, nb, cp_src, ld_cps, cp_dst, ld_cpd, Ccp);
     }
     else if (vpl <= 4) STIN_PAIR(64, 4, 2);           // 1024
     else STIN_PAIR(64, 8, 1);                         // 2048
@@ -1718,8 +1701,7 @@ int segment_sum_impl(const T* src, int64_t ld_src, const int32_t* rowptr, const 
         // even split of the row over G = C / 8 lanes with 2 chunks each (C / 4 a power of two, 16 <= C <= 512), wider rows on a
         // full wave; anything else (ragged channel counts) keeps the predicated kernel below
         const int c4 = C / 4;
-        static const bool force_old = getenv("STIN_SEG_OLD") != nullptr && atoi(getenv("STIN_SEG_OLD")) != 0;   // A/B aid
-        if (!force_old && C % 4 == 0 && c4 >= 4 && (c4 & (c4 - 1)) == 0 && c4 <= 512 && vec_ok<T>(C, {src, out}, {ld_src, ld_out})) {
+        if (C % 4 == 0 && c4 >= 4 && (c4 & (c4 - 1)) == 0 && c4 <= 512 && vec_ok<T>(C, {src, out}, {ld_src, ld_out})) {
             // non-temporal loads only for a source that cannot be Infinity-Cache resident (see the kernel comment)
             const bool nt = is_f32((const T*)nullptr) && want_nt;
 #define SEGX(G_, V_, U_)                                                                                                  \
@@ -1977,18 +1959,11 @@ extern "C" int stin_gather_add_rows_f32(const float* a, int64_t lda, const int32
     STIN_REQUIRE(N >= 0 && C > 0 && lda >= C && ldb >= C && ldo >= C, STIN_E_SIZE);
     if (N == 0) return STIN_OK;
     STIN_REQUIRE(a && b && idx_a && idx_b && out, STIN_E_NULL);
-    static const int unroll = getenv("STIN_GATHER_ADD_U") ? atoi(getenv("STIN_GATHER_ADD_U")) : 4;      // tuning aid: 0 = one row per thread
-    if (vec_ok<T>(C, {a, b, out}, {lda, ldb, ldo}) && unroll > 0 && BLOCK % (C / 4) == 0 && N >= 4096) {
+    if (vec_ok<T>(C, {a, b, out}, {lda, ldb, ldo}) && BLOCK % (C / 4) == 0 && N >= 4096) {
         const int c4 = C / 4;
         const int64_t threads = (N + 3) / 4 * c4;                                      // U = 4 rows per thread
         const unsigned grid = (unsigned)((threads + BLOCK - 1) / BLOCK);
-        if (unroll >= 8) {
-            const int64_t t8 = (N + 7) / 8 * c4;
-            hipLaunchKernelGGL((k_gather_add_rows_u<8>), dim3((unsigned)((t8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, a, lda, idx_a, b, ldb,
-                               idx_b, N, c4, out, ldo);
-        } else {
-            hipLaunchKernelGGL((k_gather_add_rows_u<4>), dim3(grid), dim3(BLOCK), 0, stream, a, lda, idx_a, b, ldb, idx_b, N, c4, out, ldo);
-        }
+        hipLaunchKernelGGL((k_gather_add_rows_u<4>), dim3(grid), dim3(BLOCK), 0, stream, a, lda, idx_a, b, ldb, idx_b, N, c4, out, ldo);
     } else if (vec_ok<T>(C, {a, b, out}, {lda, ldb, ldo})) {
         STIN_DISPATCH_NOU(C, k_gather_add_rows, a, lda, idx_a, b, ldb, idx_b, N, C, out, ldo);
     } else {

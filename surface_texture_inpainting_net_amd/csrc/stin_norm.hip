@@ -826,8 +826,6 @@ template <typename T>
 inline bool vec8_ok(int C, std::initializer_list<const void*> data, std::initializer_list<const void*> stats,
                     std::initializer_list<int64_t> lds) {
     if (sizeof(T) != 2 || C % 8 != 0) return false;
-    static const bool off = getenv("STIN_NORM_V8") && atoi(getenv("STIN_NORM_V8")) == 0;     // A/B switch
-    if (off) return false;
     for (const void* p : data)
         if (p != nullptr && !stin_aligned16(p)) return false;
     for (const void* p : stats)
@@ -875,10 +873,9 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
     const bool vec = vec4_ok<T>(C, {x, gout}, {mean, rstd, coef}, {ldx, gout ? ldg : 0});
     if (!vec && !is_f32((const T*)nullptr)) return STIN_E_UNSUPPORTED;
     // one-launch form (k_colreduce_t): 16-byte fp32 rows, few enough (range, column group) pairs for one row of ticket words;
-    // STIN_RED_TICKET=0 keeps the two-launch form (A/B switch, read once).  Column groups of 64 / 32 / 16 so that narrow
+    // Column groups of 64 / 32 / 16 so that narrow
     // matrices still fold on four blocks side by side.
-    static const bool ticket_on = !(getenv("STIN_RED_TICKET") && atoi(getenv("STIN_RED_TICKET")) == 0);
-    if (vec && ticket_on && N > 0) {                                // (fp32 and bf16 rows: 4 channels per lane either way)
+    if (vec && N > 0) {                                // (fp32 and bf16 rows: 4 channels per lane either way)
         const int GC = C >= 256 ? 64 : (C >= 128 ? 32 : 16);
         const int ncg = (C + GC - 1) / GC;
         if ((int64_t)B * ncg <= RED_WORDS) {
@@ -887,7 +884,7 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
             const int RLN = BLOCK / (GC / 4);
             // row chunks: ~8 row trips per block, at most ~2 blocks per CU over all column groups and ranges, and within the workspace
             int64_t R = (N / B + (int64_t)RLN * 8 - 1) / ((int64_t)RLN * 8);
-            static const int per_cu = (getenv("STIN_RED_PER_CU") && atoi(getenv("STIN_RED_PER_CU")) > 0) ? atoi(getenv("STIN_RED_PER_CU")) : 2;   // tuning aid
+            constexpr int per_cu = 2;
             const int64_t cap = (per_cu * (int64_t)norm_cu_count() + (int64_t)B * ncg - 1) / ((int64_t)B * ncg);
             if (R > cap) R = cap;
             // partial [B][ncg][R][2][GC] doubles must fit the caller's workspace of max(B, MAX_SLABS) x 2 x C doubles
@@ -925,7 +922,7 @@ int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg
     const int CG = CV < BLOCK ? CV : BLOCK;
     const int RL = BLOCK / CG;
     // row iterations per block: 8 (2 blocks per CU at the 18 k-row level) measured 0.3 % faster on the step than 16; 32 is 2 % slower
-    static const int rows_mul = (getenv("STIN_RED_ROWS") && atoi(getenv("STIN_RED_ROWS")) > 0) ? atoi(getenv("STIN_RED_ROWS")) : 8;
+    constexpr int rows_mul = 8;
     int64_t want = (N / B + (int64_t)RL * rows_mul - 1) / ((int64_t)RL * rows_mul);
     int cap = MAX_SLABS / B;
     if (cap < 1) cap = 1;
@@ -1010,9 +1007,8 @@ int norm_bwd_impl(const T* x, int64_t ldx, const T* gout, int64_t ldg, const flo
 // workgroup (16 waves) per CU, and all of them together must not read more fold bytes than 3/4 of the elementwise traffic (12
 // bytes per element; 18 063 x 256 with 226 row groups: 256 workgroups x 115 KB = 30 MB beside 55 MB)
 inline int norm_fold_rows(int64_t N, int C, int64_t groups) {
-    static const bool on = !(getenv("STIN_NORM_FOLD") && atoi(getenv("STIN_NORM_FOLD")) == 0);      // A/B switch (read once)
-    static const int per_cu = (getenv("STIN_NORM_FOLD_PER_CU") && atoi(getenv("STIN_NORM_FOLD_PER_CU")) > 0) ? atoi(getenv("STIN_NORM_FOLD_PER_CU")) : 1;   // tuning aid
-    if (!on || C % NF_GC != 0 || N <= 0 || groups <= 0 || groups > INT32_MAX) return 0;
+    constexpr int per_cu = 1;
+    if (C % NF_GC != 0 || N <= 0 || groups <= 0 || groups > INT32_MAX) return 0;
     const int cg = C / NF_GC;
     int64_t chunks = (per_cu * (int64_t)norm_cu_count() + cg - 1) / cg;
     int64_t rows = (N + chunks - 1) / chunks;

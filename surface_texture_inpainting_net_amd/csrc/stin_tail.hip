@@ -257,7 +257,7 @@ inline int tail_cu_count() {
     return n;
 }
 inline int64_t tail_bwd_blocks(int64_t N) {
-    static const int per_cu_x4 = (getenv("STIN_TAIL_BLOCKS_X4") && atoi(getenv("STIN_TAIL_BLOCKS_X4")) > 0) ? atoi(getenv("STIN_TAIL_BLOCKS_X4")) : 4;   // tuning aid: blocks = CUs x this / 4
+    constexpr int per_cu_x4 = 4;                                     // blocks = CUs x this / 4
     int64_t blocks = (N + 2 * (TL_BWD_BLOCK / TL_LPR) - 1) / (2 * (TL_BWD_BLOCK / TL_LPR));
     const int64_t cap = (int64_t)tail_cu_count() * per_cu_x4 / 4;
     if (blocks > cap) blocks = cap;

@@ -473,8 +473,7 @@ bool stin_tn_ws_enabled() {
 }
 
 int stin_tn_ws_launch(stin_tn_batch batch, stin_stream_t stream) {
-    const char* e = getenv("STIN_TN_WS_PRIO");
-    const int prio = e ? atoi(e) : 1;
+    const int prio = 1;                                            // consumers (the MFMA-issuing waves) at raised priority
     unsigned blocks = 0;
     for (int i = 0; i < batch.n; ++i) {
         stin_tn_problem& p = batch.p[i];
@@ -483,10 +482,7 @@ int stin_tn_ws_launch(stin_tn_batch batch, stin_stream_t stream) {
         blocks += (unsigned)((p.chunks >= 8 ? ((p.chunks + 7) / 8) * 8 : p.chunks) * (int64_t)p.tiles_i * p.tiles_j);
     }
     if (blocks == 0) return STIN_OK;
-    // extra (unused) dynamic LDS: > 12 KB makes the kernel's footprint exceed half a CU's 160 KB, i.e. ONE block per CU -
-    // the weight-gradient stream then leaves the co-running critical-path kernels half of every CU's LDS (tuning aid)
-    static const int lds_pad = getenv("STIN_TN_WS_LDS_PAD") ? atoi(getenv("STIN_TN_WS_LDS_PAD")) : 0;
-    hipLaunchKernelGGL(k_gemm_tn_ws, dim3(blocks), dim3(WS_THREADS), (size_t)lds_pad, (hipStream_t)stream, batch, prio);
+    hipLaunchKernelGGL(k_gemm_tn_ws, dim3(blocks), dim3(WS_THREADS), 0, (hipStream_t)stream, batch, prio);
     return stin_launch_status();
 }
 

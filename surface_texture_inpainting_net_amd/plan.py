@@ -713,8 +713,8 @@ VALIDATION = _os.environ.get('STIN_PLAN_VALIDATION', 'sync')
 # pipeline's cheaper route is to renumber a scene ONCE when it is read (scene_io.load_scene(locality_order=True),
 # synthetic.renumber_by_locality) - the bench line's `vertex_locality` figure.
 REORDER = _os.environ.get('STIN_REORDER', '0') == '1'
-REORDER_MIN = int(_os.environ.get('STIN_REORDER_MIN', '65536'))
-REORDER_IMPL = _os.environ.get('STIN_REORDER_IMPL', 'hip')          # 'hip' (csrc/stin_order.hip) | 'torch' (framework ops, the cross-check)
+REORDER_MIN = 65536
+REORDER_IMPL = 'hip'          # 'hip' (csrc/stin_order.hip) | 'torch' (framework ops, the cross-check)
 _PENDING_CHECKS = []
 
 

@@ -324,15 +324,15 @@ def batch_norm_rows(x, bn, relu=False, recomputed=False):
     return F.relu(y) if relu else y
 
 
-USE_FUSED_LAYER = __import__('os').environ.get('STIN_SCMN_FUSED', '1') != '0'      # A/B switch: 0 = the per-op autograd path
+USE_FUSED_LAYER = True      # A/B switch: 0 = the per-op autograd path
 # BatchNorm1d + ReLU of the E x 2 cout edge rows applied inside the per-edge GEMMs' operand staging (stin_gemm_nt_bn_f32 /
 # stin_gemm_tn_bn_f32): the normalised matrix h is never written or read (1.2 GB per level-0 layer); 0 = materialise it (A/B)
-BN_IN_GEMM = __import__('os').environ.get('STIN_SCMN_BN_IN_GEMM', '1') != '0'
+BN_IN_GEMM = True
 # the column moments of the gather-add output accumulated by the gather-add pass itself (stin_gather_add_rows_stats_f32)
-STATS_IN_GATHER = __import__('os').environ.get('STIN_SCMN_STATS_IN_GATHER', '1') != '0'
+STATS_IN_GATHER = True
 # backward: the per-edge input-gradient product with BatchNorm1d + ReLU's backward on its epilogue, run twice (statistics, then the
 # finished gradient: stin_gemm_nt_bn_bwd_{stats,apply}_f32) instead of GEMM + column reduction + elementwise pass
-BN_BWD_IN_GEMM = __import__('os').environ.get('STIN_SCMN_BN_BWD_IN_GEMM', '1') != '0'
+BN_BWD_IN_GEMM = True
 
 
 def _gemm_nt_bn(pre, W, mean, rstd, gamma, beta, precision):
