@@ -73,6 +73,31 @@ static inline int stin_ticket_slot(std::atomic<unsigned>& seq_eager, std::atomic
     return (int)(seq_eager.fetch_add(1, std::memory_order_relaxed) % half);
 }
 
+// Per-DEVICE caches (round 6; a process may drive more than one GPU): the CU count, and "this function's dynamic-LDS attribute has
+// been raised on this device" (hipFuncSetAttribute is per device: a process-wide once-flag left the second GPU's launches of the
+// > 64 KB kernels failing).
+static inline int stin_device_slot() {
+    int d = 0;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0;
+}
+static inline int stin_cu_count_dev() {
+    static std::atomic<int> n[64];
+    const int d = stin_device_slot();
+    int v = n[d].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+        n[d].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+struct stin_once_per_device {
+    std::atomic<unsigned long long> mask{0};
+    bool first() {                                     // true exactly once per device
+        const unsigned long long bit = 1ull << stin_device_slot();
+        return (mask.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
+    }
+};
+
 static inline bool stin_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Lanes that cooperate on one feature row: smallest power of two >= ceil(C/4), capped at a wave.

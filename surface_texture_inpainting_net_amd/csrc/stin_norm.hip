@@ -840,14 +840,7 @@ constexpr bool is_f32(const stin_bf16*) { return false; }
 inline const stin_bf16* b16(const stin_bf16_t* p) { return reinterpret_cast<const stin_bf16*>(p); }
 inline stin_bf16* b16(stin_bf16_t* p) { return reinterpret_cast<stin_bf16*>(p); }
 
-inline int norm_cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-    }
-    return n;
-}
+inline int norm_cu_count() { return stin_cu_count_dev(); }          // (per device: stin_common.h)
 
 template <typename T>
 int colreduce_impl(int mode, const T* x, int64_t ldx, const T* gout, int64_t ldg, int64_t N, int C, const int32_t* ptr,

@@ -248,14 +248,7 @@ __global__ __launch_bounds__(256) void k_cols_axpy_rowmask(T* __restrict__ dst, 
     if (rowptr[n + 1] > rowptr[n]) st1(dst + n * ldd + c, ld1(dst + n * ldd + c) + alpha * ld1(src + n * lds_ + c));
 }
 
-inline int tail_cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-    }
-    return n;
-}
+inline int tail_cu_count() { return stin_cu_count_dev(); }          // (per device: stin_common.h)
 inline int64_t tail_bwd_blocks(int64_t N) {
     constexpr int per_cu_x4 = 4;                                     // blocks = CUs x this / 4
     int64_t blocks = (N + 2 * (TL_BWD_BLOCK / TL_LPR) - 1) / (2 * (TL_BWD_BLOCK / TL_LPR));
@@ -320,10 +313,9 @@ int linear_tanh_bwd_impl(const float* g, const float* y, const T* x, int64_t ldx
     const int CH = K <= 64 ? 1 : (K <= 128 ? 2 : 4);
 #define STIN_TL_B(NC_, CH_)                                                                                                          \
     do {                                                                                                                             \
-        static bool attr_set = false;                                                                                                \
-        if (!attr_set) {                                                                                                             \
+        static stin_once_per_device attr_once;                                                                                                \
+        if (attr_once.first()) {                                                                                                             \
             (void)hipFuncSetAttribute((const void*)k_linear_tanh_bwd<T, NC_, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
-            attr_set = true;                                                                                                         \
         }                                                                                                                            \
         hipLaunchKernelGGL((k_linear_tanh_bwd<T, NC_, CH_>), dim3((unsigned)blocks), dim3(TL_BWD_BLOCK), lds, stream, g, y, x, ldx, W, N, K, \
                            dx, lddx, partial, slot, dW, db);                                                                         \
