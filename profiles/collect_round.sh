@@ -22,7 +22,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c2 -o run -- pyt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c3 -o run -- python3 $R/bench.py --crops 8 --levels 4 --dtype bf16 --steps 8 --warmup 5 --no-cpu-baseline --no-secondary --detail $O/prof_c3.json > $O/prof_c3_line.json 2>> $O/prof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5 -o run -- python3 $R/bench.py --vertices 1000000 --levels 5 --dtype bf16 --steps 5 --warmup 5 --no-cpu-baseline --no-secondary --detail $O/prof_c5.json > $O/prof_c5_line.json 2>> $O/prof.err
 python3 $R/profiles/gemm_shapes.py --rounds 7 --variants FRAG=1+STIN_NT_PANEL=0,FRAG=1 --md $O/gemm_shapes.md > /dev/null 2> $O/gemm_shapes.err
-python3 $R/profiles/scmn_bench.py --detail $O/scmn.json > $O/scmn_line.json 2> $O/scmn.err
+python3 $R/profiles/scmn_bench.py > $O/scmn.json 2> $O/scmn.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_scmn -o run -- python3 $R/profiles/scmn_bench.py > /dev/null 2>> $O/prof.err
 python3 $R/profiles/tn_ws_bench.py --md $O/tn_ws.md > /dev/null 2> $O/tn_ws.err
 ls -la $O

@@ -17,9 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from surface_texture_inpainting_net_amd import functional as SF  # noqa: E402
 
 N0, N1, N2 = 200704, 60211, 18063
-# (rows, Cin (padded), Cout, has_shortcut, count per step)
-BLOCKS = [(N0, 12, 64, True, 1), (N1, 64, 128, True, 1), (N2, 128, 256, True, 1), (N2, 256, 256, False, 9),
-          (N1, 256, 128, True, 1), (N0, 128, 64, True, 1), (N0, 64, 64, False, 1)]
+# (rows, Cin (padded), Cout, has_shortcut, count per step, compact trans-inv layout: only the network's first block - Y = [B | S])
+BLOCKS = [(N0, 12, 64, True, 1, True), (N1, 64, 128, True, 1, False), (N2, 128, 256, True, 1, False), (N2, 256, 256, False, 9, False),
+          (N1, 256, 128, True, 1, False), (N0, 128, 64, True, 1, False), (N0, 64, 64, False, 1, False)]
 HBM_COPY = 6.29e12
 MFMA_PEAK = 2.5e15
 dev = torch.device('cuda:0')
@@ -53,9 +53,9 @@ def main():
     jobs = []          # (name, M, Nc, K, count, fn)
     keep = []
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)      # 512 MB: evicts L2 and the Infinity Cache between launches
-    for (M, cin, cout, sc, cnt) in BLOCKS:
+    for (M, cin, cout, sc, cnt, ti) in BLOCKS:
         H = 2 * cout
-        yw = 2 * H + (cout if sc else 0)
+        yw = (H if ti else 2 * H) + (cout if sc else 0)
         x = torch.randn(M, cin, device=dev)
         wcat = torch.randn(yw, cin, device=dev) * 0.05
         w2 = torch.randn(cout, H, device=dev) * 0.05
