@@ -69,7 +69,24 @@ if NV != 200_000:
     sys.exit(0)
 # PMC_ONLY_FWD=1: the level-0 forward edge kernel of the headline mesh only (what bench.py's live `roofline.traffic` leg profiles)
 ONLY_FWD = os.environ.get('PMC_ONLY_FWD', '0') == '1'
-s = make_synthetic_mesh(200_000, 1, seed=0, dilations=()).to(dev)
+s = make_synthetic_mesh(200_000, 1, seed=0, dilations=())
+if os.environ.get('PMC_LOCALITY', '0') == '1':
+    # (round 6) the same mesh with its vertices renumbered by locality - what loader.SceneLoader's resident plans run on: forward,
+    # the one-launch backward and the compact trans-inv backward only
+    from surface_texture_inpainting_net_amd.synthetic import renumber_by_locality  # noqa: E402
+    s = renumber_by_locality(s)[0].to(dev)
+    e = plan_for(s).edges('edge_index', 0)
+    n, H = s.x.shape[0], 128
+    A, B, G = (torch.randn(n, H, device=dev) for _ in range(3))
+    out, out2 = torch.empty(n, H, device=dev), torch.empty(n, H, device=dev)
+    mask = torch.empty(e.n_edges * (H // 32), dtype=torch.int32, device=dev)
+    for _ in range(5):
+        SF.edge_relu_mean_fwd(A, B, e.by_dst, out, mask=mask)
+        SF.edge_relu_mean_bwd_mask(G, mask, e, out, out2)
+        SF.edge_relu_mean_bwd_mask_ti(G, mask, e, out)
+    torch.cuda.synchronize()
+    sys.exit(0)
+s = s.to(dev)
 plan = plan_for(s)
 e = plan.edges('edge_index', 0)
 n, H = s.x.shape[0], 128
@@ -88,6 +105,8 @@ for _ in range(5):
     SF.edge_relu_mean_bwd_dst_mask(G, mask, e.by_dst, out)
     SF.edge_relu_mean_bwd_src_mask(G, mask, e, out)
     SF.edge_relu_mean_bwd_mask(G, mask, e, out, out2)               # round 2: both halves in one launch (what the step runs)
+    SF.edge_relu_mean_fwd_ti(None, B, e.by_dst, out, mask=mask)      # round 6: the first block's compact trans-inv pair
+    SF.edge_relu_mean_bwd_mask_ti(G, mask, e, out2)
     SF.edge_relu_mean_bwd_dst(A, B, G, e.by_dst, out)               # recompute forms (STIN_EDGE_MASK=0)
     SF.edge_relu_mean_bwd_src(A, B, G, e.inv_deg, e.by_src, out)
 # bf16-storage twins of the training-step kernels

@@ -1502,11 +1502,10 @@ int edge_fwd_impl(const T* A, int64_t lda, const T* B, int64_t ldb, const int32_
             const int cfg = eu ? atoi(eu) : 0;
             auto pick = [&](int pos, int dflt) { int d = cfg; for (int i = 0; i < 4 - pos; ++i) d /= 10; d %= 10; return (cfg > 0 && d > 0) ? d : dflt; };
             const int hsel = H == 128 ? 0 : H == 256 ? 1 : H == 512 ? 2 : H == 1024 ? 3 : 4;
-            // (round 6) a gathered operand that cannot be cache resident (N x H x 2 bytes > 128 MB: BASELINE config 5's level 0, 256 MB)
-            // takes four 256-byte rows in flight per lane group: 1 M x 128: 549 / 407 / 416 / 393 / 439 us at U = 1 / 2 / 3 / 4 / 6, where
-            // the cache-resident headline size reads 82 / 76 / 73 / 76 / 98 (profiles/probes/edge8_u_sweep.py)
-            const bool hbm_served = hsel == 0 && (int64_t)N * H * 2 > ((int64_t)128 << 20);
-            const int u = pick(hsel, hbm_served ? 4 : (hsel <= 3 ? STIN_FWD8_U_SMALL : STIN_FWD8_U_BIG));
+            // (round 6, profiles/probes/edge8_u_sweep.py, random graph of mean degree 6: 1 M x 128 reads 549 / 407 / 416 / 393 / 439 us at
+            // U = 1 / 2 / 3 / 4 / 6, 200 704 x 128 82 / 76 / 73 / 76 / 98; on config 5's 6-regular mesh U = 4 measured 383.0 us against
+            // 383.7 at U = 2 - nothing: the rate of 256-byte random rows, not the rows in flight, bounds this kernel - U stays 2)
+            const int u = pick(hsel, hsel <= 3 ? STIN_FWD8_U_SMALL : STIN_FWD8_U_BIG);
 #define STIN_FWD8(U_) STIN_DISPATCH8(H, k_edge_fwd8, U_, U_, U_, U_, U_, A, lda, B, ldb, rowptr, col, N, H, out, ldo, indicator, mask)
             if (u == 1) STIN_FWD8(1);
             else if (u == 2) STIN_FWD8(2);
