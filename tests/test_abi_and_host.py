@@ -227,3 +227,23 @@ def test_cpu_tensors_are_rejected_not_silently_computed():
                      pooling_type='max')
     with pytest.raises((AssertionError, TypeError)):
         net(s)
+
+
+def test_environment_switches_are_the_documented_ones():
+    """Round 6 pruned the STIN_* environment switches from 73 to 29: every switch the product reads is in
+    that list, and the list names nothing the product no longer reads."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, 'surface_texture_inpainting_net_amd')
+    found = set()
+    for path in glob.glob(os.path.join(pkg, 'csrc', '*')):
+        if path.endswith(('.hip', '.inc', '.h')):
+            found |= set(re.findall(r'getenv\("(STIN_[A-Z0-9_]+)"\)', open(path).read()))
+    for path in glob.glob(os.path.join(pkg, '*.py')):
+        found |= set(re.findall(r"environ(?:\.get)?[\(\[]\s*'(STIN_[A-Z0-9_]+)'", open(path).read()))
+    design = open(os.path.join(root, 'DESIGN.md')).read()
+    sec = design[design.index('### 5b. Environment switches'):design.index('## 6. Measurement')]
+    documented = set(re.findall(r'`(STIN_[A-Z0-9_]+)`', sec))
+    assert found == documented, (sorted(found - documented), sorted(documented - found))
+    assert len(found) <= 30
