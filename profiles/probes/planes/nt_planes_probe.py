@@ -2,7 +2,9 @@
 """Round 6 experiment: NT products of the 18 063-row level on pre-split operands staged by LDS-DMA (profiles/probes/planes/planes.hip)
 against the shipped split kernels (fragment-order pre-split weights, operands split inside the K loop): bit-identity and stand-alone time.
 
-    python profiles/probes/planes/nt_planes_probe.py [--md out.md]
+    (build first, in this directory:
+     hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared -fno-slp-vectorize -ffp-contract=off -o libplanes_probe.so planes.hip)
+    python profiles/probes/planes/nt_planes_probe.py [--stamps] [--md out.md]
 """
 import argparse
 import ctypes
